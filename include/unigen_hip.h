@@ -1,0 +1,154 @@
+/* unigen_hip.h -- C ABI of libunigen_hip.so (gfx950 / MI355X).
+ *
+ * This is the drop-in boundary underneath the reference's Python model API:
+ * the reference itself has no native code, every entry point below replaces a third-party kernel
+ * the reference reaches through torch / transformers.  The "replaces" note on each entry cites the
+ * reference call site (paths relative to the reference repo) whose arithmetic it implements.
+ *
+ * Conventions
+ *   - plain C types only: device pointers, int64 sizes / strides (in ELEMENTS), float scalars,
+ *     a hipStream_t.  No torch types.  bf16 tensors are passed as void* (raw 16-bit storage).
+ *   - every function returns 0 on success or a negative error class (UG_ERR_*); the message is
+ *     available from ug_last_error() (thread-local).  Nothing throws or aborts across the boundary.
+ *   - every tensor is owned by the caller; the library allocates nothing, never frees caller memory,
+ *     never synchronises the device, and launches only on the stream it is given (so every entry is
+ *     legal inside a hipGraph capture).
+ *   - shape / alignment requirements are checked at entry and fail loudly (UG_ERR_ARG).
+ */
+#ifndef UNIGEN_HIP_H
+#define UNIGEN_HIP_H
+
+#include <stdint.h>
+#include <hip/hip_runtime_api.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UG_ABI_VERSION 1
+
+/* ---- library ---------------------------------------------------------------------------- */
+const char* ug_last_error(void);
+int ug_abi_version(void);
+
+/* ---- dense contraction ------------------------------------------------------------------- */
+/* C[M,N] = A[M,K] . B[N,K]^T, bf16 operands, fp32 accumulate, K % 64 == 0.
+ * epilogue: 0 = bf16 out (+ optional bf16 bias[N])
+ *           1 = fp32 out, C = (beta ? C : 0) + alpha * acc   (alpha read from device if non-null)
+ *           2 = fp32 residual: C = resid + bf16round(acc)
+ * replaces: nn.Linear inside transformers Qwen2Attention / Qwen2MLP (q,k,v,o,gate,up,down_proj) and
+ *           UniGen's tied lm_head, models/unigen.py:274-287; their autograd dgrad / wgrad. */
+#define UG_EPI_BF16 0
+#define UG_EPI_F32 1
+#define UG_EPI_RESID 2
+int ug_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
+                    int64_t M, int64_t N, int64_t K, int epilogue, const void* bias,
+                    const float* resid, int64_t ldr, int beta, const float* alpha_dev, hipStream_t stream);
+int ug_gemm_set_variant(int v); /* 0 = LDS-DMA staging (default), 1 = register staging (A/B arm) */
+
+/* in [R,C] (fp32 if in_f32 else bf16) -> out bf16 [R,C] (optional) and outT bf16 [C,ldT] with
+ * columns R..ldT-1 zero-filled.  Feeds the K-contiguous operands of wgrad / dgrad GEMMs. */
+int ug_transpose_cast(const void* in, int in_f32, int64_t ld_in, void* out, int64_t ld_out, void* outT,
+                      int64_t ldT, int64_t R, int64_t C, hipStream_t stream);
+int ug_cast_f32_bf16(const float* in, void* out, int64_t n, hipStream_t stream);
+
+/* ---- Qwen2 decoder-layer row ops ----------------------------------------------------------- */
+/* replaces: transformers Qwen2RMSNorm.forward (modeling_qwen2.py:246-252) + the autocast bf16 cast
+ * of the following Linear's input.  x fp32 [rows,cols]; y bf16 (or fp32 if out_f32); rstd optional. */
+int ug_rmsnorm_fwd(const float* x, const float* w, void* y, float* rstd, int64_t rows, int64_t cols,
+                   float eps, int out_f32, hipStream_t stream);
+/* dres += d(rmsnorm)/dx . dy ; dw += sum_rows dy * xhat      (dy bf16) */
+int ug_rmsnorm_bwd(const void* dy, const float* x, const float* rstd, const float* w, float* dres,
+                   float* dw, int64_t rows, int64_t cols, hipStream_t stream);
+/* replaces: apply_rotary_pos_emb (modeling_qwen2.py:113-135); in place on `nheads` consecutive heads of
+ * width head_dim starting at qkv (row stride ldq); position of row t is t % L; cos/sin [L, head_dim/2]. */
+int ug_rope(void* qkv, const float* cos_tab, const float* sin_tab, int64_t tokens, int64_t L, int64_t ldq,
+            int nheads, int head_dim, int backward, hipStream_t stream);
+/* replaces: Qwen2MLP act_fn(gate) * up (modeling_qwen2.py:46-48); gate_up = [tokens, 2I] = [gate | up] */
+int ug_swiglu_fwd(const void* gate_up, void* act, int64_t tokens, int64_t I, hipStream_t stream);
+int ug_swiglu_bwd(const void* gate_up, const void* dact, void* dgate_up, int64_t tokens, int64_t I,
+                  hipStream_t stream);
+/* replaces: llm.model.embed_tokens (models/unigen.py:257,370; fp32 gather) and its scatter-add grad */
+int ug_embed_fwd(const int64_t* ids, const float* W, float* out, int64_t tokens, int64_t H, int64_t V,
+                 int* err_flag, hipStream_t stream);
+int ug_embed_bwd(const int64_t* ids, const float* dout, float* dW, int64_t tokens, int64_t H, int64_t V,
+                 hipStream_t stream);
+/* out[c] += sum_r in[r,c]  (bias gradients) */
+int ug_colsum_bf16(const void* in, int64_t ld, float* out, int64_t R, int64_t C, hipStream_t stream);
+
+/* ---- attention ------------------------------------------------------------------------------ */
+/* Mask compression.  replaces the dense additive [B,1,L,L] masks of training/prompting_utils.py:975-1074
+ * as consumed by SDPA: bits[B][L][nW] (nW = ceil(L/64); bit j of word w set <=> key w*64+j visible),
+ * tileany[B][nW][nW].  err_flag bit 1 is raised if a value is neither 0 nor <= -1e9. */
+#define UG_MASK_F32 0
+#define UG_MASK_BF16 1
+#define UG_MASK_I64 2
+#define UG_MASK_BOOL 3
+int ug_attn_mask_compress(const void* mask, int mask_dtype, int64_t stride_b, int64_t stride_row,
+                          uint64_t* bits, uint8_t* tileany, int64_t B, int64_t L, int* err_flag,
+                          hipStream_t stream);
+int ug_attn_mask_causal(const uint8_t* key_valid /* [B,L] or null */, uint64_t* bits, uint8_t* tileany,
+                        int64_t B, int64_t L, hipStream_t stream);
+/* in rows (b*L+t), C columns at stride ld  ->  out[b][c][t], t zero-padded to Lp (multiple of 64) */
+int ug_attn_transpose(const void* in, int64_t ld, void* out, int64_t B, int64_t L, int64_t Lp, int64_t C,
+                      hipStream_t stream);
+/* replaces: torch SDPA in Qwen2Attention.forward (modeling_qwen2.py:196-234), GQA H:HKV, head_dim 128.
+ * q/k/v: row (b*L+t), head h at column h*128, row stride ldq.  vT: [B][HKV*128][Lp].
+ * o: [tokens, ldo] bf16, lse: [B][H][L] fp32. */
+int ug_attn_fwd(const void* q, const void* k, const void* v, int64_t ldq, const void* vT, void* o,
+                int64_t ldo, float* lse, const uint64_t* bits, const uint8_t* tileany, int64_t B, int64_t L,
+                int64_t Lp, int H, int HKV, int head_dim, float scale, hipStream_t stream);
+/* dq/dk/dv written with row stride ldg (heads laid out like q/k/v); delta: [B][H][L] workspace */
+int ug_attn_bwd(const void* q, const void* k, const void* v, int64_t ldq, const void* qT, const void* kT,
+                const void* o, const void* dout, int64_t ldo, const void* doT, const float* lse,
+                float* delta, void* dq, void* dk, void* dv, int64_t ldg, const uint64_t* bits,
+                const uint8_t* tileany, int64_t B, int64_t L, int64_t Lp, int H, int HKV, int head_dim,
+                float scale, hipStream_t stream);
+
+/* ---- loss ------------------------------------------------------------------------------------ */
+/* replaces: F.cross_entropy(ignore_index=-100) x3 in UniGen.forward (models/unigen.py:310-338) and
+ * get_batch_logps (training/train_dpo.py:51-90).  logits bf16 [R, ld], ld % 8 == 0.
+ * loss_and_count (optional): [0] = mean loss over valid rows, [1] = number of valid rows. */
+int ug_ce_fwd(const void* logits, int64_t ld, int64_t R, int64_t V, const int64_t* labels,
+              int64_t ignore_index, float* lse, float* loss_row, float* logp_label, float* loss_and_count,
+              hipStream_t stream);
+/* in place: logits <- (softmax - onehot) * (*gscale / count) (valid rows), 0 elsewhere incl. pad cols */
+int ug_ce_bwd(void* logits_inout, int64_t ld, int64_t R, int64_t V, const int64_t* labels,
+              int64_t ignore_index, const float* lse, const float* loss_and_count, const float* gscale,
+              hipStream_t stream);
+
+/* ---- optimizer ------------------------------------------------------------------------------- */
+/* replaces: torch.optim.AdamW.step (training/train.py:324-330,780) over one flat fp32 segment; also
+ * refreshes the bf16 compute copy (p_bf16 may be null).  grads are multiplied by grad_scale first. */
+int ug_adamw_flat(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr,
+                  float beta1, float beta2, float eps, float weight_decay, int64_t step, float grad_scale,
+                  hipStream_t stream);
+
+/* ---- MAGVITv2 tokenizer (fp32, NHWC) ------------------------------------------------------- */
+/* replaces: torch.nn.Conv2d in VQGANEncoder/Decoder, ResnetBlock, Downsample (asymmetric pad via
+ * pad_top/pad_left = 0, stride 2), Upsample (nearest-2x folded into the load), magvitv2.py:90-178,
+ * 319-408; common_modules.py:30-93,301-360.  w_packed: [k*k][Cin][cout_pad] fp32. */
+int ug_conv2d_f32(const float* x, const float* w_packed, const float* bias, const float* residual, float* y,
+                  int64_t B, int Hin, int Win, int Cin, int Cout, int cout_pad, int ksize, int stride,
+                  int pad_top, int pad_left, int Hout, int Wout, int upsample2x, hipStream_t stream);
+/* batched fp32 GEMM on the same kernel (AttnBlock bmm's, common_modules.py:190-214) */
+int ug_gemm_f32(const float* A, int64_t lda, int64_t stride_a, const float* B, int64_t ldb, int64_t stride_b,
+                int b_is_nk, float* C, int64_t ldc, int64_t stride_c, int64_t M, int64_t N, int64_t K,
+                int64_t batch, float alpha, hipStream_t stream);
+/* replaces: Normalize = GroupNorm(32, eps 1e-6) (+ swish), common_modules.py:19-27 */
+int ug_groupnorm_swish(const float* x, const float* gamma, const float* beta, float* y, double* stats_ws,
+                       int64_t B, int64_t HW, int C, int groups, float eps, int apply_swish, hipStream_t stream);
+int ug_softmax_rows_f32(float* x, int64_t rows, int64_t cols, float scale, hipStream_t stream);
+int ug_nchw_to_nhwc(const float* in, float* out, int64_t B, int C, int64_t HW, int c_pad, hipStream_t stream);
+int ug_nhwc_to_nchw(const float* in, float* out, int64_t B, int C, int64_t HW, int c_pad, hipStream_t stream);
+/* replaces: LFQuantizer.get_indices / get_codebook_entry, magvitv2.py:210-230 */
+int ug_lfq_pack(const float* z, int64_t ldz, int64_t* idx, int64_t n, int nbits, hipStream_t stream);
+int ug_lfq_unpack(const int64_t* idx, float* z, int64_t n, int nbits, int* err_flag, hipStream_t stream);
+
+/* ---- hardware probes (test-only: dump raw MFMA / LDS-transpose lane layouts) ---------------- */
+int ug_probe_layouts(float* out, int64_t n_floats, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UNIGEN_HIP_H */

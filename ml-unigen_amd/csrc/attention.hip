@@ -1,0 +1,538 @@
+// Masked flash attention (fwd + bwd) for the Qwen2.5-1.5B backbone on gfx950:
+// GQA 12 query heads : 2 kv heads, head_dim 128, L <= a few thousand, bf16 operands, fp32 softmax.
+// Replaces torch SDPA inside transformers' Qwen2Attention (modeling_qwen2.py:176-234) for the masks
+// the reference's builders produce (training/prompting_utils.py:975-1074): the caller's dense additive
+// [B,1,L,L] mask (0 = attend, huge negative = blocked) is compressed once per step into a bitmask
+// (one 64-bit word per query row per 64-key tile) plus per-tile "anything visible" flags, so fully
+// blocked tiles are skipped and partially blocked ones cost one bit test per score.
+//
+// Kernel shape (all three kernels): 4 waves x 16 rows = 64-row tiles, 64-wide tiles on the other
+// axis, mfma_f32_16x16x32_bf16.  Scores are produced TRANSPOSED (rows = the streamed axis) so that
+// each lane owns one query (resp. key) column: row statistics are lane-local plus two shuffles, and
+// the probabilities feed the second MFMA as a B operand straight from registers.  The second
+// contraction needs the streamed operand k-major; those come from pre-transposed global copies
+// (ug_attn_transpose) -- 16-byte loads all the way, no in-kernel transposes.
+#include "common.h"
+#include "unigen_hip.h"
+
+namespace {
+
+constexpr int HD = 128;      // head_dim
+constexpr int RM_LD = 136;   // LDS row stride (elements) of a row-major [64][128] tile
+constexpr int TR_LD = 72;    // LDS row stride (elements) of a transposed [128][64] tile
+constexpr int RM_BYTES = 64 * RM_LD * 2;    // 17408
+constexpr int TR_BYTES = 128 * TR_LD * 2;   // 18432
+
+// ------------------------------------------------------------------ mask compression
+template <typename T> __device__ __forceinline__ bool mask_attend(T v, int* err);
+template <> __device__ __forceinline__ bool mask_attend<float>(float v, int* err) {
+  if (v == 0.f) return true;
+  if (!(v <= -1e9f) && err) atomicOr(err, 2);   // neither 0 nor "blocked": not a mask we implement
+  return false;
+}
+template <> __device__ __forceinline__ bool mask_attend<bf16_t>(bf16_t v, int* err) { return mask_attend<float>(bf2f(v), err); }
+template <> __device__ __forceinline__ bool mask_attend<int64_t>(int64_t v, int* err) {
+  if (v == 0) return true;
+  if (v > -1000000000LL && err) atomicOr(err, 2);
+  return false;
+}
+template <> __device__ __forceinline__ bool mask_attend<uint8_t>(uint8_t v, int*) { return v != 0; }   // bool: True = attend
+
+// one wave per (batch, row, word); mask element (b, row, col) at mask[b*sb + row*sr + col]
+template <typename T>
+__global__ __launch_bounds__(256) void mask_compress_kernel(const T* __restrict__ mask, int64_t sb, int64_t sr,
+                                                            uint64_t* __restrict__ bits, int B, int L, int nW,
+                                                            int* __restrict__ err) {
+  const int64_t wid = blockIdx.x * 4LL + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int64_t total = (int64_t)B * L * nW;
+  if (wid >= total) return;
+  const int w = (int)(wid % nW);
+  const int row = (int)((wid / nW) % L);
+  const int b = (int)(wid / ((int64_t)nW * L));
+  const int col = w * 64 + lane;
+  bool a = false;
+  if (col < L) a = mask_attend<T>(mask[b * sb + row * sr + col], err);
+  const uint64_t word = __ballot(a);
+  if (lane == 0) bits[wid] = word;
+}
+
+// causal (optionally with a [B,L] key-validity vector): what HF applies when no 4-D mask is given
+__global__ __launch_bounds__(256) void mask_causal_kernel(uint64_t* __restrict__ bits, const uint8_t* __restrict__ key_valid,
+                                                          int B, int L, int nW) {
+  const int64_t wid = blockIdx.x * 4LL + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int64_t total = (int64_t)B * L * nW;
+  if (wid >= total) return;
+  const int w = (int)(wid % nW);
+  const int row = (int)((wid / nW) % L);
+  const int b = (int)(wid / ((int64_t)nW * L));
+  const int col = w * 64 + lane;
+  bool a = (col < L) && (col <= row);
+  if (a && key_valid) a = key_valid[(int64_t)b * L + col] != 0;
+  const uint64_t word = __ballot(a);
+  if (lane == 0) bits[wid] = word;
+}
+
+// tileany[b, qt, w] = OR over the 64 rows of q-tile qt of bits[b, row, w] != 0 ; one wave each
+__global__ __launch_bounds__(256) void mask_tiles_kernel(const uint64_t* __restrict__ bits, uint8_t* __restrict__ tileany,
+                                                         int B, int L, int nW) {
+  const int64_t wid = blockIdx.x * 4LL + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int nQ = nW;
+  const int64_t total = (int64_t)B * nQ * nW;
+  if (wid >= total) return;
+  const int w = (int)(wid % nW);
+  const int qt = (int)((wid / nW) % nQ);
+  const int b = (int)(wid / ((int64_t)nW * nQ));
+  const int row = qt * 64 + lane;
+  uint64_t word = 0;
+  if (row < L) word = bits[((int64_t)b * L + row) * nW + w];
+  const uint64_t any = __ballot(word != 0);
+  if (lane == 0) tileany[wid] = any ? 1 : 0;
+}
+
+// ------------------------------------------------------------------ batched slice transpose
+// in: rows (b*L + t), columns [0, C) at row stride ld  ->  out[b][c][t], t padded to Lp with zeros
+__global__ __launch_bounds__(256) void attn_transpose_kernel(const bf16_t* __restrict__ in, int64_t ld,
+                                                             bf16_t* __restrict__ out, int L, int Lp, int C) {
+  __shared__ bf16_t tile[64][66];
+  const int b = blockIdx.z;
+  const int t0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int t = t0 + i, c = c0 + tx;
+    tile[i][tx] = (t < L && c < C) ? in[((int64_t)b * L + t) * ld + c] : (bf16_t)0;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, t = t0 + tx;
+    if (c < C && t < Lp) out[((int64_t)b * C + c) * Lp + t] = tile[tx][i];
+  }
+}
+
+// ------------------------------------------------------------------ tile staging helpers
+// row-major tile: 64 rows x 128 cols from global rows (row_first + r, clamped to L-1)
+__device__ __forceinline__ void stage_rm(bf16_t* dst, const bf16_t* src_seq, int64_t ld, int row_first, int L, int tid) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + i * 256;
+    const int r = c >> 4, ch = c & 15;
+    const int gr = min(row_first + r, L - 1);
+    const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(src_seq + (int64_t)gr * ld + ch * 8);
+    *reinterpret_cast<bf16x8_t*>(dst + r * RM_LD + ch * 8) = v;
+  }
+}
+// transposed tile: 128 rows (d) x 64 cols from a [128][Lp] global slab starting at column col_first
+__device__ __forceinline__ void stage_tr(bf16_t* dst, const bf16_t* srcT, int Lp, int col_first, int tid) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + i * 256;
+    const int r = c >> 3, ch = c & 7;
+    const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(srcT + (int64_t)r * Lp + col_first + ch * 8);
+    *reinterpret_cast<bf16x8_t*>(dst + r * TR_LD + ch * 8) = v;
+  }
+}
+// MFMA A-fragment (16 rows x 32 k) from a row-major tile: rows rb*16.., k-step ks
+__device__ __forceinline__ bf16x8_t frag_rm(const bf16_t* t, int rb, int ks, int lane) {
+  return *reinterpret_cast<const bf16x8_t*>(t + (rb * 16 + (lane & 15)) * RM_LD + ks * 32 + (lane >> 4) * 8);
+}
+// MFMA A-fragment (16 rows x 32 k) from a transposed tile, k index mapped as
+// slot s of lane-group g  <->  column  jp*32 + (s>>2)*16 + g*4 + (s&3)   (matches the C-layout of
+// two adjacent 16-wide score blocks, so probabilities feed the B operand without a shuffle)
+__device__ __forceinline__ bf16x8_t frag_tr(const bf16_t* t, int rb, int jp, int lane) {
+  const bf16_t* p = t + (rb * 16 + (lane & 15)) * TR_LD + jp * 32 + (lane >> 4) * 4;
+  const bf16x4_t lo = *reinterpret_cast<const bf16x4_t*>(p);
+  const bf16x4_t hi = *reinterpret_cast<const bf16x4_t*>(p + 16);
+  bf16x8_t r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  return r;
+}
+__device__ __forceinline__ bf16x8_t pack_p(const f32x4_t& a, const f32x4_t& b) {
+  bf16x8_t r;
+  r[0] = (short)f2bf(a[0]); r[1] = (short)f2bf(a[1]); r[2] = (short)f2bf(a[2]); r[3] = (short)f2bf(a[3]);
+  r[4] = (short)f2bf(b[0]); r[5] = (short)f2bf(b[1]); r[6] = (short)f2bf(b[2]); r[7] = (short)f2bf(b[3]);
+  return r;
+}
+// reduce across the 4 lane groups (lanes l, l^16, l^32, l^48 share the same column)
+__device__ __forceinline__ float group_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
+__device__ __forceinline__ float group_sum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
+
+struct AttnArgs {
+  const bf16_t* q; const bf16_t* k; const bf16_t* v;   // row (b*L+t), head h at +h*128 ; row stride ldq
+  const bf16_t* kT; const bf16_t* vT;                  // [B][HKV*128][Lp]
+  const bf16_t* qT; const bf16_t* doT;                 // [B][H*128][Lp]
+  bf16_t* o; const bf16_t* dout;                       // [tokens, ldo]
+  bf16_t* dq; bf16_t* dk; bf16_t* dv;                  // row stride ldg
+  float* lse; const float* delta;                      // [B][H][L]
+  const uint64_t* bits; const uint8_t* tileany;
+  int64_t ldq, ldo, ldg;
+  int B, L, Lp, nW, H, HKV;
+  float scale;
+};
+
+// ================================================================== forward
+// grid (nQtiles, H, B)
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
+  __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * RM_LD];
+  __shared__ __attribute__((aligned(16))) bf16_t Vt[128 * TR_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+  const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int hk = h / (p.H / p.HKV);
+  const int qrow = qt * 64 + wave * 16 + (lane & 15);          // this lane's query (column of S^T)
+  const int qrow_c = min(qrow, p.L - 1);
+  const bf16_t* qseq = p.q + (int64_t)b * p.L * p.ldq + h * HD;
+  const bf16_t* kseq = p.k + (int64_t)b * p.L * p.ldq + hk * HD;
+  const bf16_t* vTs = p.vT + ((int64_t)b * p.HKV + hk) * HD * p.Lp;
+
+  bf16x8_t qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+    qf[ks] = *reinterpret_cast<const bf16x8_t*>(qseq + (int64_t)qrow_c * p.ldq + ks * 32 + g * 8);
+
+  f32x4_t ot[8];
+#pragma unroll
+  for (int d = 0; d < 8; ++d) ot[d] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  float m_i = -INFINITY, l_i = 0.f;
+  const uint64_t* wrow = p.bits + ((int64_t)b * p.L + qrow_c) * p.nW;
+  const uint8_t* tany = p.tileany + ((int64_t)b * p.nW + qt) * p.nW;
+
+  for (int t = 0; t < p.nW; ++t) {
+    if (!tany[t]) continue;                                     // uniform per block
+    __syncthreads();
+    stage_rm(Ks, kseq, p.ldq, t * 64, p.L, tid);
+    stage_tr(Vt, vTs, p.Lp, t * 64, tid);
+    __syncthreads();
+
+    f32x4_t st[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      st[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        st[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rm(Ks, j, ks, lane), qf[ks], st[j], 0, 0, 0);
+    }
+    const uint64_t word = wrow[t];
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool on = (word >> (j * 16 + g * 4 + r)) & 1ull;
+        const float s = on ? st[j][r] * p.scale : -INFINITY;
+        st[j][r] = s;
+        mloc = fmaxf(mloc, s);
+      }
+    mloc = group_max(mloc);
+    const float m_new = fmaxf(m_i, mloc);
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = __expf(m_i - m_use);
+    float rs = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const float e = __expf(st[j][r] - m_use); st[j][r] = e; rs += e; }
+    rs = group_sum(rs);
+    l_i = l_i * alpha + rs;
+    m_i = m_new;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) { ot[d][0] *= alpha; ot[d][1] *= alpha; ot[d][2] *= alpha; ot[d][3] *= alpha; }
+    const bf16x8_t pf0 = pack_p(st[0], st[1]), pf1 = pack_p(st[2], st[3]);
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      ot[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(Vt, d, 0, lane), pf0, ot[d], 0, 0, 0);
+      ot[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(Vt, d, 1, lane), pf1, ot[d], 0, 0, 0);
+    }
+  }
+  if (qrow < p.L) {
+    const float inv = (l_i > 0.f) ? 1.f / l_i : 0.f;
+    bf16_t* orow = p.o + ((int64_t)b * p.L + qrow) * p.ldo + h * HD;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      uint2 w; w.x = pack_bf2(ot[d][0] * inv, ot[d][1] * inv); w.y = pack_bf2(ot[d][2] * inv, ot[d][3] * inv);
+      *reinterpret_cast<uint2*>(orow + d * 16 + g * 4) = w;
+    }
+    if (g == 0) p.lse[((int64_t)b * p.H + h) * p.L + qrow] = (l_i > 0.f) ? m_i + __logf(l_i) : INFINITY;
+  }
+}
+
+// ================================================================== delta = rowsum(dO * O)
+// one wave per (token, head)
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
+                                                         float* __restrict__ delta, int64_t ldo, int B, int L, int H) {
+  const int64_t wid = blockIdx.x * 4LL + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (wid >= (int64_t)B * L * H) return;
+  const int h = (int)(wid % H);
+  const int64_t tok = wid / H;
+  const bf16x2_t a = *reinterpret_cast<const bf16x2_t*>(o + tok * ldo + h * HD + lane * 2);
+  const bf16x2_t d = *reinterpret_cast<const bf16x2_t*>(dout + tok * ldo + h * HD + lane * 2);
+  float s = bf2f((bf16_t)a[0]) * bf2f((bf16_t)d[0]) + bf2f((bf16_t)a[1]) * bf2f((bf16_t)d[1]);
+  s = wave_sum(s);
+  if (lane == 0) { const int b = (int)(tok / L), t = (int)(tok % L); delta[((int64_t)b * H + h) * L + t] = s; }
+}
+
+// ================================================================== backward: dQ
+// grid (nQtiles, H, B); same walk as the forward, recomputing P^T from the saved log-sum-exp
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
+  __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * RM_LD];
+  __shared__ __attribute__((aligned(16))) bf16_t Vs[64 * RM_LD];
+  __shared__ __attribute__((aligned(16))) bf16_t Kt[128 * TR_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+  const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const int hk = h / (p.H / p.HKV);
+  const int qrow = qt * 64 + wave * 16 + (lane & 15);
+  const int qrow_c = min(qrow, p.L - 1);
+  const bf16_t* qseq = p.q + (int64_t)b * p.L * p.ldq + h * HD;
+  const bf16_t* kseq = p.k + (int64_t)b * p.L * p.ldq + hk * HD;
+  const bf16_t* vseq = p.v + (int64_t)b * p.L * p.ldq + hk * HD;
+  const bf16_t* doseq = p.dout + (int64_t)b * p.L * p.ldo + h * HD;
+  const bf16_t* kTs = p.kT + ((int64_t)b * p.HKV + hk) * HD * p.Lp;
+
+  bf16x8_t qf[4], dof[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    qf[ks] = *reinterpret_cast<const bf16x8_t*>(qseq + (int64_t)qrow_c * p.ldq + ks * 32 + g * 8);
+    dof[ks] = *reinterpret_cast<const bf16x8_t*>(doseq + (int64_t)qrow_c * p.ldo + ks * 32 + g * 8);
+  }
+  const float lse = p.lse[((int64_t)b * p.H + h) * p.L + qrow_c];
+  const float dl = p.delta[((int64_t)b * p.H + h) * p.L + qrow_c];
+  f32x4_t dqt[8];
+#pragma unroll
+  for (int d = 0; d < 8; ++d) dqt[d] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const uint64_t* wrow = p.bits + ((int64_t)b * p.L + qrow_c) * p.nW;
+  const uint8_t* tany = p.tileany + ((int64_t)b * p.nW + qt) * p.nW;
+
+  for (int t = 0; t < p.nW; ++t) {
+    if (!tany[t]) continue;
+    __syncthreads();
+    stage_rm(Ks, kseq, p.ldq, t * 64, p.L, tid);
+    stage_rm(Vs, vseq, p.ldq, t * 64, p.L, tid);
+    stage_tr(Kt, kTs, p.Lp, t * 64, tid);
+    __syncthreads();
+    const uint64_t word = wrow[t];
+    f32x4_t ds[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4_t s = f32x4_t{0.f, 0.f, 0.f, 0.f}, dp = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rm(Ks, j, ks, lane), qf[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rm(Vs, j, ks, lane), dof[ks], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool on = (word >> (j * 16 + g * 4 + r)) & 1ull;
+        const float pr = on ? __expf(s[r] * p.scale - lse) : 0.f;
+        ds[j][r] = pr * (dp[r] - dl) * p.scale;
+      }
+    }
+    const bf16x8_t sf0 = pack_p(ds[0], ds[1]), sf1 = pack_p(ds[2], ds[3]);
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      dqt[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(Kt, d, 0, lane), sf0, dqt[d], 0, 0, 0);
+      dqt[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(Kt, d, 1, lane), sf1, dqt[d], 0, 0, 0);
+    }
+  }
+  if (qrow < p.L) {
+    bf16_t* drow = p.dq + ((int64_t)b * p.L + qrow) * p.ldg + h * HD;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      uint2 w; w.x = pack_bf2(dqt[d][0], dqt[d][1]); w.y = pack_bf2(dqt[d][2], dqt[d][3]);
+      *reinterpret_cast<uint2*>(drow + d * 16 + g * 4) = w;
+    }
+  }
+}
+
+// ================================================================== backward: dK, dV
+// grid (nKVtiles, HKV, B); each wave owns 16 keys (a lane owns key column kv = lane&15), walks the
+// H/HKV query heads of its group and all query tiles; dK^T/dV^T accumulate in registers, no atomics.
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
+  __shared__ __attribute__((aligned(16))) bf16_t Qs[64 * RM_LD];
+  __shared__ __attribute__((aligned(16))) bf16_t Ds[64 * RM_LD];     // dO rows
+  __shared__ __attribute__((aligned(16))) bf16_t Qt[128 * TR_LD];
+  __shared__ __attribute__((aligned(16))) bf16_t Dt[128 * TR_LD];    // dO^T
+  __shared__ float lse_s[64], dl_s[64];
+  __shared__ uint64_t word_s[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
+  const int t = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
+  const int grp = p.H / p.HKV;
+  const int krow = t * 64 + wave * 16 + (lane & 15);
+  const int krow_c = min(krow, p.L - 1);
+  const bf16_t* kseq = p.k + (int64_t)b * p.L * p.ldq + hk * HD;
+  const bf16_t* vseq = p.v + (int64_t)b * p.L * p.ldq + hk * HD;
+  bf16x8_t kf[4], vf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    kf[ks] = *reinterpret_cast<const bf16x8_t*>(kseq + (int64_t)krow_c * p.ldq + ks * 32 + g * 8);
+    vf[ks] = *reinterpret_cast<const bf16x8_t*>(vseq + (int64_t)krow_c * p.ldq + ks * 32 + g * 8);
+  }
+  f32x4_t dkt[8], dvt[8];
+#pragma unroll
+  for (int d = 0; d < 8; ++d) { dkt[d] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dvt[d] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+  const int kbit = wave * 16 + (lane & 15);
+
+  for (int hh = 0; hh < grp; ++hh) {
+    const int h = hk * grp + hh;
+    const bf16_t* qseq = p.q + (int64_t)b * p.L * p.ldq + h * HD;
+    const bf16_t* doseq = p.dout + (int64_t)b * p.L * p.ldo + h * HD;
+    const bf16_t* qTs = p.qT + ((int64_t)b * p.H + h) * HD * p.Lp;
+    const bf16_t* doTs = p.doT + ((int64_t)b * p.H + h) * HD * p.Lp;
+    for (int qt = 0; qt < p.nW; ++qt) {
+      if (!p.tileany[((int64_t)b * p.nW + qt) * p.nW + t]) continue;
+      __syncthreads();
+      stage_rm(Qs, qseq, p.ldq, qt * 64, p.L, tid);
+      stage_rm(Ds, doseq, p.ldo, qt * 64, p.L, tid);
+      stage_tr(Qt, qTs, p.Lp, qt * 64, tid);
+      stage_tr(Dt, doTs, p.Lp, qt * 64, tid);
+      if (tid < 64) {
+        const int qr = qt * 64 + tid;
+        const bool ok = qr < p.L;
+        const int qc = min(qr, p.L - 1);
+        lse_s[tid] = p.lse[((int64_t)b * p.H + h) * p.L + qc];
+        dl_s[tid] = p.delta[((int64_t)b * p.H + h) * p.L + qc];
+        word_s[tid] = ok ? p.bits[((int64_t)b * p.L + qc) * p.nW + t] : 0ull;   // rows past L contribute nothing
+      }
+      __syncthreads();
+      f32x4_t pr[4], ds[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {       // query block j: rows j*16 + g*4 + r, column = this lane's key
+        f32x4_t s = f32x4_t{0.f, 0.f, 0.f, 0.f}, dp = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rm(Qs, j, ks, lane), kf[ks], s, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rm(Ds, j, ks, lane), vf[ks], dp, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ql = j * 16 + g * 4 + r;
+          const bool on = (word_s[ql] >> kbit) & 1ull;
+          const float e = on ? __expf(s[r] * p.scale - lse_s[ql]) : 0.f;
+          pr[j][r] = e;
+          ds[j][r] = e * (dp[r] - dl_s[ql]) * p.scale;
+        }
+      }
+      const bf16x8_t pf0 = pack_p(pr[0], pr[1]), pf1 = pack_p(pr[2], pr[3]);
+      const bf16x8_t sf0 = pack_p(ds[0], ds[1]), sf1 = pack_p(ds[2], ds[3]);
+#pragma unroll
+      for (int d = 0; d < 8; ++d) {
+        dvt[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(Dt, d, 0, lane), pf0, dvt[d], 0, 0, 0);
+        dvt[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(Dt, d, 1, lane), pf1, dvt[d], 0, 0, 0);
+        dkt[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(Qt, d, 0, lane), sf0, dkt[d], 0, 0, 0);
+        dkt[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(Qt, d, 1, lane), sf1, dkt[d], 0, 0, 0);
+      }
+    }
+  }
+  if (krow < p.L) {
+    bf16_t* dkrow = p.dk + ((int64_t)b * p.L + krow) * p.ldg + hk * HD;
+    bf16_t* dvrow = p.dv + ((int64_t)b * p.L + krow) * p.ldg + hk * HD;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      uint2 w; w.x = pack_bf2(dkt[d][0], dkt[d][1]); w.y = pack_bf2(dkt[d][2], dkt[d][3]);
+      *reinterpret_cast<uint2*>(dkrow + d * 16 + g * 4) = w;
+      uint2 u; u.x = pack_bf2(dvt[d][0], dvt[d][1]); u.y = pack_bf2(dvt[d][2], dvt[d][3]);
+      *reinterpret_cast<uint2*>(dvrow + d * 16 + g * 4) = u;
+    }
+  }
+}
+
+int check_common(const char* fn, int64_t B, int64_t L, int64_t Lp, int H, int HKV, int hd, int64_t ldq) {
+  UG_REQUIRE(B > 0 && L > 0, "%s: empty batch", fn);
+  UG_REQUIRE(hd == HD, "%s: head_dim %d unsupported (this build is specialised for 128)", fn, hd);
+  UG_REQUIRE(H % HKV == 0, "%s: H=%d not a multiple of HKV=%d", fn, H, HKV);
+  UG_REQUIRE(Lp % 64 == 0 && Lp >= L, "%s: Lp=%ld must be a multiple of 64 and >= L", fn, (long)Lp);
+  UG_REQUIRE(ldq % 8 == 0, "%s: row stride must be a multiple of 8 elements", fn);
+  return UG_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------ C ABI
+extern "C" int ug_attn_mask_compress(const void* mask, int mask_dtype, int64_t stride_b, int64_t stride_row,
+                                     uint64_t* bits, uint8_t* tileany, int64_t B, int64_t L, int* err_flag,
+                                     hipStream_t st) {
+  UG_REQUIRE(B > 0 && L > 0 && mask && bits && tileany, "ug_attn_mask_compress: bad args");
+  const int nW = (int)((L + 63) / 64);
+  const int64_t nwaves = B * L * nW;
+  dim3 grid((unsigned)((nwaves + 3) / 4)), block(256);
+  switch (mask_dtype) {
+    case UG_MASK_F32: hipLaunchKernelGGL(mask_compress_kernel<float>, grid, block, 0, st, (const float*)mask, stride_b, stride_row, bits, (int)B, (int)L, nW, err_flag); break;
+    case UG_MASK_BF16: hipLaunchKernelGGL(mask_compress_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)mask, stride_b, stride_row, bits, (int)B, (int)L, nW, err_flag); break;
+    case UG_MASK_I64: hipLaunchKernelGGL(mask_compress_kernel<int64_t>, grid, block, 0, st, (const int64_t*)mask, stride_b, stride_row, bits, (int)B, (int)L, nW, err_flag); break;
+    case UG_MASK_BOOL: hipLaunchKernelGGL(mask_compress_kernel<uint8_t>, grid, block, 0, st, (const uint8_t*)mask, stride_b, stride_row, bits, (int)B, (int)L, nW, err_flag); break;
+    default: ug_set_error("ug_attn_mask_compress: unknown mask dtype %d", mask_dtype); return UG_ERR_ARG;
+  }
+  UG_CHECK_LAUNCH("ug_attn_mask_compress");
+  const int64_t ntile = B * nW * nW;
+  hipLaunchKernelGGL(mask_tiles_kernel, dim3((unsigned)((ntile + 3) / 4)), block, 0, st, bits, tileany, (int)B, (int)L, nW);
+  UG_CHECK_LAUNCH("ug_attn_mask_compress(tiles)");
+  return UG_OK;
+}
+
+extern "C" int ug_attn_mask_causal(const uint8_t* key_valid, uint64_t* bits, uint8_t* tileany, int64_t B, int64_t L,
+                                   hipStream_t st) {
+  UG_REQUIRE(B > 0 && L > 0 && bits && tileany, "ug_attn_mask_causal: bad args");
+  const int nW = (int)((L + 63) / 64);
+  const int64_t nwaves = B * L * nW;
+  dim3 block(256);
+  hipLaunchKernelGGL(mask_causal_kernel, dim3((unsigned)((nwaves + 3) / 4)), block, 0, st, bits, key_valid, (int)B, (int)L, nW);
+  UG_CHECK_LAUNCH("ug_attn_mask_causal");
+  const int64_t ntile = B * nW * nW;
+  hipLaunchKernelGGL(mask_tiles_kernel, dim3((unsigned)((ntile + 3) / 4)), block, 0, st, bits, tileany, (int)B, (int)L, nW);
+  UG_CHECK_LAUNCH("ug_attn_mask_causal(tiles)");
+  return UG_OK;
+}
+
+extern "C" int ug_attn_transpose(const void* in, int64_t ld, void* out, int64_t B, int64_t L, int64_t Lp, int64_t C,
+                                 hipStream_t st) {
+  UG_REQUIRE(B > 0 && L > 0 && C > 0 && Lp >= L, "ug_attn_transpose: bad args");
+  dim3 grid((unsigned)((C + 63) / 64), (unsigned)((Lp + 63) / 64), (unsigned)B), block(256);
+  hipLaunchKernelGGL(attn_transpose_kernel, grid, block, 0, st, (const bf16_t*)in, ld, (bf16_t*)out, (int)L, (int)Lp, (int)C);
+  UG_CHECK_LAUNCH("ug_attn_transpose");
+  return UG_OK;
+}
+
+extern "C" int ug_attn_fwd(const void* q, const void* k, const void* v, int64_t ldq, const void* vT, void* o,
+                           int64_t ldo, float* lse, const uint64_t* bits, const uint8_t* tileany, int64_t B, int64_t L,
+                           int64_t Lp, int H, int HKV, int head_dim, float scale, hipStream_t st) {
+  if (int rc = check_common("ug_attn_fwd", B, L, Lp, H, HKV, head_dim, ldq)) return rc;
+  UG_REQUIRE(ug_aligned16(q) && ug_aligned16(k) && ug_aligned16(vT) && ((uintptr_t)o & 7) == 0 && ldo % 4 == 0,
+             "ug_attn_fwd: alignment");
+  AttnArgs a{};
+  a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.vT = (const bf16_t*)vT;
+  a.o = (bf16_t*)o; a.lse = lse; a.bits = bits; a.tileany = tileany;
+  a.ldq = ldq; a.ldo = ldo; a.B = (int)B; a.L = (int)L; a.Lp = (int)Lp; a.nW = (int)((L + 63) / 64);
+  a.H = H; a.HKV = HKV; a.scale = scale;
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(a.nW, H, (unsigned)B), dim3(256), 0, st, a);
+  UG_CHECK_LAUNCH("ug_attn_fwd");
+  return UG_OK;
+}
+
+extern "C" int ug_attn_bwd(const void* q, const void* k, const void* v, int64_t ldq, const void* qT, const void* kT,
+                           const void* o, const void* dout, int64_t ldo, const void* doT, const float* lse,
+                           float* delta, void* dq, void* dk, void* dv, int64_t ldg, const uint64_t* bits,
+                           const uint8_t* tileany, int64_t B, int64_t L, int64_t Lp, int H, int HKV, int head_dim,
+                           float scale, hipStream_t st) {
+  if (int rc = check_common("ug_attn_bwd", B, L, Lp, H, HKV, head_dim, ldq)) return rc;
+  UG_REQUIRE(ug_aligned16(q) && ug_aligned16(k) && ug_aligned16(v) && ug_aligned16(qT) && ug_aligned16(kT) &&
+                 ug_aligned16(doT) && ug_aligned16(dout) && ldo % 8 == 0 && ldg % 4 == 0,
+             "ug_attn_bwd: alignment");
+  AttnArgs a{};
+  a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v;
+  a.qT = (const bf16_t*)qT; a.kT = (const bf16_t*)kT; a.doT = (const bf16_t*)doT;
+  a.dout = (const bf16_t*)dout; a.lse = const_cast<float*>(lse); a.delta = delta;
+  a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv;
+  a.bits = bits; a.tileany = tileany;
+  a.ldq = ldq; a.ldo = ldo; a.ldg = ldg; a.B = (int)B; a.L = (int)L; a.Lp = (int)Lp; a.nW = (int)((L + 63) / 64);
+  a.H = H; a.HKV = HKV; a.scale = scale;
+  const int64_t nwaves = B * L * H;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, st, (const bf16_t*)o,
+                     (const bf16_t*)dout, delta, ldo, (int)B, (int)L, H);
+  UG_CHECK_LAUNCH("ug_attn_bwd(delta)");
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(a.nW, H, (unsigned)B), dim3(256), 0, st, a);
+  UG_CHECK_LAUNCH("ug_attn_bwd(dq)");
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(a.nW, HKV, (unsigned)B), dim3(256), 0, st, a);
+  UG_CHECK_LAUNCH("ug_attn_bwd(dkv)");
+  return UG_OK;
+}

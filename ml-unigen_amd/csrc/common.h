@@ -1,0 +1,120 @@
+// Shared device/host helpers for the UniGen gfx950 kernels.
+// Everything here is CDNA4-only (wave64, MFMA); there is no other backend.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+// ---------------------------------------------------------------- error plumbing
+// No exceptions / aborts cross the C-ABI: entry points return 0 or a negative error class and
+// leave a message readable through ug_last_error().
+#define UG_OK 0
+#define UG_ERR_ARG (-1)     // bad shape / alignment / dtype
+#define UG_ERR_LAUNCH (-2)  // HIP launch or runtime failure
+#define UG_ERR_STATE (-3)   // handle / workspace misuse
+
+void ug_set_error(const char* fmt, ...);
+
+#define UG_REQUIRE(cond, ...)                  \
+  do {                                         \
+    if (!(cond)) {                             \
+      ug_set_error(__VA_ARGS__);               \
+      return UG_ERR_ARG;                       \
+    }                                          \
+  } while (0)
+
+#define UG_CHECK_LAUNCH(name)                                                     \
+  do {                                                                            \
+    hipError_t e__ = hipGetLastError();                                           \
+    if (e__ != hipSuccess) {                                                      \
+      ug_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));        \
+      return UG_ERR_LAUNCH;                                                       \
+    }                                                                             \
+  } while (0)
+
+#define UG_HIP(call)                                                              \
+  do {                                                                            \
+    hipError_t e__ = (call);                                                      \
+    if (e__ != hipSuccess) {                                                      \
+      ug_set_error("%s failed: %s", #call, hipGetErrorString(e__));               \
+      return UG_ERR_LAUNCH;                                                       \
+    }                                                                             \
+  } while (0)
+
+static inline bool ug_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// ---------------------------------------------------------------- vector types
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // 8 bf16 = 4 VGPRs (MFMA A/B operand)
+typedef __attribute__((ext_vector_type(4))) short bf16x4_t;
+typedef __attribute__((ext_vector_type(2))) short bf16x2_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;    // 16x16 MFMA accumulator
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;  // 32x32 MFMA accumulator
+typedef unsigned short bf16_t;                                 // raw bf16 bits
+
+#define UG_WAVE 64
+
+// ---------------------------------------------------------------- bf16 <-> f32
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+// round-to-nearest-even, NaN preserved (same rounding torch uses for .to(bfloat16))
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+// ---------------------------------------------------------------- wave reductions (64 lanes)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Block-wide sum for blocks of NW waves; every thread gets the result. `red` is NW floats of LDS.
+template <int NW>
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  __syncthreads();
+  if (l == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) t += red[i];
+  return t;
+}
+template <int NW>
+__device__ __forceinline__ float block_max(float v, float* red) {
+  v = wave_max(v);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  __syncthreads();
+  if (l == 0) red[w] = v;
+  __syncthreads();
+  float t = red[0];
+#pragma unroll
+  for (int i = 1; i < NW; ++i) t = fmaxf(t, red[i]);
+  return t;
+}
+
+// XCD-aware, bijective remap of a linear workgroup id: consecutive ids are dispatched round-robin
+// over the 8 XCDs (private L2 each); this gives every XCD one contiguous chunk of the tile grid.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}

@@ -1,0 +1,441 @@
+// MAGVITv2 tokenizer kernels for gfx950 (reference: models/multimodal_encoder/magvitv2.py:57-442,
+// common_modules.py:19-360).  The tokenizer runs in fp32 in the reference (outside autocast) and its
+// outputs are SIGN BITS of 13 channels, so everything here is exact-fp32: convolutions are implicit
+// GEMMs on the f32-input matrix cores (v_mfma_f32_32x32x2_f32 == an fp32 fma chain, 157 TF peak),
+// GroupNorm statistics accumulate in fp64.
+//
+// Layout: activations NHWC fp32 (channels contiguous = the implicit-GEMM contraction is contiguous),
+// weights repacked once at load time to [tap][Cin][CoutPad].  The NCHW<->NHWC conversion happens
+// only at the API boundary (image in, reconstructed image out).
+#include "common.h"
+#include "unigen_hip.h"
+
+namespace {
+
+constexpr int CBM = 128;   // output pixels per workgroup
+constexpr int CBK = 16;    // contraction slice (input channels of one tap)
+constexpr int LDS_PAD = 4;
+
+struct ConvArgs {
+  const float* x;      // [B, Hin, Win, Cin]   (or A[M, K] with lda for plain GEMM)
+  const float* w;      // [taps][Cin][ldw]     (or B)
+  const float* bias;   // [Cout] or null
+  const float* res;    // [M, ldres] residual added in the epilogue, or null
+  float* y;            // [M, ldy]
+  int B, Hin, Win, Cin, Hout, Wout, Cout;
+  int KH, KW, stride, pad_t, pad_l, ups;   // ups: nearest-2x upsample of x folded into the load
+  int ldw, ldy, ldres;
+  int M;                                   // B*Hout*Wout
+  // plain (batched) GEMM mode: x = A[M,K] row stride lda, w = B ([K][N] ldb, or [N][K] if b_nk)
+  int gemm, lda, b_nk;
+  int64_t sa, sb, sc;                      // batch strides (elements)
+  float alpha;
+};
+
+// A operand: gather 4 consecutive input channels of one tap for output pixel m (zeros off-image)
+template <bool VEC4>
+__device__ __forceinline__ float4 load_a(const ConvArgs& p, const float* xb, int m, bool mvalid, int ob, int oy, int ox,
+                                         int dy, int dx, int c) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (!mvalid) return v;
+  if (p.gemm) {
+    const float* a = xb + (int64_t)m * p.lda + c;
+    if (VEC4 && c + 3 < p.Cin) return *reinterpret_cast<const float4*>(a);
+    if (c < p.Cin) v.x = a[0];
+    if (c + 1 < p.Cin) v.y = a[1];
+    if (c + 2 < p.Cin) v.z = a[2];
+    if (c + 3 < p.Cin) v.w = a[3];
+    return v;
+  }
+  int iy = oy * p.stride + dy - p.pad_t, ix = ox * p.stride + dx - p.pad_l;
+  const int He = p.ups ? p.Hin * 2 : p.Hin, We = p.ups ? p.Win * 2 : p.Win;
+  if (iy < 0 || iy >= He || ix < 0 || ix >= We) return v;
+  if (p.ups) { iy >>= 1; ix >>= 1; }
+  const float* a = xb + (((int64_t)ob * p.Hin + iy) * p.Win + ix) * p.Cin + c;
+  if (VEC4 && c + 3 < p.Cin) return *reinterpret_cast<const float4*>(a);
+  if (c < p.Cin) v.x = a[0];
+  if (c + 1 < p.Cin) v.y = a[1];
+  if (c + 2 < p.Cin) v.z = a[2];
+  if (c + 3 < p.Cin) v.w = a[3];
+  return v;
+}
+
+// BN = 128: waves 2x2, each 64x64 (2x2 MFMA tiles);  BN = 32: waves 4x1, each 32x32
+template <int BN, bool VEC4>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs p) {
+  constexpr int WN = (BN == 128) ? 2 : 1;          // waves along n
+  constexpr int WM = 4 / WN;                       // waves along m
+  constexpr int TM = CBM / WM / 32;                // 32x32 tiles per wave along m
+  constexpr int TN = BN / WN / 32;
+  constexpr int LDA = CBM + LDS_PAD, LDB = BN + LDS_PAD;
+  __shared__ __attribute__((aligned(16))) float As[2][CBK * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[2][CBK * LDB];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int m0 = blockIdx.x * CBM, n0 = blockIdx.y * BN;
+  const int bz = blockIdx.z;
+  const float* xb = p.x + bz * p.sa;
+  const float* wb = p.w + bz * p.sb;
+  float* yb = p.y + bz * p.sc;
+  const float* rb = p.res ? p.res + bz * p.sc : nullptr;
+
+  // this thread's two A pixels (rows tid>>2 and 64 + tid>>2), channel quad tid&3
+  const int kc = tid & 3;
+  int am[2], ab[2], ay[2], ax[2]; bool av[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m0 + (tid >> 2) + i * 64;
+    am[i] = m; av[i] = m < p.M;
+    if (!p.gemm) {
+      const int hw = p.Hout * p.Wout;
+      const int mm = av[i] ? m : 0;
+      ab[i] = mm / hw; const int r = mm % hw; ay[i] = r / p.Wout; ax[i] = r % p.Wout;
+    } else { ab[i] = ay[i] = ax[i] = 0; }
+  }
+  // B tile loads: BN=128 -> 512 float4 (2/thread): k = (tid>>5)+8i, n4 = tid&31 ; BN=32 -> 128 float4: k = tid>>3, n4 = tid&7
+  const int cin_tiles = (p.Cin + CBK - 1) / CBK;
+  const int taps = p.gemm ? 1 : p.KH * p.KW;
+  const int nkt = taps * cin_tiles;
+
+  f32x16_t acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra[2], rbv[2];
+  auto fetch = [&](int kt) {
+    const int tap = kt / cin_tiles, c0 = (kt % cin_tiles) * CBK;
+    const int dy = tap / max(p.KW, 1), dx = tap % max(p.KW, 1);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) ra[i] = load_a<VEC4>(p, xb, am[i], av[i], ab[i], ay[i], ax[i], dy, dx, c0 + kc * 4);
+    if constexpr (BN == 128) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int k = (tid >> 5) + i * 8, n4 = tid & 31;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!p.b_nk) {
+          if (c0 + k < p.Cin) v = *reinterpret_cast<const float4*>(wb + ((int64_t)tap * p.Cin + c0 + k) * p.ldw + n0 + n4 * 4);
+        }
+        rbv[i] = v;
+      }
+    } else {
+      const int k = tid >> 3, n4 = tid & 7;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (tid < 128 && !p.b_nk && c0 + k < p.Cin)
+        v = *reinterpret_cast<const float4*>(wb + ((int64_t)tap * p.Cin + c0 + k) * p.ldw + n0 + n4 * 4);
+      rbv[0] = v;
+    }
+    if (p.b_nk) {   // B given as [N][K]: thread reads 4 consecutive k of one n (same pattern as A)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int n = n0 + (tid >> 2) + i * 64;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < p.Cout && (tid >> 2) + i * 64 < BN) {
+          const float* b = wb + (int64_t)n * p.ldw + c0 + kc * 4;
+          if (c0 + kc * 4 + 3 < p.Cin) v = *reinterpret_cast<const float4*>(b);
+          else { if (c0 + kc * 4 < p.Cin) v.x = b[0]; if (c0 + kc * 4 + 1 < p.Cin) v.y = b[1]; if (c0 + kc * 4 + 2 < p.Cin) v.z = b[2]; }
+        }
+        rbv[i] = v;
+      }
+    }
+  };
+  auto stash = [&](int buf) {
+    float* a = As[buf]; float* b = Bs[buf];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ml = (tid >> 2) + i * 64;
+      a[(kc * 4 + 0) * LDA + ml] = ra[i].x; a[(kc * 4 + 1) * LDA + ml] = ra[i].y;
+      a[(kc * 4 + 2) * LDA + ml] = ra[i].z; a[(kc * 4 + 3) * LDA + ml] = ra[i].w;
+    }
+    if (p.b_nk) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int nl = (tid >> 2) + i * 64;
+        if (nl < BN) {
+          b[(kc * 4 + 0) * LDB + nl] = rbv[i].x; b[(kc * 4 + 1) * LDB + nl] = rbv[i].y;
+          b[(kc * 4 + 2) * LDB + nl] = rbv[i].z; b[(kc * 4 + 3) * LDB + nl] = rbv[i].w;
+        }
+      }
+    } else if constexpr (BN == 128) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int k = (tid >> 5) + i * 8, n4 = tid & 31;
+        *reinterpret_cast<float4*>(b + k * LDB + n4 * 4) = rbv[i];
+      }
+    } else {
+      if (tid < 128) { const int k = tid >> 3, n4 = tid & 7; *reinterpret_cast<float4*>(b + k * LDB + n4 * 4) = rbv[0]; }
+    }
+  };
+
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nkt) fetch(kt + 1);             // global loads in flight under the MFMAs below
+    const float* a = As[cur]; const float* b = Bs[cur];
+#pragma unroll
+    for (int kk = 0; kk < CBK / 2; ++kk) {
+      const int krow = kk * 2 + (lane >> 5);
+      float fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = a[krow * LDA + wm * (CBM / WM) + i * 32 + (lane & 31)];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j] = b[krow * LDB + wn * (BN / WN) + j * 32 + (lane & 31)];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nkt) stash(cur ^ 1);            // other buffer: last read before the previous barrier
+    __syncthreads();
+  }
+
+  // epilogue: C layout of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
+      if (n >= p.Cout) continue;
+      const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * (CBM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m >= p.M) continue;
+        float v = acc[i][j][r] * p.alpha + bv;
+        if (rb) v += rb[(int64_t)m * p.ldres + n];
+        yb[(int64_t)m * p.ldy + n] = v;
+      }
+    }
+}
+
+// ------------------------------------------------------------------ GroupNorm (32 groups) + swish
+// stats[b][g] = {sum, sumsq} in fp64; x NHWC [B, HW, C]
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, double* __restrict__ stats, int HW,
+                                                       int C, int G, int pix_per_block) {
+  __shared__ double s1[32], s2[32];
+  const int b = blockIdx.y;
+  const int c4n = C >> 2;
+  const int cpg = C / G;
+  if (threadIdx.x < 32) { s1[threadIdx.x] = 0.0; s2[threadIdx.x] = 0.0; }
+  __syncthreads();
+  const int p0 = blockIdx.x * pix_per_block, p1 = min(HW, p0 + pix_per_block);
+  // thread owns channel quad (tid % c4n) and walks pixels with stride 256 / c4n  (c4n divides 256 for C<=1024 pow2)
+  const int cq = threadIdx.x % c4n, prow = threadIdx.x / c4n, pstep = 256 / c4n;
+  double a1 = 0.0, a2 = 0.0;
+  if (pstep > 0) {
+    for (int px = p0 + prow; px < p1; px += pstep) {
+      const float4 v = *reinterpret_cast<const float4*>(x + ((int64_t)b * HW + px) * C + cq * 4);
+      a1 += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+      a2 += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    }
+  }
+  const int grp = (cq * 4) / cpg;     // cpg >= 4 so a quad never straddles groups
+  atomicAdd(&s1[grp], a1);
+  atomicAdd(&s2[grp], a2);
+  __syncthreads();
+  if (threadIdx.x < G) {
+    atomicAdd(stats + ((int64_t)b * G + threadIdx.x) * 2 + 0, s1[threadIdx.x]);
+    atomicAdd(stats + ((int64_t)b * G + threadIdx.x) * 2 + 1, s2[threadIdx.x]);
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, const double* __restrict__ stats,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float* __restrict__ y, int64_t total4, int HW, int C, int G,
+                                                       float eps, int swish) {
+  const int c4n = C >> 2, cpg = C / G;
+  const double n = (double)HW * cpg;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total4; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int cq = (int)(idx % c4n);
+    const int64_t pix = idx / c4n;
+    const int b = (int)(pix / HW);
+    const int g = (cq * 4) / cpg;
+    const double s1 = stats[((int64_t)b * G + g) * 2], s2 = stats[((int64_t)b * G + g) * 2 + 1];
+    const double mean = s1 / n;
+    double var = s2 / n - mean * mean; if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float mu = (float)mean;
+    const float4 v = reinterpret_cast<const float4*>(x)[idx];
+    const float4 ga = reinterpret_cast<const float4*>(gamma)[cq], be = reinterpret_cast<const float4*>(beta)[cq];
+    float o[4] = {(v.x - mu) * rstd * ga.x + be.x, (v.y - mu) * rstd * ga.y + be.y,
+                  (v.z - mu) * rstd * ga.z + be.z, (v.w - mu) * rstd * ga.w + be.w};
+    if (swish) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = o[k] / (1.f + expf(-o[k]));   // x * sigmoid(x)
+    }
+    reinterpret_cast<float4*>(y)[idx] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// ------------------------------------------------------------------ row softmax (AttnBlock), fp32
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ x, int rows, int cols, float scale) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float* r = x + (int64_t)row * cols;
+  float m = -INFINITY;
+  for (int c = lane; c < cols; c += 64) m = fmaxf(m, r[c] * scale);
+  m = wave_max(m);
+  float s = 0.f;
+  for (int c = lane; c < cols; c += 64) { const float e = expf(r[c] * scale - m); r[c] = e; s += e; }
+  s = wave_sum(s);
+  const float inv = 1.f / s;
+  for (int c = lane; c < cols; c += 64) r[c] *= inv;
+}
+
+// ------------------------------------------------------------------ layout conversion at the API boundary
+// NCHW [B,C,H,W] -> NHWC [B,H,W,Cp] (channels C..Cp-1 zero)
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int B,
+                                                           int C, int HW, int Cp) {
+  const int64_t total = (int64_t)B * HW * Cp;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(idx % Cp);
+    const int64_t pix = idx / Cp;
+    const int b = (int)(pix / HW); const int hw = (int)(pix % HW);
+    out[idx] = (c < C) ? in[((int64_t)b * C + c) * HW + hw] : 0.f;
+  }
+}
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out, int B,
+                                                           int C, int HW, int Cp) {
+  const int64_t total = (int64_t)B * C * HW;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int hw = (int)(idx % HW);
+    const int c = (int)((idx / HW) % C);
+    const int b = (int)(idx / ((int64_t)HW * C));
+    out[idx] = in[((int64_t)b * HW + hw) * Cp + c];
+  }
+}
+
+// ------------------------------------------------------------------ lookup-free quantiser
+// index = sum_c 2^(nbits-1-c) * [z_c > 0]   (LFQuantizer.get_indices, magvitv2.py:210-215; channel 0 = MSB)
+__global__ __launch_bounds__(256) void lfq_pack_kernel(const float* __restrict__ z, int64_t ldz, int64_t* __restrict__ idx,
+                                                       int64_t n, int nbits) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int64_t code = 0;
+  for (int c = 0; c < nbits; ++c) code |= (int64_t)(z[i * ldz + c] > 0.f) << (nbits - 1 - c);
+  idx[i] = code;
+}
+// codes -> +-1 entries  (LFQuantizer.get_codebook_entry, magvitv2.py:217-230), NHWC [n, nbits]
+__global__ __launch_bounds__(256) void lfq_unpack_kernel(const int64_t* __restrict__ idx, float* __restrict__ z, int64_t n,
+                                                         int nbits, int* __restrict__ err) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int64_t code = idx[i];
+  if (code < 0 || code >= (1LL << nbits)) { if (err) atomicOr(err, 4); code = 0; }
+  for (int c = 0; c < nbits; ++c) z[i * nbits + c] = ((code >> (nbits - 1 - c)) & 1) ? 1.f : -1.f;
+}
+
+int launch_conv(const ConvArgs& a, int nb, hipStream_t st) {
+  const bool vec4 = a.gemm ? (a.lda % 4 == 0 && ug_aligned16(a.x) && a.sa % 4 == 0) : (a.Cin % 4 == 0 && ug_aligned16(a.x));
+  const bool wide = a.Cout > 32;
+  dim3 block(256);
+  if (wide) {
+    dim3 grid((a.M + CBM - 1) / CBM, (a.Cout + 127) / 128, nb);
+    if (vec4) hipLaunchKernelGGL((conv_igemm_kernel<128, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((conv_igemm_kernel<128, false>), grid, block, 0, st, a);
+  } else {
+    dim3 grid((a.M + CBM - 1) / CBM, 1, nb);
+    if (vec4) hipLaunchKernelGGL((conv_igemm_kernel<32, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((conv_igemm_kernel<32, false>), grid, block, 0, st, a);
+  }
+  return UG_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------ C ABI
+extern "C" int ug_conv2d_f32(const float* x, const float* w_packed, const float* bias, const float* residual, float* y,
+                             int64_t B, int Hin, int Win, int Cin, int Cout, int cout_pad, int ksize, int stride,
+                             int pad_top, int pad_left, int Hout, int Wout, int upsample2x, hipStream_t st) {
+  UG_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && (ksize == 1 || ksize == 3), "ug_conv2d_f32: bad shape");
+  UG_REQUIRE(cout_pad % 4 == 0 && cout_pad >= ((Cout > 32) ? (Cout + 127) / 128 * 128 : 32),
+             "ug_conv2d_f32: packed weights must be padded to the N tile (cout_pad=%d for Cout=%d)", cout_pad, Cout);
+  UG_REQUIRE(ug_aligned16(w_packed) && x && y, "ug_conv2d_f32: pointers");
+  ConvArgs a{};
+  a.x = x; a.w = w_packed; a.bias = bias; a.res = residual; a.y = y;
+  a.B = (int)B; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Hout = Hout; a.Wout = Wout; a.Cout = Cout;
+  a.KH = ksize; a.KW = ksize; a.stride = stride; a.pad_t = pad_top; a.pad_l = pad_left; a.ups = upsample2x;
+  a.ldw = cout_pad; a.ldy = Cout; a.ldres = Cout;
+  const int64_t M = B * Hout * Wout;
+  UG_REQUIRE(M < (1LL << 31), "ug_conv2d_f32: too many output pixels");
+  a.M = (int)M; a.gemm = 0; a.alpha = 1.f;
+  launch_conv(a, 1, st);
+  UG_CHECK_LAUNCH("ug_conv2d_f32");
+  return UG_OK;
+}
+
+extern "C" int ug_gemm_f32(const float* A, int64_t lda, int64_t stride_a, const float* Bm, int64_t ldb, int64_t stride_b,
+                           int b_is_nk, float* C, int64_t ldc, int64_t stride_c, int64_t M, int64_t N, int64_t K,
+                           int64_t batch, float alpha, hipStream_t st) {
+  UG_REQUIRE(M > 0 && N > 0 && K > 0 && batch > 0, "ug_gemm_f32: empty");
+  UG_REQUIRE(b_is_nk || (ldb % 4 == 0 && ug_aligned16(Bm) && stride_b % 4 == 0 && ldb >= ((N > 32) ? (N + 127) / 128 * 128 : 32)),
+             "ug_gemm_f32: [K][N] operand needs ldb padded to the N tile and 16B alignment");
+  ConvArgs a{};
+  a.x = A; a.w = Bm; a.y = C; a.Cin = (int)K; a.Cout = (int)N; a.M = (int)M;
+  a.gemm = 1; a.lda = (int)lda; a.ldw = (int)ldb; a.ldy = (int)ldc; a.b_nk = b_is_nk;
+  a.sa = stride_a; a.sb = stride_b; a.sc = stride_c; a.alpha = alpha; a.KH = a.KW = 1;
+  launch_conv(a, (int)batch, st);
+  UG_CHECK_LAUNCH("ug_gemm_f32");
+  return UG_OK;
+}
+
+extern "C" int ug_groupnorm_swish(const float* x, const float* gamma, const float* beta, float* y, double* stats_ws,
+                                  int64_t B, int64_t HW, int C, int groups, float eps, int apply_swish, hipStream_t st) {
+  UG_REQUIRE(B > 0 && HW > 0 && groups > 0 && groups <= 32 && C % groups == 0 && (C / groups) % 4 == 0,
+             "ug_groupnorm_swish: unsupported C=%d groups=%d", C, groups);
+  UG_REQUIRE(C / 4 <= 256 && 256 % (C / 4) == 0, "ug_groupnorm_swish: C=%d must be 4*2^k <= 1024", C);
+  UG_HIP(hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * B * groups, st));
+  const int ppb = 1024;
+  dim3 grid((unsigned)((HW + ppb - 1) / ppb), (unsigned)B);
+  hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), 0, st, x, stats_ws, (int)HW, C, groups, ppb);
+  UG_CHECK_LAUNCH("ug_groupnorm_swish(stats)");
+  const int64_t total4 = B * HW * (C / 4);
+  int64_t g = (total4 + 255) / 256; if (g > 256 * 16) g = 256 * 16;
+  hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)g), dim3(256), 0, st, x, stats_ws, gamma, beta, y, total4, (int)HW, C,
+                     groups, eps, apply_swish);
+  UG_CHECK_LAUNCH("ug_groupnorm_swish(apply)");
+  return UG_OK;
+}
+
+extern "C" int ug_softmax_rows_f32(float* x, int64_t rows, int64_t cols, float scale, hipStream_t st) {
+  UG_REQUIRE(rows > 0 && cols > 0, "ug_softmax_rows_f32: empty");
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, (int)rows, (int)cols, scale);
+  UG_CHECK_LAUNCH("ug_softmax_rows_f32");
+  return UG_OK;
+}
+
+extern "C" int ug_nchw_to_nhwc(const float* in, float* out, int64_t B, int C, int64_t HW, int c_pad, hipStream_t st) {
+  UG_REQUIRE(B > 0 && C > 0 && c_pad >= C, "ug_nchw_to_nhwc: bad args");
+  const int64_t total = B * HW * c_pad; int64_t g = (total + 255) / 256; if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((unsigned)g), dim3(256), 0, st, in, out, (int)B, C, (int)HW, c_pad);
+  UG_CHECK_LAUNCH("ug_nchw_to_nhwc");
+  return UG_OK;
+}
+extern "C" int ug_nhwc_to_nchw(const float* in, float* out, int64_t B, int C, int64_t HW, int c_pad, hipStream_t st) {
+  UG_REQUIRE(B > 0 && C > 0 && c_pad >= C, "ug_nhwc_to_nchw: bad args");
+  const int64_t total = B * HW * C; int64_t g = (total + 255) / 256; if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)g), dim3(256), 0, st, in, out, (int)B, C, (int)HW, c_pad);
+  UG_CHECK_LAUNCH("ug_nhwc_to_nchw");
+  return UG_OK;
+}
+
+extern "C" int ug_lfq_pack(const float* z, int64_t ldz, int64_t* idx, int64_t n, int nbits, hipStream_t st) {
+  UG_REQUIRE(n > 0 && nbits > 0 && nbits < 63, "ug_lfq_pack: bad args");
+  hipLaunchKernelGGL(lfq_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, z, ldz, idx, n, nbits);
+  UG_CHECK_LAUNCH("ug_lfq_pack");
+  return UG_OK;
+}
+extern "C" int ug_lfq_unpack(const int64_t* idx, float* z, int64_t n, int nbits, int* err_flag, hipStream_t st) {
+  UG_REQUIRE(n > 0 && nbits > 0 && nbits < 63, "ug_lfq_unpack: bad args");
+  hipLaunchKernelGGL(lfq_unpack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, idx, z, n, nbits, err_flag);
+  UG_CHECK_LAUNCH("ug_lfq_unpack");
+  return UG_OK;
+}

@@ -1,0 +1,453 @@
+// HBM-bound row/elementwise kernels of the Qwen2.5 backbone for gfx950: RMSNorm fwd/bwd, RoPE,
+// SwiGLU, transpose/cast, embedding gather / scatter-add, column sums, fused AdamW.
+// All are one pass over their operands with 16-byte per-lane accesses and wave64 shuffles for the
+// row reductions (no LDS round trip unless a cross-wave sum is needed).
+//
+// Numerics follow the reference's autocast(bf16) path (SURVEY.md §8a "precision modes", mode A):
+// fp32 residual stream and norm statistics, bf16 Linear inputs/outputs, fp32 master weights.
+#include "common.h"
+#include "unigen_hip.h"
+
+namespace {
+
+// =========================================================================== RMSNorm
+// y = bf16( w * (x * rsqrt(mean(x^2) + eps)) )      (transformers Qwen2RMSNorm.forward,
+// modeling_qwen2.py:246-252 followed by the autocast bf16 cast of the next Linear's input)
+// one wave per row; COLS = columns per lane handled in float4 chunks.
+template <bool OUT_F32>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          void* __restrict__ y, float* __restrict__ rstd,
+                                                          int rows, int cols, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * cols);
+  const int nv = cols >> 2;
+  float ss = 0.f;
+  for (int i = lane; i < nv; i += 64) {
+    const float4 v = xr[i];
+    ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  ss = wave_sum(ss);
+  const float r = rsqrtf(ss / (float)cols + eps);
+  if (lane == 0 && rstd) rstd[row] = r;
+  const float4* wr = reinterpret_cast<const float4*>(w);
+  for (int i = lane; i < nv; i += 64) {
+    const float4 v = xr[i], g = wr[i];
+    const float o0 = g.x * (v.x * r), o1 = g.y * (v.y * r), o2 = g.z * (v.z * r), o3 = g.w * (v.w * r);
+    if constexpr (OUT_F32) {
+      reinterpret_cast<float4*>(reinterpret_cast<float*>(y) + (int64_t)row * cols)[i] = make_float4(o0, o1, o2, o3);
+    } else {
+      uint2 o; o.x = pack_bf2(o0, o1); o.y = pack_bf2(o2, o3);
+      reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(y) + (int64_t)row * cols)[i] = o;
+    }
+  }
+}
+
+// dres += rstd * (g - xhat * mean(g * xhat)),  g = dy * w,  xhat = x * rstd;   dw += sum_rows dy * xhat
+// Each wave walks ROWS_PER_WAVE rows keeping its dw partials in registers (cols <= 64*4*MAXV).
+constexpr int RN_MAXV = 8;   // supports cols <= 2048
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ x,
+                                                          const float* __restrict__ rstd, const float* __restrict__ w,
+                                                          float* __restrict__ dres, float* __restrict__ dw,
+                                                          int rows, int cols, int rows_per_block) {
+  __shared__ float red[4][64 * 4];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int nv = cols >> 2;
+  float4 dwp[RN_MAXV];
+#pragma unroll
+  for (int k = 0; k < RN_MAXV; ++k) dwp[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4* wr = reinterpret_cast<const float4*>(w);
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = min(rows, r0 + rows_per_block);
+  for (int row = r0 + wave; row < r1; row += 4) {
+    const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * cols);
+    const uint2* dyr = reinterpret_cast<const uint2*>(dy + (int64_t)row * cols);
+    float4* dr = reinterpret_cast<float4*>(dres + (int64_t)row * cols);
+    const float r = rstd[row];
+    float4 g[RN_MAXV], xh[RN_MAXV];
+    float dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < RN_MAXV; ++k) {
+      const int i = lane + k * 64;
+      if (i < nv) {
+        const float4 v = xr[i], ww = wr[i]; const uint2 d = dyr[i];
+        const float d0 = bf2f(d.x & 0xffff), d1 = bf2f(d.x >> 16), d2 = bf2f(d.y & 0xffff), d3 = bf2f(d.y >> 16);
+        xh[k] = make_float4(v.x * r, v.y * r, v.z * r, v.w * r);
+        g[k] = make_float4(d0 * ww.x, d1 * ww.y, d2 * ww.z, d3 * ww.w);
+        dot += g[k].x * xh[k].x + g[k].y * xh[k].y + g[k].z * xh[k].z + g[k].w * xh[k].w;
+        dwp[k].x += d0 * xh[k].x; dwp[k].y += d1 * xh[k].y; dwp[k].z += d2 * xh[k].z; dwp[k].w += d3 * xh[k].w;
+      }
+    }
+    dot = wave_sum(dot) / (float)cols;
+#pragma unroll
+    for (int k = 0; k < RN_MAXV; ++k) {
+      const int i = lane + k * 64;
+      if (i < nv) {
+        float4 o = dr[i];
+        o.x += r * (g[k].x - xh[k].x * dot); o.y += r * (g[k].y - xh[k].y * dot);
+        o.z += r * (g[k].z - xh[k].z * dot); o.w += r * (g[k].w - xh[k].w * dot);
+        dr[i] = o;
+      }
+    }
+  }
+  // cross-wave dw reduction through LDS, then one atomic per column per block
+#pragma unroll
+  for (int k = 0; k < RN_MAXV; ++k) {
+    if (k * 64 >= nv) break;   // uniform
+    __syncthreads();
+    red[wave][lane * 4 + 0] = dwp[k].x; red[wave][lane * 4 + 1] = dwp[k].y;
+    red[wave][lane * 4 + 2] = dwp[k].z; red[wave][lane * 4 + 3] = dwp[k].w;
+    __syncthreads();
+    const int c = threadIdx.x;           // 256 threads <-> 256 columns of this chunk
+    const int col = k * 256 + c;
+    if (col < cols) atomicAdd(dw + col, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+  }
+}
+
+// =========================================================================== RoPE (rotate-half)
+// In place on the q and k heads of the fused qkv buffer [tokens, ldq]; cos/sin tables [L, hd/2] fp32
+// built on the host exactly as Qwen2RotaryEmbedding does (modeling_qwen2.py:91-102); the products
+// and the sum are separate fp32 roundings like apply_rotary_pos_emb (:131-135), then one bf16 round.
+template <bool BWD>
+__global__ __launch_bounds__(256) void rope_kernel(bf16_t* __restrict__ qkv, const float* __restrict__ cs,
+                                                   const float* __restrict__ sn, int64_t tokens, int L, int ldq,
+                                                   int nheads, int hd) {
+#pragma clang fp contract(off)   // products and sum must round separately (HIP's __fmul_rn is a plain '*')
+  const int half = hd >> 1, per_head = half >> 2;          // 4 pairs per thread
+  const int64_t total = tokens * nheads * per_head;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int p4 = (int)(idx % per_head);
+    const int h = (int)((idx / per_head) % nheads);
+    const int64_t t = idx / ((int64_t)per_head * nheads);
+    const int pos = (int)(t % L);
+    bf16_t* base = qkv + t * ldq + h * hd + p4 * 4;
+    const uint2 lo = *reinterpret_cast<const uint2*>(base);
+    const uint2 hi = *reinterpret_cast<const uint2*>(base + half);
+    const float4 c = *reinterpret_cast<const float4*>(cs + (int64_t)pos * half + p4 * 4);
+    const float4 s = *reinterpret_cast<const float4*>(sn + (int64_t)pos * half + p4 * 4);
+    const float x1[4] = {bf2f(lo.x & 0xffff), bf2f(lo.x >> 16), bf2f(lo.y & 0xffff), bf2f(lo.y >> 16)};
+    const float x2[4] = {bf2f(hi.x & 0xffff), bf2f(hi.x >> 16), bf2f(hi.y & 0xffff), bf2f(hi.y >> 16)};
+    const float cc[4] = {c.x, c.y, c.z, c.w}, ss[4] = {s.x, s.y, s.z, s.w};
+    float o1[4], o2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if constexpr (!BWD) {
+        o1[k] = __fadd_rn(__fmul_rn(x1[k], cc[k]), __fmul_rn(-x2[k], ss[k]));
+        o2[k] = __fadd_rn(__fmul_rn(x2[k], cc[k]), __fmul_rn(x1[k], ss[k]));
+      } else {   // transpose of the rotation
+        o1[k] = __fadd_rn(__fmul_rn(x1[k], cc[k]), __fmul_rn(x2[k], ss[k]));
+        o2[k] = __fadd_rn(__fmul_rn(x2[k], cc[k]), __fmul_rn(-x1[k], ss[k]));
+      }
+    }
+    uint2 olo, ohi;
+    olo.x = pack_bf2(o1[0], o1[1]); olo.y = pack_bf2(o1[2], o1[3]);
+    ohi.x = pack_bf2(o2[0], o2[1]); ohi.y = pack_bf2(o2[2], o2[3]);
+    *reinterpret_cast<uint2*>(base) = olo;
+    *reinterpret_cast<uint2*>(base + half) = ohi;
+  }
+}
+
+// =========================================================================== SwiGLU
+// act = bf16( bf16(silu(gate)) * up )     (Qwen2MLP.forward, modeling_qwen2.py:46-48, bf16 autocast:
+// silu and the product are separate bf16-rounded ops).  gu = [tokens, 2*I] = [gate | up].
+__device__ __forceinline__ float silu_f(float g) { return g / (1.f + __expf(-g)); }
+
+__global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict__ act,
+                                                         int64_t tokens, int I) {
+  const int per_row = I >> 3;
+  const int64_t total = tokens * per_row;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = idx / per_row; const int c = (int)(idx % per_row) * 8;
+    const bf16x8_t g = *reinterpret_cast<const bf16x8_t*>(gu + t * 2 * I + c);
+    const bf16x8_t u = *reinterpret_cast<const bf16x8_t*>(gu + t * 2 * I + I + c);
+    bf16x8_t o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float s = bf2f(f2bf(silu_f(bf2f((bf16_t)g[k]))));
+      o[k] = (short)f2bf(s * bf2f((bf16_t)u[k]));
+    }
+    *reinterpret_cast<bf16x8_t*>(act + t * I + c) = o;
+  }
+}
+
+// dgate = dact * up * silu'(gate),  dup = dact * silu(gate);   dgu = [dgate | dup]
+__global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restrict__ gu, const bf16_t* __restrict__ dact,
+                                                         bf16_t* __restrict__ dgu, int64_t tokens, int I) {
+  const int per_row = I >> 3;
+  const int64_t total = tokens * per_row;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = idx / per_row; const int c = (int)(idx % per_row) * 8;
+    const bf16x8_t g = *reinterpret_cast<const bf16x8_t*>(gu + t * 2 * I + c);
+    const bf16x8_t u = *reinterpret_cast<const bf16x8_t*>(gu + t * 2 * I + I + c);
+    const bf16x8_t d = *reinterpret_cast<const bf16x8_t*>(dact + t * I + c);
+    bf16x8_t og, ou;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float gf = bf2f((bf16_t)g[k]), uf = bf2f((bf16_t)u[k]), df = bf2f((bf16_t)d[k]);
+      const float sg = 1.f / (1.f + __expf(-gf));
+      const float s = bf2f(f2bf(gf * sg));                    // bf16 silu output saved by autograd
+      const float dsilu = bf2f(f2bf(df * uf));                // grad wrt silu output (bf16 mul backward)
+      ou[k] = (short)f2bf(df * s);
+      og[k] = (short)f2bf(dsilu * (sg * (1.f + gf * (1.f - sg))));
+    }
+    *reinterpret_cast<bf16x8_t*>(dgu + t * 2 * I + c) = og;
+    *reinterpret_cast<bf16x8_t*>(dgu + t * 2 * I + I + c) = ou;
+  }
+}
+
+// =========================================================================== transpose / cast
+// in [R, C] (fp32 or bf16, row stride ld_in)  ->  out bf16 [R, C] (optional, stride ld_out)
+//                                               outT bf16 [C, ldT] with columns R..ldT-1 zeroed
+// 64x64 tiles through LDS (+1 padding), 256 threads.
+template <typename TIn>
+__global__ __launch_bounds__(256) void transpose_kernel(const TIn* __restrict__ in, int64_t ld_in,
+                                                        bf16_t* __restrict__ out, int64_t ld_out,
+                                                        bf16_t* __restrict__ outT, int64_t ldT, int R, int C) {
+  __shared__ bf16_t tile[64][66];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    bf16_t v = 0;
+    if (r < R && c < C) {
+      if constexpr (sizeof(TIn) == 4) v = f2bf(in[(int64_t)r * ld_in + c]);
+      else v = in[(int64_t)r * ld_in + c];
+      if (out) out[(int64_t)r * ld_out + c] = v;
+    }
+    tile[i][tx] = v;
+  }
+  __syncthreads();
+  if (outT) {
+    for (int i = ty; i < 64; i += 4) {
+      const int c = c0 + i, r = r0 + tx;
+      if (c < C && r < ldT) outT[(int64_t)c * ldT + r] = tile[tx][i];
+    }
+  }
+}
+
+// =========================================================================== embedding
+__global__ __launch_bounds__(256) void embed_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ W,
+                                                        float* __restrict__ out, int64_t tokens, int H, int64_t V,
+                                                        int* __restrict__ err) {
+  const int per_row = H >> 2;
+  const int64_t total = tokens * per_row;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = idx / per_row; const int c = (int)(idx % per_row);
+    int64_t id = ids[t];
+    if (id < 0 || id >= V) { if (err) atomicOr(err, 1); id = 0; }
+    reinterpret_cast<float4*>(out + t * H)[c] = reinterpret_cast<const float4*>(W + id * H)[c];
+  }
+}
+
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ dout,
+                                                        float* __restrict__ dW, int64_t tokens, int H, int64_t V) {
+  const int64_t total = tokens * H;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = idx / H; const int c = (int)(idx % H);
+    const int64_t id = ids[t];
+    if (id >= 0 && id < V) atomicAdd(dW + id * H + c, dout[idx]);
+  }
+}
+
+// =========================================================================== column sums (bias grad)
+// out[c] += sum_r in[r, c]   (bf16 in, fp32 out); block = 64 columns x 4 row-lanes
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ in, int64_t ld, float* __restrict__ out,
+                                                     int R, int C, int rows_per_block) {
+  __shared__ float red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(R, r0 + rows_per_block);
+  float s = 0.f;
+  if (c < C) for (int r = r0 + ty; r < r1; r += 4) s += bf2f(in[(int64_t)r * ld + c]);
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && c < C) atomicAdd(out + c, red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx]);
+}
+
+// =========================================================================== AdamW (flat, fused)
+// Same update order as torch.optim.AdamW's single-tensor path (reference optimizer,
+// training/train.py:324-330): decay, lerp first moment, second moment, bias-corrected step.
+// Also refreshes the bf16 compute copy of the weights in the same pass.
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v,
+                                                    bf16_t* __restrict__ p_bf16, int64_t n, float lr, float beta1,
+                                                    float beta2, float eps, float wd, float bc1, float bc2_sqrt,
+                                                    float grad_scale) {
+  const int64_t n4 = n >> 2;
+  const float step_size = lr / bc1;
+  const float decay = 1.f - lr * wd;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    float4 pp = reinterpret_cast<float4*>(p)[i];
+    float4 gg = reinterpret_cast<const float4*>(g)[i];
+    float4 mm = reinterpret_cast<float4*>(m)[i];
+    float4 vv = reinterpret_cast<float4*>(v)[i];
+    float* pa = &pp.x; float* ga = &gg.x; float* ma = &mm.x; float* va = &vv.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gr = ga[k] * grad_scale;
+      float pk = pa[k] * decay;
+      const float mk = ma[k] + (gr - ma[k]) * (1.f - beta1);
+      const float vk = va[k] * beta2 + (1.f - beta2) * gr * gr;
+      const float denom = sqrtf(vk) / bc2_sqrt + eps;
+      pk = pk - step_size * (mk / denom);
+      pa[k] = pk; ma[k] = mk; va[k] = vk;
+    }
+    reinterpret_cast<float4*>(p)[i] = pp;
+    reinterpret_cast<float4*>(m)[i] = mm;
+    reinterpret_cast<float4*>(v)[i] = vv;
+    if (p_bf16) { uint2 o; o.x = pack_bf2(pp.x, pp.y); o.y = pack_bf2(pp.z, pp.w); reinterpret_cast<uint2*>(p_bf16)[i] = o; }
+  }
+  // tail (n % 4)
+  const int64_t tail0 = n4 << 2;
+  const int64_t ti = tail0 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (ti < n) {
+    const float gr = g[ti] * grad_scale;
+    float pk = p[ti] * decay;
+    const float mk = m[ti] + (gr - m[ti]) * (1.f - beta1);
+    const float vk = v[ti] * beta2 + (1.f - beta2) * gr * gr;
+    pk = pk - step_size * (mk / (sqrtf(vk) / bc2_sqrt + eps));
+    p[ti] = pk; m[ti] = mk; v[ti] = vk;
+    if (p_bf16) p_bf16[ti] = f2bf(pk);
+  }
+}
+
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, int64_t n) {
+  const int64_t n4 = n >> 2;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 v = reinterpret_cast<const float4*>(in)[i];
+    uint2 o; o.x = pack_bf2(v.x, v.y); o.y = pack_bf2(v.z, v.w);
+    reinterpret_cast<uint2*>(out)[i] = o;
+  }
+  const int64_t ti = (n4 << 2) + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (ti < n) out[ti] = f2bf(in[ti]);
+}
+
+inline int grid_for(int64_t work_items, int block = 256, int cap = 256 * 8) {
+  int64_t g = (work_items + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (int)g;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------ C ABI
+extern "C" int ug_rmsnorm_fwd(const float* x, const float* w, void* y, float* rstd, int64_t rows, int64_t cols,
+                              float eps, int out_f32, hipStream_t st) {
+  UG_REQUIRE(rows > 0 && cols > 0 && cols % 4 == 0, "ug_rmsnorm_fwd: cols=%ld must be a positive multiple of 4", (long)cols);
+  UG_REQUIRE(ug_aligned16(x) && ug_aligned16(w) && ug_aligned16(y), "ug_rmsnorm_fwd: pointers must be 16B aligned");
+  dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  if (out_f32) hipLaunchKernelGGL(rmsnorm_fwd_kernel<true>, grid, block, 0, st, x, w, y, rstd, (int)rows, (int)cols, eps);
+  else hipLaunchKernelGGL(rmsnorm_fwd_kernel<false>, grid, block, 0, st, x, w, y, rstd, (int)rows, (int)cols, eps);
+  UG_CHECK_LAUNCH("ug_rmsnorm_fwd");
+  return UG_OK;
+}
+
+extern "C" int ug_rmsnorm_bwd(const void* dy, const float* x, const float* rstd, const float* w, float* dres,
+                              float* dw, int64_t rows, int64_t cols, hipStream_t st) {
+  UG_REQUIRE(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= 64 * 4 * RN_MAXV,
+             "ug_rmsnorm_bwd: cols=%ld unsupported (multiple of 4, <= %d)", (long)cols, 64 * 4 * RN_MAXV);
+  UG_REQUIRE(ug_aligned16(x) && ug_aligned16(w) && ug_aligned16(dres) && ((uintptr_t)dy & 7) == 0,
+             "ug_rmsnorm_bwd: pointers must be aligned");
+  const int rpb = 32;
+  dim3 grid((unsigned)((rows + rpb - 1) / rpb)), block(256);
+  hipLaunchKernelGGL(rmsnorm_bwd_kernel, grid, block, 0, st, (const bf16_t*)dy, x, rstd, w, dres, dw, (int)rows,
+                     (int)cols, rpb);
+  UG_CHECK_LAUNCH("ug_rmsnorm_bwd");
+  return UG_OK;
+}
+
+extern "C" int ug_rope(void* qkv, const float* cos_tab, const float* sin_tab, int64_t tokens, int64_t L, int64_t ldq,
+                       int nheads, int head_dim, int backward, hipStream_t st) {
+  UG_REQUIRE(tokens > 0 && L > 0 && tokens % L == 0, "ug_rope: tokens=%ld must be a multiple of L=%ld", (long)tokens, (long)L);
+  UG_REQUIRE(head_dim % 8 == 0 && ldq % 4 == 0, "ug_rope: head_dim must be a multiple of 8");
+  UG_REQUIRE(((uintptr_t)qkv & 7) == 0 && ug_aligned16(cos_tab) && ug_aligned16(sin_tab), "ug_rope: alignment");
+  const int64_t total = tokens * nheads * (head_dim / 8);
+  dim3 grid(grid_for(total)), block(256);
+  if (backward) hipLaunchKernelGGL(rope_kernel<true>, grid, block, 0, st, (bf16_t*)qkv, cos_tab, sin_tab, tokens, (int)L, (int)ldq, nheads, head_dim);
+  else hipLaunchKernelGGL(rope_kernel<false>, grid, block, 0, st, (bf16_t*)qkv, cos_tab, sin_tab, tokens, (int)L, (int)ldq, nheads, head_dim);
+  UG_CHECK_LAUNCH("ug_rope");
+  return UG_OK;
+}
+
+extern "C" int ug_swiglu_fwd(const void* gate_up, void* act, int64_t tokens, int64_t I, hipStream_t st) {
+  UG_REQUIRE(tokens > 0 && I % 8 == 0, "ug_swiglu_fwd: I=%ld must be a multiple of 8", (long)I);
+  UG_REQUIRE(ug_aligned16(gate_up) && ug_aligned16(act), "ug_swiglu_fwd: alignment");
+  dim3 grid(grid_for(tokens * (I / 8))), block(256);
+  hipLaunchKernelGGL(swiglu_fwd_kernel, grid, block, 0, st, (const bf16_t*)gate_up, (bf16_t*)act, tokens, (int)I);
+  UG_CHECK_LAUNCH("ug_swiglu_fwd");
+  return UG_OK;
+}
+
+extern "C" int ug_swiglu_bwd(const void* gate_up, const void* dact, void* dgate_up, int64_t tokens, int64_t I,
+                             hipStream_t st) {
+  UG_REQUIRE(tokens > 0 && I % 8 == 0, "ug_swiglu_bwd: I=%ld must be a multiple of 8", (long)I);
+  UG_REQUIRE(ug_aligned16(gate_up) && ug_aligned16(dact) && ug_aligned16(dgate_up), "ug_swiglu_bwd: alignment");
+  dim3 grid(grid_for(tokens * (I / 8))), block(256);
+  hipLaunchKernelGGL(swiglu_bwd_kernel, grid, block, 0, st, (const bf16_t*)gate_up, (const bf16_t*)dact, (bf16_t*)dgate_up, tokens, (int)I);
+  UG_CHECK_LAUNCH("ug_swiglu_bwd");
+  return UG_OK;
+}
+
+extern "C" int ug_transpose_cast(const void* in, int in_f32, int64_t ld_in, void* out, int64_t ld_out, void* outT,
+                                 int64_t ldT, int64_t R, int64_t C, hipStream_t st) {
+  UG_REQUIRE(R > 0 && C > 0, "ug_transpose_cast: empty");
+  UG_REQUIRE(outT == nullptr || ldT >= R, "ug_transpose_cast: ldT=%ld < R=%ld", (long)ldT, (long)R);
+  const int64_t rext = outT ? ldT : R;   // sweep the zero padding too
+  dim3 grid((unsigned)((C + 63) / 64), (unsigned)((rext + 63) / 64)), block(256);
+  if (in_f32) hipLaunchKernelGGL(transpose_kernel<float>, grid, block, 0, st, (const float*)in, ld_in, (bf16_t*)out, ld_out, (bf16_t*)outT, ldT, (int)R, (int)C);
+  else hipLaunchKernelGGL(transpose_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)in, ld_in, (bf16_t*)out, ld_out, (bf16_t*)outT, ldT, (int)R, (int)C);
+  UG_CHECK_LAUNCH("ug_transpose_cast");
+  return UG_OK;
+}
+
+extern "C" int ug_embed_fwd(const int64_t* ids, const float* W, float* out, int64_t tokens, int64_t H, int64_t V,
+                            int* err_flag, hipStream_t st) {
+  UG_REQUIRE(tokens > 0 && H % 4 == 0, "ug_embed_fwd: H must be a multiple of 4");
+  dim3 grid(grid_for(tokens * (H / 4))), block(256);
+  hipLaunchKernelGGL(embed_fwd_kernel, grid, block, 0, st, ids, W, out, tokens, (int)H, V, err_flag);
+  UG_CHECK_LAUNCH("ug_embed_fwd");
+  return UG_OK;
+}
+
+extern "C" int ug_embed_bwd(const int64_t* ids, const float* dout, float* dW, int64_t tokens, int64_t H, int64_t V,
+                            hipStream_t st) {
+  UG_REQUIRE(tokens > 0 && H > 0, "ug_embed_bwd: empty");
+  dim3 grid(grid_for(tokens * H)), block(256);
+  hipLaunchKernelGGL(embed_bwd_kernel, grid, block, 0, st, ids, dout, dW, tokens, (int)H, V);
+  UG_CHECK_LAUNCH("ug_embed_bwd");
+  return UG_OK;
+}
+
+extern "C" int ug_colsum_bf16(const void* in, int64_t ld, float* out, int64_t R, int64_t C, hipStream_t st) {
+  UG_REQUIRE(R > 0 && C > 0, "ug_colsum_bf16: empty");
+  const int rpb = 256;
+  dim3 grid((unsigned)((C + 63) / 64), (unsigned)((R + rpb - 1) / rpb)), block(256);
+  hipLaunchKernelGGL(colsum_kernel, grid, block, 0, st, (const bf16_t*)in, ld, out, (int)R, (int)C, rpb);
+  UG_CHECK_LAUNCH("ug_colsum_bf16");
+  return UG_OK;
+}
+
+extern "C" int ug_adamw_flat(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr,
+                             float beta1, float beta2, float eps, float weight_decay, int64_t step, float grad_scale,
+                             hipStream_t st) {
+  UG_REQUIRE(n > 0 && step >= 1, "ug_adamw_flat: n=%ld step=%ld", (long)n, (long)step);
+  UG_REQUIRE(ug_aligned16(p) && ug_aligned16(g) && ug_aligned16(m) && ug_aligned16(v) && ((uintptr_t)p_bf16 & 7) == 0,
+             "ug_adamw_flat: buffers must be 16B aligned");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  dim3 grid(grid_for(n / 4 + 1)), block(256);
+  hipLaunchKernelGGL(adamw_kernel, grid, block, 0, st, p, g, m, v, (bf16_t*)p_bf16, n, lr, beta1, beta2, eps,
+                     weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale);
+  UG_CHECK_LAUNCH("ug_adamw_flat");
+  return UG_OK;
+}
+
+extern "C" int ug_cast_f32_bf16(const float* in, void* out, int64_t n, hipStream_t st) {
+  UG_REQUIRE(n > 0 && ug_aligned16(in) && ((uintptr_t)out & 7) == 0, "ug_cast_f32_bf16: bad args");
+  dim3 grid(grid_for(n / 4 + 1)), block(256);
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, grid, block, 0, st, in, (bf16_t*)out, n);
+  UG_CHECK_LAUNCH("ug_cast_f32_bf16");
+  return UG_OK;
+}

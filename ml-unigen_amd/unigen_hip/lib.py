@@ -1,0 +1,97 @@
+"""ctypes binding of libunigen_hip.so (the C ABI declared in include/unigen_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing the import of any op fails
+loudly with the build command.  Nothing under oracle/ is ever imported from here.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC_DIR = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
+LIB_PATH = os.path.join(CSRC_DIR, "libunigen_hip.so")
+
+P = ctypes.c_void_p
+I64 = ctypes.c_int64
+I32 = ctypes.c_int
+F32 = ctypes.c_float
+
+# name -> argtypes (must mirror include/unigen_hip.h exactly; tests/test_abi.py cross-checks the
+# exported symbol list against the header)
+SIGNATURES = {
+    "ug_abi_version": [],
+    "ug_gemm_bf16_nt": [P, I64, P, I64, P, I64, I64, I64, I64, I32, P, P, I64, I32, P, P],
+    "ug_gemm_set_variant": [I32],
+    "ug_transpose_cast": [P, I32, I64, P, I64, P, I64, I64, I64, P],
+    "ug_cast_f32_bf16": [P, P, I64, P],
+    "ug_rmsnorm_fwd": [P, P, P, P, I64, I64, F32, I32, P],
+    "ug_rmsnorm_bwd": [P, P, P, P, P, P, I64, I64, P],
+    "ug_rope": [P, P, P, I64, I64, I64, I32, I32, I32, P],
+    "ug_swiglu_fwd": [P, P, I64, I64, P],
+    "ug_swiglu_bwd": [P, P, P, I64, I64, P],
+    "ug_embed_fwd": [P, P, P, I64, I64, I64, P, P],
+    "ug_embed_bwd": [P, P, P, I64, I64, I64, P],
+    "ug_colsum_bf16": [P, I64, P, I64, I64, P],
+    "ug_attn_mask_compress": [P, I32, I64, I64, P, P, I64, I64, P, P],
+    "ug_attn_mask_causal": [P, P, P, I64, I64, P],
+    "ug_attn_transpose": [P, I64, P, I64, I64, I64, I64, P],
+    "ug_attn_fwd": [P, P, P, I64, P, P, I64, P, P, P, I64, I64, I64, I32, I32, I32, F32, P],
+    "ug_attn_bwd": [P, P, P, I64, P, P, P, P, I64, P, P, P, P, P, P, I64, P, P, I64, I64, I64, I32, I32, I32, F32, P],
+    "ug_ce_fwd": [P, I64, I64, I64, P, I64, P, P, P, P, P],
+    "ug_ce_bwd": [P, I64, I64, I64, P, I64, P, P, P, P],
+    "ug_adamw_flat": [P, P, P, P, P, I64, F32, F32, F32, F32, F32, I64, F32, P],
+    "ug_conv2d_f32": [P, P, P, P, P, I64, I32, I32, I32, I32, I32, I32, I32, I32, I32, I32, I32, I32, P],
+    "ug_gemm_f32": [P, I64, I64, P, I64, I64, I32, P, I64, I64, I64, I64, I64, I64, F32, P],
+    "ug_groupnorm_swish": [P, P, P, P, P, I64, I64, I32, I32, F32, I32, P],
+    "ug_softmax_rows_f32": [P, I64, I64, F32, P],
+    "ug_nchw_to_nhwc": [P, P, I64, I32, I64, I32, P],
+    "ug_nhwc_to_nchw": [P, P, I64, I32, I64, I32, P],
+    "ug_lfq_pack": [P, I64, P, I64, I32, P],
+    "ug_lfq_unpack": [P, P, I64, I32, P, P],
+    "ug_probe_layouts": [P, I64, P],
+}
+
+_lib = None
+
+
+class UniGenHipError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """Compile csrc/*.hip for gfx950 (cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC_DIR, "-j8"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout[-4000:])
+        print(res.stderr[-4000:])
+    if res.returncode != 0:
+        raise UniGenHipError("building libunigen_hip.so failed (see output above)")
+    return LIB_PATH
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise UniGenHipError(
+            f"{LIB_PATH} is missing: the HIP extension is the only implementation of this path "
+            f"(no CPU fallback). Build it with `make -C {CSRC_DIR}` or `python -c 'import __graft_entry__ as g; g.build()'`.")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.ug_last_error.restype = ctypes.c_char_p
+    lib.ug_last_error.argtypes = []
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError here = header/library mismatch: fail loudly
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    if lib.ug_abi_version() != 1:
+        raise UniGenHipError(f"ABI version mismatch: library reports {lib.ug_abi_version()}, binding expects 1")
+    _lib = lib
+    return lib
+
+
+def check(rc, name="ug call"):
+    if rc != 0:
+        msg = load().ug_last_error().decode("utf-8", "replace")
+        raise UniGenHipError(f"{name} failed (rc={rc}): {msg}")

@@ -1,0 +1,338 @@
+"""Tensor-level wrappers over the C ABI: torch supplies device memory and the stream, the kernels do
+the work.  Every wrapper launches on torch's current HIP stream and never synchronises."""
+import math
+import torch
+
+from . import lib as _l
+
+UG_EPI_BF16, UG_EPI_F32, UG_EPI_RESID = 0, 1, 2
+_MASK_DTYPES = {torch.float32: 0, torch.bfloat16: 1, torch.int64: 2, torch.bool: 3}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _l.UniGenHipError("unigen_hip ops need tensors in GPU memory (no CPU fallback exists)")
+
+
+def round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+# ------------------------------------------------------------------------------------ GEMM
+def gemm_nt(a, b, out=None, *, M=None, N=None, K=None, epilogue=UG_EPI_BF16, bias=None, resid=None,
+            beta=0, alpha_dev=None, out_dtype=None):
+    """out[M,N] = a[M,K] @ b[N,K]^T.  a, b bf16 2-D (row stride = .stride(0), K contiguous)."""
+    _need_cuda(a, b)
+    M = a.shape[0] if M is None else M
+    N = b.shape[0] if N is None else N
+    K = a.shape[1] if K is None else K
+    if out is None:
+        dt = out_dtype or (torch.bfloat16 if epilogue == UG_EPI_BF16 else torch.float32)
+        out = torch.empty((M, N), dtype=dt, device=a.device)
+    lib = _l.load()
+    rc = lib.ug_gemm_bf16_nt(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, K, epilogue,
+                             _p(bias), _p(resid), resid.stride(0) if resid is not None else 0, beta,
+                             _p(alpha_dev), _stream())
+    _l.check(rc, "ug_gemm_bf16_nt")
+    return out
+
+
+def transpose_cast(x, R=None, C=None, *, want_out=False, want_T=True, ldT=None):
+    """x [R,C] fp32|bf16 -> (out bf16 [R,C] | None, outT bf16 [C, ldT] zero padded)."""
+    _need_cuda(x)
+    R = x.shape[0] if R is None else R
+    C = x.shape[1] if C is None else C
+    out = torch.empty((R, C), dtype=torch.bfloat16, device=x.device) if want_out else None
+    outT = None
+    if want_T:
+        ldT = round_up(R, 64) if ldT is None else ldT
+        outT = torch.empty((C, ldT), dtype=torch.bfloat16, device=x.device)
+    lib = _l.load()
+    rc = lib.ug_transpose_cast(_p(x), 1 if x.dtype == torch.float32 else 0, x.stride(0), _p(out),
+                               out.stride(0) if out is not None else 0, _p(outT), ldT if want_T else 0, R, C, _stream())
+    _l.check(rc, "ug_transpose_cast")
+    return out, outT
+
+
+def cast_bf16(x, out=None):
+    _need_cuda(x)
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    _l.check(_l.load().ug_cast_f32_bf16(_p(x), _p(out), x.numel(), _stream()), "ug_cast_f32_bf16")
+    return out
+
+
+# ------------------------------------------------------------------------------------ row ops
+def rmsnorm_fwd(x, w, eps, out_f32=False, want_rstd=True):
+    _need_cuda(x, w)
+    rows, cols = x.shape
+    y = torch.empty((rows, cols), dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
+    rstd = torch.empty((rows,), dtype=torch.float32, device=x.device) if want_rstd else None
+    _l.check(_l.load().ug_rmsnorm_fwd(_p(x), _p(w), _p(y), _p(rstd), rows, cols, eps, int(out_f32), _stream()),
+             "ug_rmsnorm_fwd")
+    return y, rstd
+
+
+def rmsnorm_bwd(dy, x, rstd, w, dres, dw):
+    """dres (fp32 [rows,cols]) += dx ; dw (fp32 [cols]) += sum dy*xhat."""
+    rows, cols = x.shape
+    _l.check(_l.load().ug_rmsnorm_bwd(_p(dy), _p(x), _p(rstd), _p(w), _p(dres), _p(dw), rows, cols, _stream()),
+             "ug_rmsnorm_bwd")
+
+
+def rope_tables(L, head_dim, theta, device):
+    """cos/sin [L, head_dim/2] fp32, built with the same fp32 ops as transformers'
+    Qwen2RotaryEmbedding (modeling_qwen2.py:80-102): inv_freq = 1/theta^(2i/d); freqs = inv_freq*pos."""
+    inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float) / head_dim))
+    pos = torch.arange(L, dtype=torch.float)
+    freqs = (inv_freq[None, :, None] @ pos[None, None, :]).transpose(1, 2)[0]     # [L, d/2]
+    return freqs.cos().contiguous().to(device), freqs.sin().contiguous().to(device)
+
+
+def rope_(qkv, cos, sin, L, nheads, head_dim, backward=False):
+    tokens = qkv.shape[0]
+    _l.check(_l.load().ug_rope(_p(qkv), _p(cos), _p(sin), tokens, L, qkv.stride(0), nheads, head_dim,
+                               int(backward), _stream()), "ug_rope")
+    return qkv
+
+
+def swiglu_fwd(gu):
+    tokens, two_i = gu.shape
+    act = torch.empty((tokens, two_i // 2), dtype=torch.bfloat16, device=gu.device)
+    _l.check(_l.load().ug_swiglu_fwd(_p(gu), _p(act), tokens, two_i // 2, _stream()), "ug_swiglu_fwd")
+    return act
+
+
+def swiglu_bwd(gu, dact):
+    dgu = torch.empty_like(gu)
+    _l.check(_l.load().ug_swiglu_bwd(_p(gu), _p(dact), _p(dgu), gu.shape[0], gu.shape[1] // 2, _stream()),
+             "ug_swiglu_bwd")
+    return dgu
+
+
+def embed_fwd(ids, W, err_flag=None):
+    tokens = ids.numel()
+    V, H = W.shape
+    out = torch.empty((tokens, H), dtype=torch.float32, device=W.device)
+    _l.check(_l.load().ug_embed_fwd(_p(ids), _p(W), _p(out), tokens, H, V, _p(err_flag), _stream()), "ug_embed_fwd")
+    return out
+
+
+def embed_bwd(ids, dout, dW):
+    V, H = dW.shape
+    _l.check(_l.load().ug_embed_bwd(_p(ids), _p(dout), _p(dW), ids.numel(), H, V, _stream()), "ug_embed_bwd")
+
+
+def colsum_(x, out, R=None, C=None):
+    R = x.shape[0] if R is None else R
+    C = x.shape[1] if C is None else C
+    _l.check(_l.load().ug_colsum_bf16(_p(x), x.stride(0), _p(out), R, C, _stream()), "ug_colsum_bf16")
+
+
+# ------------------------------------------------------------------------------------ attention
+class MaskBits:
+    """Compressed attention mask: bits [B, L, nW] uint64 words + tileany [B, nW, nW]."""
+
+    def __init__(self, bits, tileany, B, L):
+        self.bits, self.tileany, self.B, self.L = bits, tileany, B, L
+        self.nW = (L + 63) // 64
+        self.Lp = self.nW * 64
+
+
+def _alloc_mask(B, L, device):
+    nW = (L + 63) // 64
+    bits = torch.empty((B, L, nW), dtype=torch.int64, device=device)
+    tileany = torch.empty((B, nW, nW), dtype=torch.uint8, device=device)
+    return bits, tileany
+
+
+def mask_compress(mask4d, err_flag=None):
+    """mask4d: [B,1,L,L] (or [B,L,L]) additive fp32/bf16/int64 (0 = attend) or bool (True = attend)."""
+    _need_cuda(mask4d)
+    if mask4d.dim() == 4:
+        if mask4d.shape[1] != 1:
+            raise _l.UniGenHipError("per-head attention masks are not part of the reference path")
+        m = mask4d[:, 0]
+    else:
+        m = mask4d
+    B, L, L2 = m.shape
+    if L != L2 or m.stride(2) != 1:
+        raise _l.UniGenHipError(f"attention mask must be [B,1,L,L] with contiguous rows, got {tuple(mask4d.shape)}")
+    if m.dtype not in _MASK_DTYPES:
+        raise _l.UniGenHipError(f"unsupported attention-mask dtype {m.dtype}")
+    bits, tileany = _alloc_mask(B, L, m.device)
+    _l.check(_l.load().ug_attn_mask_compress(_p(m), _MASK_DTYPES[m.dtype], m.stride(0), m.stride(1), _p(bits),
+                                             _p(tileany), B, L, _p(err_flag), _stream()), "ug_attn_mask_compress")
+    return MaskBits(bits, tileany, B, L)
+
+
+def mask_causal(B, L, device, key_valid=None):
+    bits, tileany = _alloc_mask(B, L, device)
+    kv = None if key_valid is None else key_valid.to(torch.uint8).contiguous()
+    _l.check(_l.load().ug_attn_mask_causal(_p(kv), _p(bits), _p(tileany), B, L, _stream()), "ug_attn_mask_causal")
+    return MaskBits(bits, tileany, B, L)
+
+
+def attn_transpose(x, B, L, Lp, C):
+    """x: rows (b*L+t), C columns starting at x's first column (row stride x.stride(0)) -> [B, C, Lp]."""
+    out = torch.empty((B, C, Lp), dtype=torch.bfloat16, device=x.device)
+    _l.check(_l.load().ug_attn_transpose(_p(x), x.stride(0), _p(out), B, L, Lp, C, _stream()), "ug_attn_transpose")
+    return out
+
+
+def attn_fwd(qkv, mb, H, HKV, hd, scale=None):
+    """qkv bf16 [B*L, (H+2*HKV)*hd] (q heads | k heads | v heads, RoPE already applied).  -> (o, lse)"""
+    B, L, Lp = mb.B, mb.L, mb.Lp
+    scale = 1.0 / math.sqrt(hd) if scale is None else scale
+    q = qkv[:, : H * hd]
+    k = qkv[:, H * hd: (H + HKV) * hd]
+    v = qkv[:, (H + HKV) * hd:]
+    vT = attn_transpose(v, B, L, Lp, HKV * hd)
+    o = torch.empty((B * L, H * hd), dtype=torch.bfloat16, device=qkv.device)
+    lse = torch.empty((B, H, L), dtype=torch.float32, device=qkv.device)
+    _l.check(_l.load().ug_attn_fwd(_p(q), _p(k), _p(v), qkv.stride(0), _p(vT), _p(o), o.stride(0), _p(lse), _p(mb.bits),
+                                   _p(mb.tileany), B, L, Lp, H, HKV, hd, scale, _stream()), "ug_attn_fwd")
+    return o, lse
+
+
+def attn_bwd(qkv, o, lse, dout, mb, H, HKV, hd, scale=None):
+    """-> dqkv bf16 [B*L, (H+2*HKV)*hd] (gradient w.r.t. the post-RoPE q/k and v)."""
+    B, L, Lp = mb.B, mb.L, mb.Lp
+    scale = 1.0 / math.sqrt(hd) if scale is None else scale
+    q = qkv[:, : H * hd]
+    k = qkv[:, H * hd: (H + HKV) * hd]
+    v = qkv[:, (H + HKV) * hd:]
+    qT = attn_transpose(q, B, L, Lp, H * hd)
+    kT = attn_transpose(k, B, L, Lp, HKV * hd)
+    doT = attn_transpose(dout, B, L, Lp, H * hd)
+    dqkv = torch.empty_like(qkv)
+    dq = dqkv[:, : H * hd]
+    dk = dqkv[:, H * hd: (H + HKV) * hd]
+    dv = dqkv[:, (H + HKV) * hd:]
+    delta = torch.empty((B, H, L), dtype=torch.float32, device=qkv.device)
+    _l.check(_l.load().ug_attn_bwd(_p(q), _p(k), _p(v), qkv.stride(0), _p(qT), _p(kT), _p(o), _p(dout), o.stride(0),
+                                   _p(doT), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), dqkv.stride(0), _p(mb.bits),
+                                   _p(mb.tileany), B, L, Lp, H, HKV, hd, scale, _stream()), "ug_attn_bwd")
+    return dqkv
+
+
+# ------------------------------------------------------------------------------------ loss
+def ce_fwd(logits, V, labels, ignore_index=-100, want_logp=False):
+    """logits bf16 [R, ld>=V]; -> (loss_and_count [2], lse [R], loss_row [R], logp|None)"""
+    R, ld = logits.shape[0], logits.stride(0)
+    dev = logits.device
+    lse = torch.empty((R,), dtype=torch.float32, device=dev)
+    loss_row = torch.empty((R,), dtype=torch.float32, device=dev)
+    logp = torch.empty((R,), dtype=torch.float32, device=dev) if want_logp else None
+    lc = torch.empty((2,), dtype=torch.float32, device=dev)
+    _l.check(_l.load().ug_ce_fwd(_p(logits), ld, R, V, _p(labels), ignore_index, _p(lse), _p(loss_row), _p(logp),
+                                 _p(lc), _stream()), "ug_ce_fwd")
+    return lc, lse, loss_row, logp
+
+
+def ce_bwd_(logits, V, labels, lse, lc, gscale=None, ignore_index=-100):
+    R, ld = logits.shape[0], logits.stride(0)
+    _l.check(_l.load().ug_ce_bwd(_p(logits), ld, R, V, _p(labels), ignore_index, _p(lse), _p(lc), _p(gscale),
+                                 _stream()), "ug_ce_bwd")
+    return logits
+
+
+# ------------------------------------------------------------------------------------ optimizer
+def adamw_flat_(p, g, m, v, p_bf16, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
+    _l.check(_l.load().ug_adamw_flat(_p(p), _p(g), _p(m), _p(v), _p(p_bf16), p.numel(), lr, beta1, beta2, eps, wd,
+                                     step, grad_scale, _stream()), "ug_adamw_flat")
+
+
+# ------------------------------------------------------------------------------------ tokenizer (fp32 NHWC)
+def pack_conv_weight(w):
+    """torch Conv2d weight [Cout, Cin, k, k] -> ([k*k, Cin, cout_pad] fp32, cout_pad). Done once at load."""
+    cout, cin, kh, kw = w.shape
+    cout_pad = round_up(cout, 128) if cout > 32 else 32
+    wp = torch.zeros((kh * kw, cin, cout_pad), dtype=torch.float32, device=w.device)
+    wp[:, :, :cout] = w.detach().float().permute(2, 3, 1, 0).reshape(kh * kw, cin, cout)
+    return wp.contiguous(), cout_pad
+
+
+def conv2d_nhwc(x, wp, cout_pad, bias, cout, ksize, *, stride=1, pad=None, residual=None, upsample=False,
+                asym_pad=False):
+    """x [B,H,W,Cin] fp32 NHWC -> [B,Ho,Wo,Cout].  asym_pad: the reference Downsample's pad (0,1,0,1) +
+    stride-2 valid conv (common_modules.py:86-93)."""
+    B, H, W, Cin = x.shape
+    He, We = (2 * H, 2 * W) if upsample else (H, W)
+    if asym_pad:
+        pt = pl = 0
+        Ho, Wo = (He + 1 - ksize) // stride + 1, (We + 1 - ksize) // stride + 1
+    else:
+        pt = pl = (ksize // 2) if pad is None else pad
+        Ho, Wo = (He + 2 * pt - ksize) // stride + 1, (We + 2 * pl - ksize) // stride + 1
+    y = torch.empty((B, Ho, Wo, cout), dtype=torch.float32, device=x.device)
+    _l.check(_l.load().ug_conv2d_f32(_p(x), _p(wp), _p(bias), _p(residual), _p(y), B, H, W, Cin, cout, cout_pad, ksize,
+                                     stride, pt, pl, Ho, Wo, int(upsample), _stream()), "ug_conv2d_f32")
+    return y
+
+
+def gemm_f32(a, b, *, b_is_nk, M, N, K, batch=1, lda=None, ldb=None, stride_a=0, stride_b=0, alpha=1.0, out=None):
+    if out is None:
+        out = torch.empty((batch, M, N), dtype=torch.float32, device=a.device)
+    _l.check(_l.load().ug_gemm_f32(_p(a), lda, stride_a, _p(b), ldb, stride_b, int(b_is_nk), _p(out), N, M * N, M, N,
+                                   K, batch, alpha, _stream()), "ug_gemm_f32")
+    return out
+
+
+def groupnorm_swish(x, gamma, beta, *, groups=32, eps=1e-6, swish=True):
+    """x NHWC [B,H,W,C] fp32."""
+    B, H, W, C = x.shape
+    y = torch.empty_like(x)
+    ws = torch.empty((B, groups, 2), dtype=torch.float64, device=x.device)
+    _l.check(_l.load().ug_groupnorm_swish(_p(x), _p(gamma), _p(beta), _p(y), _p(ws), B, H * W, C, groups, eps,
+                                          int(swish), _stream()), "ug_groupnorm_swish")
+    return y
+
+
+def softmax_rows_(x2d, scale):
+    _l.check(_l.load().ug_softmax_rows_f32(_p(x2d), x2d.shape[0], x2d.shape[1], scale, _stream()),
+             "ug_softmax_rows_f32")
+    return x2d
+
+
+def nchw_to_nhwc(x, c_pad):
+    B, C, H, W = x.shape
+    out = torch.empty((B, H, W, c_pad), dtype=torch.float32, device=x.device)
+    _l.check(_l.load().ug_nchw_to_nhwc(_p(x), _p(out), B, C, H * W, c_pad, _stream()), "ug_nchw_to_nhwc")
+    return out
+
+
+def nhwc_to_nchw(x, C):
+    B, H, W, Cp = x.shape
+    out = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
+    _l.check(_l.load().ug_nhwc_to_nchw(_p(x), _p(out), B, C, H * W, Cp, _stream()), "ug_nhwc_to_nchw")
+    return out
+
+
+def lfq_pack(z2d, nbits):
+    n = z2d.shape[0]
+    idx = torch.empty((n,), dtype=torch.int64, device=z2d.device)
+    _l.check(_l.load().ug_lfq_pack(_p(z2d), z2d.stride(0), _p(idx), n, nbits, _stream()), "ug_lfq_pack")
+    return idx
+
+
+def lfq_unpack(idx, nbits, err_flag=None):
+    n = idx.numel()
+    z = torch.empty((n, nbits), dtype=torch.float32, device=idx.device)
+    _l.check(_l.load().ug_lfq_unpack(_p(idx), _p(z), n, nbits, _p(err_flag), _stream()), "ug_lfq_unpack")
+    return z
+
+
+def probe_layouts(device):
+    out = torch.zeros((512,), dtype=torch.float32, device=device)
+    _l.check(_l.load().ug_probe_layouts(_p(out), 512, _stream()), "ug_probe_layouts")
+    return out

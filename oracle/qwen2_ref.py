@@ -1,0 +1,216 @@
+"""ORACLE (test infrastructure): plain-torch CPU restatement of the Qwen2.5 backbone + UniGen's
+multi-task forward, i.e. what `UniGen.forward` executes through transformers' Qwen2ForCausalLM.
+
+Follows, line by line:
+  * models/unigen.py:240-342 (embed / inputs_embeds, backbone, tied lm_head on ALL positions, the
+    three masked cross-entropies and their slicing),
+  * transformers modeling_qwen2.py: Qwen2RMSNorm :238-252, Qwen2RotaryEmbedding :51-102 (default
+    rope, position_ids = arange(L)), apply_rotary_pos_emb :113-135, Qwen2Attention :176-234 with the
+    `sdpa` backend (integrations/sdpa_attention.py: repeat_kv + F.scaled_dot_product_attention with the
+    caller's 4-D additive mask, is_causal=False), Qwen2MLP :35-48, Qwen2DecoderLayer :258-298,
+    Qwen2Model.forward :331-400.
+Third-party pin: the reference pins transformers==4.51.0; this restatement was validated against
+the 5.15.0 present in the build container (same arithmetic for this path).
+
+Parameter names equal the reference checkpoint's `llm.*` keys so the reference's state_dict loads
+unchanged.  Precision mode A (accelerate DDP + bf16 autocast) is reproduced by running the same
+code under torch.autocast('cpu', dtype=torch.bfloat16) exactly like accelerate wraps the reference.
+"""
+import contextlib
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .ops_ref import rope_ref
+
+
+class Qwen2Cfg:
+    def __init__(self, vocab_size, hidden_size=1536, intermediate_size=8960, num_hidden_layers=28,
+                 num_attention_heads=12, num_key_value_heads=2, head_dim=None, rope_theta=1e6, rms_norm_eps=1e-6,
+                 initializer_range=0.02):
+        self.vocab_size = vocab_size
+        self.hidden_size = hidden_size
+        self.intermediate_size = intermediate_size
+        self.num_hidden_layers = num_hidden_layers
+        self.num_attention_heads = num_attention_heads
+        self.num_key_value_heads = num_key_value_heads
+        self.head_dim = head_dim or hidden_size // num_attention_heads
+        self.rope_theta = rope_theta
+        self.rms_norm_eps = rms_norm_eps
+        self.initializer_range = initializer_range
+
+    def to_hf_dict(self):
+        return dict(architectures=["Qwen2ForCausalLM"], model_type="qwen2", vocab_size=self.vocab_size,
+                    hidden_size=self.hidden_size, intermediate_size=self.intermediate_size,
+                    num_hidden_layers=self.num_hidden_layers, num_attention_heads=self.num_attention_heads,
+                    num_key_value_heads=self.num_key_value_heads, rope_theta=self.rope_theta,
+                    rms_norm_eps=self.rms_norm_eps, hidden_act="silu", max_position_embeddings=32768,
+                    tie_word_embeddings=True, attention_dropout=0.0, use_sliding_window=False,
+                    initializer_range=self.initializer_range, torch_dtype="float32", use_cache=False)
+
+
+QWEN25_1P5B = dict(hidden_size=1536, intermediate_size=8960, num_hidden_layers=28, num_attention_heads=12,
+                   num_key_value_heads=2, rope_theta=1e6, rms_norm_eps=1e-6)
+
+
+class _Norm(nn.Module):
+    def __init__(self, n, eps):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(n))
+        self.eps = eps
+
+    def forward(self, x):
+        dt = x.dtype
+        xf = x.to(torch.float32)
+        xf = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + self.eps)
+        return self.weight * xf.to(dt)
+
+
+class _Attn(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.c = c
+        hd = c.head_dim
+        self.q_proj = nn.Linear(c.hidden_size, c.num_attention_heads * hd, bias=True)
+        self.k_proj = nn.Linear(c.hidden_size, c.num_key_value_heads * hd, bias=True)
+        self.v_proj = nn.Linear(c.hidden_size, c.num_key_value_heads * hd, bias=True)
+        self.o_proj = nn.Linear(c.num_attention_heads * hd, c.hidden_size, bias=False)
+
+    def forward(self, x, cos, sin, mask, cache=None):
+        c = self.c
+        B, L, _ = x.shape
+        hd = c.head_dim
+        q = self.q_proj(x).view(B, L, -1, hd).transpose(1, 2)
+        k = self.k_proj(x).view(B, L, -1, hd).transpose(1, 2)
+        v = self.v_proj(x).view(B, L, -1, hd).transpose(1, 2)
+        q, k = rope_ref(q, cos, sin), rope_ref(k, cos, sin)
+        if cache is not None:                         # DynamicCache: concatenate along the sequence
+            if cache.get("k") is not None:
+                k = torch.cat([cache["k"], k], dim=2)
+                v = torch.cat([cache["v"], v], dim=2)
+            cache["k"], cache["v"] = k, v
+        rep = c.num_attention_heads // c.num_key_value_heads
+        k = k[:, :, None].expand(B, k.shape[1], rep, k.shape[2], hd).reshape(B, -1, k.shape[2], hd)
+        v = v[:, :, None].expand(B, v.shape[1], rep, v.shape[2], hd).reshape(B, -1, v.shape[2], hd)
+        causal = mask is None and L > 1
+        o = F.scaled_dot_product_attention(q, k, v, attn_mask=mask, dropout_p=0.0, scale=hd ** -0.5, is_causal=causal)
+        return self.o_proj(o.transpose(1, 2).reshape(B, L, -1).contiguous())
+
+
+class _MLP(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.gate_proj = nn.Linear(c.hidden_size, c.intermediate_size, bias=False)
+        self.up_proj = nn.Linear(c.hidden_size, c.intermediate_size, bias=False)
+        self.down_proj = nn.Linear(c.intermediate_size, c.hidden_size, bias=False)
+
+    def forward(self, x):
+        return self.down_proj(F.silu(self.gate_proj(x)) * self.up_proj(x))
+
+
+class _Layer(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.self_attn = _Attn(c)
+        self.mlp = _MLP(c)
+        self.input_layernorm = _Norm(c.hidden_size, c.rms_norm_eps)
+        self.post_attention_layernorm = _Norm(c.hidden_size, c.rms_norm_eps)
+
+    def forward(self, h, cos, sin, mask, cache=None):
+        h = h + self.self_attn(self.input_layernorm(h), cos, sin, mask, cache)
+        return h + self.mlp(self.post_attention_layernorm(h))
+
+
+class _Backbone(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.embed_tokens = nn.Embedding(c.vocab_size, c.hidden_size)
+        self.layers = nn.ModuleList([_Layer(c) for _ in range(c.num_hidden_layers)])
+        self.norm = _Norm(c.hidden_size, c.rms_norm_eps)
+
+
+class RefCausalLM(nn.Module):
+    """state_dict keys: model.embed_tokens.weight, model.layers.N.*, model.norm.weight, lm_head.weight (tied)."""
+
+    def __init__(self, c):
+        super().__init__()
+        self.cfg = c
+        self.model = _Backbone(c)
+        self.lm_head = nn.Linear(c.hidden_size, c.vocab_size, bias=False)
+        self.lm_head.weight = self.model.embed_tokens.weight
+
+    def rope(self, L, dtype, offset=0):
+        c = self.cfg
+        inv_freq = 1.0 / (c.rope_theta ** (torch.arange(0, c.head_dim, 2, dtype=torch.float) / c.head_dim))
+        pos = torch.arange(offset, offset + L, dtype=torch.float)
+        with torch.autocast("cpu", enabled=False):
+            freqs = (inv_freq[None, :, None].float() @ pos[None, None, :].float()).transpose(1, 2)
+            emb = torch.cat((freqs, freqs), dim=-1)
+            cos, sin = emb.cos(), emb.sin()
+        return cos.to(dtype)[:, None], sin.to(dtype)[:, None]      # [1,1,L,d] broadcast over heads
+
+    def backbone(self, input_ids=None, inputs_embeds=None, mask=None, caches=None, pos_offset=0):
+        h = self.model.embed_tokens(input_ids) if inputs_embeds is None else inputs_embeds
+        cos, sin = self.rope(h.shape[1], h.dtype, pos_offset)
+        for i, layer in enumerate(self.model.layers):
+            h = layer(h, cos, sin, mask, None if caches is None else caches[i])
+        return self.model.norm(h)
+
+    def forward(self, input_ids=None, inputs_embeds=None, mask=None):
+        return self.lm_head(self.backbone(input_ids, inputs_embeds, mask))
+
+
+def init_like_hf(model, seed):
+    """HF Qwen2 `_init_weights`: N(0, initializer_range) for Linear/Embedding weights, zeros for
+    biases, ones for norms (what Qwen2ForCausalLM(config) does at models/unigen.py:65)."""
+    g = torch.Generator().manual_seed(seed)
+    std = model.cfg.initializer_range
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if name.endswith("norm.weight") or name.endswith("layernorm.weight"):
+                p.fill_(1.0)
+            elif name.endswith(".bias"):
+                p.zero_()
+            else:
+                p.copy_(torch.randn(p.shape, generator=g) * std)
+    return model
+
+
+def autocast_ctx(enabled):
+    return torch.autocast("cpu", dtype=torch.bfloat16) if enabled else contextlib.nullcontext()
+
+
+def unigen_forward_ref(lm, input_ids, attention_mask, labels=None, input_embeddings=None, batch_size_t2i=0,
+                       batch_size_lm=0, batch_size_mmu=0, num_vq_tokens=256, t2i_mode="mask", autocast=True):
+    """UniGen.forward (models/unigen.py:240-342), gen_proj_depth == 0 branch (the only one any shipped
+    config reaches).  Returns logits if labels is None else (logits, loss_t2i, loss_lm, loss_mmu);
+    under autocast the returned tensors are converted to fp32 like accelerate's forward wrapper does."""
+    V = lm.cfg.vocab_size
+    with autocast_ctx(autocast):
+        logits = lm(input_ids if input_embeddings is None else None, input_embeddings, attention_mask)
+        if labels is None:
+            return logits.float() if autocast else logits
+        n = num_vq_tokens
+        if t2i_mode == "mask":
+            loss_t2i = F.cross_entropy(logits[:batch_size_t2i, -(n + 1):-1].contiguous().view(-1, V),
+                                       labels[:batch_size_t2i, -(n + 1):-1].contiguous().view(-1), ignore_index=-100)
+        else:
+            loss_t2i = F.cross_entropy(logits[:batch_size_t2i, -(n + 2):-1].contiguous().view(-1, V),
+                                       labels[:batch_size_t2i, -(n + 1):].contiguous().view(-1), ignore_index=-100)
+        loss_lm = 0.0
+        if batch_size_lm > 0:
+            loss_lm = F.cross_entropy(logits[batch_size_t2i:batch_size_t2i + batch_size_lm, :-1].contiguous().view(-1, V),
+                                      labels[batch_size_t2i:batch_size_t2i + batch_size_lm, 1:].contiguous().view(-1),
+                                      ignore_index=-100)
+        loss_mmu = 0.0
+        if batch_size_mmu > 0:
+            loss_mmu = F.cross_entropy(logits[-batch_size_mmu:, :-1].contiguous().view(-1, V),
+                                       labels[-batch_size_mmu:, 1:].contiguous().view(-1), ignore_index=-100)
+    if autocast:
+        logits = logits.float()
+        loss_t2i = loss_t2i.float()
+        loss_lm = loss_lm.float() if torch.is_tensor(loss_lm) else loss_lm
+        loss_mmu = loss_mmu.float() if torch.is_tensor(loss_mmu) else loss_mmu
+    return logits, loss_t2i, loss_lm, loss_mmu

@@ -1,0 +1,380 @@
+"""Kernel-level parity: every HIP entry point against the CPU oracle (oracle/ops_ref.py) on seeded
+inputs.  All tests call through the C ABI (ctypes) -- there is no other implementation."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from unigen_hip import ops
+    return ops
+
+
+def _rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def _maxabs(a, b):
+    return (a.float().cpu() - b.float().cpu()).abs().max().item()
+
+
+# ------------------------------------------------------------------ probes (recorded, not asserted beyond basics)
+def test_probe_layouts(dev):
+    ops = _ops()
+    out = ops.probe_layouts(dev).cpu()
+    c = out[256:512].view(64, 4)
+    # D[i][j] = i*(j+1) ; lane holds row (lane>>4)*4 + r, col lane&15
+    for lane in (0, 5, 17, 63):
+        for r in range(4):
+            i, j = (lane >> 4) * 4 + r, lane & 15
+            assert c[lane, r].item() == i * (j + 1)
+    import os
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/tr16_b64_layout.txt", "w") as f:
+        for lane in range(64):
+            f.write(f"{lane}: {[int(v) for v in out[lane*4:lane*4+4]]}\n")
+
+
+# ------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (300, 200, 192), (771, 1536, 1536), (64, 333, 256)])
+def test_gemm_nt_bf16(dev, variant, M, N, K):
+    ops = _ops()
+    from unigen_hip import lib
+    lib.load().ug_gemm_set_variant(variant)
+    try:
+        g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+        a = torch.randn(M, K, generator=g).to(torch.bfloat16)
+        b = torch.randn(N, K, generator=g).to(torch.bfloat16)
+        bias = torch.randn(N, generator=g).to(torch.bfloat16)
+        ref = a.float() @ b.float().t()
+        ldc = (N + 7) // 8 * 8
+        cbuf = torch.zeros(M, ldc, dtype=torch.bfloat16, device=dev)
+        ops.gemm_nt(a.to(dev), b.to(dev), out=cbuf, M=M, N=N, K=K, bias=bias.to(dev))
+        got = cbuf[:, :N]
+        assert _rel(got, ref + bias.float()) < 4e-3
+        if ldc > N:
+            assert cbuf[:, N:].abs().max().item() == 0      # guarded stores never touch padding
+        # fp32 epilogue with accumulate
+        c32 = torch.ones(M, ldc, dtype=torch.float32, device=dev)
+        ops.gemm_nt(a.to(dev), b.to(dev), out=c32, M=M, N=N, K=K, epilogue=ops.UG_EPI_F32, beta=1)
+        assert _rel(c32[:, :N], ref + 1.0) < 1e-5 * math.sqrt(K) + 1e-6
+        # residual epilogue
+        res = torch.randn(M, ldc, generator=g)
+        r32 = torch.empty(M, ldc, dtype=torch.float32, device=dev)
+        ops.gemm_nt(a.to(dev), b.to(dev), out=r32, M=M, N=N, K=K, epilogue=ops.UG_EPI_RESID, resid=res.to(dev))
+        want = res[:, :N] + ref.to(torch.bfloat16).float()
+        # one bf16 ulp of slack on the rounded projection
+        assert ((r32[:, :N].cpu() - want).abs() <= ref.abs() * 2.0 ** -7 + 1e-3).all()
+        assert _rel(r32[:, :N], want) < 3e-3
+    finally:
+        lib.load().ug_gemm_set_variant(0)
+
+
+def test_gemm_rejects_bad_k(dev):
+    ops = _ops()
+    from unigen_hip.lib import UniGenHipError
+    a = torch.zeros(64, 72, dtype=torch.bfloat16, device=dev)
+    with pytest.raises(UniGenHipError):
+        ops.gemm_nt(a, a)
+
+
+def test_transpose_cast(dev):
+    ops = _ops()
+    for dt in (torch.float32, torch.bfloat16):
+        x = torch.randn(203, 130).to(dt)
+        out, outT = ops.transpose_cast(x.to(dev), want_out=True, ldT=256)
+        assert torch.equal(out.cpu(), x.to(torch.bfloat16))
+        assert torch.equal(outT[:, :203].cpu(), x.to(torch.bfloat16).t())
+        assert outT[:, 203:].abs().max().item() == 0
+
+
+# ------------------------------------------------------------------ row ops
+def test_rmsnorm_fwd_bwd(dev):
+    ops = _ops()
+    from oracle.ops_ref import rmsnorm_ref, rmsnorm_bwd_ref
+    torch.manual_seed(0)
+    for rows, cols in [(37, 1536), (130, 256)]:
+        x = torch.randn(rows, cols) * 3
+        w = torch.randn(cols) * 0.1 + 1
+        y, rstd = ops.rmsnorm_fwd(x.to(dev), w.to(dev), 1e-6)
+        ref = rmsnorm_ref(x, w, 1e-6)
+        assert _maxabs(y, ref.to(torch.bfloat16)) <= 0.04 and _rel(y, ref) < 4e-3
+        y32, _ = ops.rmsnorm_fwd(x.to(dev), w.to(dev), 1e-6, out_f32=True)
+        assert _rel(y32, ref) < 1e-6
+        dy = torch.randn(rows, cols).to(torch.bfloat16)
+        dres0 = torch.randn(rows, cols)
+        dres = dres0.clone().to(dev)
+        dw = torch.zeros(cols, device=dev)
+        ops.rmsnorm_bwd(dy.to(dev), x.to(dev), rstd, w.to(dev), dres, dw)
+        dx_ref, dw_ref = rmsnorm_bwd_ref(dy.float(), x, w, 1e-6)
+        assert _rel(dres, dres0 + dx_ref) < 1e-5
+        assert _rel(dw, dw_ref) < 1e-5
+
+
+def test_rope_fwd_bwd(dev):
+    ops = _ops()
+    from oracle.ops_ref import rope_tables_ref, rope_ref
+    torch.manual_seed(1)
+    B, L, H, HKV, hd = 2, 45, 3, 1, 128
+    qkv = torch.randn(B * L, (H + 2 * HKV) * hd).to(torch.bfloat16)
+    cos, sin = ops.rope_tables(L, hd, 1e6, dev)
+    cr, sr = rope_tables_ref(L, hd, 1e6)
+    assert torch.equal(cos.cpu(), cr[:, : hd // 2]) and torch.equal(sin.cpu(), sr[:, : hd // 2])
+    got = ops.rope_(qkv.clone().to(dev), cos, sin, L, H + HKV, hd).cpu()
+    x = qkv[:, : (H + HKV) * hd].view(B, L, H + HKV, hd).permute(0, 2, 1, 3)       # [B, heads, L, d] bf16
+    ref = rope_ref(x, cr, sr).to(torch.bfloat16)                                   # fp32 math, one bf16 round
+    assert torch.equal(got[:, : (H + HKV) * hd].view(B, L, H + HKV, hd).permute(0, 2, 1, 3), ref)
+    assert torch.equal(got[:, (H + HKV) * hd:], qkv[:, (H + HKV) * hd:])            # v untouched
+    # backward = transpose of the rotation: <R x, y> == <x, R^T y>
+    y = torch.randn_like(qkv)
+    fx = ops.rope_(qkv.clone().to(dev), cos, sin, L, H + HKV, hd).float().cpu()[:, : (H + HKV) * hd]
+    bty = ops.rope_(y.clone().to(dev), cos, sin, L, H + HKV, hd, backward=True).float().cpu()[:, : (H + HKV) * hd]
+    lhs = (fx * y.float()[:, : (H + HKV) * hd]).sum()
+    rhs = (qkv.float()[:, : (H + HKV) * hd] * bty).sum()
+    assert abs(lhs - rhs) / abs(lhs) < 2e-3
+
+
+def test_swiglu_fwd_bwd(dev):
+    ops = _ops()
+    from oracle.ops_ref import swiglu_ref
+    torch.manual_seed(2)
+    gu = (torch.randn(77, 2 * 512) * 2).to(torch.bfloat16)
+    act = ops.swiglu_fwd(gu.to(dev))
+    ref = swiglu_ref(gu)                       # bf16 ops on CPU == the reference's autocast arithmetic
+    assert _maxabs(act, ref) <= 0.07 and _rel(act, ref) < 6e-3
+    dact = torch.randn(77, 512).to(torch.bfloat16)
+    dgu = ops.swiglu_bwd(gu.to(dev), dact.to(dev))
+    g32 = gu.float().clone().requires_grad_(True)
+    i = 512
+    (F.silu(g32[:, :i]) * g32[:, i:]).backward(dact.float())
+    assert _rel(dgu, g32.grad) < 8e-3
+
+
+def test_embed_fwd_bwd(dev):
+    ops = _ops()
+    torch.manual_seed(3)
+    V, H = 333, 256
+    W = torch.randn(V, H)
+    ids = torch.randint(0, V, (97,))
+    ids[::5] = 7
+    out = ops.embed_fwd(ids.to(dev), W.to(dev))
+    assert torch.equal(out.cpu(), W[ids])
+    dout = torch.randn(97, H)
+    dW = torch.zeros(V, H, device=dev)
+    ops.embed_bwd(ids.to(dev), dout.to(dev), dW)
+    ref = torch.zeros(V, H).index_add_(0, ids, dout)
+    assert _rel(dW, ref) < 1e-6
+    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    bad = ids.clone(); bad[3] = V + 5
+    ops.embed_fwd(bad.to(dev), W.to(dev), err)
+    assert err.item() == 1
+
+
+def test_colsum(dev):
+    ops = _ops()
+    x = torch.randn(1000, 200).to(torch.bfloat16)
+    out = torch.ones(200, device=dev)
+    ops.colsum_(x.to(dev), out)
+    assert _rel(out, x.float().sum(0) + 1) < 1e-5
+
+
+def test_adamw_matches_torch(dev):
+    ops = _ops()
+    torch.manual_seed(4)
+    n = 4099
+    p0 = torch.randn(n); p_ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([p_ref], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    p = p0.clone().to(dev); m = torch.zeros(n, device=dev); v = torch.zeros(n, device=dev)
+    pb = torch.empty(n, dtype=torch.bfloat16, device=dev)
+    for step in range(1, 4):
+        g = torch.randn(n)
+        p_ref.grad = g.clone(); opt.step()
+        ops.adamw_flat_(p, g.to(dev), m, v, pb, 1e-3, 0.9, 0.999, 1e-8, 0.01, step)
+        assert _maxabs(p, p_ref.detach()) < 2e-6
+    assert torch.equal(pb.cpu(), p.cpu().to(torch.bfloat16))
+
+
+# ------------------------------------------------------------------ cross entropy
+def test_ce_fwd_bwd(dev):
+    ops = _ops()
+    torch.manual_seed(5)
+    R, V = 19, 1003
+    ld = (V + 63) // 64 * 64
+    logits = (torch.randn(R, V) * 3).to(torch.bfloat16)
+    labels = torch.randint(0, V, (R,)); labels[::4] = -100
+    buf = torch.full((R, ld), 7.0, dtype=torch.bfloat16, device=dev)
+    buf[:, :V] = logits.to(dev)
+    lc, lse, loss_row, logp = ops.ce_fwd(buf, V, labels.to(dev), want_logp=True)
+    ref = F.cross_entropy(logits.float(), labels, ignore_index=-100)
+    assert abs(lc[0].item() - ref.item()) / ref.item() < 1e-5
+    assert lc[1].item() == (labels != -100).sum().item()
+    lp_ref = torch.log_softmax(logits.float(), -1).gather(1, labels.clamp(min=0)[:, None])[:, 0]
+    assert _maxabs(logp[labels != -100], lp_ref[labels != -100]) < 1e-4
+    gscale = torch.tensor([0.5], device=dev)
+    ops.ce_bwd_(buf, V, labels.to(dev), lse, lc, gscale)
+    lg = logits.float().clone().requires_grad_(True)
+    (0.5 * F.cross_entropy(lg, labels, ignore_index=-100)).backward()
+    assert _rel(buf[:, :V], lg.grad) < 6e-3
+    assert buf[:, V:].abs().max().item() == 0
+
+
+# ------------------------------------------------------------------ attention
+def _ref_masks(B, L, kind, gen):
+    """additive masks with the structure the reference builders emit (prompting_utils.py:975-1074)"""
+    neg = float(torch.iinfo(torch.int64).min)
+    allow = torch.zeros(B, L, L, dtype=torch.bool)
+    tril = torch.tril(torch.ones(L, L, dtype=torch.bool))
+    for b in range(B):
+        if kind == "causal":
+            allow[b] = tril
+        elif kind == "t2i":       # left pads | causal text | bidirectional image tail
+            npad = int(torch.randint(0, L // 4, (1,), generator=gen))
+            nimg = L // 3
+            a = tril.clone()
+            a[npad:, :npad] = False
+            a[L - nimg:, npad:] = True
+            allow[b] = a
+        elif kind == "mmu":       # prefix fully visible, causal after
+            pre = L // 2
+            a = tril.clone(); a[:, :pre] = True
+            allow[b] = a
+        elif kind == "random":
+            a = torch.rand(L, L, generator=gen) < 0.3
+            a[torch.arange(L), torch.arange(L)] = True
+            allow[b] = a
+    add = torch.where(allow, torch.zeros(()), torch.full((), neg))
+    return add[:, None].contiguous(), allow
+
+
+@pytest.mark.parametrize("kind", ["causal", "t2i", "mmu", "random"])
+@pytest.mark.parametrize("B,L,H,HKV", [(2, 70, 2, 1), (1, 200, 12, 2), (2, 129, 6, 2)])
+def test_attention_fwd_bwd(dev, kind, B, L, H, HKV):
+    ops = _ops()
+    from oracle.ops_ref import attention_ref
+    hd = 128
+    gen = torch.Generator().manual_seed(B * 1000 + L + H)
+    qkv = (torch.randn(B * L, (H + 2 * HKV) * hd, generator=gen)).to(torch.bfloat16)
+    mask_add, allow = _ref_masks(B, L, kind, gen)
+    for mdt in (torch.float32, torch.bfloat16):
+        err = torch.zeros(1, dtype=torch.int32, device=dev)
+        mb = ops.mask_compress(mask_add.to(mdt).to(dev), err)
+        assert err.item() == 0
+        bits = mb.bits.cpu()
+        for b in range(B):
+            for w in range(mb.nW):
+                cols = allow[b, :, w * 64:(w + 1) * 64]
+                want = (cols.long() << torch.arange(cols.shape[1])).sum(1)   # as signed int64 words
+                assert torch.equal(bits[b, :, w], want)
+    o, lse = ops.attn_fwd(qkv.to(dev), mb, H, HKV, hd)
+    q = qkv[:, : H * hd].view(B, L, H, hd).permute(0, 2, 1, 3)
+    k = qkv[:, H * hd:(H + HKV) * hd].view(B, L, HKV, hd).permute(0, 2, 1, 3)
+    v = qkv[:, (H + HKV) * hd:].view(B, L, HKV, hd).permute(0, 2, 1, 3)
+    qf, kf, vf = (t.float().clone().requires_grad_(True) for t in (q, k, v))
+    ref = attention_ref(qf, kf, vf, mask_add, 1.0 / math.sqrt(hd))            # [B,H,L,d]
+    got = o.view(B, L, H, hd).permute(0, 2, 1, 3)
+    assert _rel(got, ref) < 8e-3, f"fwd rel {_rel(got, ref)}"
+    dout = torch.randn(B * L, H * hd, generator=gen).to(torch.bfloat16)
+    ref.backward(dout.float().view(B, L, H, hd).permute(0, 2, 1, 3))
+    dqkv = ops.attn_bwd(qkv.to(dev), o, lse, dout.to(dev), mb, H, HKV, hd).float().cpu()
+    dq = dqkv[:, : H * hd].view(B, L, H, hd).permute(0, 2, 1, 3)
+    dk = dqkv[:, H * hd:(H + HKV) * hd].view(B, L, HKV, hd).permute(0, 2, 1, 3)
+    dv = dqkv[:, (H + HKV) * hd:].view(B, L, HKV, hd).permute(0, 2, 1, 3)
+    assert _rel(dq, qf.grad) < 2e-2, f"dq rel {_rel(dq, qf.grad)}"
+    assert _rel(dk, kf.grad) < 2e-2, f"dk rel {_rel(dk, kf.grad)}"
+    assert _rel(dv, vf.grad) < 2e-2, f"dv rel {_rel(dv, vf.grad)}"
+
+
+def test_mask_rejects_soft_values(dev):
+    ops = _ops()
+    m = torch.zeros(1, 1, 64, 64, device=dev); m[0, 0, 3, 5] = -1.5
+    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    ops.mask_compress(m, err)
+    assert err.item() & 2
+
+
+def test_mask_causal_builder(dev):
+    ops = _ops()
+    mb = ops.mask_causal(2, 100, dev)
+    bits = mb.bits.cpu()
+    tril = torch.tril(torch.ones(100, 100, dtype=torch.bool))
+    for w in range(2):
+        cols = tril[:, w * 64:(w + 1) * 64]
+        assert torch.equal(bits[0, :, w], (cols.long() << torch.arange(cols.shape[1])).sum(1))
+
+
+# ------------------------------------------------------------------ tokenizer kernels (exact fp32)
+@pytest.mark.parametrize("cin,cout,k,stride,asym,ups,H", [
+    (128, 128, 3, 1, False, False, 16), (4, 128, 3, 1, False, False, 16), (128, 256, 1, 1, False, False, 8),
+    (128, 128, 3, 2, True, False, 16), (256, 256, 3, 1, False, True, 8), (512, 13, 3, 1, False, False, 16),
+    (13, 13, 1, 1, False, False, 16), (13, 512, 3, 1, False, False, 16), (128, 3, 3, 1, False, False, 16)])
+def test_conv2d_f32(dev, cin, cout, k, stride, asym, ups, H):
+    ops = _ops()
+    gen = torch.Generator().manual_seed(cin * 31 + cout)
+    B = 2
+    x = torch.randn(B, cin, H, H, generator=gen)
+    w = torch.randn(cout, cin, k, k, generator=gen) / math.sqrt(cin * k * k)
+    bias = torch.randn(cout, generator=gen)
+    xin = F.interpolate(x, scale_factor=2.0, mode="nearest") if ups else x
+    if asym:
+        ref = F.conv2d(F.pad(xin, (0, 1, 0, 1)), w, bias, stride=stride)
+    else:
+        ref = F.conv2d(xin, w, bias, stride=stride, padding=k // 2)
+    res = torch.randn_like(ref)
+    wp, cpad = ops.pack_conv_weight(w.to(dev))
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    y = ops.conv2d_nhwc(x_nhwc, wp, cpad, bias.to(dev), cout, k, stride=stride, asym_pad=asym, upsample=ups,
+                        residual=res.permute(0, 2, 3, 1).contiguous().to(dev))
+    got = y.permute(0, 3, 1, 2)
+    assert got.shape == ref.shape
+    assert _maxabs(got, ref + res) < 2e-5, _maxabs(got, ref + res)
+
+
+def test_groupnorm_swish(dev):
+    ops = _ops()
+    torch.manual_seed(7)
+    for C, H in [(128, 16), (256, 8), (512, 4)]:
+        x = torch.randn(2, C, H, H) * 2 + 0.5
+        g = torch.randn(C); b = torch.randn(C)
+        ref = F.group_norm(x, 32, g, b, eps=1e-6)
+        xn = x.permute(0, 2, 3, 1).contiguous().to(dev)
+        y0 = ops.groupnorm_swish(xn, g.to(dev), b.to(dev), swish=False).permute(0, 3, 1, 2)
+        assert _maxabs(y0, ref) < 5e-6
+        y1 = ops.groupnorm_swish(xn, g.to(dev), b.to(dev), swish=True).permute(0, 3, 1, 2)
+        assert _maxabs(y1, ref * torch.sigmoid(ref)) < 5e-6
+
+
+def test_gemm_f32_and_softmax(dev):
+    ops = _ops()
+    torch.manual_seed(8)
+    Bn, T, C = 2, 256, 512
+    q = torch.randn(Bn, T, C); k = torch.randn(Bn, T, C); v = torch.randn(Bn, T, C)
+    s = ops.gemm_f32(q.to(dev), k.to(dev), b_is_nk=True, M=T, N=T, K=C, batch=Bn, lda=C, ldb=C, stride_a=T * C,
+                     stride_b=T * C)
+    assert _maxabs(s, q @ k.transpose(1, 2)) < 2e-4
+    ops.softmax_rows_(s.view(-1, T), C ** -0.5)
+    ref = torch.softmax((q @ k.transpose(1, 2)) * C ** -0.5, -1)
+    assert _maxabs(s, ref) < 1e-6
+    h = ops.gemm_f32(s, v.to(dev), b_is_nk=False, M=T, N=C, K=T, batch=Bn, lda=T, ldb=C, stride_a=T * T,
+                     stride_b=T * C)
+    assert _maxabs(h, ref @ v) < 1e-5
+
+
+def test_lfq_and_layout(dev):
+    ops = _ops()
+    from oracle.ops_ref import lfq_indices_ref, lfq_entries_ref
+    torch.manual_seed(9)
+    z = torch.randn(3, 13, 16, 16); z[0, :, 0, 0] = 0.0
+    idx = ops.lfq_pack(z.permute(0, 2, 3, 1).reshape(-1, 13).contiguous().to(dev), 13).view(3, 256)
+    assert torch.equal(idx.cpu(), lfq_indices_ref(z))
+    ent = ops.lfq_unpack(idx, 13).view(3, 16, 16, 13).permute(0, 3, 1, 2)
+    assert torch.equal(ent.cpu(), lfq_entries_ref(idx.cpu(), 13))
+    img = torch.randn(2, 3, 8, 8)
+    nhwc = ops.nchw_to_nhwc(img.to(dev), 4)
+    assert torch.equal(nhwc[..., :3].cpu(), img.permute(0, 2, 3, 1)) and nhwc[..., 3].abs().max().item() == 0
+    assert torch.equal(ops.nhwc_to_nchw(nhwc, 3).cpu(), img)
