@@ -73,6 +73,10 @@ int ug_embed_fwd(const int64_t* ids, const float* W, float* out, int64_t tokens,
                  int* err_flag, hipStream_t stream);
 int ug_embed_bwd(const int64_t* ids, const float* dout, float* dW, int64_t tokens, int64_t H, int64_t V,
                  hipStream_t stream);
+/* gather (scatter=0): out[i,:] = in[idx[i],:] ; scatter (1): out[idx[i],:] = in[i,:]   (bf16 rows)
+ * replaces the logits[..., -(n+1):-1] / [:, :-1] position slicing of models/unigen.py:310-338 */
+int ug_gather_rows_bf16(const void* in, int64_t ld_in, const int64_t* idx, void* out, int64_t ld_out,
+                        int64_t n, int64_t C, int scatter, hipStream_t stream);
 /* out[c] += sum_r in[r,c]  (bias gradients) */
 int ug_colsum_bf16(const void* in, int64_t ld, float* out, int64_t R, int64_t C, hipStream_t stream);
 

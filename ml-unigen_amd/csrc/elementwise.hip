@@ -132,13 +132,11 @@ __global__ __launch_bounds__(256) void rope_kernel(bf16_t* __restrict__ qkv, con
     float o1[4], o2[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      if constexpr (!BWD) {
-        o1[k] = __fadd_rn(__fmul_rn(x1[k], cc[k]), __fmul_rn(-x2[k], ss[k]));
-        o2[k] = __fadd_rn(__fmul_rn(x2[k], cc[k]), __fmul_rn(x1[k], ss[k]));
-      } else {   // transpose of the rotation
-        o1[k] = __fadd_rn(__fmul_rn(x1[k], cc[k]), __fmul_rn(x2[k], ss[k]));
-        o2[k] = __fadd_rn(__fmul_rn(x2[k], cc[k]), __fmul_rn(-x1[k], ss[k]));
-      }
+      // plain '*' and '+' lexically inside this contract(off) scope: each rounds on its own
+      const float a1 = x1[k] * cc[k], a2 = x2[k] * cc[k];
+      const float b1 = x2[k] * ss[k], b2 = x1[k] * ss[k];
+      if constexpr (!BWD) { o1[k] = a1 - b1; o2[k] = a2 + b2; }
+      else { o1[k] = a1 + b1; o2[k] = a2 - b2; }      // transpose of the rotation
     }
     uint2 olo, ohi;
     olo.x = pack_bf2(o1[0], o1[1]); olo.y = pack_bf2(o1[2], o1[3]);
@@ -323,6 +321,21 @@ __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restr
   if (ti < n) out[ti] = f2bf(in[ti]);
 }
 
+// =========================================================================== row gather / scatter
+// out[i, :] = in[idx[i], :]  (bf16 rows, 16-byte chunks).  Used to pick the label positions that feed
+// the lm_head GEMM and to route their gradient back.
+__global__ __launch_bounds__(256) void gather_rows_kernel(const bf16_t* __restrict__ in, int64_t ld_in,
+                                                          const int64_t* __restrict__ idx, bf16_t* __restrict__ out,
+                                                          int64_t ld_out, int64_t n, int C, int scatter) {
+  const int per_row = C >> 3;
+  const int64_t total = n * per_row;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / per_row; const int c = (int)(i % per_row) * 8;
+    const int64_t src = scatter ? r : idx[r], dst = scatter ? idx[r] : r;
+    *reinterpret_cast<bf16x8_t*>(out + dst * ld_out + c) = *reinterpret_cast<const bf16x8_t*>(in + src * ld_in + c);
+  }
+}
+
 inline int grid_for(int64_t work_items, int block = 256, int cap = 256 * 8) {
   int64_t g = (work_items + block - 1) / block;
   if (g < 1) g = 1;
@@ -449,5 +462,15 @@ extern "C" int ug_cast_f32_bf16(const float* in, void* out, int64_t n, hipStream
   dim3 grid(grid_for(n / 4 + 1)), block(256);
   hipLaunchKernelGGL(cast_f32_bf16_kernel, grid, block, 0, st, in, (bf16_t*)out, n);
   UG_CHECK_LAUNCH("ug_cast_f32_bf16");
+  return UG_OK;
+}
+
+extern "C" int ug_gather_rows_bf16(const void* in, int64_t ld_in, const int64_t* idx, void* out, int64_t ld_out,
+                                   int64_t n, int64_t C, int scatter, hipStream_t st) {
+  UG_REQUIRE(n > 0 && C % 8 == 0 && ld_in % 8 == 0 && ld_out % 8 == 0, "ug_gather_rows_bf16: C and strides must be multiples of 8");
+  UG_REQUIRE(ug_aligned16(in) && ug_aligned16(out) && idx, "ug_gather_rows_bf16: alignment");
+  dim3 grid(grid_for(n * (C / 8))), block(256);
+  hipLaunchKernelGGL(gather_rows_kernel, grid, block, 0, st, (const bf16_t*)in, ld_in, idx, (bf16_t*)out, ld_out, n, (int)C, scatter);
+  UG_CHECK_LAUNCH("ug_gather_rows_bf16");
   return UG_OK;
 }

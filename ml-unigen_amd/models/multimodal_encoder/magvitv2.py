@@ -1,0 +1,261 @@
+"""MAGVITv2 image tokenizer on the gfx950 fp32 kernels -- drop-in for the reference's
+`models/multimodal_encoder/magvitv2.py` (`MAGVITv2.get_code / encode / decode_code`, same
+state-dict keys: `encoder.*`, `decoder.*`, `quantize.{embedding,power_vals}`).
+
+Architecture restated from the reference (magvitv2.py:57-178 encoder, :286-408 decoder,
+common_modules.py ResnetBlock :301-360, AttnBlock :171-214, Downsample :76-93, Upsample :30-43,
+Normalize :24-27): ch 128, encoder multipliers (1,2,2,4,4) with (4,3,4,3,4) res-blocks, decoder
+multipliers (1,1,2,2,4) with (4,4,3,4,3), one single-head attention block in each `mid`, 13
+latent channels, lookup-free quantiser with 2^13 codes.
+
+Execution is NHWC fp32 end to end: every conv is an implicit GEMM on the f32 matrix cores
+(`ug_conv2d_f32`), GroupNorm+swish is one stats pass + one apply pass, the residual add rides in
+the conv epilogue, nearest-2x upsampling and the asymmetric stride-2 padding are folded into the
+conv's gather.  torch modules below only HOLD parameters (names/shapes/initialisation); none of
+their forward()s is ever called.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from unigen_hip import ops
+from unigen_hip.lib import UniGenHipError
+
+from ..modeling_utils import ConfigMixin, ModelMixin, register_to_config
+
+_CH = 128
+_ENC_MULT, _ENC_BLOCKS = (1, 2, 2, 4, 4), (4, 3, 4, 3, 4)
+_DEC_MULT, _DEC_BLOCKS = (1, 1, 2, 2, 4), (4, 4, 3, 4, 3)
+_ZC = 13
+
+
+def _gn(c):
+    return nn.GroupNorm(32, c, eps=1e-6, affine=True)
+
+
+class _Res(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.norm1 = _gn(cin)
+        self.conv1 = nn.Conv2d(cin, cout, 3, 1, 1)
+        self.norm2 = _gn(cout)
+        self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1)
+        if cin != cout:
+            self.nin_shortcut = nn.Conv2d(cin, cout, 1, 1, 0)
+
+
+class _Attn(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.norm = _gn(c)
+        self.q = nn.Conv2d(c, c, 1)
+        self.k = nn.Conv2d(c, c, 1)
+        self.v = nn.Conv2d(c, c, 1)
+        self.proj_out = nn.Conv2d(c, c, 1)
+
+
+class _Resample(nn.Module):
+    def __init__(self, c, stride):
+        super().__init__()
+        self.conv = nn.Conv2d(c, c, 3, stride, 0 if stride == 2 else 1)
+
+
+class _Mid(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.block_1 = _Res(c, c)
+        self.attn_1 = _Attn(c)
+        self.block_2 = _Res(c, c)
+
+
+class _Level(nn.Module):
+    pass
+
+
+class VQGANEncoder(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv_in = nn.Conv2d(3, _CH, 3, 1, 1)
+        self.down = nn.ModuleList()
+        cin = _CH
+        for lvl, (mult, nblk) in enumerate(zip(_ENC_MULT, _ENC_BLOCKS)):
+            level = _Level()
+            level.block = nn.ModuleList()
+            level.attn = nn.ModuleList()
+            for _ in range(nblk):
+                level.block.append(_Res(cin, _CH * mult))
+                cin = _CH * mult
+            if lvl != len(_ENC_MULT) - 1:
+                level.downsample = _Resample(cin, 2)
+            self.down.append(level)
+        self.mid = _Mid(cin)
+        self.norm_out = _gn(cin)
+        self.conv_out = nn.Conv2d(cin, _ZC, 3, 1, 1)
+        self.quant_conv = nn.Conv2d(_ZC, _ZC, 1)
+
+
+class VQGANDecoder(nn.Module):
+    def __init__(self):
+        super().__init__()
+        cin = _CH * _DEC_MULT[-1]
+        self.conv_in = nn.Conv2d(_ZC, cin, 3, 1, 1)
+        self.mid = _Mid(cin)
+        levels = {}
+        for lvl in reversed(range(len(_DEC_MULT))):
+            level = _Level()
+            level.block = nn.ModuleList()
+            level.attn = nn.ModuleList()
+            for _ in range(_DEC_BLOCKS[lvl]):
+                level.block.append(_Res(cin, _CH * _DEC_MULT[lvl]))
+                cin = _CH * _DEC_MULT[lvl]
+            if lvl != 0:
+                level.upsample = _Resample(cin, 1)
+            levels[lvl] = level
+        self.up = nn.ModuleList([levels[i] for i in range(len(_DEC_MULT))])
+        self.norm_out = _gn(cin)
+        self.conv_out = nn.Conv2d(cin, 3, 3, 1, 1)
+        self.post_quant_conv = nn.Conv2d(_ZC, _ZC, 1)
+
+
+class LFQuantizer(nn.Module):
+    def __init__(self, codebook_dim=_ZC):
+        super().__init__()
+        self.codebook_size = 2 ** codebook_dim
+        self.e_dim = codebook_dim
+        codes = torch.arange(self.codebook_size)
+        bits = (codes.unsqueeze(1) >> torch.arange(codebook_dim - 1, -1, -1, dtype=torch.long)) & 1
+        self.register_buffer("embedding", bits.float() * 2 - 1)
+        self.register_buffer("power_vals", 2 ** torch.arange(codebook_dim - 1, -1, -1))
+
+
+class _Packed:
+    """Per-conv packed weights [k*k][Cin][cout_pad] + bias, built once per weight version."""
+    __slots__ = ("w", "cpad", "bias", "cout", "cin", "k")
+
+
+class MAGVITv2(ModelMixin, ConfigMixin):
+    @register_to_config
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        self.encoder = VQGANEncoder()
+        self.decoder = VQGANDecoder()
+        self.quantize = LFQuantizer()
+        self._packed = {}
+        self._err = None
+
+    # ------------------------------------------------------------------ plumbing
+    def _apply(self, fn, *a, **k):
+        self.__dict__["_packed"] = {}
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self.__dict__["_packed"] = {}
+        return super().load_state_dict(*a, **k)
+
+    def _pk(self, conv, pad_cin_to=None):
+        key = id(conv)
+        ver = conv.weight._version
+        hit = self._packed.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        w = conv.weight.detach().float()
+        if not w.is_cuda:
+            raise UniGenHipError("MAGVITv2 must live in GPU memory (.to('cuda')); there is no CPU implementation")
+        if pad_cin_to is not None and w.shape[1] < pad_cin_to:
+            w = torch.cat([w, w.new_zeros(w.shape[0], pad_cin_to - w.shape[1], *w.shape[2:])], 1)
+        p = _Packed()
+        p.w, p.cpad = ops.pack_conv_weight(w)
+        p.bias = conv.bias.detach().float().contiguous()
+        p.cout, p.cin, p.k = w.shape[0], w.shape[1], w.shape[2]
+        self._packed[key] = (ver, p)
+        return p
+
+    def _conv(self, x, conv, residual=None, upsample=False, asym=False, pad_cin_to=None):
+        p = self._pk(conv, pad_cin_to)
+        return ops.conv2d_nhwc(x, p.w, p.cpad, p.bias, p.cout, p.k, stride=2 if asym else 1, asym_pad=asym,
+                               upsample=upsample, residual=residual)
+
+    @staticmethod
+    def _norm(x, gn, swish=True):
+        return ops.groupnorm_swish(x, gn.weight.detach(), gn.bias.detach(), groups=32, eps=gn.eps, swish=swish)
+
+    def _res(self, x, blk):
+        h = self._conv(self._norm(x, blk.norm1), blk.conv1)
+        h = self._norm(h, blk.norm2)
+        skip = self._conv(x, blk.nin_shortcut) if hasattr(blk, "nin_shortcut") else x
+        return self._conv(h, blk.conv2, residual=skip)
+
+    def _attn(self, x, a):
+        B, H, W, C = x.shape
+        T = H * W
+        hn = self._norm(x, a.norm, swish=False)
+        q, k, v = self._conv(hn, a.q), self._conv(hn, a.k), self._conv(hn, a.v)
+        s = ops.gemm_f32(q, k, b_is_nk=True, M=T, N=T, K=C, batch=B, lda=C, ldb=C, stride_a=T * C, stride_b=T * C)
+        ops.softmax_rows_(s.view(B * T, T), float(int(C) ** (-0.5)))
+        ctx = ops.gemm_f32(s, v, b_is_nk=False, M=T, N=C, K=T, batch=B, lda=T, ldb=C, stride_a=T * T, stride_b=T * C)
+        return self._conv(ctx.view(B, H, W, C), a.proj_out, residual=x)
+
+    def _mid(self, x, mid):
+        return self._res(self._attn(self._res(x, mid.block_1), mid.attn_1), mid.block_2)
+
+    # ------------------------------------------------------------------ encoder / decoder graphs
+    @torch.no_grad()
+    def _encode_z(self, pixel_values):
+        """NCHW fp32 image -> pre-quantisation latents, NHWC [B, 16, 16, 13]."""
+        e = self.encoder
+        x = ops.nchw_to_nhwc(pixel_values.float().contiguous(), 4)        # pad RGB to 4 channels (16-byte pixels)
+        h = self._conv(x, e.conv_in, pad_cin_to=4)
+        for lvl, level in enumerate(e.down):
+            for blk in level.block:
+                h = self._res(h, blk)
+            if hasattr(level, "downsample"):
+                h = self._conv(h, level.downsample.conv, asym=True)
+        h = self._mid(h, e.mid)
+        h = self._conv(self._norm(h, e.norm_out), e.conv_out)
+        return self._conv(h, e.quant_conv)
+
+    @torch.no_grad()
+    def _decode_z(self, z_nhwc):
+        d = self.decoder
+        h = self._conv(self._conv(z_nhwc, d.post_quant_conv), d.conv_in)
+        h = self._mid(h, d.mid)
+        for lvl in reversed(range(len(d.up))):
+            level = d.up[lvl]
+            for blk in level.block:
+                h = self._res(h, blk)
+            if hasattr(level, "upsample"):
+                h = self._conv(h, level.upsample.conv, upsample=True)
+        return self._conv(self._norm(h, d.norm_out), d.conv_out)
+
+    # ------------------------------------------------------------------ reference API
+    def forward(self, pixel_values, return_loss=False):
+        pass
+
+    @torch.no_grad()
+    def encode(self, pixel_values, return_loss=False):
+        z = self._encode_z(pixel_values)
+        B = z.shape[0]
+        idx = ops.lfq_pack(z.view(-1, _ZC), _ZC).view(B, -1)
+        zq = ops.lfq_unpack(idx.view(-1), _ZC).view(B, z.shape[1], z.shape[2], _ZC).permute(0, 3, 1, 2).contiguous()
+        return zq, idx
+
+    @torch.no_grad()
+    def get_code(self, pixel_values):
+        z = self._encode_z(pixel_values)
+        return ops.lfq_pack(z.view(-1, _ZC), _ZC).view(z.shape[0], -1)
+
+    @torch.no_grad()
+    def get_latents(self, pixel_values):
+        """Test hook: pre-quantisation z in the reference's NCHW layout [B, 13, 16, 16]."""
+        return self._encode_z(pixel_values).permute(0, 3, 1, 2).contiguous()
+
+    @torch.no_grad()
+    def decode_code(self, codebook_indices, shape=None):
+        b, n = codebook_indices.shape
+        h, w = (int(math.sqrt(n)), int(math.sqrt(n))) if shape is None else shape
+        if self._err is None or self._err.device != codebook_indices.device:
+            self._err = torch.zeros(1, dtype=torch.int32, device=codebook_indices.device)
+        z = ops.lfq_unpack(codebook_indices.reshape(-1).long().contiguous(), _ZC, self._err).view(b, h, w, _ZC)
+        out = self._decode_z(z)
+        return ops.nhwc_to_nchw(out, 3)

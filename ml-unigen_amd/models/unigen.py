@@ -1,0 +1,390 @@
+"""UniGen on the MI355X kernels -- drop-in for the reference's `models/unigen.py` (same class name,
+constructor, method signatures and return conventions), so `training/train*.py` and
+`evaluation/inference_*.py` run against it unchanged.  The backbone the reference builds from
+transformers (`Qwen2ForCausalLM`, models/unigen.py:56-69) is `unigen_hip.modules.HipQwen2ForCausalLM`:
+hand-written HIP kernels behind a C ABI, no torch math on the hot path.
+
+Behavioural notes (all mirror the reference unless stated):
+  * forward() with labels returns (logits, loss_t2i, loss_lm, loss_mmu); the three losses are the
+    masked cross-entropies of models/unigen.py:310-338 (same slices, mean over non-ignored labels).
+    `logits` is a lazy view that evaluates the lm_head only for the positions a caller slices
+    (the reference materialises [B, L, 159867]); `label_smoothing` is accepted and ignored exactly
+    like the reference (it never reaches F.cross_entropy).
+  * precision: the reference's bf16-autocast training mode (fp32 master weights / residual stream,
+    bf16 matmuls, fp32 statistics) is what the kernels implement, with or without an enclosing
+    torch.autocast.
+  * gen_proj_depth > 0 (alternate image embedding + img_head, unigen.py:74-92) is not used by any
+    shipped config and is rejected loudly.
+"""
+import json
+import os
+from typing import Optional
+
+import torch
+
+from unigen_hip.lib import UniGenHipError
+from unigen_hip.modules import HipQwen2ForCausalLM, LazyLogits, _HeadLossFn
+from unigen_hip.qwen2 import Qwen2Dims
+
+from .modeling_utils import ConfigMixin, ModelMixin, register_to_config
+from .sampling import cosine_schedule, mask_by_random_topk
+
+# public Qwen2.5-1.5B(-Instruct) architecture (its config.json), used when no local HF directory exists
+_KNOWN_LLM = {
+    "qwen2.5-1.5b": dict(hidden_size=1536, intermediate_size=8960, num_hidden_layers=28, num_attention_heads=12,
+                         num_key_value_heads=2, rope_theta=1000000.0, rms_norm_eps=1e-6, vocab_size=151936),
+}
+
+
+def _load_llm_config(llm_model_path, ckpt_base_path=""):
+    """The reference reads this with AutoConfig.from_pretrained (models/unigen.py:52)."""
+    cands = [llm_model_path]
+    if ckpt_base_path:
+        cands.insert(0, os.path.join(ckpt_base_path, os.path.basename(str(llm_model_path).rstrip("/"))))
+    for c in cands:
+        f = os.path.join(str(c), "config.json")
+        if os.path.exists(f):
+            with open(f) as fh:
+                return json.load(fh)
+    low = str(llm_model_path).lower()
+    for key, cfg in _KNOWN_LLM.items():
+        if key in low:
+            return dict(cfg)
+    raise UniGenHipError(f"cannot find an LLM config for '{llm_model_path}' (no config.json, unknown name)")
+
+
+class UniGen(ModelMixin, ConfigMixin):
+    _supports_gradient_checkpointing = True
+
+    @register_to_config
+    def __init__(
+            self,
+            w_und_encoder: bool,
+            vocab_size: int,
+            llm_vocab_size: int,
+            llm_model_path: str = '',
+            codebook_size: int = 8192,
+            num_vq_tokens: int = 256,
+            load_from_pretrained: bool = True,
+            mm_input_dim: int = 1024,
+            gen_input_dim: int = 16,
+            und_proj_depth: int = 0,
+            gen_proj_depth: int = 0,
+            use_gen_dim: bool = False,
+            rope_theta: Optional[float] = None,
+            scaling_factor: float = 1.0,
+            rope_type: str = 'linear',
+            vision_tower_name: Optional[str] = None,
+            ckpt_base_path: str = "",
+            **kwargs,
+    ):
+        super().__init__()
+        if gen_proj_depth > 0:
+            raise UniGenHipError("gen_proj_depth > 0 (gen_embed / gen_projector / img_head) is outside the shipped "
+                                 "configurations and not implemented")
+        if scaling_factor != 1:
+            raise UniGenHipError("rope scaling is not used by any shipped config and is not implemented")
+        device = kwargs.get("device", None) or torch.device("cuda", torch.cuda.current_device())
+        self.vocab_size = vocab_size
+        self.num_vq_tokens = num_vq_tokens
+        llm_cfg = _load_llm_config(llm_model_path, ckpt_base_path)
+        self.register_to_config(hidden_size=llm_cfg["hidden_size"])
+        llm_cfg["vocab_size"] = vocab_size          # reference: config.vocab_size = vocab_size / resize_token_embeddings
+        if rope_theta is not None:
+            llm_cfg["rope_theta"] = rope_theta
+        dims = Qwen2Dims(**llm_cfg)
+        seed = kwargs.get("init_seed", None)
+        if seed is None:
+            seed = int(torch.initial_seed() % (2 ** 31))
+        # load_from_pretrained=True in the reference means "random-init from config" (sic, unigen.py:58-65);
+        # False means "load HF weights from llm_model_path".
+        self.llm = HipQwen2ForCausalLM(dims, device, seed=seed)
+        if not load_from_pretrained:
+            self._load_hf_llm_weights(llm_model_path, ckpt_base_path)
+        self.output_size = self.vocab_size
+        self.img_output_size = codebook_size
+        self.register_to_config(mask_token_id=vocab_size - 1)
+        self._loss_idx_cache = {}
+        if w_und_encoder:
+            if vision_tower_name is not None:
+                self.init_vision_tower(vision_tower_name)
+            self.add_mm_projector(max(2, und_proj_depth), mm_input_dim)
+
+    # ------------------------------------------------------------------ construction helpers
+    def _load_hf_llm_weights(self, llm_model_path, ckpt_base_path):
+        path = llm_model_path
+        if ckpt_base_path and not os.path.exists(str(path)):
+            path = os.path.join(ckpt_base_path, os.path.basename(str(llm_model_path).rstrip("/")))
+        files = [f for f in os.listdir(path) if f.endswith(".safetensors")]
+        if not files:
+            raise UniGenHipError(f"no *.safetensors under {path}")
+        from safetensors.torch import load_file
+        sd = {}
+        for f in files:
+            sd.update(load_file(os.path.join(path, f)))
+        own = self.llm.state_dict()
+        V_ckpt = sd["model.embed_tokens.weight"].shape[0]
+        with torch.no_grad():
+            for k, v in sd.items():
+                if k == "lm_head.weight" or k not in own:
+                    continue
+                if k == "model.embed_tokens.weight":      # == resize_token_embeddings(vocab_size) (unigen.py:68-69)
+                    n = min(V_ckpt, own[k].shape[0])
+                    own[k][:n].copy_(v[:n])
+                else:
+                    own[k].copy_(v)
+
+    def _set_gradient_checkpointing(self, module, value=False):
+        self.gradient_checkpointing = True
+
+    def resize_token_embeddings(self, vocab_size):
+        self.vocab_size = vocab_size
+        self.llm.resize_token_embeddings(self.vocab_size)
+        self.output_size = self.vocab_size
+
+    def init_vision_tower(self, vision_tower_name):
+        from .multimodal_encoder.builder import get_vision_tower
+        self.register_to_config(vision_tower_name=vision_tower_name)
+        if self.config.ckpt_base_path:
+            vision_tower_name = os.path.join(self.config.ckpt_base_path, os.path.basename(vision_tower_name.rstrip("/")))
+        self.vision_tower = get_vision_tower(vision_tower_name, freeze=False)
+
+    def add_vision_tower(self, config):
+        vision_tower_name = config.model.vision_tower.name
+        self.init_vision_tower(vision_tower_name)
+        vt = self.vision_tower
+        mm_input_dim = vt.config.hidden_size if hasattr(vt, 'config') else vt.hidden_size
+        self.add_mm_projector(config.model.unigen.get('und_proj_depth', 2), mm_input_dim)
+
+    def add_mm_projector(self, mlp_depth, mm_input_dim):
+        self.register_to_config(w_und_encoder=True)
+        self.register_to_config(mm_input_dim=mm_input_dim)
+        self.register_to_config(und_proj_depth=mlp_depth)
+        hidden = self.config.hidden_size
+        layers = [torch.nn.Linear(mm_input_dim, hidden)]
+        for _ in range(1, mlp_depth):
+            layers += [torch.nn.GELU(), torch.nn.Linear(hidden, hidden)]
+        self.mm_projector = torch.nn.Sequential(*layers).to(self.llm.engine.device)
+
+    def get_gen_embed(self, img_tokens):
+        raise UniGenHipError("gen_projector path (gen_proj_depth > 0) is not implemented")
+
+    def prepare_inputs_for_t2i(self, input_ids, num_vq_tokens):
+        return self.llm.model.embed_tokens(input_ids)
+
+    # ------------------------------------------------------------------ forward
+    def _loss_rows(self, B, L, bt, blm, bmmu, n, mode, device):
+        """Row indices (into [B*L]) of the logits each loss reads and of the labels it compares to
+        (the slices of models/unigen.py:310-338)."""
+        key = (B, L, bt, blm, bmmu, n, mode)
+        if key not in self._loss_idx_cache:
+            def grid(b0, b1, p0, p1):
+                b = torch.arange(b0, b1, device=device)[:, None] * L
+                return (b + torch.arange(p0, p1, device=device)[None, :]).reshape(-1)
+            segs = []
+            if mode == 'mask':
+                segs.append((grid(0, bt, L - (n + 1), L - 1), 0))
+            else:
+                segs.append((grid(0, bt, L - (n + 2), L - 1), 1))
+            if blm > 0:
+                segs.append((grid(bt, bt + blm, 0, L - 1), 1))
+            if bmmu > 0:
+                segs.append((grid(B - bmmu, B, 0, L - 1), 1))
+            bounds, r = [], 0
+            for ix, _ in segs:
+                bounds.append((r, r + ix.numel()))
+                r += ix.numel()
+            idx = torch.cat([ix for ix, _ in segs]) if r > 0 else torch.zeros(0, dtype=torch.long, device=device)
+            lab = torch.cat([ix + s for ix, s in segs]) if r > 0 else idx
+            self._loss_idx_cache[key] = (idx, lab, bounds)
+        return self._loss_idx_cache[key]
+
+    def forward(
+            self,
+            input_ids: torch.LongTensor,
+            input_embeddings: Optional[torch.Tensor] = None,
+            attention_mask: Optional[torch.Tensor] = None,
+            labels: Optional[torch.LongTensor] = None,
+            label_smoothing: float = 0.0,
+            batch_size_t2i: int = 0,
+            batch_size_lm: int = 0,
+            batch_size_mmu: int = 0,
+            max_seq_length: int = 128,
+            num_vq_tokens: int = 256,
+            t2i_mode: str = 'mask',
+            **kwargs,
+    ):
+        eng = self.llm.engine
+        if input_embeddings is None:
+            out = self.llm.model(input_ids=input_ids, attention_mask=attention_mask)
+        else:
+            out = self.llm.model(inputs_embeds=input_embeddings, attention_mask=attention_mask)
+        hn = out.last_hidden_state                                  # bf16 [B, L, H] (final norm applied)
+        logits = LazyLogits(eng, hn.detach())
+        if labels is None:
+            return logits
+        B, L, _ = hn.shape
+        idx, lab_idx, bounds = self._loss_rows(B, L, batch_size_t2i, batch_size_lm, batch_size_mmu, num_vq_tokens,
+                                               t2i_mode, hn.device)
+        nan = torch.full((), float("nan"), device=hn.device)
+        if idx.numel() == 0:
+            return logits, nan, 0., 0.
+        lab = labels.to(hn.device).reshape(-1)[lab_idx].contiguous()
+        live = [(s, b) for s, b in enumerate(bounds) if b[1] > b[0]]
+        losses = _HeadLossFn.apply(eng._anchor, hn, eng, idx, lab, tuple(b for _, b in live))
+        by_seg = {s: losses[j] for j, (s, _) in enumerate(live)}
+        s = 0
+        loss_t2i = by_seg.get(s, nan)
+        s += 1
+        loss_lm = 0.
+        if batch_size_lm > 0:
+            loss_lm = by_seg[s]
+            s += 1
+        loss_mmu = 0.
+        if batch_size_mmu > 0:
+            loss_mmu = by_seg[s]
+        return logits, loss_t2i, loss_lm, loss_mmu
+
+    # ------------------------------------------------------------------ MaskGIT generation
+    @torch.no_grad()
+    def t2i_generate(
+            self,
+            input_ids: Optional[torch.LongTensor] = None,
+            uncond_input_ids: Optional[torch.LongTensor] = None,
+            input_embeddings: Optional[torch.Tensor] = None,
+            uncond_input_embeddings: Optional[torch.Tensor] = None,
+            attention_mask: Optional[torch.Tensor] = None,
+            temperature: float = 1.0,
+            timesteps: int = 18,
+            guidance_scale: int = 0,
+            noise_schedule=cosine_schedule,
+            generator: Optional[torch.Generator] = None,
+            image_token_num_per_image: int = 256,
+            text_vocab_size: int = 151936,
+            **kwargs,
+    ):
+        """Iterative parallel decoding; step-for-step the procedure of reference models/unigen.py:344-455
+        (incl. its quirks: untempered multinomial, compounded Gumbel temperature, >=1 token re-masked
+        even on the last step, `sampled_ids` returned)."""
+        n = image_token_num_per_image
+        mask_token_id = self.config.mask_token_id
+        embed = self.llm.model.embed_tokens
+        cur_ids = input_ids[:, -(n + 1):-1].clone()
+        if input_embeddings is None:
+            input_embeddings = embed(input_ids)
+        image_embeddings = input_embeddings[:, -(n + 1):-1]
+        bsz = image_embeddings.shape[0]
+        prefix = input_embeddings[:, :-(n + 1)]
+        suffix = input_embeddings[:, -1:]
+        cfg = guidance_scale > 1
+        if cfg:
+            un_prefix = (embed(uncond_input_ids[:, :-(n + 1)]) if uncond_input_embeddings is None
+                         else uncond_input_embeddings[:, :-(n + 1)])
+            prefix = torch.cat([prefix, un_prefix])
+            suffix = torch.cat([suffix, suffix])
+        sampled_ids = None
+        for step in range(timesteps):
+            img = torch.cat([image_embeddings, image_embeddings]) if cfg else image_embeddings
+            seq = torch.cat([prefix, img, suffix], 1)
+            out = self(input_ids=input_ids, input_embeddings=seq, attention_mask=attention_mask)
+            # only the image positions x codebook columns are ever read (reference slices the dense logits)
+            lg = out[:, -(n + 1):-1, text_vocab_size:-1].float()
+            if cfg:
+                cond, uncond = lg[:bsz], lg[bsz:]
+                lg = guidance_scale * (cond - uncond[:bsz]) + uncond[:bsz]
+            probs = lg.softmax(dim=-1)
+            flat = probs.reshape(-1, lg.size(-1))
+            sampled_ids = torch.multinomial(flat, 1, generator=generator)[:, 0].view(*lg.shape[:-1])
+            unknown = cur_ids == mask_token_id
+            sampled_ids = torch.where(unknown, sampled_ids, cur_ids)
+            ratio = 1.0 * (step + 1) / timesteps
+            mask_ratio = noise_schedule(torch.tensor(ratio))
+            sel = torch.gather(probs, -1, sampled_ids.long()[..., None]).squeeze(-1)
+            sel = torch.where(unknown, sel, torch.finfo(sel.dtype).max)
+            mask_len = (n * mask_ratio).floor().unsqueeze(0).to(lg.device)
+            mask_len = torch.max(torch.tensor([1], device=lg.device),
+                                 torch.min(unknown.sum(dim=-1, keepdim=True) - 1, mask_len))
+            temperature = temperature * (1.0 - ratio)
+            masking = mask_by_random_topk(mask_len, sel, temperature, generator=generator)
+            next_ids = torch.where(masking, mask_token_id, sampled_ids + text_vocab_size)
+            image_embeddings = embed(next_ids)
+            cur_ids = torch.where(masking, mask_token_id, sampled_ids)
+        return sampled_ids
+
+    # ------------------------------------------------------------------ autoregressive generation
+    @torch.no_grad()
+    def t2i_generate_ar(
+            self,
+            input_ids: Optional[torch.LongTensor] = None,
+            uncond_input_ids: Optional[torch.LongTensor] = None,
+            input_embeddings: Optional[torch.Tensor] = None,
+            uncond_input_embeddings: Optional[torch.Tensor] = None,
+            attention_mask: Optional[torch.Tensor] = None,
+            guidance_scale: int = 0,
+            temperature: float = 1.0,
+            text_vocab_size: int = 151936,
+            image_token_num_per_image: int = 256,
+            generator: Optional[torch.Generator] = None,
+            **kwargs,
+    ):
+        """Token-by-token image generation with CFG (reference models/unigen.py:457-521).  The reference
+        only works when both embedding tensors are supplied; ids are accepted here too
+        and embedded, which is what its callers intend."""
+        n = image_token_num_per_image
+        embed = self.llm.model.embed_tokens
+        dev = self.llm.engine.device
+        if input_embeddings is None:
+            input_embeddings = embed(input_ids)
+        if uncond_input_embeddings is None:
+            uncond_input_embeddings = embed(uncond_input_ids)
+        bsz = input_embeddings.shape[0]
+        seq = torch.cat([input_embeddings[:, :-(n + 1)], uncond_input_embeddings[:, :-(n + 1)]])
+        out_tokens = torch.zeros((bsz, n), dtype=torch.int, device=dev)
+        for i in range(n):
+            L = seq.shape[1]
+            am = None if attention_mask is None else attention_mask[:, :L]
+            hn = self.llm.model(inputs_embeds=seq, attention_mask=am).last_hidden_state
+            lg = LazyLogits(self.llm.engine, hn)[:, L - 1, text_vocab_size:-1].float()
+            cond, uncond = lg.chunk(2)
+            lg = uncond + guidance_scale * (cond - uncond)
+            probs = torch.softmax(lg / temperature, dim=-1)
+            nxt = torch.multinomial(probs, num_samples=1, generator=generator)
+            out_tokens[:, i] = nxt.squeeze(-1)
+            seq = torch.cat([seq, embed(torch.cat([nxt, nxt]) + text_vocab_size)], 1)
+        return out_tokens
+
+    # ------------------------------------------------------------------ text decoding for understanding
+    @torch.no_grad()
+    def mmu_generate(self, idx=None, input_embeddings=None, attention_mask=None, max_new_tokens=100, temperature=1.0,
+                     top_k=None, eot_token=None):
+        """Greedy / top-k text continuation (reference models/unigen.py:523-581): the whole growing
+        sequence is re-run each step and the additive mask is extended by one causal row/column."""
+        device = idx.device if idx is not None else input_embeddings.device
+        result = []
+        neg = torch.finfo(torch.bfloat16).min
+        for _ in range(max_new_tokens):
+            logits = self(idx, input_embeddings=input_embeddings, attention_mask=attention_mask)
+            last = logits[:, -1, :].float()
+            L = attention_mask.shape[-1]
+            m = attention_mask.reshape(L, L)
+            grown = torch.full((L + 1, L + 1), float(neg), device=m.device, dtype=m.dtype)
+            grown[:L, :L] = m
+            grown[L, :L] = m[-1]
+            grown[L, L] = 0
+            attention_mask = grown[None, None]
+            if temperature > 0:
+                last = last / temperature
+                if top_k is not None:
+                    v, _ = torch.topk(last, min(top_k, last.size(-1)))
+                    last[last < v[:, [-1]]] = -float('Inf')
+                idx_next = torch.multinomial(torch.softmax(last, dim=-1), num_samples=1)
+            else:
+                idx_next = torch.argmax(last, dim=-1).reshape(-1, 1)
+            result.append(idx_next[0][0])
+            if self.config.w_und_encoder:
+                input_embeddings = torch.cat([input_embeddings, self.llm.model.embed_tokens(idx_next)], dim=1)
+            else:
+                idx = torch.cat((idx, idx_next), dim=1)
+            if eot_token is not None and idx_next.cpu() == eot_token:
+                break
+        return result

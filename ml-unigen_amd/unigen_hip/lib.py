@@ -31,6 +31,7 @@ SIGNATURES = {
     "ug_swiglu_bwd": [P, P, P, I64, I64, P],
     "ug_embed_fwd": [P, P, P, I64, I64, I64, P, P],
     "ug_embed_bwd": [P, P, P, I64, I64, I64, P],
+    "ug_gather_rows_bf16": [P, I64, P, P, I64, I64, I64, I32, P],
     "ug_colsum_bf16": [P, I64, P, I64, I64, P],
     "ug_attn_mask_compress": [P, I32, I64, I64, P, P, I64, I64, P, P],
     "ug_attn_mask_causal": [P, P, P, I64, I64, P],

@@ -1,0 +1,347 @@
+"""nn.Module façade over Qwen2Engine with the attribute paths the reference's callers reach into
+(SURVEY.md §8b): `llm.model.embed_tokens(ids)`, `llm.lm_head`, `llm.config.{use_cache,vocab_size}`,
+`llm.resize_token_embeddings`, `llm.gradient_checkpointing_enable()`, and parameter names equal to
+the reference checkpoint keys (`llm.model.layers.N.self_attn.q_proj.weight`, ...).
+
+Autograd: three coarse `torch.autograd.Function`s (embedding, decoder stack, head+loss).  Weight
+gradients are written by the kernels straight into the flat fp32 gradient buffer; every
+`nn.Parameter` is a view of the flat master buffer and its `.grad` a view of the flat grad buffer,
+so torch optimizers, `named_parameters()` and `zero_grad(set_to_none=True)` behave as usual.
+"""
+import math
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .lib import UniGenHipError
+from .qwen2 import Qwen2Dims, Qwen2Engine, _hf_name_map
+
+
+def _anchor_of(engine):
+    return engine._anchor
+
+
+# ------------------------------------------------------------------------------------ autograd
+class _EmbedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, ids, engine):
+        flat_ids = ids.reshape(-1).contiguous()
+        out = ops.embed_fwd(flat_ids, engine.fp.p("embed"), engine.err_flag)
+        ctx.engine, ctx.ids = engine, flat_ids
+        return out.view(*ids.shape, engine.dims.hidden_size)
+
+    @staticmethod
+    def backward(ctx, dout):
+        eng = ctx.engine
+        eng.begin_grad_pass()
+        ops.embed_bwd(ctx.ids, dout.reshape(-1, eng.dims.hidden_size).float().contiguous(), eng.fp.g("embed"))
+        if eng.grad_ready_hook:
+            eng.grad_ready_hook("embed")
+        return None, None, None
+
+
+class _StackFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, h0, engine, mb):
+        B, L, H = h0.shape
+        need = any(ctx.needs_input_grad)
+        saved = [] if need else None
+        h_last, hn, rstd = engine.stack_fwd(h0.reshape(B * L, H).float().contiguous(), mb, L, saved)
+        if need:
+            ctx.engine, ctx.saved, ctx.h_last, ctx.rstd, ctx.mb, ctx.shape = engine, saved, h_last, rstd, mb, (B, L, H)
+        return hn.view(B, L, H)
+
+    @staticmethod
+    def backward(ctx, dhn):
+        eng = ctx.engine
+        B, L, H = ctx.shape
+        eng.begin_grad_pass()
+        dhn = dhn.reshape(B * L, H).to(torch.bfloat16).contiguous()
+        dh0 = eng.stack_bwd(ctx.saved, ctx.h_last, ctx.rstd, dhn, ctx.mb, L)
+        ctx.saved = None
+        return None, dh0.view(B, L, H), None, None
+
+
+class _HeadLossFn(torch.autograd.Function):
+    """losses[s] = mean CE over segment s of the selected rows (tied lm_head + F.cross_entropy,
+    reference models/unigen.py:287,310-338); logits exist only for the selected rows."""
+
+    @staticmethod
+    def forward(ctx, anchor, hn, engine, idx, labels, bounds):
+        B, L, H = hn.shape
+        V = engine.dims.vocab_size
+        rows = ops.gather_rows(hn.reshape(B * L, H), idx)
+        logits = engine.logits_rows(rows)
+        outs, stats = [], []
+        for (r0, r1) in bounds:
+            lc, lse, _, _ = ops.ce_fwd(logits[r0:r1], V, labels[r0:r1])
+            outs.append(lc[:1])
+            stats.append((lse, lc))
+        ctx.engine, ctx.rows, ctx.logits, ctx.idx, ctx.labels, ctx.bounds, ctx.stats = engine, rows, logits, idx, labels, bounds, stats
+        ctx.shape = (B, L, H)
+        return torch.cat(outs)
+
+    @staticmethod
+    def backward(ctx, dloss):
+        eng = ctx.engine
+        B, L, H = ctx.shape
+        V = eng.dims.vocab_size
+        eng.begin_grad_pass()
+        dloss = dloss.float().contiguous()
+        for s, (r0, r1) in enumerate(ctx.bounds):
+            lse, lc = ctx.stats[s]
+            ops.ce_bwd_(ctx.logits[r0:r1], V, ctx.labels[r0:r1], lse, lc, dloss[s:s + 1])
+        drows = eng.head_bwd(ctx.logits, ctx.rows)
+        ctx.logits = None
+        dhn = torch.zeros((B * L, H), dtype=torch.bfloat16, device=drows.device)
+        ops.scatter_rows_(drows, ctx.idx, dhn)
+        return None, dhn.view(B, L, H), None, None, None, None
+
+
+# ------------------------------------------------------------------------------------ lazy logits
+class LazyLogits:
+    """Stand-in for the dense [B, L, V] logits tensor the reference returns (models/unigen.py:287-290).
+    Callers only ever slice it (train.py:926-936, unigen.py:416,507, train_dpo.py:602-609); rows are
+    produced on demand by the lm_head GEMM for exactly the positions / vocabulary range requested."""
+
+    def __init__(self, engine, hn):
+        self.engine, self.hn = engine, hn      # hn bf16 [B, L, H]
+        B, L, _ = hn.shape
+        self.shape = torch.Size((B, L, engine.dims.vocab_size))
+        self.dtype, self.device = torch.bfloat16, hn.device
+
+    def size(self, dim=None):
+        return self.shape if dim is None else self.shape[dim]
+
+    def dim(self):
+        return 3
+
+    def _rows(self, bsel, psel, vsel):
+        eng = self.engine
+        B, L, V = self.shape
+        bs = list(range(B))[bsel] if isinstance(bsel, slice) else [int(bsel) % B]
+        ps = list(range(L))[psel] if isinstance(psel, slice) else [int(psel) % L]
+        v0, v1, vstep = vsel.indices(V) if isinstance(vsel, slice) else (int(vsel) % V, int(vsel) % V + 1, 1)
+        if vstep != 1:
+            raise UniGenHipError("strided vocabulary slices are not supported")
+        idx = (torch.tensor(bs, device=self.device)[:, None] * L + torch.tensor(ps, device=self.device)[None, :]).reshape(-1)
+        rows = ops.gather_rows(self.hn.reshape(B * L, -1), idx)
+        n = v1 - v0
+        npad = ops.round_up(max(n, 1), 8)
+        out = torch.empty((rows.shape[0], npad), dtype=torch.bfloat16, device=self.device)
+        ops.gemm_nt(rows, eng.fp.w("embed")[v0:v1], out=out, N=n, K=eng.dims.hidden_size)
+        out = out[:, :n].reshape(len(bs), len(ps), n)
+        if not isinstance(vsel, slice):
+            out = out[..., 0]
+        if not isinstance(psel, slice):
+            out = out[:, 0]
+        if not isinstance(bsel, slice):
+            out = out[0]
+        return out
+
+    def __getitem__(self, key):
+        if not isinstance(key, tuple):
+            key = (key,)
+        if any(k is Ellipsis for k in key):
+            raise UniGenHipError("LazyLogits does not support Ellipsis indexing; call .materialize()")
+        key = tuple(key) + (slice(None),) * (3 - len(key))
+        if not all(isinstance(k, (slice, int)) for k in key):
+            return self.materialize()[key]
+        return self._rows(*key)
+
+    def materialize(self):
+        return self._rows(slice(None), slice(None), slice(None))
+
+    def float(self):
+        return self.materialize().float()
+
+    def to(self, *a, **k):
+        return self.materialize().to(*a, **k)
+
+    def chunk(self, n, dim=0):
+        B = self.shape[0]
+        step = (B + n - 1) // n
+        return tuple(self[i:i + step] for i in range(0, B, step))
+
+
+# ------------------------------------------------------------------------------------ modules
+class _ParamHolder(nn.Module):
+    """Container giving parameters the reference's dotted names; forward is never called."""
+
+
+class HipEmbedding(nn.Module):
+    def __init__(self, engine, weight):
+        super().__init__()
+        self.__dict__["_engine"] = engine
+        self.weight = weight
+        self.num_embeddings, self.embedding_dim = weight.shape
+
+    def forward(self, ids):
+        eng = self.__dict__["_engine"]
+        return _EmbedFn.apply(eng._anchor, ids.to(eng.device), eng)
+
+
+class HipLMHead(nn.Module):
+    def __init__(self, engine, weight):
+        super().__init__()
+        self.__dict__["_engine"] = engine
+        self.weight = weight
+
+    def forward(self, hidden):
+        eng = self.__dict__["_engine"]
+        h = hidden if hidden.dim() == 3 else hidden[None]
+        return LazyLogits(eng, h.to(torch.bfloat16).contiguous())
+
+
+class HipQwen2Model(nn.Module):
+    """`llm.model`: embed_tokens / layers / norm with reference parameter names."""
+
+    def __init__(self, engine):
+        super().__init__()
+        self.__dict__["_engine"] = engine
+        d = engine.dims
+        params = engine.named_param_views()
+        self.embed_tokens = HipEmbedding(engine, params["model.embed_tokens.weight"])
+        self.layers = nn.ModuleList()
+        for i in range(d.num_hidden_layers):
+            layer = _ParamHolder()
+            layer.self_attn = _ParamHolder()
+            for proj in ("q_proj", "k_proj", "v_proj", "o_proj"):
+                holder = _ParamHolder()
+                holder.weight = params[f"model.layers.{i}.self_attn.{proj}.weight"]
+                if proj != "o_proj":
+                    holder.bias = params[f"model.layers.{i}.self_attn.{proj}.bias"]
+                setattr(layer.self_attn, proj, holder)
+            layer.mlp = _ParamHolder()
+            for proj in ("gate_proj", "up_proj", "down_proj"):
+                holder = _ParamHolder()
+                holder.weight = params[f"model.layers.{i}.mlp.{proj}.weight"]
+                setattr(layer.mlp, proj, holder)
+            for nm in ("input_layernorm", "post_attention_layernorm"):
+                holder = _ParamHolder()
+                holder.weight = params[f"model.layers.{i}.{nm}.weight"]
+                setattr(layer, nm, holder)
+            self.layers.append(layer)
+        self.norm = _ParamHolder()
+        self.norm.weight = params["model.norm.weight"]
+
+    def forward(self, input_ids=None, attention_mask=None, inputs_embeds=None, output_hidden_states=False,
+                return_dict=True, **kwargs):
+        eng = self.__dict__["_engine"]
+        if (input_ids is None) == (inputs_embeds is None):
+            raise ValueError("You must specify exactly one of input_ids or inputs_embeds")
+        if inputs_embeds is None:
+            inputs_embeds = self.embed_tokens(input_ids)
+        B, L, _ = inputs_embeds.shape
+        mb = eng.mask_bits(attention_mask, B, L)
+        hn = _StackFn.apply(eng._anchor, inputs_embeds, eng, mb)
+        return SimpleNamespace(last_hidden_state=hn, past_key_values=None)
+
+
+class HipQwen2ForCausalLM(nn.Module):
+    """`UniGen.llm` (reference: transformers Qwen2ForCausalLM built at models/unigen.py:56-69)."""
+
+    def __init__(self, dims, device, seed=None):
+        super().__init__()
+        engine = TrainEngine(dims, device)
+        self.__dict__["_engine"] = engine
+        self.config = SimpleNamespace(vocab_size=dims.vocab_size, hidden_size=dims.hidden_size, use_cache=False,
+                                      num_hidden_layers=dims.num_hidden_layers, intermediate_size=dims.intermediate_size,
+                                      num_attention_heads=dims.num_attention_heads,
+                                      num_key_value_heads=dims.num_key_value_heads, rope_theta=dims.rope_theta,
+                                      rms_norm_eps=dims.rms_norm_eps)
+        self.model = HipQwen2Model(engine)
+        self.lm_head = HipLMHead(engine, self.model.embed_tokens.weight)     # tied
+        self.vocab_size = dims.vocab_size
+        if seed is not None:
+            self.init_weights(seed)
+
+    @property
+    def engine(self):
+        return self.__dict__["_engine"]
+
+    def init_weights(self, seed):
+        """HF Qwen2 init (N(0, initializer_range) matrices, zero biases, unit norms): what
+        `Qwen2ForCausalLM(config)` gives the reference at models/unigen.py:65.  Drawn on the host
+        parameter by parameter in named_parameters() order so the CPU oracle can reproduce it."""
+        g = torch.Generator().manual_seed(seed)
+        std = self.engine.dims.initializer_range
+        with torch.no_grad():
+            for name, p in self.named_parameters():
+                if name.endswith("norm.weight") or name.endswith("layernorm.weight"):
+                    p.fill_(1.0)
+                elif name.endswith(".bias"):
+                    p.zero_()
+                else:
+                    p.copy_((torch.randn(p.shape, generator=g) * std).to(p.device))
+
+    def gradient_checkpointing_enable(self, *a, **k):
+        # 288 GB of HBM holds every activation of the shipped configs; nothing to recompute.
+        return None
+
+    def gradient_checkpointing_disable(self):
+        return None
+
+    def resize_token_embeddings(self, vocab_size):
+        if vocab_size != self.engine.dims.vocab_size:
+            raise UniGenHipError("resize_token_embeddings after construction is not implemented: build the model "
+                                 "with the final vocab_size (the reference does, models/unigen.py:59-60)")
+        return self.model.embed_tokens
+
+    def forward(self, input_ids=None, attention_mask=None, inputs_embeds=None, **kwargs):
+        out = self.model(input_ids=input_ids, attention_mask=attention_mask, inputs_embeds=inputs_embeds)
+        return SimpleNamespace(logits=self.lm_head(out.last_hidden_state), past_key_values=None)
+
+
+class TrainEngine(Qwen2Engine):
+    """Qwen2Engine + the glue the module layer needs (parameter views, grad bookkeeping, masks)."""
+
+    def __init__(self, dims, device):
+        super().__init__(dims, device)
+        self._anchor = torch.zeros(1, device=device, requires_grad=True)
+        self._params = None
+        self._mask_cache = (None, None)
+
+    def named_param_views(self):
+        if self._params is None:
+            self._params = {}
+            for name, (key, rows) in _hf_name_map(self.dims).items():
+                v, g = self.fp.p(key), self.fp.g(key)
+                if rows is not None:
+                    v, g = v[rows[0]:rows[1]], g[rows[0]:rows[1]]
+                p = nn.Parameter(v, requires_grad=True)
+                p.grad = g
+                self.__dict__.setdefault("_grad_views", {})[name] = (p, g)
+                self._params[name] = p
+        return self._params
+
+    def begin_grad_pass(self):
+        """Called at the start of every backward segment.  If the caller dropped the gradients
+        (`optimizer.zero_grad(set_to_none=True)`, reference training/train.py:793) the flat buffer is
+        cleared once and every Parameter gets its persistent grad view back."""
+        views = self.__dict__.get("_grad_views", {})
+        probe = views.get("model.norm.weight")
+        if probe is not None and probe[0].grad is None:
+            self.fp.grad.zero_()
+            for p, g in views.values():
+                p.grad = g
+
+    def mask_bits(self, attention_mask, B, L):
+        if attention_mask is None:
+            key = ("causal", B, L)
+            if self._mask_cache[0] != key:
+                self._mask_cache = (key, ops.mask_causal(B, L, self.device))
+            return self._mask_cache[1]
+        if isinstance(attention_mask, ops.MaskBits):
+            return attention_mask
+        if attention_mask.dim() == 2:         # [B, L] key-validity mask: causal + padding (HF semantics)
+            return ops.mask_causal(B, L, self.device, key_valid=attention_mask.to(self.device) != 0)
+        # cache per mask OBJECT (MaskGIT calls forward T times with the same mask); holding the
+        # reference keeps the allocator from recycling its address under a different mask
+        cached = self._mask_cache[0]
+        if not (isinstance(cached, tuple) and cached[0] is attention_mask and cached[1] == attention_mask._version):
+            mb = ops.mask_compress(attention_mask.to(self.device), self.err_flag)
+            self._mask_cache = ((attention_mask, attention_mask._version), mb)
+        return self._mask_cache[1]

@@ -132,6 +132,20 @@ def embed_bwd(ids, dout, dW):
     _l.check(_l.load().ug_embed_bwd(_p(ids), _p(dout), _p(dW), ids.numel(), H, V, _stream()), "ug_embed_bwd")
 
 
+def gather_rows(x, idx):
+    n, C = idx.numel(), x.shape[1]
+    out = torch.empty((n, C), dtype=torch.bfloat16, device=x.device)
+    _l.check(_l.load().ug_gather_rows_bf16(_p(x), x.stride(0), _p(idx), _p(out), C, n, C, 0, _stream()), "ug_gather_rows_bf16")
+    return out
+
+
+def scatter_rows_(src, idx, out):
+    n, C = idx.numel(), src.shape[1]
+    _l.check(_l.load().ug_gather_rows_bf16(_p(src), src.stride(0), _p(idx), _p(out), out.stride(0), n, C, 1, _stream()),
+             "ug_gather_rows_bf16")
+    return out
+
+
 def colsum_(x, out, R=None, C=None):
     R = x.shape[0] if R is None else R
     C = x.shape[1] if C is None else C

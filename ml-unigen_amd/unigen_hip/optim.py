@@ -1,0 +1,72 @@
+"""Fused AdamW over flat parameter runs (replaces torch.optim.AdamW.step at reference
+training/train.py:324-330,780; same constructor / param-group interface, same update rule).
+
+Parameters that are adjacent views of one buffer (the UniGen backbone's flat fp32 master/grad
+buffers) are merged into runs, so a 1.56 B-parameter step is a few dozen launches of one
+HBM-bound kernel instead of one launch per tensor."""
+import torch
+
+from . import ops
+
+
+class _Run:
+    __slots__ = ("params", "p_ptr", "numel", "m", "v", "group")
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._runs = None
+        self._step = 0
+
+    def _build_runs(self):
+        runs = []
+        for gi, group in enumerate(self.param_groups):
+            ps = [p for p in group["params"] if p.requires_grad]
+            for p in ps:
+                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
+                    raise ops._l.UniGenHipError("FusedAdamW needs contiguous fp32 parameters in GPU memory")
+            ps.sort(key=lambda t: t.data_ptr())
+            cur = None
+            for p in ps:
+                end = None if cur is None else cur.p_ptr + cur.numel * 4
+                same_store = cur is not None and cur.params[-1].untyped_storage().data_ptr() == p.untyped_storage().data_ptr()
+                if cur is not None and same_store and 0 <= p.data_ptr() - end <= 1024 and (p.data_ptr() - cur.p_ptr) % 16 == 0:
+                    cur.params.append(p)
+                    cur.numel = (p.data_ptr() - cur.p_ptr) // 4 + p.numel()
+                else:
+                    cur = _Run()
+                    cur.params, cur.p_ptr, cur.numel, cur.group = [p], p.data_ptr(), p.numel(), gi
+                    runs.append(cur)
+        for r in runs:
+            dev = r.params[0].device
+            r.m = torch.zeros(r.numel, dtype=torch.float32, device=dev)
+            r.v = torch.zeros(r.numel, dtype=torch.float32, device=dev)
+        self._runs = runs
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale=1.0):
+        loss = closure() if closure is not None else None
+        if self._runs is None:
+            self._build_runs()
+        self._step += 1
+        lib = ops._l.load()
+        for r in self._runs:
+            g = self.param_groups[r.group]
+            first = r.params[0]
+            if first.grad is None:
+                if any(p.grad is not None for p in r.params):
+                    raise ops._l.UniGenHipError("FusedAdamW: partially missing gradients inside a flat run")
+                continue
+            g_ptr = first.grad.data_ptr()
+            for p in r.params[1:]:
+                if p.grad is None or p.grad.data_ptr() - g_ptr != p.data_ptr() - r.p_ptr:
+                    raise ops._l.UniGenHipError("FusedAdamW: gradient views do not mirror the parameter layout")
+            b1, b2 = g["betas"]
+            rc = lib.ug_adamw_flat(r.p_ptr, g_ptr, r.m.data_ptr(), r.v.data_ptr(), 0, r.numel, float(g["lr"]), b1, b2,
+                                   g["eps"], g["weight_decay"], self._step, float(grad_scale), ops._stream())
+            ops._l.check(rc, "ug_adamw_flat")
+            # the kernel wrote through a raw pointer: bump the (shared) version counter so the engine
+            # knows its bf16 compute copies are stale
+            torch.autograd.graph.increment_version(first)
+        return loss

@@ -1,0 +1,253 @@
+"""Qwen2.5 backbone engine on the gfx950 kernels: flat parameter storage, decoder-stack forward /
+backward, tied lm_head + cross-entropy.  This is the arithmetic behind `UniGen.llm`
+(reference: models/unigen.py:56-69 builds transformers' Qwen2ForCausalLM; call sites :274-287).
+
+Memory plan (sized for 288 GB HBM3E, no activation recompute):
+  * ONE flat fp32 buffer holds every parameter (q/k/v and gate/up stored fused so one GEMM serves
+    each), ONE flat fp32 gradient buffer mirrors it (this is also what the data-parallel
+    all-reduce moves), ONE flat bf16 compute copy plus per-matrix transposed bf16 copies feed the
+    matrix cores.  `nn.Parameter`s with the reference checkpoint's names are views into the flat
+    buffers, so optimizers / state_dict / named_parameters() see the reference layout.
+  * precision = the reference's accelerate-DDP bf16-autocast mode: fp32 master weights and residual
+    stream, bf16 GEMM operands, fp32 accumulation / statistics / gradients.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .lib import UniGenHipError
+
+
+class Qwen2Dims:
+    def __init__(self, vocab_size, hidden_size=1536, intermediate_size=8960, num_hidden_layers=28,
+                 num_attention_heads=12, num_key_value_heads=2, rope_theta=1e6, rms_norm_eps=1e-6,
+                 initializer_range=0.02, **_unused):
+        self.vocab_size = int(vocab_size)
+        self.hidden_size = hidden_size
+        self.intermediate_size = intermediate_size
+        self.num_hidden_layers = num_hidden_layers
+        self.num_attention_heads = num_attention_heads
+        self.num_key_value_heads = num_key_value_heads
+        self.head_dim = hidden_size // num_attention_heads
+        self.rope_theta = float(rope_theta)
+        self.rms_norm_eps = float(rms_norm_eps)
+        self.initializer_range = initializer_range
+        if self.head_dim != 128:
+            raise UniGenHipError(f"attention kernels are specialised for head_dim 128 (got {self.head_dim})")
+        if hidden_size % 64 or intermediate_size % 64:
+            raise UniGenHipError("hidden / intermediate sizes must be multiples of 64 for the MFMA GEMM")
+        self.vocab_pad = ops.round_up(self.vocab_size, 64)
+        self.qkv_out = (num_attention_heads + 2 * num_key_value_heads) * self.head_dim
+
+
+class FlatParams:
+    """Flat fp32 master / grad buffers + bf16 compute copies, with named views."""
+
+    ALIGN = 64
+
+    def __init__(self, dims, device):
+        d, self.dims, self.device = dims, dims, device
+        H, I = d.hidden_size, d.intermediate_size
+        self.spec = []   # (key, shape)
+        self.spec.append(("embed", (d.vocab_size, H)))
+        for i in range(d.num_hidden_layers):
+            self.spec += [(f"l{i}.wqkv", (d.qkv_out, H)), (f"l{i}.bqkv", (d.qkv_out,)), (f"l{i}.wo", (H, H)),
+                          (f"l{i}.wgu", (2 * I, H)), (f"l{i}.wdown", (H, I)), (f"l{i}.ln1", (H,)), (f"l{i}.ln2", (H,))]
+        self.spec.append(("norm", (H,)))
+        self.off = {}
+        n = 0
+        for k, shp in self.spec:
+            self.off[k] = (n, shp)
+            n += ops.round_up(math.prod(shp), self.ALIGN)
+        self.numel = n
+        self.master = torch.zeros(n, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(n, dtype=torch.float32, device=device)
+        self.bf16 = torch.zeros(n, dtype=torch.bfloat16, device=device)
+        self.wT = {}                 # key -> transposed bf16 [K, Npad]
+        self._seen_version = -1
+
+    def view(self, buf, key):
+        o, shp = self.off[key]
+        return buf[o:o + math.prod(shp)].view(shp)
+
+    def p(self, key):
+        return self.view(self.master, key)
+
+    def g(self, key):
+        return self.view(self.grad, key)
+
+    def w(self, key):
+        return self.view(self.bf16, key)
+
+    def refresh_compute_copies(self, force=False):
+        """bf16 + transposed-bf16 copies of the fp32 master weights (one pass per optimizer step)."""
+        ver = self.master._version
+        if not force and ver == self._seen_version:
+            return
+        d = self.dims
+        mats = ["embed"] + [f"l{i}.{n}" for i in range(d.num_hidden_layers) for n in ("wqkv", "wo", "wgu", "wdown")]
+        for key in mats:
+            src = self.p(key)
+            R, C = src.shape
+            ldT = ops.round_up(R, 64)
+            if key not in self.wT:
+                self.wT[key] = torch.empty((C, ldT), dtype=torch.bfloat16, device=self.device)
+            lib = ops._l.load()
+            rc = lib.ug_transpose_cast(src.data_ptr(), 1, C, self.w(key).data_ptr(), C, self.wT[key].data_ptr(), ldT,
+                                       R, C, ops._stream())
+            ops._l.check(rc, "ug_transpose_cast")
+        for key, _ in self.spec:
+            if key.endswith(("bqkv", "ln1", "ln2")) or key == "norm":
+                ops.cast_bf16(self.p(key), self.w(key))
+        self._seen_version = ver
+
+
+def _hf_name_map(dims):
+    """reference checkpoint key (under `llm.`) -> (flat key, row slice | None)."""
+    d = dims
+    hd, Hq, Hk = d.head_dim, d.num_attention_heads, d.num_key_value_heads
+    q_end, k_end = Hq * hd, (Hq + Hk) * hd
+    m = {"model.embed_tokens.weight": ("embed", None), "model.norm.weight": ("norm", None)}
+    for i in range(d.num_hidden_layers):
+        p = f"model.layers.{i}."
+        m[p + "self_attn.q_proj.weight"] = (f"l{i}.wqkv", (0, q_end))
+        m[p + "self_attn.k_proj.weight"] = (f"l{i}.wqkv", (q_end, k_end))
+        m[p + "self_attn.v_proj.weight"] = (f"l{i}.wqkv", (k_end, d.qkv_out))
+        m[p + "self_attn.q_proj.bias"] = (f"l{i}.bqkv", (0, q_end))
+        m[p + "self_attn.k_proj.bias"] = (f"l{i}.bqkv", (q_end, k_end))
+        m[p + "self_attn.v_proj.bias"] = (f"l{i}.bqkv", (k_end, d.qkv_out))
+        m[p + "self_attn.o_proj.weight"] = (f"l{i}.wo", None)
+        m[p + "mlp.gate_proj.weight"] = (f"l{i}.wgu", (0, d.intermediate_size))
+        m[p + "mlp.up_proj.weight"] = (f"l{i}.wgu", (d.intermediate_size, 2 * d.intermediate_size))
+        m[p + "mlp.down_proj.weight"] = (f"l{i}.wdown", None)
+        m[p + "input_layernorm.weight"] = (f"l{i}.ln1", None)
+        m[p + "post_attention_layernorm.weight"] = (f"l{i}.ln2", None)
+    return m
+
+
+class _Saved:
+    __slots__ = ("h", "rstd1", "xn1", "qkv", "o", "lse", "h_mid", "rstd2", "xn2", "gu", "act")
+
+
+class Qwen2Engine:
+    """Decoder stack + head on the HIP kernels.  Not an nn.Module: the module tree lives in
+    `modules.py`; this object owns buffers and orchestrates kernel launches."""
+
+    def __init__(self, dims, device):
+        self.dims, self.device = dims, device
+        self.fp = FlatParams(dims, device)
+        self._rope_cache = {}
+        self.err_flag = torch.zeros(1, dtype=torch.int32, device=device)
+        self.grad_ready_hook = None      # callable(layer_index | 'embed' | 'norm') fired as grads complete (DDP)
+
+    # ---------------------------------------------------------------- helpers
+    def rope(self, L):
+        if L not in self._rope_cache:
+            self._rope_cache[L] = ops.rope_tables(L, self.dims.head_dim, self.dims.rope_theta, self.device)
+        return self._rope_cache[L]
+
+    def check_errors(self):
+        """Device-side error flags (out-of-range token id = 1, non-binary attention mask = 2, bad VQ code = 4)."""
+        v = int(self.err_flag.item())
+        if v:
+            self.err_flag.zero_()
+            raise UniGenHipError(f"device-side input check failed (flags={v}): 1=token id out of range, "
+                                 f"2=attention mask value neither 0 nor <= -1e9, 4=VQ code out of range")
+
+    # ---------------------------------------------------------------- forward
+    def layer_fwd(self, i, h, mb, L, save):
+        d, fp = self.dims, self.fp
+        Hq, Hk, hd = d.num_attention_heads, d.num_key_value_heads, d.head_dim
+        cos, sin = self.rope(L)
+        xn1, rstd1 = ops.rmsnorm_fwd(h, fp.p(f"l{i}.ln1"), d.rms_norm_eps)
+        qkv = ops.gemm_nt(xn1, fp.w(f"l{i}.wqkv"), bias=fp.w(f"l{i}.bqkv"))
+        ops.rope_(qkv, cos, sin, L, Hq + Hk, hd)
+        o, lse = ops.attn_fwd(qkv, mb, Hq, Hk, hd)
+        h_mid = ops.gemm_nt(o, fp.w(f"l{i}.wo"), epilogue=ops.UG_EPI_RESID, resid=h)
+        xn2, rstd2 = ops.rmsnorm_fwd(h_mid, fp.p(f"l{i}.ln2"), d.rms_norm_eps)
+        gu = ops.gemm_nt(xn2, fp.w(f"l{i}.wgu"))
+        act = ops.swiglu_fwd(gu)
+        h_out = ops.gemm_nt(act, fp.w(f"l{i}.wdown"), epilogue=ops.UG_EPI_RESID, resid=h_mid)
+        if save is not None:
+            s = _Saved()
+            s.h, s.rstd1, s.xn1, s.qkv, s.o, s.lse = h, rstd1, xn1, qkv, o, lse
+            s.h_mid, s.rstd2, s.xn2, s.gu, s.act = h_mid, rstd2, xn2, gu, act
+            save.append(s)
+        return h_out
+
+    def stack_fwd(self, h0, mb, L, save):
+        """h0 fp32 [B*L, H] -> (h_last fp32, hn bf16 = final-norm output, rstd of the final norm)."""
+        self.fp.refresh_compute_copies()
+        h = h0
+        for i in range(self.dims.num_hidden_layers):
+            h = self.layer_fwd(i, h, mb, L, save)
+        hn, rstd = ops.rmsnorm_fwd(h, self.fp.p("norm"), self.dims.rms_norm_eps)
+        return h, hn, rstd
+
+    # ---------------------------------------------------------------- backward
+    def layer_bwd(self, i, s, dh, mb, L):
+        """dh fp32 [M,H]: grad w.r.t. the layer output on entry, w.r.t. the layer input on exit (in place).
+        Weight gradients accumulate into the flat fp32 grad buffer."""
+        d, fp = self.dims, self.fp
+        Hq, Hk, hd = d.num_attention_heads, d.num_key_value_heads, d.head_dim
+        M = dh.shape[0]
+        Mp = ops.round_up(M, 64)
+        cos, sin = self.rope(L)
+        F32 = ops.UG_EPI_F32
+        # ---- MLP
+        dyd, dydT = ops.transpose_cast(dh, want_out=True, ldT=Mp)
+        _, actT = ops.transpose_cast(s.act, ldT=Mp)
+        ops.gemm_nt(dydT, actT, out=fp.g(f"l{i}.wdown"), K=Mp, epilogue=F32, beta=1)
+        dact = ops.gemm_nt(dyd, fp.wT[f"l{i}.wdown"], N=d.intermediate_size, K=d.hidden_size)
+        dgu = ops.swiglu_bwd(s.gu, dact)
+        _, dguT = ops.transpose_cast(dgu, ldT=Mp)
+        _, xn2T = ops.transpose_cast(s.xn2, ldT=Mp)
+        ops.gemm_nt(dguT, xn2T, out=fp.g(f"l{i}.wgu"), K=Mp, epilogue=F32, beta=1)
+        dxn2 = ops.gemm_nt(dgu, fp.wT[f"l{i}.wgu"], N=d.hidden_size, K=2 * d.intermediate_size)
+        ops.rmsnorm_bwd(dxn2, s.h_mid, s.rstd2, fp.p(f"l{i}.ln2"), dh, fp.g(f"l{i}.ln2"))
+        # ---- attention
+        dyo, dyoT = ops.transpose_cast(dh, want_out=True, ldT=Mp)
+        _, oT = ops.transpose_cast(s.o, ldT=Mp)
+        ops.gemm_nt(dyoT, oT, out=fp.g(f"l{i}.wo"), K=Mp, epilogue=F32, beta=1)
+        do = ops.gemm_nt(dyo, fp.wT[f"l{i}.wo"], N=d.hidden_size, K=d.hidden_size)
+        dqkv = ops.attn_bwd(s.qkv, s.o, s.lse, do, mb, Hq, Hk, hd)
+        ops.rope_(dqkv, cos, sin, L, Hq + Hk, hd, backward=True)
+        ops.colsum_(dqkv, fp.g(f"l{i}.bqkv"))
+        _, dqkvT = ops.transpose_cast(dqkv, ldT=Mp)
+        _, xn1T = ops.transpose_cast(s.xn1, ldT=Mp)
+        ops.gemm_nt(dqkvT, xn1T, out=fp.g(f"l{i}.wqkv"), K=Mp, epilogue=F32, beta=1)
+        dxn1 = ops.gemm_nt(dqkv, fp.wT[f"l{i}.wqkv"], N=d.hidden_size, K=d.qkv_out)
+        ops.rmsnorm_bwd(dxn1, s.h, s.rstd1, fp.p(f"l{i}.ln1"), dh, fp.g(f"l{i}.ln1"))
+        return dh
+
+    def stack_bwd(self, saved, h_last, rstd_last, dhn, mb, L):
+        """dhn bf16 [M,H] (grad of the final-norm output) -> dh0 fp32 [M,H]."""
+        dh = torch.zeros_like(h_last)
+        ops.rmsnorm_bwd(dhn, h_last, rstd_last, self.fp.p("norm"), dh, self.fp.g("norm"))
+        if self.grad_ready_hook:
+            self.grad_ready_hook("norm")
+        for i in reversed(range(self.dims.num_hidden_layers)):
+            dh = self.layer_bwd(i, saved[i], dh, mb, L)
+            saved[i] = None                       # release this layer's activations
+            if self.grad_ready_hook:
+                self.grad_ready_hook(i)
+        return dh
+
+    # ---------------------------------------------------------------- head
+    def logits_rows(self, hn_rows):
+        """hn_rows bf16 [R, H] -> logits bf16 [R, vocab_pad] (columns >= vocab_size are unspecified)."""
+        d = self.dims
+        out = torch.empty((hn_rows.shape[0], d.vocab_pad), dtype=torch.bfloat16, device=self.device)
+        return ops.gemm_nt(hn_rows, self.fp.w("embed"), out=out, N=d.vocab_size, K=d.hidden_size)
+
+    def head_bwd(self, dlogits, hn_rows):
+        """dlogits bf16 [R, vocab_pad] (pad columns zero) -> dhn_rows bf16 [R,H]; embed grad accumulated."""
+        d, fp = self.dims, self.fp
+        R = hn_rows.shape[0]
+        Rp = ops.round_up(R, 64)
+        _, dlT = ops.transpose_cast(dlogits, R=R, C=d.vocab_size, ldT=Rp)
+        _, hT = ops.transpose_cast(hn_rows, ldT=Rp)
+        ops.gemm_nt(dlT, hT, out=fp.g("embed"), M=d.vocab_size, N=d.hidden_size, K=Rp, epilogue=ops.UG_EPI_F32, beta=1)
+        return ops.gemm_nt(dlogits, fp.wT["embed"], M=R, N=d.hidden_size, K=d.vocab_pad)

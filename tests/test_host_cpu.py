@@ -1,0 +1,100 @@
+"""CPU suite, part 2: host-side logic of the product that needs no GPU -- the C ABI library loads and
+exports every symbol the header declares, the sampling helpers reproduce the reference's outputs,
+config/registry semantics."""
+import ctypes
+import math
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+from helpers import golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, "include", "unigen_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ug_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_abi_library_exports_every_declared_symbol():
+    from unigen_hip import lib
+    syms = _header_symbols()
+    assert len(syms) >= 30
+    L = ctypes.CDLL(lib.LIB_PATH)
+    missing = [s for s in syms if not hasattr(L, s)]
+    assert not missing, missing
+    # the ctypes signature table covers the same set (no drift between header and binding)
+    bound = set(lib.SIGNATURES) | {"ug_last_error"}
+    assert set(syms) == bound, (set(syms) ^ bound)
+    lib.load()
+    assert lib.load().ug_abi_version() == 1
+
+
+def test_abi_argument_errors_are_reported_not_thrown():
+    from unigen_hip import lib
+    L = lib.load()
+    rc = L.ug_gemm_bf16_nt(0, 8, 0, 8, 0, 8, 16, 16, 72, 0, 0, 0, 0, 0, 0, 0)     # K % 64 != 0: rejected before any launch
+    assert rc == -1 and b"multiple of 64" in L.ug_last_error()
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "ml-unigen_amd")
+    out = subprocess.run(["grep", "-rIl", "-E", r"^\s*(from|import)\s+oracle", pkg], capture_output=True, text=True).stdout
+    assert out.strip() == "", out
+
+
+def test_sampling_helpers_match_reference_outputs():
+    from models import sampling
+    g = golden("g5_sampling.pt")
+    t = g["t"]
+    for name in ("cosine", "linear", "pow2", "pow0.5", "sigmoid"):
+        assert torch.equal(sampling.get_mask_chedule(name)(t), g["sched_" + name]), name
+    m = sampling.mask_by_random_topk(g["mask_len"], g["probs"], 0.7, generator=torch.Generator().manual_seed(6))
+    assert torch.equal(m, g["topk_mask"])
+    assert torch.equal(sampling.top_k_top_p_filtering(g["filter_in"].clone(), top_k=5), g["filter_k5"])
+    assert torch.equal(sampling.top_k_top_p_filtering(g["filter_in"].clone(), top_p=0.8), g["filter_p"])
+    assert torch.equal(sampling.gumbel_noise(torch.zeros(2, 5), generator=torch.Generator().manual_seed(7)), g["gumbel"])
+    with pytest.raises(ValueError):
+        sampling.get_mask_chedule("nope")
+    names = ["log", "gumbel_noise", "gumbel_sample", "top_k", "mask_by_random_topk", "cosine_schedule", "linear_schedule",
+             "pow", "sigmoid_schedule", "get_mask_chedule", "top_k_top_p_filtering"]
+    assert all(hasattr(sampling, n) for n in names)
+
+
+def test_registry_and_config_semantics():
+    from models.model_registry import get_model_creator, MODEL_REGISTRY
+    from models import UniGen, MAGVITv2
+    assert get_model_creator("unigen") is UniGen and get_model_creator("/ckpt/MAGVITv2-x") is MAGVITv2
+    with pytest.raises(ValueError):
+        MODEL_REGISTRY.get("resnet")
+    from models.modeling_utils import ConfigMixin, ModelMixin, register_to_config
+
+    class M(ModelMixin, ConfigMixin):
+        @register_to_config
+        def __init__(self, a, b=2, **kw):
+            super().__init__()
+            self.register_to_config(c=a + b)
+    m = M(1)
+    assert m.config.a == 1 and m.config.get("b") == 2 and m.config["c"] == 3 and m.c == 3
+    assert m.config.get("missing", 7) == 7
+    with pytest.raises(AttributeError):
+        m.config.a = 5
+
+
+def test_missing_extension_fails_loudly(monkeypatch, tmp_path):
+    from unigen_hip import lib
+    monkeypatch.setattr(lib, "_lib", None)
+    monkeypatch.setattr(lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(lib.UniGenHipError):
+        lib.load()
+
+
+def test_ops_refuse_cpu_tensors():
+    from unigen_hip import ops, lib
+    with pytest.raises(lib.UniGenHipError):
+        ops.gemm_nt(torch.zeros(64, 64, dtype=torch.bfloat16), torch.zeros(64, 64, dtype=torch.bfloat16))

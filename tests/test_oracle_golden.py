@@ -1,0 +1,71 @@
+"""CPU suite, part 1: the oracle (oracle/) against the golden vectors captured from the real
+reference (tools/make_golden.py).  This is what pins the oracle; the GPU suite then checks the HIP
+path against the oracle and against the same fixtures."""
+import math
+
+import torch
+
+from helpers import golden, oracle_lm, additive
+
+
+def test_mask_builders_match_reference():
+    from oracle import host_ref
+    g = golden("g4_masks.pt")
+    ids = g["ids"]
+    t2i = host_ref.mask_predict_next_ref(g["t2i_seq"], ids["pad"], ids["soi"], ids["eoi"], rm_pad_in_image=True)
+    assert torch.equal(t2i, g["t2i_allow"])
+    assert torch.equal(host_ref.to_additive(t2i), g["t2i_additive"])
+    assert torch.equal(host_ref.mask_predict_next_ref(g["lm_seq"], ids["pad"], ids["soi"], ids["eoi"]), g["lm_allow"])
+    assert torch.equal(host_ref.mask_mmu_ref(g["mmu_seq"], ids["eoi"]), g["mmu_allow"])
+    assert torch.equal(host_ref.mask_mmu_vit_ref(2, 24, prefix_length=5, num_tokens=9), g["mmu_vit_allow"])
+    # semantics the kernels rely on: no fully blocked row; image rows see every non-pad column
+    assert g["t2i_allow"].any(-1).all()
+
+
+def test_maskgit_train_masking_matches_reference():
+    from oracle import host_ref
+    g = golden("g5_sampling.pt")
+    torch.manual_seed(g["mask_seed"])
+    ts, sc = torch.rand(4), torch.rand(4, 16)
+    ids, labels, mp = host_ref.maskgit_train_mask_ref(g["mask_tokens"], 332, ts, sc, lambda x: torch.cos(x * math.pi * 0.5))
+    assert torch.equal(ids, g["mask_ids"]) and torch.equal(labels, g["mask_labels"]) and torch.equal(mp, g["mask_prob"])
+
+
+def test_tiny_unigen_oracle_bit_exact_vs_reference():
+    from oracle import qwen2_ref
+    g = golden("g2_tiny_unigen.pt")
+    lm, _ = oracle_lm(g["cfg"], g["weight_seed"])
+    mask = additive(g["mask_allow"])
+    kw = {k: v for k, v in g["kw"].items() if k != "max_seq_length"}
+    for mode, ac in (("fp32", False), ("bf16", True)):
+        lm.zero_grad(set_to_none=True)
+        logits, l1, l2, l3 = qwen2_ref.unigen_forward_ref(lm, g["input_ids"], mask, g["labels"], autocast=ac, **kw)
+        want = g[mode]
+        assert torch.equal(logits.to(want["logits"].dtype), want["logits"])
+        assert torch.equal(torch.stack([l1, l2, l3]).float(), want["losses"])
+        (1.0 * l1 + 0.1 * l2 + 1.0 * l3).backward()
+        grads = dict(lm.named_parameters())
+        for n, gg in want["grads_small"].items():
+            assert torch.equal(grads[n].grad, gg), n
+        assert torch.equal(grads["model.embed_tokens.weight"].grad[[0, 5, 300, 303, 304, 312, 320, 332]], want["grad_embed_rows"])
+        for n, v in want["grad_norms"].items():
+            assert abs(grads[n].grad.norm().item() - v) <= 1e-6 * max(1.0, v), n
+
+
+def test_magvit_oracle_vs_reference():
+    from oracle import magvit_ref, weights
+    g = golden("g1_magvit.pt")
+    sd = weights.synth_magvit_state(magvit_ref.magvit_param_shapes(), seed=g["weight_seed"])
+    assert sum(v.numel() for v in sd.values()) == g["n_params"]
+    x = weights.synth_images(2, 256, seed=g["image_seed"])[:1]      # one image keeps the CPU suite short
+    with torch.no_grad():
+        z = magvit_ref.encode_z_ref(sd, x)
+        idx = magvit_ref.get_code_ref(sd, x)
+    # mkldnn picks different blockings for different batch sizes / hosts: fp32 round-off level agreement
+    assert (z - g["z"][:1]).abs().max().item() < 2e-5
+    from oracle.ops_ref import lfq_indices_ref
+    safe = (g["z"][:1].abs() > 1e-4)
+    bits_ref, bits = (g["z"][:1] > 0), (z > 0)
+    assert torch.equal(bits[safe], bits_ref[safe])
+    assert (idx != g["indices"][:1]).float().mean().item() <= (~safe).float().mean().item() * 13 + 1e-9
+    assert torch.equal(lfq_indices_ref(g["z"]), g["indices"])

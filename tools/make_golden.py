@@ -1,0 +1,302 @@
+"""Generate the golden vectors under tests/golden/ by running the REAL reference (imported from
+/root/reference through tools/ref_shims.py) on seeded synthetic inputs, and check the CPU oracle
+(oracle/) against it at generation time.  Run in the build container only:
+
+    python tools/make_golden.py            # writes tests/golden/*.pt, prints oracle-vs-reference deltas
+
+The fixtures contain inputs and expected outputs only (no reference source).  Weights are never
+stored: they are rebuilt from (name, shape, seed) by oracle/weights.py.
+"""
+import os
+import re
+import sys
+import types
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+import torch  # noqa: E402
+
+import ref_shims  # noqa: E402
+
+ref_shims.install()
+
+from oracle import host_ref, magvit_ref, qwen2_ref, weights  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+
+# ------------------------------------------------------------------ a deterministic fake tokenizer
+TEXT_V = 300
+SPECIALS = ["[PAD]", "<|im_start|>", "<|im_end|>"]
+
+
+class _Enc(dict):
+    """tokenizer output: both enc['input_ids'] and enc.input_ids (prompting_utils.py:67-70,394-420)"""
+    __getattr__ = dict.__getitem__
+
+
+class FakeTok:
+    """Covers exactly what UniversalPromptingQwen2 and the step body touch."""
+
+    def __init__(self):
+        self.table = {s: TEXT_V + i for i, s in enumerate(SPECIALS)}
+        self.pad_token_id = self.table["[PAD]"]
+        self.eos_token_id = self.table["<|im_end|>"]
+        self.vocab_size = TEXT_V
+        self.model_max_length = 4096
+
+    def add_tokens(self, toks):
+        for t in toks:
+            if t not in self.table:
+                self.table[t] = TEXT_V + len(self.table)
+
+    def convert_tokens_to_ids(self, toks):
+        return [self.table[t] for t in toks]
+
+    def __len__(self):
+        return TEXT_V + len(self.table)
+
+    def _enc(self, s):
+        pat = "(" + "|".join(re.escape(k) for k in sorted(self.table, key=len, reverse=True)) + ")"
+        ids = []
+        for piece in re.split(pat, s):
+            if piece in self.table:
+                ids.append(self.table[piece])
+            else:
+                ids += [(ord(c) * 7 + 3) % TEXT_V for c in piece]
+        return ids
+
+    def __call__(self, text, **kw):
+        ids = [self._enc(t) for t in text] if isinstance(text, (list, tuple)) else self._enc(text)
+        return _Enc(input_ids=ids)
+
+
+def maxdiff(a, b):
+    return (a.float() - b.float()).abs().max().item()
+
+
+# ------------------------------------------------------------------ G4: attention-mask builders
+def golden_masks():
+    from training.prompting_utils import (create_attention_mask_for_mmu, create_attention_mask_for_mmu_vit,
+                                          create_attention_mask_predict_next)
+    PAD, SOI, EOI = 300, 303, 304
+    g = torch.Generator().manual_seed(11)
+    L = 24
+    seqs = []
+    for npad, ntext, nimg in [(4, 8, 10), (0, 12, 10), (9, 3, 10)]:
+        s = [PAD] * npad + torch.randint(0, 290, (ntext,), generator=g).tolist() + [SOI] + \
+            torch.randint(312, 330, (nimg,), generator=g).tolist() + [EOI]
+        seqs.append(s)
+    t2i = torch.tensor(seqs)
+    lm = torch.tensor([torch.randint(0, 290, (L - 5,), generator=g).tolist() + [PAD] * 5])
+    mmu = torch.tensor([[301, 308, SOI] + torch.randint(312, 330, (8,), generator=g).tolist() + [EOI]
+                        + torch.randint(0, 290, (L - 12,), generator=g).tolist()] * 2)
+    out = {"t2i_seq": t2i, "lm_seq": lm, "mmu_seq": mmu, "ids": dict(pad=PAD, soi=SOI, eoi=EOI)}
+    ref = create_attention_mask_predict_next(t2i, pad_id=PAD, soi_id=SOI, eoi_id=EOI, rm_pad_in_image=True)
+    out["t2i_additive"] = ref
+    out["t2i_allow"] = (ref[:, 0] == 0)
+    mine = host_ref.mask_predict_next_ref(t2i, PAD, SOI, EOI, rm_pad_in_image=True)
+    assert torch.equal(mine, out["t2i_allow"]), "oracle t2i mask != reference"
+    assert torch.equal(host_ref.to_additive(mine), ref)
+    ref = create_attention_mask_predict_next(lm, pad_id=PAD, soi_id=SOI, eoi_id=EOI)
+    out["lm_allow"] = (ref[:, 0] == 0)
+    assert torch.equal(host_ref.mask_predict_next_ref(lm, PAD, SOI, EOI), out["lm_allow"])
+    ref = create_attention_mask_for_mmu(mmu, eoi_id=EOI)
+    out["mmu_allow"] = (ref[:, 0] == 0)
+    assert torch.equal(host_ref.mask_mmu_ref(mmu, EOI), out["mmu_allow"])
+    emb = torch.zeros(2, L, 4)
+    ref = create_attention_mask_for_mmu_vit(emb, prefix_length=5, num_tokens=9)
+    out["mmu_vit_allow"] = (ref[:, 0] == 0)
+    assert torch.equal(host_ref.mask_mmu_vit_ref(2, L, prefix_length=5, num_tokens=9), out["mmu_vit_allow"])
+    torch.save(out, os.path.join(OUT, "g4_masks.pt"))
+    print("G4 masks: oracle == reference (4 builders)")
+
+
+# ------------------------------------------------------------------ G5: sampling helpers + masking
+def golden_sampling():
+    import importlib
+    import math
+    ref_s = importlib.import_module("models.sampling")
+    from data.masking import mask_or_random_replace_tokens
+    out = {}
+    t = torch.linspace(0, 1, 11)
+    out["t"] = t
+    for name in ("cosine", "linear", "pow2", "pow0.5", "sigmoid"):
+        out["sched_" + name] = ref_s.get_mask_chedule(name)(t)
+    g = torch.Generator().manual_seed(5)
+    probs = torch.rand(3, 16, generator=g)
+    mask_len = torch.tensor([[3], [1], [9]])
+    out["probs"], out["mask_len"] = probs, mask_len
+    out["topk_mask"] = ref_s.mask_by_random_topk(mask_len, probs, 0.7, generator=torch.Generator().manual_seed(6))
+    logits = torch.randn(2, 50, generator=g)
+    out["filter_in"] = logits.clone()
+    out["filter_k5"] = ref_s.top_k_top_p_filtering(logits.clone(), top_k=5)
+    out["filter_p"] = ref_s.top_k_top_p_filtering(logits.clone(), top_p=0.8)
+    out["gumbel"] = ref_s.gumbel_noise(torch.zeros(2, 5), generator=torch.Generator().manual_seed(7))
+    # MaskGIT training-time masking with the global RNG seeded (data/masking.py draws rand(B) then rand(B,N))
+    cfgd = types.SimpleNamespace(training=types.SimpleNamespace(min_masking_rate=0.0, get=lambda k, d=None: d),
+                                 model=types.SimpleNamespace(codebook_size=20))
+    toks = torch.randint(312, 332, (4, 16), generator=g)
+    torch.manual_seed(123)
+    ids, labels, _, mp = mask_or_random_replace_tokens(toks, 332, cfgd, mask_schedule=ref_s.cosine_schedule)
+    torch.manual_seed(123)
+    ts, sc = torch.rand(4), torch.rand(4, 16)
+    i2, l2, mp2 = host_ref.maskgit_train_mask_ref(toks, 332, ts, sc, lambda x: torch.cos(x * math.pi * 0.5))
+    assert torch.equal(ids, i2) and torch.equal(labels, l2) and torch.equal(mp, mp2), "oracle masking != reference"
+    out.update(mask_tokens=toks, mask_ids=ids, mask_labels=labels, mask_prob=mp, mask_seed=123)
+    torch.save(out, os.path.join(OUT, "g5_sampling.pt"))
+    print("G5 sampling/masking: captured; oracle masking == reference")
+
+
+# ------------------------------------------------------------------ G2: tiny UniGen step
+TINY = dict(hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1,
+            rope_theta=1e6, rms_norm_eps=1e-6)
+
+
+def golden_unigen():
+    from models import UniGen
+    from training.prompting_utils import (UniversalPromptingQwen2, create_attention_mask_for_mmu,
+                                          create_attention_mask_predict_next)
+    tok = FakeTok()
+    NVQ, CODEBOOK, MAXTXT = 16, 20, 21
+    up = UniversalPromptingQwen2(tok, max_seq_len=MAXTXT + NVQ + 3, cond_dropout_prob=0.0, ignore_id=-100)
+    V = len(tok) + CODEBOOK + 1
+    assert len(tok) == 312 and V == 333
+    mask_id = V - 1
+    cfg = qwen2_ref.Qwen2Cfg(vocab_size=V, **TINY)
+    d = ref_shims.write_llm_config_dir(cfg.to_hf_dict())
+    torch.manual_seed(0)
+    model = UniGen(w_und_encoder=False, vocab_size=V, llm_vocab_size=len(tok), llm_model_path=d,
+                   codebook_size=CODEBOOK, num_vq_tokens=NVQ, load_from_pretrained=True)
+    model.train()
+    names = [(n, tuple(p.shape)) for n, p in model.llm.named_parameters()]
+    sd = weights.synth_llm_state(names, seed=21)
+    model.llm.load_state_dict(sd, strict=False)
+    assert model.llm.lm_head.weight.data_ptr() == model.llm.model.embed_tokens.weight.data_ptr()
+
+    g = torch.Generator().manual_seed(3)
+    img = torch.randint(0, CODEBOOK, (3, NVQ), generator=g) + len(tok)
+    ts, sc = torch.rand(2, generator=g), torch.rand(2, NVQ, generator=g)
+    import math
+    in_img, lab_img, _ = host_ref.maskgit_train_mask_ref(img[:2], mask_id, ts, sc, lambda x: torch.cos(x * math.pi * 0.5))
+    def rand_text(n):
+        return "".join(chr(97 + v) for v in torch.randint(0, 26, (n,), generator=g).tolist())
+    texts_s = [rand_text(5), rand_text(14)]
+    texts = tok(texts_s).input_ids
+    ids_t2i, _, lab_t2i = up((list(texts_s), in_img, lab_img), 't2i')
+    lm_s = [rand_text(17)]
+    lm_texts = tok(lm_s).input_ids
+    ids_lm, _, lab_lm = up((list(lm_s), ids_t2i.shape[-1]), 'lm')
+    ids_mmu, _, lab_mmu = up((img[2:3], [rand_text(9)]), 'mmu')
+    PAD, SOI, EOI = int(up.sptids_dict['<|pad|>']), int(up.sptids_dict['<|soi|>']), int(up.sptids_dict['<|eoi|>'])
+    m_t2i = create_attention_mask_predict_next(ids_t2i, pad_id=PAD, soi_id=SOI, eoi_id=EOI, rm_pad_in_image=True)
+    m_lm = create_attention_mask_predict_next(ids_lm, pad_id=PAD, soi_id=SOI, eoi_id=EOI)
+    m_mmu = create_attention_mask_for_mmu(ids_mmu, eoi_id=EOI)
+    input_ids = torch.cat([ids_t2i, ids_lm, ids_mmu])
+    labels = torch.cat([lab_t2i, lab_lm, lab_mmu])
+    mask = torch.cat([m_t2i, m_lm, m_mmu]).to(torch.float32)        # mask_dtype = embedding dtype (train.py:498-503,597)
+    kw = dict(batch_size_t2i=2, batch_size_lm=1, batch_size_mmu=1, max_seq_length=MAXTXT, num_vq_tokens=NVQ)
+
+    out = {"cfg": dict(TINY, vocab_size=V), "weight_seed": 21, "input_ids": input_ids, "labels": labels,
+           "mask_allow": (mask[:, 0] == 0), "kw": kw, "ids": dict(pad=PAD, soi=SOI, eoi=EOI, mask=mask_id, text_vocab=len(tok)),
+           "layout": dict(t2i_texts=texts, t2i_in=in_img, t2i_lab=lab_img, ids_t2i=ids_t2i, lab_t2i=lab_t2i,
+                          lm_texts=lm_texts, ids_lm=ids_lm, lab_lm=lab_lm, max_seq_len=up.max_seq_len,
+                          conv_start=tok("<|im_start|><|t2i|>user\n").input_ids,
+                          conv_end=tok("<|im_end|>\n<|im_start|>assistant\n").input_ids)}
+
+    lm_ref = qwen2_ref.RefCausalLM(cfg)
+    lm_ref.load_state_dict(sd, strict=False)
+
+    for mode, ac in (("fp32", False), ("bf16", True)):
+        model.zero_grad(set_to_none=True)
+        ctx = torch.autocast("cpu", dtype=torch.bfloat16) if ac else torch.autocast("cpu", enabled=False)
+        with ctx:
+            logits, l1, l2, l3 = model(input_ids=input_ids, attention_mask=mask, labels=labels, **kw)
+        loss = 1.0 * l1.float() + 0.1 * l2.float() + 1.0 * l3.float()
+        loss.backward()
+        grads = {n: p.grad.detach().clone() for n, p in model.llm.named_parameters()}
+        # --- the oracle, same inputs
+        lm_ref.zero_grad(set_to_none=True)
+        lo, r1, r2, r3 = qwen2_ref.unigen_forward_ref(lm_ref, input_ids, mask, labels, autocast=ac, **{k: v for k, v in kw.items() if k != "max_seq_length"})
+        (1.0 * r1 + 0.1 * r2 + 1.0 * r3).backward()
+        gd = max(maxdiff(grads[n], p.grad) for n, p in lm_ref.named_parameters())
+        print(f"G2[{mode}] oracle vs reference: logits {maxdiff(lo, logits):.3e}  losses "
+              f"{abs(r1.item()-l1.item()):.2e} {abs(r2.item()-l2.item()):.2e} {abs(r3.item()-l3.item()):.2e}  grads {gd:.3e}")
+        assert maxdiff(lo, logits) == 0 and gd == 0, "oracle is not bit-identical to the reference on CPU"
+        out[mode] = {"logits": logits.detach().to(torch.bfloat16 if ac else torch.float32),
+                     "losses": torch.stack([l1.detach().float(), l2.detach().float(), l3.detach().float()]),
+                     "grad_norms": {n: gg.norm().item() for n, gg in grads.items()},
+                     "grads_small": {n: gg for n, gg in grads.items() if gg.numel() <= 4096},
+                     "grad_embed_rows": grads["model.embed_tokens.weight"][[0, 5, 300, 303, 304, 312, 320, 332]],
+                     "grad_q0_rows": grads["model.layers.0.self_attn.q_proj.weight"][:4],
+                     "grad_down1_rows": grads["model.layers.1.mlp.down_proj.weight"][:4]}
+        if ac:      # one AdamW step exactly like training/train.py:291-330 (decay all but names containing 'bias')
+            decay = [p for n, p in model.named_parameters() if "bias" not in n]
+            nodecay = [p for n, p in model.named_parameters() if "bias" in n]
+            opt = torch.optim.AdamW([{"params": decay, "weight_decay": 0.01}, {"params": nodecay, "weight_decay": 0.0}],
+                                    lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
+            opt.step()
+            after = dict(model.llm.named_parameters())
+            out[mode]["adamw"] = {"lr": 1e-3, "q0_rows": after["model.layers.0.self_attn.q_proj.weight"][:4].detach().clone(),
+                                  "bias": after["model.layers.0.self_attn.q_proj.bias"].detach().clone(),
+                                  "norm": after["model.norm.weight"].detach().clone()}
+            model.llm.load_state_dict(sd, strict=False)
+    # --- G6: MaskGIT trajectory (4 steps, CFG, CPU generator) on the same tiny model, fp32 like the eval scripts
+    model.eval()
+    gen_ids = ids_t2i.clone()
+    gen_ids[:, -(NVQ + 1):-1] = mask_id
+    un_ids = gen_ids.clone()
+    un_ids[:, :-(NVQ + 2)] = PAD     # "empty prompt" rows
+    am = torch.cat([m_t2i, create_attention_mask_predict_next(un_ids, pad_id=PAD, soi_id=SOI, eoi_id=EOI, rm_pad_in_image=True)]).float()
+    with torch.no_grad():
+        traj = model.t2i_generate(input_ids=gen_ids, uncond_input_ids=un_ids, attention_mask=am, guidance_scale=2.0,
+                                  temperature=1.0, timesteps=4, noise_schedule=__import__("models.sampling", fromlist=["x"]).cosine_schedule,
+                                  generator=torch.Generator().manual_seed(9), image_token_num_per_image=NVQ,
+                                  text_vocab_size=len(tok))
+    out["maskgit"] = {"input_ids": gen_ids, "uncond_ids": un_ids, "mask_allow": (am[:, 0] == 0), "seed": 9, "steps": 4,
+                      "scale": 2.0, "result": traj}
+    torch.save(out, os.path.join(OUT, "g2_tiny_unigen.pt"))
+    print("G2/G6 tiny UniGen: captured")
+
+
+# ------------------------------------------------------------------ G1: MAGVITv2
+def golden_magvit():
+    from models import MAGVITv2
+    torch.manual_seed(0)
+    vq = MAGVITv2().eval()
+    ref_shapes = [(n, tuple(p.shape)) for n, p in vq.named_parameters()]
+    mine = magvit_ref.magvit_param_shapes()
+    assert sorted(ref_shapes) == sorted(mine), "oracle parameter inventory != reference"
+    sd = weights.synth_magvit_state(ref_shapes, seed=31)
+    missing = vq.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys and all(k.startswith("quantize.") for k in missing.missing_keys)
+    x = weights.synth_images(2, 256, seed=32)
+    with torch.no_grad():
+        z = vq.encoder(x)
+        idx = vq.get_code(x)
+        rec = vq.decode_code(idx)
+        z_o = magvit_ref.encode_z_ref(sd, x)
+        idx_o = magvit_ref.get_code_ref(sd, x)
+        rec_o = magvit_ref.decode_code_ref(sd, idx)
+    print(f"G1 oracle vs reference: z {maxdiff(z, z_o):.3e} idx_equal {torch.equal(idx, idx_o)} rec {maxdiff(rec, rec_o):.3e}"
+          f"  |z| mean {z.abs().mean():.3f} min {z.abs().min():.2e}")
+    assert torch.equal(idx, idx_o)
+    out = {"weight_seed": 31, "image_seed": 32, "z": z, "indices": idx, "rec_crop": rec[:, :, 96:160, 96:160].clone(),
+           "rec_mean": rec.mean(dim=(2, 3)), "rec_std": rec.std(dim=(2, 3)), "rec_sum": rec.double().sum().item(),
+           "n_params": sum(p.numel() for p in vq.parameters())}
+    torch.save(out, os.path.join(OUT, "g1_magvit.pt"))
+    print("G1 MAGVITv2: captured")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["masks", "sampling", "unigen", "magvit"]
+    if "masks" in which:
+        golden_masks()
+    if "sampling" in which:
+        golden_sampling()
+    if "unigen" in which:
+        golden_unigen()
+    if "magvit" in which:
+        golden_magvit()
