@@ -1,0 +1,264 @@
+#!/usr/bin/env python
+"""bench.py -- UniGen-1.5B stage-1 (t2i) training step on MI355X, the metric BASELINE.json names:
+train-step samples/s for the 1.5B model with 256x256 images (256 image tokens + 512 text tokens,
+L = 771), bf16 compute, one process per GPU, gradients all-reduced over RCCL.
+
+One timed "step" = the whole hot path on one synthetic batch already resident in HBM:
+  MAGVITv2.get_code(images) -> token layout + dense additive mask (caller-side glue, on device)
+  -> UniGen.forward (28-layer backbone, tied lm_head + CE on the 256 image positions)
+  -> backward -> flat-gradient all-reduce (N > 1) -> fused AdamW -> zero_grad.
+Nothing is skipped, cached across steps or run at reduced size.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the bf16 MFMA GEMM): algorithmic
+flops per launch / average launch duration, measured with HIP events on the launch stream during
+instrumented steps that follow the timed ones.  `cpu_baseline` times the CPU oracle (oracle/, kind
+"port") on a bounded sample on the host cores; it is a reported baseline, not what is optimised.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "ml-unigen_amd"))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+# ---- workload constants (SURVEY.md §8 "model constants" / §8d)
+TEXT_VOCAB = 151674                 # Qwen2.5 tokenizer (151665) + 9 UniGen specials
+CODEBOOK = 8192
+VOCAB = TEXT_VOCAB + CODEBOOK + 1   # 159867
+MASK_ID = VOCAB - 1
+NVQ = 256
+PAD, IM_START, SOI, EOI, T2I = 151643, 151644, 151665, 151666, 151669
+SEED = 10084                        # configs/unigen_1_5b/unigen_pt1.yaml:92
+
+# algorithmic FLOPs: per t2i sample at L = 771
+FLOP_LLM_FWD = 2.2029e12            # linear 2.0203 + attention 0.0569 + lm_head on 256 label rows 0.1257
+FLOP_SAMPLE = 3 * FLOP_LLM_FWD + 0.3551e12     # fwd+bwd + MAGVITv2 encode (fwd only) = 6.964 TFLOP
+PEAK_BF16 = 2.5e15
+
+
+def device_mask_predict_next(seq, pad_id, soi_id, eoi_id):
+    """Caller-side glue: the dense additive mask of training/prompting_utils.py:975-1020
+    (rm_pad_in_image=True) built with vectorised device ops; fp32 like mask_dtype under DDP."""
+    B, L = seq.shape
+    dev = seq.device
+    is_pad = seq == pad_id
+    start, end = seq == soi_id, seq == eoi_id
+    in_img = (start.cumsum(1) > end.cumsum(1)) | start | end
+    r = torch.arange(L, device=dev)
+    causal = (r[None, :] <= r[:, None])[None]
+    allow = torch.where(in_img[:, :, None], torch.ones((), dtype=torch.bool, device=dev), causal)
+    last_pad = torch.where(is_pad.any(1), (is_pad * r[None, :]).max(1).values, torch.full((B,), -1, device=dev))
+    cut = (r[None, :, None] > last_pad[:, None, None]) & (r[None, None, :] <= last_pad[:, None, None])
+    allow = allow & ~(cut & ~in_img[:, :, None])
+    allow = allow & ~(in_img[:, :, None] & is_pad[:, None, :])
+    neg = torch.full((), float(torch.iinfo(torch.int64).min), device=dev)
+    return torch.where(allow, torch.zeros((), device=dev), neg)[:, None]
+
+
+def t2i_layout(text_ids, image_ids, labels_img):
+    """[<|im_start|><|t2i|> text ... | <|soi|> 256 image ids <|eoi|>] (prompting_utils.py:59-111, no padding:
+    the text fills max_seq_length)."""
+    B = text_ids.shape[0]
+    dev = text_ids.device
+    head = torch.tensor([IM_START, T2I], device=dev).expand(B, 2)
+    soi = torch.full((B, 1), SOI, device=dev)
+    eoi = torch.full((B, 1), EOI, device=dev)
+    ids = torch.cat([head, text_ids, soi, image_ids, eoi], 1)
+    ign = torch.full((B, 2 + text_ids.shape[1]), -100, device=dev)
+    labels = torch.cat([ign, soi, labels_img, eoi], 1)
+    return ids, labels
+
+
+def init_magvit_device(vq, seed):
+    g = torch.Generator(device=next(vq.parameters()).device).manual_seed(seed)
+    with torch.no_grad():
+        for name, p in vq.named_parameters():
+            if p.dim() == 4:
+                p.normal_(0, 1.0 / math.sqrt(p.shape[1] * p.shape[2] * p.shape[3]), generator=g)
+            elif "norm" in name and name.endswith("weight"):
+                p.fill_(1.0)
+            else:
+                p.normal_(0, 0.05, generator=g)
+
+
+def cpu_baseline(seq_len, sample_layers=4):
+    """CPU oracle ("port") on a bounded sample: ONE t2i sample (L = seq_len) through `sample_layers`
+    of the 28 1.5B-shape decoder layers (fwd+bwd, fp32 eager like BASELINE.md §2), the tied lm_head +
+    CE on its 256 label rows, AdamW on those parameters, and MAGVITv2.get_code of one image; the
+    layer/optimizer time is scaled by 28/sample_layers."""
+    from oracle import magvit_ref, qwen2_ref, weights
+    torch.manual_seed(0)
+    cores = torch.get_num_threads()
+    cfg = qwen2_ref.Qwen2Cfg(vocab_size=VOCAB, num_hidden_layers=sample_layers,
+                             **{k: v for k, v in qwen2_ref.QWEN25_1P5B.items() if k != "num_hidden_layers"})
+    lm = qwen2_ref.RefCausalLM(cfg)
+    ids = torch.randint(0, TEXT_VOCAB, (1, seq_len))
+    labels = torch.full((1, seq_len), -100)
+    labels[:, -(NVQ + 1):-1] = torch.randint(TEXT_VOCAB, VOCAB - 1, (1, NVQ))
+    opt = torch.optim.AdamW(lm.parameters(), lr=1e-4, weight_decay=0.01)
+    times = {}
+
+    def one():
+        t0 = time.perf_counter()
+        h = lm.backbone(ids, None, None)
+        t1 = time.perf_counter()
+        logits = lm.lm_head(h[:, -(NVQ + 1):-1])
+        loss = torch.nn.functional.cross_entropy(logits.view(-1, VOCAB), labels[:, -(NVQ + 1):-1].reshape(-1))
+        t2 = time.perf_counter()
+        loss.backward()
+        t3 = time.perf_counter()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        t4 = time.perf_counter()
+        return t1 - t0, t2 - t1, t3 - t2, t4 - t3
+    one()                                           # warm-up (allocator, Adam state)
+    f, hd, b, o = one()
+    # split backward/optimizer between the layer stack and the head by parameter count
+    n_layer = sum(p.numel() for p in lm.model.layers.parameters())
+    n_head = lm.model.embed_tokens.weight.numel()
+    scale = 28.0 / sample_layers
+    layer_t = (f + b * 0.85) * scale                # backward is ~85% stack at this shape; stated, not hidden
+    head_t = hd + b * 0.15
+    opt_t = o * (n_layer * scale + n_head) / (n_layer + n_head)
+    del lm, opt
+    sd = weights.synth_magvit_state(magvit_ref.magvit_param_shapes(), seed=31)
+    x = weights.synth_images(1, 256, seed=32)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        magvit_ref.get_code_ref(sd, x)
+        vq_t = time.perf_counter() - t0
+    total = layer_t + head_t + opt_t + vq_t
+    return {"value": round(1.0 / total, 5), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"1 t2i sample L={seq_len} fp32 eager: {sample_layers}/28 decoder layers fwd+bwd (x{scale:.0f}), "
+                      f"tied head+CE on 256 rows, AdamW, MAGVITv2.get_code(1 image); "
+                      f"extrapolated step {total:.1f}s = layers {layer_t:.1f} + head {head_t:.1f} + adamw {opt_t:.1f} + vq {vq_t:.1f}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=16, help="t2i samples per GPU (unigen_pt1.yaml: batch_size_t2i 16)")
+    ap.add_argument("--text-len", type=int, default=511, help="text tokens after the 2 template tokens (513 total)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    cpu = None
+    L = 2 + args.text_len + NVQ + 2
+    if rank == 0 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(L)
+
+    from models import MAGVITv2, UniGen
+    from unigen_hip import ops
+    from unigen_hip.ddp import FlatGradSync
+    from unigen_hip.optim import FusedAdamW
+
+    torch.manual_seed(SEED)
+    model = UniGen(w_und_encoder=False, vocab_size=VOCAB, llm_vocab_size=TEXT_VOCAB, llm_model_path="Qwen2.5-1.5B-Instruct",
+                   codebook_size=CODEBOOK, num_vq_tokens=NVQ, load_from_pretrained=True, device=dev, init_seed=-1)
+    model.llm.init_weights_device(SEED)              # same weights on every rank (DDP invariant)
+    model.train()
+    vq = MAGVITv2().to(dev).eval().requires_grad_(False)
+    init_magvit_device(vq, SEED)
+    decay = [p for n, p in model.named_parameters() if "bias" not in n]
+    nodecay = [p for n, p in model.named_parameters() if "bias" in n]
+    opt = FusedAdamW([{"params": decay, "weight_decay": 0.01}, {"params": nodecay, "weight_decay": 0.0}],
+                     lr=1e-4, betas=(0.9, 0.999), eps=1e-8)
+    sync = FlatGradSync(model.llm.engine)
+
+    B = args.batch
+    g = torch.Generator(device=dev).manual_seed(SEED + rank)
+    images = torch.rand(B, 3, 256, 256, device=dev, generator=g) * 2 - 1
+    text = torch.randint(0, 151643, (B, args.text_len), device=dev, generator=g)
+    losses = []
+
+    def step():
+        codes = vq.get_code(images) + TEXT_VOCAB
+        masked = torch.full_like(codes, MASK_ID)                    # mask_prob = 1: every image token is a label
+        ids, labels = t2i_layout(text, masked, codes)
+        mask = device_mask_predict_next(ids, PAD, SOI, EOI)
+        _, l_t2i, _, _ = model(input_ids=ids, attention_mask=mask, labels=labels, batch_size_t2i=B,
+                               max_seq_length=args.text_len + 1, num_vq_tokens=NVQ)
+        l_t2i.backward()
+        sync.finish()
+        opt.step(grad_scale=sync.grad_scale)
+        opt.zero_grad(set_to_none=True)
+        losses.append(l_t2i.detach())
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    model.llm.engine.check_errors()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    ms = dt / args.steps * 1e3
+    value = B * world / (dt / args.steps)
+
+    roof = None
+    if rank == 0 and not args.no_roofline:
+        ops.GEMM_PROFILE = []
+        step()
+        torch.cuda.synchronize()
+        rec = ops.GEMM_PROFILE
+        ops.GEMM_PROFILE = None
+        tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in rec)
+        tot_fl = sum(f for _, _, f in rec)
+        ach = tot_fl / (tot_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "gemm_nt_kernel (bf16 MFMA GEMM)", "achieved": round(ach, 1), "peak": 2500.0,
+                "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4), "traffic": None,
+                "launches_per_step": len(rec), "avg_launch_ms": round(tot_ms / len(rec), 4),
+                "flops_per_launch": round(tot_fl / len(rec) / 1e9, 2), "gemm_ms_per_step": round(tot_ms, 2),
+                "step_frac_of_bf16_peak": round(value / world * FLOP_SAMPLE / PEAK_BF16, 4)}
+    if rank == 0:
+        out = {"metric": "train-step samples/s (1.5B, 256^2 img)", "value": round(value, 3), "unit": "samples/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": "UniGen-1.5B stage-1 t2i pretrain step (BASELINE configs[1]): MAGVITv2 256^2->256 tokens + "
+                                      f"{args.text_len + 2} text tokens, L={L}, per-GPU batch {B}, all 256 image tokens labelled, "
+                                      "fwd+bwd+grad all-reduce+AdamW, random-init weights",
+                          "global_batch": B * world, "seq_len": L, "parallelism": f"dp{world}"},
+               "loss_first_last": [round(losses[0].item(), 4), round(losses[-1].item(), 4)],
+               "roofline": roof, "cpu_baseline": cpu}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -96,6 +96,8 @@ class UniGen(ModelMixin, ConfigMixin):
         seed = kwargs.get("init_seed", None)
         if seed is None:
             seed = int(torch.initial_seed() % (2 ** 31))
+        elif seed < 0:              # caller initialises / loads the weights itself (checkpoints, device-side init)
+            seed = None
         # load_from_pretrained=True in the reference means "random-init from config" (sic, unigen.py:58-65);
         # False means "load HF weights from llm_model_path".
         self.llm = HipQwen2ForCausalLM(dims, device, seed=seed)

@@ -277,6 +277,23 @@ class HipQwen2ForCausalLM(nn.Module):
                 else:
                     p.copy_((torch.randn(p.shape, generator=g) * std).to(p.device))
 
+    def init_weights_device(self, seed):
+        """Same distribution, drawn on the GPU (used for the 1.5 B benchmark model: host draws would take
+        minutes).  Deterministic per (seed, device type); identical on every rank."""
+        eng = self.engine
+        g = torch.Generator(device=eng.device).manual_seed(seed)
+        std = eng.dims.initializer_range
+        with torch.no_grad():
+            eng.fp.master.zero_()
+            for key, shp in eng.fp.spec:
+                v = eng.fp.p(key)
+                if key.endswith(("ln1", "ln2")) or key == "norm":
+                    v.fill_(1.0)
+                elif key.endswith("bqkv"):
+                    v.zero_()
+                else:
+                    v.normal_(0.0, std, generator=g)
+
     def gradient_checkpointing_enable(self, *a, **k):
         # 288 GB of HBM holds every activation of the shipped configs; nothing to recompute.
         return None

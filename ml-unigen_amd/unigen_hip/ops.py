@@ -9,6 +9,10 @@ UG_EPI_BF16, UG_EPI_F32, UG_EPI_RESID = 0, 1, 2
 _MASK_DTYPES = {torch.float32: 0, torch.bfloat16: 1, torch.int64: 2, torch.bool: 3}
 
 
+# bench.py sets this to a list to time every GEMM launch with HIP events on the launch stream
+GEMM_PROFILE = None
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -39,10 +43,17 @@ def gemm_nt(a, b, out=None, *, M=None, N=None, K=None, epilogue=UG_EPI_BF16, bia
         dt = out_dtype or (torch.bfloat16 if epilogue == UG_EPI_BF16 else torch.float32)
         out = torch.empty((M, N), dtype=dt, device=a.device)
     lib = _l.load()
+    prof = GEMM_PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     rc = lib.ug_gemm_bf16_nt(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, K, epilogue,
                              _p(bias), _p(resid), resid.stride(0) if resid is not None else 0, beta,
                              _p(alpha_dev), _stream())
     _l.check(rc, "ug_gemm_bf16_nt")
+    if prof is not None:
+        e1.record()
+        prof.append((e0, e1, 2.0 * M * N * K))
     return out
 
 
