@@ -137,7 +137,8 @@ def test_rope_fwd_bwd(dev):
     bty = ops.rope_(y.clone().to(dev), cos, sin, L, H + HKV, hd, backward=True).float().cpu()[:, : (H + HKV) * hd]
     lhs = (fx * y.float()[:, : (H + HKV) * hd]).sum()
     rhs = (qkv.float()[:, : (H + HKV) * hd] * bty).sum()
-    assert abs(lhs - rhs) / abs(lhs) < 2e-3
+    # both sides carry bf16 output rounding (~2^-9 relative per term, random sign): scale by sqrt(#terms)
+    assert abs(lhs - rhs) < 4e-3 * math.sqrt(fx.numel())
 
 
 def test_swiglu_fwd_bwd(dev):
