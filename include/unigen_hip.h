@@ -32,7 +32,10 @@ const char* ug_last_error(void);
 int ug_abi_version(void);
 
 /* ---- dense contraction ------------------------------------------------------------------- */
-/* C[M,N] = A[M,K] . B[N,K]^T, bf16 operands, fp32 accumulate, K % 64 == 0.
+/* C[M,N] = opA . opB^T, bf16 operands, fp32 accumulate.  Each operand is given either row-major
+ * (k contiguous: A[M][K] lda, B[N][K] ldb) or k-major (A[K][M] lda, B[K][N] ldb; a_kmajor/b_kmajor = 1),
+ * so forward (0,0), dgrad (0,1: B = W[N_out][K_in]) and wgrad (1,1: contraction over tokens) need no
+ * transposed copies.  K is the true contraction length (no padding; see gemm_bf16.hip for the K%8 rule).
  * epilogue: 0 = bf16 out (+ optional bf16 bias[N])
  *           1 = fp32 out, C = (beta ? C : 0) + alpha * acc   (alpha read from device if non-null)
  *           2 = fp32 residual: C = resid + bf16round(acc)
@@ -41,13 +44,13 @@ int ug_abi_version(void);
 #define UG_EPI_BF16 0
 #define UG_EPI_F32 1
 #define UG_EPI_RESID 2
-int ug_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
-                    int64_t M, int64_t N, int64_t K, int epilogue, const void* bias,
-                    const float* resid, int64_t ldr, int beta, const float* alpha_dev, hipStream_t stream);
-int ug_gemm_set_variant(int v); /* 0 = LDS-DMA staging (default), 1 = register staging (A/B arm) */
+int ug_gemm_bf16(const void* A, int64_t lda, int a_kmajor, const void* B, int64_t ldb, int b_kmajor,
+                 void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int epilogue, const void* bias,
+                 const float* resid, int64_t ldr, int beta, const float* alpha_dev, hipStream_t stream);
+int ug_gemm_set_tile_policy(int policy); /* -1 auto (default), 0 = two LDS stages, 2 = one LDS stage: A/B benchmarking */
 
 /* in [R,C] (fp32 if in_f32 else bf16) -> out bf16 [R,C] (optional) and outT bf16 [C,ldT] with
- * columns R..ldT-1 zero-filled.  Feeds the K-contiguous operands of wgrad / dgrad GEMMs. */
+ * columns R..ldT-1 zero-filled (layout utility; the training path no longer needs it). */
 int ug_transpose_cast(const void* in, int in_f32, int64_t ld_in, void* out, int64_t ld_out, void* outT,
                       int64_t ldT, int64_t R, int64_t C, hipStream_t stream);
 int ug_cast_f32_bf16(const float* in, void* out, int64_t n, hipStream_t stream);

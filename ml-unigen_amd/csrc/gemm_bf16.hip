@@ -1,29 +1,51 @@
-// bf16 MFMA GEMM for gfx950:  C[M,N] = A[M,K] · B[N,K]^T   (both operands K-contiguous, "NT").
+// bf16 MFMA GEMM for gfx950, fp32 accumulate:   C[M,N] = opA . opB^T
 //
-// This is the only dense-contraction kernel of the Qwen2.5 backbone (reference call sites:
-// transformers Qwen2Attention q/k/v/o_proj, Qwen2MLP gate/up/down_proj and UniGen's lm_head,
-// models/unigen.py:274-287).  Dgrad and wgrad reuse it: the host keeps W^T copies of the weights
-// and transposes activations with ug_transpose_* so every contraction is K-contiguous.
+// The only dense-contraction kernel of the Qwen2.5 backbone (reference call sites: transformers
+// Qwen2Attention q/k/v/o_proj, Qwen2MLP gate/up/down_proj, UniGen's tied lm_head --
+// models/unigen.py:274-287 -- and their autograd dgrad / wgrad).  Each operand can be given in
+// either storage order, so forward, dgrad and wgrad all run on it with no transposed copies:
+//     row-major "RowK":  X[row][k]   (k contiguous)          A: [M][K] lda      B: [N][K] ldb
+//     k-major   "KRow":  X[k][row]   (row contiguous)        A: [K][M] lda      B: [K][N] ldb
+//   forward  y = x W^T        : A = x   RowK, B = W  RowK
+//   dgrad    dx = dy W        : A = dy  RowK, B = W  KRow   (W is [N_out][K_in] = [k][row])
+//   wgrad    dW = dy^T x      : A = dy  KRow, B = x  KRow   (contraction over tokens)
 //
 // Structure: 128x128 tile, BK=64, 4 waves (2x2, 64x64 per wave = 4x4 mfma_f32_16x16x32_bf16
-// fragments), operands staged HBM->LDS with 16-byte LDS-DMA (global_load_lds), two LDS buffers
-// (tile k+1 in flight while tile k feeds the matrix pipe, one barrier per k-tile), XOR-swizzled
-// LDS image (swizzle applied to the per-lane SOURCE address because LDS-DMA writes lane-linear),
-// XCD-aware grouped tile order, operands passed swapped to the MFMA so each lane ends up with
-// four consecutive output columns (8/16-byte epilogue stores).
+// fragments), operands staged HBM->LDS with 16-byte LDS-DMA (global_load_lds).  Two pipelining
+// modes, chosen per launch (measured on MI355X, tools/gemm_bench.py):
+//   single LDS stage (32 KiB, <=128 VGPRs -> 4 workgroups/CU): latency is hidden by the other resident
+//     workgroups; fastest for almost every backbone shape (e.g. dgrad 1536x8960: 1017 vs 772 TF/s);
+//   two LDS stages (64 KiB, 2 workgroups/CU, tile k+1's DMA under tile k's MFMAs): kept for long-K
+//     row-major forward GEMMs where it is ~5 % ahead.
+// A 256x128 / 8-wave / 3-stage counted-vmcnt variant was measured 10-25 % SLOWER on every shape
+// (one lock-stepped workgroup per CU) and removed.  Small weight-gradient outputs (fewer tiles than
+// CUs) are split along K across gridDim.y with fp32 atomics into the (already accumulating) output.
+// LDS images are
+// XOR-swizzled through the per-lane SOURCE address (LDS-DMA writes lane-linear):
+//     RowK tile [128 rows][8 chunks]:  chunk ^= (row>>1)&7        -> conflict-free ds_read_b128
+//     KRow tile [64 k][16 chunks]:     chunk ^= h(k)<<1, h(k) = (k&3)|((k>>3)&1)<<2
+//                                      -> conflict-free ds_read_b64_tr_b16 (hardware transpose read:
+//                                         lane i of a 16-lane group receives column i of the 4x16
+//                                         block whose row j is the 4 pieces addressed by lanes 4j..4j+3)
+// Out-of-range contraction rows/chunks are fetched from a zero page, so K needs no padding in KRow
+// mode; M/N edges are clamped on load and guarded on store.  XCD-aware grouped tile order; operands
+// are passed swapped to the MFMA so each lane ends up with four consecutive output columns.
 #include "common.h"
 #include "unigen_hip.h"
 
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;   // 16 KiB per operand tile
+constexpr int TILE_BYTES = BM * BK * 2;   // 16 KiB per operand tile (either layout)
 constexpr int GROUP_M = 8;
 
 enum Epi { EPI_BF16 = 0, EPI_F32 = 1, EPI_RESID = 2 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+__device__ __attribute__((aligned(16))) uint32_t g_zero_page[64];   // 256 B of zeros: source of masked DMA lanes
 
 struct GemmArgs {
   const bf16_t* A; const bf16_t* B; void* C;
@@ -36,110 +58,96 @@ struct GemmArgs {
   int tiles_m, tiles_n;
 };
 
-// LDS image of one operand tile: [128 rows][8 chunks of 16 B]; chunk c of row r lives at
-// physical chunk c ^ ((r >> 1) & 7)  -> ds_read_b128 fragment reads are bank-conflict free.
-__device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+__device__ __forceinline__ int swz_rowk(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+__device__ __forceinline__ int swz_krow(int k, int chunk) { return chunk ^ ((((k & 3) | (((k >> 3) & 1) << 2))) << 1); }
 
-template <bool DMA>
-__device__ __forceinline__ void stage_tile(const bf16_t* const (&src)[4], int koff, char* lds_tile,
-                                           int wave, int lane) {
-  // instruction i of wave w fills LDS bytes [(i*4+w)*1024, +1024): rows (i*4+w)*8 .. +8
+// Per-lane staging plan for one operand tile of ROWS rows x 64 k, staged by NW waves: NI = ROWS/(8*NW)
+// 1-KiB DMA instructions per wave per k-tile.  Lanes whose source lies outside the operand point at
+// the zero page with a zero stride, so the steady-state loop is branch-free; only a ragged LAST k-tile
+// takes the checked path.
+template <bool KMAJOR, int ROWS, int NW>
+struct Stager {
+  static constexpr int NI = ROWS / (8 * NW);
+  const bf16_t* src[NI];   // source for k-tile 0 (zero page for statically masked lanes)
+  int64_t step[NI];        // elements to advance per k-tile (0 for zero-page lanes)
+  int kofs[NI];            // contraction offset inside the tile of what this lane fetches (k-row, or chunk*8)
+  __device__ __forceinline__ void init(const bf16_t* X, int64_t ld, int row0, int rows_total, int wave, int lane) {
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
+    constexpr int CPR = ROWS / 8;          // 16-byte chunks per k-row of a k-major tile
+    constexpr int KPI = 64 / CPR;          // k-rows covered by one 1-KiB instruction
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if constexpr (DMA) {
-      char* dst = lds_tile + (i * 4 + wave) * 1024;   // wave-uniform; HW adds lane*16
-      __builtin_amdgcn_global_load_lds((gptr_t)(src[i] + koff), (lptr_t)dst, 16, 0, 0);
-    } else {
-      const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(src[i] + koff);
-      *reinterpret_cast<bf16x8_t*>(lds_tile + (i * 4 + wave) * 1024 + lane * 16) = v;
+    for (int i = 0; i < NI; ++i) {
+      const int inst = i * NW + wave;
+      if constexpr (!KMAJOR) {
+        const int row = inst * 8 + (lane >> 3);
+        const int chunk = swz_rowk(row, lane & 7);
+        const int r = min(row0 + row, rows_total - 1);          // clamped: products land in discarded rows
+        src[i] = X + (int64_t)r * ld + chunk * 8;
+        step[i] = BK;
+        kofs[i] = chunk * 8;
+      } else {
+        const int k = inst * KPI + lane / CPR;
+        const int chunk = swz_krow(k, lane % CPR);
+        const int col = row0 + chunk * 8;
+        const bool ok = (col + 8 <= ld);
+        src[i] = ok ? X + (int64_t)k * ld + col : zero;
+        step[i] = ok ? (int64_t)BK * ld : 0;
+        kofs[i] = k;
+      }
     }
+  }
+  template <bool CHECK>
+  __device__ __forceinline__ void issue(int kt, int K, char* lds_tile, int wave) const {
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const bf16_t* s = src[i] + kt * step[i];
+      if constexpr (CHECK) {
+        // past the contraction extent: zero page.  (row-major operands are fetched in 8-element chunks;
+        // the chunk straddling K is read whole -- its tail must be finite, see the entry-point contract)
+        const bool past = kt * BK + kofs[i] >= (KMAJOR ? K : ((K + 7) & ~7));
+        s = reinterpret_cast<const bf16_t*>(past ? reinterpret_cast<uintptr_t>(zero) : reinterpret_cast<uintptr_t>(s));
+      }
+      char* dst = lds_tile + (i * NW + wave) * 1024;            // wave-uniform; HW adds lane*16
+      __builtin_amdgcn_global_load_lds((gptr_t)s, (lptr_t)dst, 16, 0, 0);
+    }
+  }
+};
+
+// MFMA fragment (16 rows x 32 k) for rows r0.., k-step ks, from either LDS image (ROWS = tile rows)
+template <bool KMAJOR, int ROWS>
+__device__ __forceinline__ bf16x8_t load_frag(const char* tile, int r0, int ks, int lane) {
+  if constexpr (!KMAJOR) {
+    const int row = r0 + (lane & 15);
+    const int chunk = swz_rowk(row, ks * 4 + (lane >> 4));
+    return *reinterpret_cast<const bf16x8_t*>(tile + row * 128 + chunk * 16);
+  } else {
+    const int i16 = lane & 15, g = lane >> 4;
+    const int k = ks * 32 + g * 8 + (i16 >> 2);                 // rows k..k+3 <-> lanes 4j..4j+3 of the group
+    const int chunk = (r0 >> 3) + ((i16 & 3) >> 1);
+    const int sub = (i16 & 1) * 8;
+    const char* p0 = tile + k * (ROWS * 2) + swz_krow(k, chunk) * 16 + sub;
+    const char* p1 = tile + (k + 4) * (ROWS * 2) + swz_krow(k + 4, chunk) * 16 + sub;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p0);
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p1);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
   }
 }
 
-template <int EPI, bool DMA>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
-  __shared__ __attribute__((aligned(16))) char lds[4 * TILE_BYTES];   // A0 B0 A1 B1
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-
-  // ---- tile coordinates: XCD-contiguous chunks, GROUP_M row panels swept column-major
-  const int nwg = p.tiles_m * p.tiles_n;
-  const int pid = xcd_remap(blockIdx.x, nwg);
-  const int per_group = GROUP_M * p.tiles_n;
-  const int gid = pid / per_group, first_m = gid * GROUP_M;
-  const int gsz = min(p.tiles_m - first_m, GROUP_M);
-  const int tm = first_m + (pid % per_group) % gsz;
-  const int tn = (pid % per_group) / gsz;
-  const int m0 = tm * BM, n0 = tn * BN;
-
-  // ---- per-lane source pointers for the 4+4 staging instructions (rows clamped: an out-of-range
-  // row re-reads the last valid row, its products are discarded by the guarded epilogue)
-  const bf16_t* srcA[4]; const bf16_t* srcB[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int row = (i * 4 + wave) * 8 + (lane >> 3);
-    const int chunk = swz(row, lane & 7);           // logical k-chunk this lane fetches
-    const int ra = min(m0 + row, p.M - 1), rb = min(n0 + row, p.N - 1);
-    srcA[i] = p.A + (int64_t)ra * p.lda + chunk * 8;
-    srcB[i] = p.B + (int64_t)rb * p.ldb + chunk * 8;
-  }
-
-  f32x4_t acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  // fragment read offsets (bytes inside a tile) for k-step 0; k-step 1 flips chunk bit 2
-  int offA[4], offB[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int ra = wm * 64 + i * 16 + (lane & 15), rb = wn * 64 + i * 16 + (lane & 15);
-    offA[i] = ra * 128 + swz(ra, lane >> 4) * 16;
-    offB[i] = rb * 128 + swz(rb, lane >> 4) * 16;
-  }
-
-  const int nk = p.K / BK;
-  stage_tile<DMA>(srcA, 0, lds, wave, lane);
-  stage_tile<DMA>(srcB, 0, lds + TILE_BYTES, wave, lane);
-  __syncthreads();   // hipcc drains vmcnt(0) for in-flight LDS-DMA here
-
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) {
-      char* nxt = lds + (cur ^ 1) * 2 * TILE_BYTES;
-      stage_tile<DMA>(srcA, (kt + 1) * BK, nxt, wave, lane);
-      stage_tile<DMA>(srcB, (kt + 1) * BK, nxt + TILE_BYTES, wave, lane);
-    }
-    const char* tA = lds + cur * 2 * TILE_BYTES;
-    const char* tB = tA + TILE_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8_t fa[4], fb[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        fa[i] = *reinterpret_cast<const bf16x8_t*>(tA + (offA[i] ^ (ks << 6)));
-        fb[i] = *reinterpret_cast<const bf16x8_t*>(tB + (offB[i] ^ (ks << 6)));
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)   // swapped operands: lane gets C[m=lane&15][n=(lane>>4)*4+r]
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-    }
-    __syncthreads();
-  }
-
-  // ---- epilogue
+// Epilogue for one wave's 64x64 block of accumulators (swapped-operand C layout: lane holds
+// C[m = lane&15 (+16i)][n = (lane>>4)*4 + r (+16j)]).
+template <int EPI>
+__device__ __forceinline__ void store_tile(const GemmArgs& p, f32x4_t (&acc)[4][4], int mbase, int nbase, int lane,
+                                           bool split) {
   float alpha = 1.f;
   if constexpr (EPI == EPI_F32) { if (p.alpha_dev) alpha = *p.alpha_dev; }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+    const int m = mbase + i * 16 + (lane & 15);
     if (m >= p.M) continue;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+      const int n = nbase + j * 16 + (lane >> 4) * 4;
       if (n >= p.N) continue;
       f32x4_t v = acc[i][j];
       const bool full = (n + 3 < p.N);
@@ -157,7 +165,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
         }
       } else if constexpr (EPI == EPI_F32) {
         float* c = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n;
-        if (full) {
+        if (split) {         // split-K partial: accumulate with device-scope fp32 atomics (beta == 1 by contract)
+          for (int r = 0; r < 4; ++r) if (n + r < p.N) atomicAdd(c + r, v[r] * alpha);
+        } else if (full) {
           float4 o = make_float4(v[0] * alpha, v[1] * alpha, v[2] * alpha, v[3] * alpha);
           if (p.beta) { const float4 old = *reinterpret_cast<const float4*>(c);
                         o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w; }
@@ -183,43 +193,142 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs p) {
   }
 }
 
-template <int EPI>
-int launch(const GemmArgs& a, int variant, hipStream_t st) {
-  dim3 grid(a.tiles_m * a.tiles_n), block(256);
-  if (variant == 1) hipLaunchKernelGGL((gemm_nt_kernel<EPI, false>), grid, block, 0, st, a);
-  else hipLaunchKernelGGL((gemm_nt_kernel<EPI, true>), grid, block, 0, st, a);
-  UG_CHECK_LAUNCH("ug_gemm_bf16_nt");
+// DBUF = true : two LDS stages (64 KiB, 2 workgroups/CU), next tile's DMA overlaps this tile's MFMAs.
+// DBUF = false: one LDS stage (32 KiB, up to 4 workgroups/CU), overlap comes from the other workgroups.
+template <int EPI, bool AK, bool BKM, bool DBUF>
+__global__ __launch_bounds__(256, DBUF ? 2 : 4) void gemm_kernel(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) char lds[(DBUF ? 4 : 2) * TILE_BYTES];   // A0 B0 [A1 B1]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // ---- tile coordinates: XCD-contiguous chunks, GROUP_M row panels swept column-major
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int pid = xcd_remap(blockIdx.x, nwg);
+  const int per_group = GROUP_M * p.tiles_n;
+  const int gid = pid / per_group, first_m = gid * GROUP_M;
+  const int gsz = min(p.tiles_m - first_m, GROUP_M);
+  const int tm = first_m + (pid % per_group) % gsz;
+  const int tn = (pid % per_group) / gsz;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  Stager<AK, BM, 4> sa; Stager<BKM, BN, 4> sb;
+  sa.init(p.A, p.lda, m0, p.M, wave, lane);
+  sb.init(p.B, p.ldb, n0, p.N, wave, lane);
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int nk_all = (p.K + BK - 1) / BK;
+  const int per_split = (nk_all + gridDim.y - 1) / gridDim.y;       // split-K: this workgroup's k-tile range
+  const int kt0 = blockIdx.y * per_split;
+  const int nk = min(nk_all, kt0 + per_split);
+  if (kt0 >= nk) return;
+  const bool ragged = (p.K % BK) != 0;          // only the last k-tile can need the zero-page checks
+  if (kt0 + 1 == nk_all && ragged) { sa.template issue<true>(kt0, p.K, lds, wave); sb.template issue<true>(kt0, p.K, lds + TILE_BYTES, wave); }
+  else { sa.template issue<false>(kt0, p.K, lds, wave); sb.template issue<false>(kt0, p.K, lds + TILE_BYTES, wave); }
+  __syncthreads();   // hipcc drains vmcnt(0) for in-flight LDS-DMA here
+
+  for (int kt = kt0; kt < nk; ++kt) {
+    const int cur = DBUF ? ((kt - kt0) & 1) : 0;
+    if (DBUF && kt + 1 < nk) {
+      char* nxt = lds + (cur ^ 1) * 2 * TILE_BYTES;
+      if (ragged && kt + 2 == nk_all) { sa.template issue<true>(kt + 1, p.K, nxt, wave); sb.template issue<true>(kt + 1, p.K, nxt + TILE_BYTES, wave); }
+      else { sa.template issue<false>(kt + 1, p.K, nxt, wave); sb.template issue<false>(kt + 1, p.K, nxt + TILE_BYTES, wave); }
+    }
+    const char* tA = lds + cur * 2 * TILE_BYTES;
+    const char* tB = tA + TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        fa[i] = load_frag<AK, BM>(tA, wm * 64 + i * 16, ks, lane);
+        fb[i] = load_frag<BKM, BN>(tB, wn * 64 + i * 16, ks, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)   // swapped operands: lane gets C[m=lane&15][n=(lane>>4)*4+r]
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+    if constexpr (!DBUF) {
+      if (kt + 1 < nk) {
+        if (ragged && kt + 2 == nk_all) { sa.template issue<true>(kt + 1, p.K, lds, wave); sb.template issue<true>(kt + 1, p.K, lds + TILE_BYTES, wave); }
+        else { sa.template issue<false>(kt + 1, p.K, lds, wave); sb.template issue<false>(kt + 1, p.K, lds + TILE_BYTES, wave); }
+        __syncthreads();
+      }
+    }
+  }
+
+  store_tile<EPI>(p, acc, m0 + wm * 64, n0 + wn * 64, lane, gridDim.y > 1);
+}
+
+int g_tile_policy = -1;   // -1 auto, 0 force two LDS stages, 2 force one LDS stage (ug_gemm_set_tile_policy; A/B runs)
+
+template <int EPI, bool AK, bool BKM>
+int launch(GemmArgs a, hipStream_t st) {
+  const int tiles = a.tiles_m * a.tiles_n;
+  int splits = 1;
+  if (EPI == EPI_F32 && a.beta == 1 && tiles < 384) {            // wgrad of a small weight: fill the chip along K
+    const int nk = (a.K + BK - 1) / BK;
+    splits = min(8, max(1, 768 / tiles));
+    splits = max(1, min(splits, nk / 8));
+  }
+  bool dbuf = (!AK && !BKM && a.K >= 4096);
+  if (g_tile_policy == 0) dbuf = true;
+  if (g_tile_policy == 2) dbuf = false;
+  dim3 grid(tiles, splits);
+  if (dbuf) hipLaunchKernelGGL((gemm_kernel<EPI, AK, BKM, true>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((gemm_kernel<EPI, AK, BKM, false>), grid, dim3(256), 0, st, a);
+  UG_CHECK_LAUNCH("ug_gemm_bf16");
   return UG_OK;
 }
 
-int g_gemm_variant = 0;   // 0 = LDS-DMA staging (default), 1 = register staging (validation arm)
-
 }  // namespace
 
-extern "C" int ug_gemm_set_variant(int v) { g_gemm_variant = v; return UG_OK; }
+extern "C" int ug_gemm_set_tile_policy(int v) { g_tile_policy = v; return UG_OK; }
 
-extern "C" int ug_gemm_bf16_nt(const void* A, int64_t lda, const void* B, int64_t ldb, void* C, int64_t ldc,
-                               int64_t M, int64_t N, int64_t K, int epilogue, const void* bias,
-                               const float* resid, int64_t ldr, int beta, const float* alpha_dev,
-                               hipStream_t stream) {
-  UG_REQUIRE(M > 0 && N > 0 && K > 0, "ug_gemm_bf16_nt: empty problem M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
-  UG_REQUIRE(K % BK == 0, "ug_gemm_bf16_nt: K=%ld must be a multiple of %d (pad the contraction dim)", (long)K, BK);
-  UG_REQUIRE(lda % 8 == 0 && ldb % 8 == 0, "ug_gemm_bf16_nt: lda/ldb must be multiples of 8 elements");
-  UG_REQUIRE(ug_aligned16(A) && ug_aligned16(B) && ug_aligned16(C), "ug_gemm_bf16_nt: A/B/C must be 16-byte aligned");
-  UG_REQUIRE(ldc % 4 == 0, "ug_gemm_bf16_nt: ldc must be a multiple of 4 elements");
-  UG_REQUIRE(M < (1 << 30) && N < (1 << 30), "ug_gemm_bf16_nt: dims too large");
+extern "C" int ug_gemm_bf16(const void* A, int64_t lda, int a_kmajor, const void* B, int64_t ldb, int b_kmajor,
+                            void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int epilogue, const void* bias,
+                            const float* resid, int64_t ldr, int beta, const float* alpha_dev, hipStream_t stream) {
+  UG_REQUIRE(M > 0 && N > 0 && K > 0, "ug_gemm_bf16: empty problem M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
+  UG_REQUIRE(lda % 8 == 0 && ldb % 8 == 0, "ug_gemm_bf16: lda/ldb must be multiples of 8 elements (16-byte rows)");
+  UG_REQUIRE(ug_aligned16(A) && ug_aligned16(B) && ug_aligned16(C), "ug_gemm_bf16: A/B/C must be 16-byte aligned");
+  UG_REQUIRE(ldc % 4 == 0, "ug_gemm_bf16: ldc must be a multiple of 4 elements");
+  UG_REQUIRE(M < (1 << 30) && N < (1 << 30) && K < (1 << 30), "ug_gemm_bf16: dims too large");
+  // K needs no tile alignment: lanes past the contraction extent fetch from a zero page.  A row-major
+  // operand is fetched in 8-element chunks, so when K % 8 != 0 the chunk straddling K is read whole: the
+  // other operand must then be k-major (its rows >= K come from the zero page) and the straddling tail
+  // must hold finite values (the callers keep it zero).
+  UG_REQUIRE(a_kmajor || b_kmajor || K % 8 == 0,
+             "ug_gemm_bf16: K=%ld must be a multiple of 8 when both operands are row-major", (long)K);
+  UG_REQUIRE(a_kmajor || lda >= ((K + 7) & ~7LL), "ug_gemm_bf16: row-major A needs lda >= round_up(K,8)");
+  UG_REQUIRE(b_kmajor || ldb >= ((K + 7) & ~7LL), "ug_gemm_bf16: row-major B needs ldb >= round_up(K,8)");
+  UG_REQUIRE(!a_kmajor || lda >= M, "ug_gemm_bf16: k-major A needs lda >= M");
+  UG_REQUIRE(!b_kmajor || ldb >= N, "ug_gemm_bf16: k-major B needs ldb >= N");
   GemmArgs a;
   a.A = (const bf16_t*)A; a.B = (const bf16_t*)B; a.C = C;
   a.bias = (const bf16_t*)bias; a.resid = resid; a.alpha_dev = alpha_dev;
   a.M = (int)M; a.N = (int)N; a.K = (int)K;
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = ldr; a.beta = beta;
   a.tiles_m = (int)((M + BM - 1) / BM); a.tiles_n = (int)((N + BN - 1) / BN);
-  switch (epilogue) {
-    case EPI_BF16: return launch<EPI_BF16>(a, g_gemm_variant, stream);
-    case EPI_F32: return launch<EPI_F32>(a, g_gemm_variant, stream);
-    case EPI_RESID:
-      UG_REQUIRE(resid != nullptr && ldr % 4 == 0, "ug_gemm_bf16_nt: EPI_RESID needs a 16B-aligned residual");
-      return launch<EPI_RESID>(a, g_gemm_variant, stream);
-    default: ug_set_error("ug_gemm_bf16_nt: unknown epilogue %d", epilogue); return UG_ERR_ARG;
+  const int mode = (a_kmajor ? 2 : 0) | (b_kmajor ? 1 : 0);
+  if (epilogue == EPI_RESID) UG_REQUIRE(resid != nullptr && ldr % 4 == 0, "ug_gemm_bf16: EPI_RESID needs a 16B-aligned residual");
+  switch (mode * 4 + epilogue) {
+    case 0 * 4 + EPI_BF16: return launch<EPI_BF16, false, false>(a, stream);
+    case 0 * 4 + EPI_F32: return launch<EPI_F32, false, false>(a, stream);
+    case 0 * 4 + EPI_RESID: return launch<EPI_RESID, false, false>(a, stream);
+    case 1 * 4 + EPI_BF16: return launch<EPI_BF16, false, true>(a, stream);
+    case 1 * 4 + EPI_F32: return launch<EPI_F32, false, true>(a, stream);
+    case 3 * 4 + EPI_F32: return launch<EPI_F32, true, true>(a, stream);
+    case 3 * 4 + EPI_BF16: return launch<EPI_BF16, true, true>(a, stream);
+    default:
+      ug_set_error("ug_gemm_bf16: layout/epilogue combination (a_kmajor=%d b_kmajor=%d epilogue=%d) is not instantiated",
+                   a_kmajor, b_kmajor, epilogue);
+      return UG_ERR_ARG;
   }
 }

@@ -20,8 +20,8 @@ F32 = ctypes.c_float
 # exported symbol list against the header)
 SIGNATURES = {
     "ug_abi_version": [],
-    "ug_gemm_bf16_nt": [P, I64, P, I64, P, I64, I64, I64, I64, I32, P, P, I64, I32, P, P],
-    "ug_gemm_set_variant": [I32],
+    "ug_gemm_bf16": [P, I64, I32, P, I64, I32, P, I64, I64, I64, I64, I32, P, P, I64, I32, P, P],
+    "ug_gemm_set_tile_policy": [I32],
     "ug_transpose_cast": [P, I32, I64, P, I64, P, I64, I64, I64, P],
     "ug_cast_f32_bf16": [P, P, I64, P],
     "ug_rmsnorm_fwd": [P, P, P, P, I64, I64, F32, I32, P],

@@ -32,13 +32,17 @@ def round_up(x, m):
 
 
 # ------------------------------------------------------------------------------------ GEMM
-def gemm_nt(a, b, out=None, *, M=None, N=None, K=None, epilogue=UG_EPI_BF16, bias=None, resid=None,
-            beta=0, alpha_dev=None, out_dtype=None):
-    """out[M,N] = a[M,K] @ b[N,K]^T.  a, b bf16 2-D (row stride = .stride(0), K contiguous)."""
+def gemm(a, b, out=None, *, M=None, N=None, K=None, a_kmajor=False, b_kmajor=False, epilogue=UG_EPI_BF16,
+         bias=None, resid=None, beta=0, alpha_dev=None, out_dtype=None):
+    """out[M,N] = opA @ opB^T on the bf16 matrix cores.  Row-major operands are [rows, K] (K contiguous),
+    k-major operands are [K, rows]; .stride(0) is the leading dimension either way."""
     _need_cuda(a, b)
-    M = a.shape[0] if M is None else M
-    N = b.shape[0] if N is None else N
-    K = a.shape[1] if K is None else K
+    if M is None:
+        M = a.shape[1] if a_kmajor else a.shape[0]
+    if N is None:
+        N = b.shape[1] if b_kmajor else b.shape[0]
+    if K is None:
+        K = a.shape[0] if a_kmajor else a.shape[1]
     if out is None:
         dt = out_dtype or (torch.bfloat16 if epilogue == UG_EPI_BF16 else torch.float32)
         out = torch.empty((M, N), dtype=dt, device=a.device)
@@ -47,14 +51,24 @@ def gemm_nt(a, b, out=None, *, M=None, N=None, K=None, epilogue=UG_EPI_BF16, bia
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    rc = lib.ug_gemm_bf16_nt(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, K, epilogue,
-                             _p(bias), _p(resid), resid.stride(0) if resid is not None else 0, beta,
-                             _p(alpha_dev), _stream())
-    _l.check(rc, "ug_gemm_bf16_nt")
+    rc = lib.ug_gemm_bf16(_p(a), a.stride(0), int(a_kmajor), _p(b), b.stride(0), int(b_kmajor), _p(out), out.stride(0),
+                          M, N, K, epilogue, _p(bias), _p(resid), resid.stride(0) if resid is not None else 0, beta,
+                          _p(alpha_dev), _stream())
+    _l.check(rc, "ug_gemm_bf16")
     if prof is not None:
         e1.record()
         prof.append((e0, e1, 2.0 * M * N * K))
     return out
+
+
+def set_gemm_tile_policy(policy):
+    """-1 auto, 0 = 128x128 tiles, 1 = 256x128 tiles (A/B benchmarking and tests)."""
+    _l.check(_l.load().ug_gemm_set_tile_policy(int(policy)), "ug_gemm_set_tile_policy")
+
+
+def gemm_nt(a, b, out=None, **kw):
+    """Both operands row-major: out = a[M,K] @ b[N,K]^T."""
+    return gemm(a, b, out, **kw)
 
 
 def transpose_cast(x, R=None, C=None, *, want_out=False, want_T=True, ldT=None):

@@ -65,7 +65,6 @@ class FlatParams:
         self.master = torch.zeros(n, dtype=torch.float32, device=device)
         self.grad = torch.zeros(n, dtype=torch.float32, device=device)
         self.bf16 = torch.zeros(n, dtype=torch.bfloat16, device=device)
-        self.wT = {}                 # key -> transposed bf16 [K, Npad]
         self._seen_version = -1
 
     def view(self, buf, key):
@@ -82,25 +81,12 @@ class FlatParams:
         return self.view(self.bf16, key)
 
     def refresh_compute_copies(self, force=False):
-        """bf16 + transposed-bf16 copies of the fp32 master weights (one pass per optimizer step)."""
+        """bf16 compute copy of the fp32 master weights (one HBM pass per optimizer step; dgrad / wgrad read
+        the same copy through the GEMM's k-major operand mode, so no transposed copies exist)."""
         ver = self.master._version
         if not force and ver == self._seen_version:
             return
-        d = self.dims
-        mats = ["embed"] + [f"l{i}.{n}" for i in range(d.num_hidden_layers) for n in ("wqkv", "wo", "wgu", "wdown")]
-        for key in mats:
-            src = self.p(key)
-            R, C = src.shape
-            ldT = ops.round_up(R, 64)
-            if key not in self.wT:
-                self.wT[key] = torch.empty((C, ldT), dtype=torch.bfloat16, device=self.device)
-            lib = ops._l.load()
-            rc = lib.ug_transpose_cast(src.data_ptr(), 1, C, self.w(key).data_ptr(), C, self.wT[key].data_ptr(), ldT,
-                                       R, C, ops._stream())
-            ops._l.check(rc, "ug_transpose_cast")
-        for key, _ in self.spec:
-            if key.endswith(("bqkv", "ln1", "ln2")) or key == "norm":
-                ops.cast_bf16(self.p(key), self.w(key))
+        ops.cast_bf16(self.master, self.bf16)
         self._seen_version = ver
 
 
@@ -192,33 +178,25 @@ class Qwen2Engine:
         Weight gradients accumulate into the flat fp32 grad buffer."""
         d, fp = self.dims, self.fp
         Hq, Hk, hd = d.num_attention_heads, d.num_key_value_heads, d.head_dim
-        M = dh.shape[0]
-        Mp = ops.round_up(M, 64)
         cos, sin = self.rope(L)
         F32 = ops.UG_EPI_F32
-        # ---- MLP
-        dyd, dydT = ops.transpose_cast(dh, want_out=True, ldT=Mp)
-        _, actT = ops.transpose_cast(s.act, ldT=Mp)
-        ops.gemm_nt(dydT, actT, out=fp.g(f"l{i}.wdown"), K=Mp, epilogue=F32, beta=1)
-        dact = ops.gemm_nt(dyd, fp.wT[f"l{i}.wdown"], N=d.intermediate_size, K=d.hidden_size)
+        # ---- MLP   (wgrad: both operands k-major over the token axis; dgrad: weight read k-major)
+        dyd = ops.cast_bf16(dh)
+        ops.gemm(dyd, s.act, out=fp.g(f"l{i}.wdown"), a_kmajor=True, b_kmajor=True, epilogue=F32, beta=1)
+        dact = ops.gemm(dyd, fp.w(f"l{i}.wdown"), b_kmajor=True)
         dgu = ops.swiglu_bwd(s.gu, dact)
-        _, dguT = ops.transpose_cast(dgu, ldT=Mp)
-        _, xn2T = ops.transpose_cast(s.xn2, ldT=Mp)
-        ops.gemm_nt(dguT, xn2T, out=fp.g(f"l{i}.wgu"), K=Mp, epilogue=F32, beta=1)
-        dxn2 = ops.gemm_nt(dgu, fp.wT[f"l{i}.wgu"], N=d.hidden_size, K=2 * d.intermediate_size)
+        ops.gemm(dgu, s.xn2, out=fp.g(f"l{i}.wgu"), a_kmajor=True, b_kmajor=True, epilogue=F32, beta=1)
+        dxn2 = ops.gemm(dgu, fp.w(f"l{i}.wgu"), b_kmajor=True)
         ops.rmsnorm_bwd(dxn2, s.h_mid, s.rstd2, fp.p(f"l{i}.ln2"), dh, fp.g(f"l{i}.ln2"))
         # ---- attention
-        dyo, dyoT = ops.transpose_cast(dh, want_out=True, ldT=Mp)
-        _, oT = ops.transpose_cast(s.o, ldT=Mp)
-        ops.gemm_nt(dyoT, oT, out=fp.g(f"l{i}.wo"), K=Mp, epilogue=F32, beta=1)
-        do = ops.gemm_nt(dyo, fp.wT[f"l{i}.wo"], N=d.hidden_size, K=d.hidden_size)
+        dyo = ops.cast_bf16(dh)
+        ops.gemm(dyo, s.o, out=fp.g(f"l{i}.wo"), a_kmajor=True, b_kmajor=True, epilogue=F32, beta=1)
+        do = ops.gemm(dyo, fp.w(f"l{i}.wo"), b_kmajor=True)
         dqkv = ops.attn_bwd(s.qkv, s.o, s.lse, do, mb, Hq, Hk, hd)
         ops.rope_(dqkv, cos, sin, L, Hq + Hk, hd, backward=True)
         ops.colsum_(dqkv, fp.g(f"l{i}.bqkv"))
-        _, dqkvT = ops.transpose_cast(dqkv, ldT=Mp)
-        _, xn1T = ops.transpose_cast(s.xn1, ldT=Mp)
-        ops.gemm_nt(dqkvT, xn1T, out=fp.g(f"l{i}.wqkv"), K=Mp, epilogue=F32, beta=1)
-        dxn1 = ops.gemm_nt(dqkv, fp.wT[f"l{i}.wqkv"], N=d.hidden_size, K=d.qkv_out)
+        ops.gemm(dqkv, s.xn1, out=fp.g(f"l{i}.wqkv"), a_kmajor=True, b_kmajor=True, epilogue=F32, beta=1)
+        dxn1 = ops.gemm(dqkv, fp.w(f"l{i}.wqkv"), b_kmajor=True)
         ops.rmsnorm_bwd(dxn1, s.h, s.rstd1, fp.p(f"l{i}.ln1"), dh, fp.g(f"l{i}.ln1"))
         return dh
 
@@ -246,8 +224,9 @@ class Qwen2Engine:
         """dlogits bf16 [R, vocab_pad] (pad columns zero) -> dhn_rows bf16 [R,H]; embed grad accumulated."""
         d, fp = self.dims, self.fp
         R = hn_rows.shape[0]
-        Rp = ops.round_up(R, 64)
-        _, dlT = ops.transpose_cast(dlogits, R=R, C=d.vocab_size, ldT=Rp)
-        _, hT = ops.transpose_cast(hn_rows, ldT=Rp)
-        ops.gemm_nt(dlT, hT, out=fp.g("embed"), M=d.vocab_size, N=d.hidden_size, K=Rp, epilogue=ops.UG_EPI_F32, beta=1)
-        return ops.gemm_nt(dlogits, fp.wT["embed"], M=R, N=d.hidden_size, K=d.vocab_pad)
+        # dW[V,H] += dlogits^T hn : both k-major over the R selected rows (dlogits' leading dim is vocab_pad)
+        ops.gemm(dlogits, hn_rows, out=fp.g("embed"), M=d.vocab_size, N=d.hidden_size, K=R, a_kmajor=True, b_kmajor=True,
+                 epilogue=ops.UG_EPI_F32, beta=1)
+        # dhn[R,H] = dlogits[R,V] W[V,H] : W read k-major; its rows >= V come from the zero page and the
+        # dlogits pad columns are zero (ug_ce_bwd), so K = V needs no padding
+        return ops.gemm(dlogits, fp.w("embed"), M=R, N=d.hidden_size, K=d.vocab_size, b_kmajor=True)

@@ -38,8 +38,8 @@ def test_abi_library_exports_every_declared_symbol():
 def test_abi_argument_errors_are_reported_not_thrown():
     from unigen_hip import lib
     L = lib.load()
-    rc = L.ug_gemm_bf16_nt(0, 8, 0, 8, 0, 8, 16, 16, 72, 0, 0, 0, 0, 0, 0, 0)     # K % 64 != 0: rejected before any launch
-    assert rc == -1 and b"multiple of 64" in L.ug_last_error()
+    rc = L.ug_gemm_bf16(0, 80, 0, 0, 80, 0, 0, 8, 16, 16, 68, 0, 0, 0, 0, 0, 0, 0)   # K % 8 != 0, both row-major: rejected before any launch
+    assert rc == -1 and b"multiple of 8" in L.ug_last_error()
 
 
 def test_product_never_imports_oracle():

@@ -41,47 +41,65 @@ def test_probe_layouts(dev):
 
 
 # ------------------------------------------------------------------ GEMM
-@pytest.mark.parametrize("variant", [0, 1])
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (300, 200, 192), (771, 1536, 1536), (64, 333, 256)])
-def test_gemm_nt_bf16(dev, variant, M, N, K):
+@pytest.fixture(params=[0, 2], ids=["two_lds_stages", "one_lds_stage"])
+def tile_policy(request):
     ops = _ops()
-    from unigen_hip import lib
-    lib.load().ug_gemm_set_variant(variant)
-    try:
-        g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
-        a = torch.randn(M, K, generator=g).to(torch.bfloat16)
-        b = torch.randn(N, K, generator=g).to(torch.bfloat16)
-        bias = torch.randn(N, generator=g).to(torch.bfloat16)
-        ref = a.float() @ b.float().t()
-        ldc = (N + 7) // 8 * 8
-        cbuf = torch.zeros(M, ldc, dtype=torch.bfloat16, device=dev)
-        ops.gemm_nt(a.to(dev), b.to(dev), out=cbuf, M=M, N=N, K=K, bias=bias.to(dev))
-        got = cbuf[:, :N]
-        assert _rel(got, ref + bias.float()) < 4e-3
-        if ldc > N:
-            assert cbuf[:, N:].abs().max().item() == 0      # guarded stores never touch padding
-        # fp32 epilogue with accumulate
-        c32 = torch.ones(M, ldc, dtype=torch.float32, device=dev)
-        ops.gemm_nt(a.to(dev), b.to(dev), out=c32, M=M, N=N, K=K, epilogue=ops.UG_EPI_F32, beta=1)
-        assert _rel(c32[:, :N], ref + 1.0) < 1e-5 * math.sqrt(K) + 1e-6
-        # residual epilogue
+    ops.set_gemm_tile_policy(request.param)
+    yield request.param
+    ops.set_gemm_tile_policy(-1)
+
+
+@pytest.mark.parametrize("mode", ["nt", "dgrad", "wgrad"])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (300, 200, 192), (771, 1536, 1536), (64, 336, 256),
+                                   (130, 72, 100), (1536, 512, 771)])
+def test_gemm_bf16_layouts(dev, tile_policy, mode, M, N, K):
+    """forward (both row-major), dgrad (B k-major), wgrad (both k-major); ragged M/N/K edges."""
+    ops = _ops()
+    ak, bk = {"nt": (False, False), "dgrad": (False, True), "wgrad": (True, True)}[mode]
+    if mode == "nt" and K % 8:
+        K = K // 8 * 8
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    b = torch.randn(N, K, generator=g).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g).to(torch.bfloat16)
+    ref = a.float() @ b.float().t()
+
+    def store(x, kmajor):       # [rows, K] logical -> device tensor in the requested storage order, padded ld
+        rows, kk = x.shape
+        if kmajor:
+            buf = torch.full((kk, (rows + 7) // 8 * 8 + 8), 3.0, dtype=torch.bfloat16)   # finite garbage in the padding
+            buf[:, :rows] = x.t()
+        else:
+            buf = torch.zeros((rows, (kk + 7) // 8 * 8), dtype=torch.bfloat16)             # K tail must be zero (contract)
+            buf[:, :kk] = x
+        return buf.to(dev)
+    A, B = store(a, ak), store(b, bk)
+    ldc = (N + 7) // 8 * 8
+    cbuf = torch.zeros(M, ldc, dtype=torch.bfloat16, device=dev)
+    ops.gemm(A, B, out=cbuf, M=M, N=N, K=K, a_kmajor=ak, b_kmajor=bk, bias=bias.to(dev))
+    assert _rel(cbuf[:, :N], ref + bias.float()) < 4e-3
+    if ldc > N:
+        assert cbuf[:, N:].abs().max().item() == 0      # guarded stores never touch padding
+    c32 = torch.ones(M, ldc, dtype=torch.float32, device=dev)
+    ops.gemm(A, B, out=c32, M=M, N=N, K=K, a_kmajor=ak, b_kmajor=bk, epilogue=ops.UG_EPI_F32, beta=1)
+    assert _rel(c32[:, :N], ref + 1.0) < 1e-5 * math.sqrt(K) + 1e-6
+    if mode == "nt":
         res = torch.randn(M, ldc, generator=g)
         r32 = torch.empty(M, ldc, dtype=torch.float32, device=dev)
-        ops.gemm_nt(a.to(dev), b.to(dev), out=r32, M=M, N=N, K=K, epilogue=ops.UG_EPI_RESID, resid=res.to(dev))
+        ops.gemm(A, B, out=r32, M=M, N=N, K=K, epilogue=ops.UG_EPI_RESID, resid=res.to(dev))
         want = res[:, :N] + ref.to(torch.bfloat16).float()
         # one bf16 ulp of slack on the rounded projection
         assert ((r32[:, :N].cpu() - want).abs() <= ref.abs() * 2.0 ** -7 + 1e-3).all()
-        assert _rel(r32[:, :N], want) < 3e-3
-    finally:
-        lib.load().ug_gemm_set_variant(0)
 
 
-def test_gemm_rejects_bad_k(dev):
+def test_gemm_rejects_bad_args(dev):
     ops = _ops()
     from unigen_hip.lib import UniGenHipError
     a = torch.zeros(64, 72, dtype=torch.bfloat16, device=dev)
     with pytest.raises(UniGenHipError):
-        ops.gemm_nt(a, a)
+        ops.gemm(a, a, K=68)                                # both row-major: K must be a multiple of 8
+    with pytest.raises(UniGenHipError):
+        ops.gemm(a, a, epilogue=ops.UG_EPI_RESID)           # residual epilogue without a residual
 
 
 def test_transpose_cast(dev):
