@@ -1,0 +1,29 @@
+"""Micro-benchmark of the fp32 MFMA implicit-GEMM conv on the MAGVITv2 encoder's layer shapes."""
+import os
+import sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "ml-unigen_amd"))
+import torch
+from unigen_hip import ops
+
+dev = torch.device("cuda:0")
+B = int(os.environ.get("B", "16"))
+shapes = [(128, 128, 256, 3), (128, 256, 128, 3), (256, 256, 128, 3), (256, 256, 64, 3), (256, 512, 32, 3), (512, 512, 32, 3),
+          (512, 512, 16, 3), (128, 256, 128, 1), (4, 128, 256, 3)]
+for cin, cout, H, k in shapes:
+    x = torch.randn(B, H, H, cin, device=dev)
+    w = torch.randn(cout, cin, k, k, device=dev) * 0.05
+    bias = torch.zeros(cout, device=dev)
+    wp, cpad = ops.pack_conv_weight(w)
+    ops.conv2d_nhwc(x, wp, cpad, bias, cout, k)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 3
+    e0.record()
+    for _ in range(reps):
+        ops.conv2d_nhwc(x, wp, cpad, bias, cout, k)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    fl = 2.0 * B * H * H * cin * cout * k * k
+    print(f"conv {cin:4d}->{cout:4d} k{k} @{H:3d}^2 B={B}: {ms:8.3f} ms  {fl / ms / 1e9:7.1f} TF/s", flush=True)
