@@ -144,6 +144,32 @@ def cpu_baseline(seq_len, sample_layers=4):
                       f"extrapolated step {total:.1f}s = layers {layer_t:.1f} + head {head_t:.1f} + adamw {opt_t:.1f} + vq {vq_t:.1f}"}
 
 
+def ar_decode_bench(model, dev, n_img=8, prefix=138, reps=2):
+    """Second half of BASELINE.json's metric: AR image-tokens/s, BASELINE configs[3] shape (Best-of-N = 8 with CFG ->
+    16 rows, prefix 138 = 128 text + template, 256 decode steps through the static-KV captured-graph path)."""
+    model.eval()
+    g = torch.Generator(device=dev).manual_seed(1)
+    L = prefix + NVQ + 1
+    ids = torch.randint(0, 151643, (n_img, L), device=dev, generator=g)
+    un = torch.randint(0, 151643, (n_img, L), device=dev, generator=g)
+    am = torch.ones((2 * n_img, L), dtype=torch.long, device=dev)
+    best = None
+    for _ in range(reps + 1):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        toks = model.t2i_generate_ar(input_ids=ids, uncond_input_ids=un, attention_mask=am, guidance_scale=6.0,
+                                     temperature=1.0, text_vocab_size=TEXT_VOCAB, image_token_num_per_image=NVQ)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    model.train()
+    floor_ms = (1310.3e6 * 2 + CODEBOOK * 1536 * 2) / 6.3e12 * 1e3      # layer + code-head weights streamed once per step
+    return {"value": round(n_img * NVQ / best, 1), "unit": "img-tokens/s", "images": n_img, "rows_with_cfg": 2 * n_img,
+            "prefix": prefix, "decode_steps": NVQ, "hipgraph": bool(model.llm.engine.last_decode_graph),
+            "ms_per_step": round(best / NVQ * 1e3, 3), "roofline": {"bound": "hbm", "floor_ms_per_step": round(floor_ms, 3),
+                                                                      "frac": round(floor_ms / (best / NVQ * 1e3), 4)}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -153,6 +179,7 @@ def main():
     ap.add_argument("--text-len", type=int, default=511, help="text tokens after the 2 template tokens (513 total)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-ar", action="store_true", help="skip the AR image-token generation measurement (second half of the metric)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -245,6 +272,9 @@ def main():
                 "launches_per_step": len(rec), "avg_launch_ms": round(tot_ms / len(rec), 4),
                 "flops_per_launch": round(tot_fl / len(rec) / 1e9, 2), "gemm_ms_per_step": round(tot_ms, 2),
                 "step_frac_of_bf16_peak": round(value / world * FLOP_SAMPLE / PEAK_BF16, 4)}
+    ar = None
+    if rank == 0 and world == 1 and not args.no_ar:
+        ar = ar_decode_bench(model, dev)
     if rank == 0:
         out = {"metric": "train-step samples/s (1.5B, 256^2 img)", "value": round(value, 3), "unit": "samples/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2),
@@ -254,7 +284,7 @@ def main():
                                       "fwd+bwd+grad all-reduce+AdamW, random-init weights",
                           "global_batch": B * world, "seq_len": L, "parallelism": f"dp{world}"},
                "loss_first_last": [round(losses[0].item(), 4), round(losses[-1].item(), 4)],
-               "roofline": roof, "cpu_baseline": cpu}
+               "roofline": roof, "cpu_baseline": cpu, "ar_decode": ar}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -112,6 +112,22 @@ int ug_attn_bwd(const void* q, const void* k, const void* v, int64_t ldq, const 
                 const uint8_t* tileany, int64_t B, int64_t L, int64_t Lp, int H, int HKV, int head_dim,
                 float scale, hipStream_t stream);
 
+/* ---- autoregressive decode (static KV cache, graph-capturable) -------------------------------- */
+/* replaces: transformers DynamicCache.update + SDPA on one new token per row inside
+ * UniGen.t2i_generate_ar (models/unigen.py:485-519).  Cache layout K,V [rows][HKV][Tmax][128] bf16.
+ * Positions / lengths are read from DEVICE ints so a captured graph can be replayed for every step. */
+int ug_kv_store(const void* qkv, int64_t ldq, int64_t k_col, int64_t v_col, void* cache_k, void* cache_v,
+                int64_t rows, int64_t L, int HKV, int head_dim, int64_t Tmax, const int* pos_dev, int pos_host,
+                hipStream_t stream);
+int ug_rope_at(void* qkv, const float* cos_tab, const float* sin_tab, int64_t rows, int64_t ldq, int nheads,
+               int head_dim, const int* pos_dev, int64_t max_pos, hipStream_t stream);
+int ug_attn_decode(const void* q, int64_t ldq, const void* cache_k, const void* cache_v, const uint8_t* key_valid,
+                   void* o, int64_t ldo, int64_t rows, int H, int HKV, int head_dim, int64_t Tmax,
+                   const int* len_dev, float scale, hipStream_t stream);
+/* finish a split-K fp32 accumulation: mode 0: out_bf16 = bf16(acc + bias); mode 1: resid += bf16round(acc) */
+int ug_skinny_finish(const float* acc, const void* bias, void* out_bf16, float* resid, int64_t M, int64_t N,
+                     int mode, hipStream_t stream);
+
 /* ---- loss ------------------------------------------------------------------------------------ */
 /* replaces: F.cross_entropy(ignore_index=-100) x3 in UniGen.forward (models/unigen.py:310-338) and
  * get_batch_logps (training/train_dpo.py:51-90).  logits bf16 [R, ld], ld % 8 == 0.

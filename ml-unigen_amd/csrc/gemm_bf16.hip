@@ -275,8 +275,8 @@ int launch(GemmArgs a, hipStream_t st) {
   int splits = 1;
   if (EPI == EPI_F32 && a.beta == 1 && tiles < 384) {            // wgrad of a small weight: fill the chip along K
     const int nk = (a.K + BK - 1) / BK;
-    splits = min(8, max(1, 768 / tiles));
-    splits = max(1, min(splits, nk / 8));
+    splits = min(32, max(1, 768 / tiles));                         // skinny decode GEMMs (M = 16) get up to 32 slices
+    splits = max(1, min(splits, nk / 2));
   }
   bool dbuf = (!AK && !BKM && a.K >= 4096);
   if (g_tile_policy == 0) dbuf = true;

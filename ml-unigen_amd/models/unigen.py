@@ -332,27 +332,64 @@ class UniGen(ModelMixin, ConfigMixin):
         """Token-by-token image generation with CFG (reference models/unigen.py:457-521).  The reference
         only works when both embedding tensors are supplied; ids are accepted here too
         and embedded, which is what its callers intend."""
+        from unigen_hip.qwen2 import DecodeState
         n = image_token_num_per_image
         embed = self.llm.model.embed_tokens
-        dev = self.llm.engine.device
+        eng = self.llm.engine
+        dev = eng.device
         if input_embeddings is None:
             input_embeddings = embed(input_ids)
         if uncond_input_embeddings is None:
             uncond_input_embeddings = embed(uncond_input_ids)
         bsz = input_embeddings.shape[0]
-        seq = torch.cat([input_embeddings[:, :-(n + 1)], uncond_input_embeddings[:, :-(n + 1)]])
+        prefix = torch.cat([input_embeddings[:, :-(n + 1)], uncond_input_embeddings[:, :-(n + 1)]]).float()
+        R, P, _ = prefix.shape
+        key_valid = None
+        if attention_mask is not None:
+            if attention_mask.dim() != 2:
+                raise UniGenHipError("t2i_generate_ar expects the 2-D [rows, L] attention mask the reference slices")
+            key_valid = attention_mask[:, :P].to(dev) != 0
+        greedy = bool(kwargs.get("greedy", False))          # argmax instead of multinomial: deterministic parity tests
+        use_graph = bool(kwargs.get("use_graph", True))
+        code_lo, code_hi = text_vocab_size, self.vocab_size - 1          # logits[..., text_vocab_size:-1]
+        st = DecodeState(eng.dims, R, P + n, dev, key_valid=key_valid)
         out_tokens = torch.zeros((bsz, n), dtype=torch.int, device=dev)
-        for i in range(n):
-            L = seq.shape[1]
-            am = None if attention_mask is None else attention_mask[:, :L]
-            hn = self.llm.model(inputs_embeds=seq, attention_mask=am).last_hidden_state
-            lg = LazyLogits(self.llm.engine, hn)[:, L - 1, text_vocab_size:-1].float()
-            cond, uncond = lg.chunk(2)
+        x = torch.empty((R, eng.dims.hidden_size), dtype=torch.float32, device=dev)      # static: next token's embedding
+        tok = torch.zeros((bsz, 1), dtype=torch.long, device=dev)                        # static: last sampled token
+
+        def sample(hn):
+            lg = eng.head_slice(hn, code_lo, code_hi).float()
+            cond, uncond = lg[:bsz], lg[bsz:]
             lg = uncond + guidance_scale * (cond - uncond)
-            probs = torch.softmax(lg / temperature, dim=-1)
-            nxt = torch.multinomial(probs, num_samples=1, generator=generator)
-            out_tokens[:, i] = nxt.squeeze(-1)
-            seq = torch.cat([seq, embed(torch.cat([nxt, nxt]) + text_vocab_size)], 1)
+            if greedy:
+                nxt = lg.argmax(-1, keepdim=True)
+            else:
+                nxt = torch.multinomial(torch.softmax(lg / temperature, dim=-1), num_samples=1, generator=generator)
+            tok.copy_(nxt)
+            x.copy_(embed(torch.cat([nxt, nxt]) + text_vocab_size)[:, 0])
+
+        sample(eng.prefill(st, prefix, key_valid))
+        out_tokens[:, 0] = tok[:, 0]
+
+        def step():
+            hn = eng.decode_step(st, x)
+            st.advance()
+            sample(hn)
+
+        graph = None
+        for i in range(1, n):
+            if use_graph and generator is None and i == 2:
+                # step 1 ran eagerly (warm-up: allocations, lazy inits); capture step 2 and replay it from then on
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    step()
+            elif graph is not None:
+                graph.replay()
+            else:
+                step()
+            out_tokens[:, i] = tok[:, 0]
+        eng.last_decode_graph = graph is not None
         return out_tokens
 
     # ------------------------------------------------------------------ text decoding for understanding

@@ -264,6 +264,39 @@ def attn_bwd(qkv, o, lse, dout, mb, H, HKV, hd, scale=None):
     return dqkv
 
 
+# ------------------------------------------------------------------------------------ decode
+def kv_store(qkv, cache_k, cache_v, rows, L, H, HKV, hd, Tmax, pos_dev=None, pos_host=0):
+    _l.check(_l.load().ug_kv_store(_p(qkv), qkv.stride(0), H * hd, (H + HKV) * hd, _p(cache_k), _p(cache_v), rows, L, HKV, hd,
+                                   Tmax, _p(pos_dev), pos_host, _stream()), "ug_kv_store")
+
+
+def rope_at_(qkv, cos, sin, nheads, hd, pos_dev):
+    _l.check(_l.load().ug_rope_at(_p(qkv), _p(cos), _p(sin), qkv.shape[0], qkv.stride(0), nheads, hd, _p(pos_dev),
+                                  cos.shape[0], _stream()), "ug_rope_at")
+    return qkv
+
+
+def attn_decode(qkv, cache_k, cache_v, key_valid, H, HKV, hd, Tmax, len_dev, scale=None):
+    rows = qkv.shape[0]
+    scale = 1.0 / math.sqrt(hd) if scale is None else scale
+    o = torch.empty((rows, H * hd), dtype=torch.bfloat16, device=qkv.device)
+    _l.check(_l.load().ug_attn_decode(_p(qkv), qkv.stride(0), _p(cache_k), _p(cache_v), _p(key_valid), _p(o), o.stride(0),
+                                      rows, H, HKV, hd, Tmax, _p(len_dev), scale, _stream()), "ug_attn_decode")
+    return o
+
+
+def skinny_linear(x, w, bias=None, resid=None):
+    """Decode-time Linear for a handful of rows: split-K fp32 accumulation (fills the chip while the weights
+    stream once) + a finishing pass.  resid given -> in-place residual update, else bf16 output."""
+    M, N = x.shape[0], w.shape[0]
+    acc = torch.zeros((M, N), dtype=torch.float32, device=x.device)
+    gemm(x, w, out=acc, epilogue=UG_EPI_F32, beta=1)
+    out = None if resid is not None else torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
+    _l.check(_l.load().ug_skinny_finish(_p(acc), _p(bias), _p(out), _p(resid), M, N, 0 if resid is None else 1, _stream()),
+             "ug_skinny_finish")
+    return resid if resid is not None else out
+
+
 # ------------------------------------------------------------------------------------ loss
 def ce_fwd(logits, V, labels, ignore_index=-100, want_logp=False):
     """logits bf16 [R, ld>=V]; -> (loss_and_count [2], lse [R], loss_row [R], logp|None)"""

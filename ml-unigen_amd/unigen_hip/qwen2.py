@@ -230,3 +230,78 @@ class Qwen2Engine:
         # dhn[R,H] = dlogits[R,V] W[V,H] : W read k-major; its rows >= V come from the zero page and the
         # dlogits pad columns are zero (ug_ce_bwd), so K = V needs no padding
         return ops.gemm(dlogits, fp.w("embed"), M=R, N=d.hidden_size, K=d.vocab_size, b_kmajor=True)
+
+
+class DecodeState:
+    """Static KV cache for autoregressive generation: per layer K,V [rows][HKV][Tmax][128] bf16, the write
+    position and visible length as DEVICE ints (so one captured graph serves every step)."""
+
+    def __init__(self, dims, rows, Tmax, device, key_valid=None):
+        self.rows, self.Tmax = rows, Tmax
+        n, hk, hd = dims.num_hidden_layers, dims.num_key_value_heads, dims.head_dim
+        self.k = [torch.zeros((rows, hk, Tmax, hd), dtype=torch.bfloat16, device=device) for _ in range(n)]
+        self.v = [torch.zeros((rows, hk, Tmax, hd), dtype=torch.bfloat16, device=device) for _ in range(n)]
+        self.pos = torch.zeros(1, dtype=torch.int32, device=device)
+        self.len = torch.zeros(1, dtype=torch.int32, device=device)
+        self.key_valid = None
+        if key_valid is not None:
+            kv = torch.ones((rows, Tmax), dtype=torch.uint8, device=device)
+            kv[:, :key_valid.shape[1]] = key_valid.to(device=device, dtype=torch.uint8)
+            self.key_valid = kv
+
+    def advance(self):
+        self.pos.add_(1)
+        self.len.add_(1)
+
+
+def _decode_methods(cls):
+    def prefill(self, st, embeds, key_valid=None):
+        """embeds fp32 [rows, P, H] -> final-norm hidden of the LAST position, bf16 [rows, H]; fills the cache."""
+        d = self.dims
+        R, P, H = embeds.shape
+        Hq, Hk, hd = d.num_attention_heads, d.num_key_value_heads, d.head_dim
+        self.fp.refresh_compute_copies()
+        mb = ops.mask_causal(R, P, self.device, key_valid=key_valid)
+        h = embeds.reshape(R * P, H).float().contiguous()
+        for i in range(d.num_hidden_layers):
+            saved = []
+            h = self.layer_fwd(i, h, mb, P, saved)
+            ops.kv_store(saved[0].qkv, st.k[i], st.v[i], R, P, Hq, Hk, hd, st.Tmax, None, 0)
+        st.pos.fill_(P)
+        st.len.fill_(P + 1)
+        hn, _ = ops.rmsnorm_fwd(h, self.fp.p("norm"), d.rms_norm_eps, want_rstd=False)
+        return hn.view(R, P, H)[:, -1].contiguous()
+
+    def decode_step(self, st, x):
+        """x fp32 [rows, H] = embedding of the newest token (updated in place as the residual stream);
+        appends its K/V at st.pos and returns the final-norm hidden bf16 [rows, H].  No host sync, no
+        shape depends on the step: capturable."""
+        d, fp = self.dims, self.fp
+        Hq, Hk, hd = d.num_attention_heads, d.num_key_value_heads, d.head_dim
+        cos, sin = self.rope(st.Tmax)
+        for i in range(d.num_hidden_layers):
+            xn, _ = ops.rmsnorm_fwd(x, fp.p(f"l{i}.ln1"), d.rms_norm_eps, want_rstd=False)
+            qkv = ops.skinny_linear(xn, fp.w(f"l{i}.wqkv"), bias=fp.w(f"l{i}.bqkv"))
+            ops.rope_at_(qkv, cos, sin, Hq + Hk, hd, st.pos)
+            ops.kv_store(qkv, st.k[i], st.v[i], st.rows, 1, Hq, Hk, hd, st.Tmax, st.pos, 0)
+            o = ops.attn_decode(qkv, st.k[i], st.v[i], st.key_valid, Hq, Hk, hd, st.Tmax, st.len)
+            ops.skinny_linear(o, fp.w(f"l{i}.wo"), resid=x)
+            xn2, _ = ops.rmsnorm_fwd(x, fp.p(f"l{i}.ln2"), d.rms_norm_eps, want_rstd=False)
+            gu = ops.skinny_linear(xn2, fp.w(f"l{i}.wgu"))
+            act = ops.swiglu_fwd(gu)
+            ops.skinny_linear(act, fp.w(f"l{i}.wdown"), resid=x)
+        hn, _ = ops.rmsnorm_fwd(x, fp.p("norm"), d.rms_norm_eps, want_rstd=False)
+        return hn
+
+    def head_slice(self, hn, v0, v1):
+        """logits bf16 [rows, v1-v0] for vocabulary rows [v0, v1) of the tied embedding."""
+        n = v1 - v0
+        out = torch.empty((hn.shape[0], ops.round_up(n, 8)), dtype=torch.bfloat16, device=self.device)
+        ops.gemm(hn, self.fp.w("embed")[v0:v1], out=out, N=n, K=self.dims.hidden_size)
+        return out[:, :n]
+
+    cls.prefill, cls.decode_step, cls.head_slice = prefill, decode_step, head_slice
+    return cls
+
+
+_decode_methods(Qwen2Engine)

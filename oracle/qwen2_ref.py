@@ -214,3 +214,44 @@ def unigen_forward_ref(lm, input_ids, attention_mask, labels=None, input_embeddi
         loss_lm = loss_lm.float() if torch.is_tensor(loss_lm) else loss_lm
         loss_mmu = loss_mmu.float() if torch.is_tensor(loss_mmu) else loss_mmu
     return logits, loss_t2i, loss_lm, loss_mmu
+
+
+def ar_generate_ref(lm, cond_embeds, uncond_embeds, n_tokens, guidance_scale, text_vocab, key_valid=None, autocast=True):
+    """Greedy (argmax) version of UniGen.t2i_generate_ar (models/unigen.py:457-521): prefix = embeddings with the
+    last n+1 positions already cut off; KV cache grown by concatenation like DynamicCache; CFG
+    `uncond + s * (cond - uncond)` on logits[text_vocab:-1]; next token embedded for both halves.
+    Returns (tokens [B, n], top-2 margin of the mixed logits per step [B, n])."""
+    B = cond_embeds.shape[0]
+    x = torch.cat([cond_embeds, uncond_embeds])
+    caches = [dict() for _ in lm.model.layers]
+    toks, margins = [], []
+    pos = 0
+    with torch.no_grad(), autocast_ctx(autocast):
+        for i in range(n_tokens):
+            L_new = x.shape[1]
+            total = pos + L_new
+            if i == 0:
+                r = torch.arange(total)
+                allow = (r[None, :] <= r[:, None])[None, None].expand(2 * B, 1, total, total).clone()
+                if key_valid is not None:
+                    allow = allow & key_valid[:, None, None, :total].bool()
+                mask = torch.where(allow, 0.0, float("-inf"))
+                mask = torch.where(allow.any(-1, keepdim=True), mask, torch.zeros(()))    # fully padded rows: harmless
+            else:
+                allow = torch.ones(2 * B, 1, 1, total, dtype=torch.bool)
+                if key_valid is not None:
+                    kv = torch.ones(2 * B, total, dtype=torch.bool)
+                    kv[:, :key_valid.shape[1]] = key_valid.bool()
+                    allow = allow & kv[:, None, None, :]
+                mask = torch.where(allow, 0.0, float("-inf"))
+            h = lm.backbone(inputs_embeds=x, mask=mask, caches=caches, pos_offset=pos)
+            logits = lm.lm_head(h[:, -1]).float()[:, text_vocab:-1]
+            cond, uncond = logits[:B], logits[B:]
+            mixed = uncond + guidance_scale * (cond - uncond)
+            top2 = mixed.topk(2, -1).values
+            nxt = mixed.argmax(-1, keepdim=True)
+            toks.append(nxt)
+            margins.append(top2[:, 0] - top2[:, 1])
+            pos = total
+            x = lm.model.embed_tokens(torch.cat([nxt, nxt]) + text_vocab)
+    return torch.cat(toks, 1), torch.stack(margins, 1)

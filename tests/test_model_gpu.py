@@ -155,3 +155,38 @@ def test_magvit_tokens_match_reference_golden(dev):
     assert rec.shape == (2, 3, 256, 256)
     assert (rec[:, :, 96:160, 96:160] - g["rec_crop"]).abs().max().item() < 2e-4
     assert (rec.mean(dim=(2, 3)) - g["rec_mean"]).abs().max().item() < 1e-5
+
+
+def test_ar_generation_kv_cache_matches_oracle(dev):
+    """t2i_generate_ar (static KV cache, captured graph) vs the oracle's DynamicCache-style greedy decode:
+    tokens must agree step by step until the oracle's own top-2 margin drops below bf16 noise."""
+    from oracle import qwen2_ref
+    g = golden("g2_tiny_unigen.pt")
+    model, _ = _tiny_unigen(g, dev)
+    model.eval()
+    lm, _ = oracle_lm(g["cfg"], g["weight_seed"])
+    ids = g["ids"]
+    n, B, P = 16, 2, 30
+    gen = torch.Generator().manual_seed(5)
+    cond = torch.randint(0, 290, (B, P + n + 1), generator=gen)
+    uncond = torch.randint(0, 290, (B, P + n + 1), generator=gen)
+    cond[0, :6] = ids["pad"]; uncond[:, :20] = ids["pad"]                     # left padding like t2i_gen_prompt
+    am = torch.cat([cond != ids["pad"], uncond != ids["pad"]]).long()
+    am[:, P:] = 1
+    with torch.no_grad():
+        ce, ue = lm.model.embed_tokens(cond[:, :P]), lm.model.embed_tokens(uncond[:, :P])
+    want, margin = qwen2_ref.ar_generate_ref(lm, ce, ue, n, 3.0, ids["text_vocab"], key_valid=am[:, :P])
+    for use_graph in (False, True):
+        got = model.t2i_generate_ar(input_ids=cond.to(dev), uncond_input_ids=uncond.to(dev), attention_mask=am.to(dev),
+                                    guidance_scale=3.0, temperature=1.0, text_vocab_size=ids["text_vocab"],
+                                    image_token_num_per_image=n, greedy=True, use_graph=use_graph).cpu()
+        assert got.shape == (B, n) and got.dtype == torch.int32
+        assert model.llm.engine.last_decode_graph == use_graph
+        compared = 0
+        for b in range(B):
+            for i in range(n):
+                if margin[b, i] < 0.05:
+                    break                      # an oracle near-tie: later tokens may legitimately diverge
+                assert got[b, i].item() == want[b, i].item(), (use_graph, b, i, got[b], want[b])
+                compared += 1
+        assert compared >= 8, compared
