@@ -71,6 +71,8 @@ int ug_rope(void* qkv, const float* cos_tab, const float* sin_tab, int64_t token
 int ug_swiglu_fwd(const void* gate_up, void* act, int64_t tokens, int64_t I, hipStream_t stream);
 int ug_swiglu_bwd(const void* gate_up, const void* dact, void* dgate_up, int64_t tokens, int64_t I,
                   hipStream_t stream);
+/* GELU(erf) of UniGen.mm_projector (models/unigen.py:119-128), bf16: out = gelu(x), or dgelu(x)*dy if dy given */
+int ug_gelu(const void* x, const void* dy_or_null, void* out, int64_t n, hipStream_t stream);
 /* replaces: llm.model.embed_tokens (models/unigen.py:257,370; fp32 gather) and its scatter-add grad */
 int ug_embed_fwd(const int64_t* ids, const float* W, float* out, int64_t tokens, int64_t H, int64_t V,
                  int* err_flag, hipStream_t stream);
@@ -161,7 +163,17 @@ int ug_gemm_f32(const float* A, int64_t lda, int64_t stride_a, const float* B, i
 /* replaces: Normalize = GroupNorm(32, eps 1e-6) (+ swish), common_modules.py:19-27 */
 int ug_groupnorm_swish(const float* x, const float* gamma, const float* beta, float* y, double* stats_ws,
                        int64_t B, int64_t HW, int C, int groups, float eps, int apply_swish, hipStream_t stream);
-int ug_softmax_rows_f32(float* x, int64_t rows, int64_t cols, float scale, hipStream_t stream);
+int ug_softmax_rows_f32(float* x, int64_t rows, int64_t cols, int64_t ld, float scale, hipStream_t stream);
+/* ---- SigLIP ViT (fp32, frozen; reference models/multimodal_encoder/siglip_encoder.py:152-309) ---- */
+/* y = act(x W^T + bias) + residual, W [N][K] as nn.Linear stores it; act 1 = gelu_pytorch_tanh.
+ * replaces: q/k/v/out_proj, fc1/fc2 (siglip_encoder.py:196-199,250-259); the 14x14/14 patch embedding is
+ * ug_conv2d_f32 with ksize 14, stride 14. */
+int ug_linear_f32(const float* x, int64_t ldx, const float* W, int64_t ldw, const float* bias,
+                  const float* residual, int64_t ldres, float* y, int64_t ldy, int64_t M, int64_t N, int64_t K,
+                  int act, hipStream_t stream);
+/* replaces: nn.LayerNorm(eps 1e-6) (siglip_encoder.py:267-269) */
+int ug_layernorm_f32(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int64_t cols,
+                     float eps, hipStream_t stream);
 int ug_nchw_to_nhwc(const float* in, float* out, int64_t B, int C, int64_t HW, int c_pad, hipStream_t stream);
 int ug_nhwc_to_nchw(const float* in, float* out, int64_t B, int C, int64_t HW, int c_pad, hipStream_t stream);
 /* replaces: LFQuantizer.get_indices / get_codebook_entry, magvitv2.py:210-230 */

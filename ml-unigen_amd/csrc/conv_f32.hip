@@ -30,6 +30,7 @@ struct ConvArgs {
   int gemm, lda, b_nk;
   int64_t sa, sb, sc;                      // batch strides (elements)
   float alpha;
+  int act;                                 // 0 none, 1 GELU(tanh) applied before the residual add
 };
 
 // A operand: gather 4 consecutive input channels of one tap for output pixel m (zeros off-image)
@@ -209,6 +210,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs p) {
         const int m = m0 + wm * (CBM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (m >= p.M) continue;
         float v = acc[i][j][r] * p.alpha + bv;
+        if (p.act == 1) {   // gelu_pytorch_tanh: 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
+          const float u = 0.7978845608028654f * (v + 0.044715f * v * v * v);
+          v = 0.5f * v * (1.f + tanhf(u));
+        }
         if (rb) v += rb[(int64_t)m * p.ldres + n];
         yb[(int64_t)m * p.ldy + n] = v;
       }
@@ -275,11 +280,11 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------ row softmax (AttnBlock), fp32
-__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ x, int rows, int cols, float scale) {
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ x, int rows, int cols, int64_t ld, float scale) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
-  float* r = x + (int64_t)row * cols;
+  float* r = x + (int64_t)row * ld;
   float m = -INFINITY;
   for (int c = lane; c < cols; c += 64) m = fmaxf(m, r[c] * scale);
   m = wave_max(m);
@@ -288,6 +293,24 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ x
   s = wave_sum(s);
   const float inv = 1.f / s;
   for (int c = lane; c < cols; c += 64) r[c] *= inv;
+}
+
+// ------------------------------------------------------------------ LayerNorm (SigLIP, eps 1e-6), fp32, one wave per row
+__global__ __launch_bounds__(256) void layernorm_f32_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                            const float* __restrict__ b, float* __restrict__ y, int rows,
+                                                            int cols, float eps) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* r = x + (int64_t)row * cols;
+  float s = 0.f;
+  for (int c = lane; c < cols; c += 64) s += r[c];
+  const float mean = wave_sum(s) / (float)cols;
+  float v = 0.f;
+  for (int c = lane; c < cols; c += 64) { const float d = r[c] - mean; v += d * d; }
+  const float rstd = rsqrtf(wave_sum(v) / (float)cols + eps);
+  float* o = y + (int64_t)row * cols;
+  for (int c = lane; c < cols; c += 64) o[c] = (r[c] - mean) * rstd * g[c] + b[c];
 }
 
 // ------------------------------------------------------------------ layout conversion at the API boundary
@@ -355,7 +378,7 @@ int launch_conv(const ConvArgs& a, int nb, hipStream_t st) {
 extern "C" int ug_conv2d_f32(const float* x, const float* w_packed, const float* bias, const float* residual, float* y,
                              int64_t B, int Hin, int Win, int Cin, int Cout, int cout_pad, int ksize, int stride,
                              int pad_top, int pad_left, int Hout, int Wout, int upsample2x, hipStream_t st) {
-  UG_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && (ksize == 1 || ksize == 3), "ug_conv2d_f32: bad shape");
+  UG_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && ksize >= 1 && ksize <= 16, "ug_conv2d_f32: bad shape");
   UG_REQUIRE(cout_pad % 4 == 0 && cout_pad >= ((Cout > 32) ? (Cout + 127) / 128 * 128 : 32),
              "ug_conv2d_f32: packed weights must be padded to the N tile (cout_pad=%d for Cout=%d)", cout_pad, Cout);
   UG_REQUIRE(ug_aligned16(w_packed) && x && y, "ug_conv2d_f32: pointers");
@@ -387,6 +410,29 @@ extern "C" int ug_gemm_f32(const float* A, int64_t lda, int64_t stride_a, const 
   return UG_OK;
 }
 
+extern "C" int ug_linear_f32(const float* x, int64_t ldx, const float* W, int64_t ldw, const float* bias,
+                             const float* residual, int64_t ldres, float* y, int64_t ldy, int64_t M, int64_t N, int64_t K,
+                             int act, hipStream_t st) {
+  UG_REQUIRE(M > 0 && N > 0 && K > 0 && (act == 0 || act == 1), "ug_linear_f32: bad args");
+  UG_REQUIRE(M < (1LL << 31), "ug_linear_f32: too many rows");
+  ConvArgs a{};
+  a.x = x; a.w = W; a.bias = bias; a.res = residual; a.y = y; a.Cin = (int)K; a.Cout = (int)N; a.M = (int)M;
+  a.gemm = 1; a.lda = (int)ldx; a.ldw = (int)ldw; a.ldy = (int)ldy; a.ldres = (int)ldres; a.b_nk = 1;     // W is [N][K] like nn.Linear
+  a.alpha = 1.f; a.act = act; a.KH = a.KW = 1;
+  launch_conv(a, 1, st);
+  UG_CHECK_LAUNCH("ug_linear_f32");
+  return UG_OK;
+}
+
+extern "C" int ug_layernorm_f32(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int64_t cols,
+                                float eps, hipStream_t st) {
+  UG_REQUIRE(rows > 0 && cols > 0, "ug_layernorm_f32: empty");
+  hipLaunchKernelGGL(layernorm_f32_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, gamma, beta, y, (int)rows,
+                     (int)cols, eps);
+  UG_CHECK_LAUNCH("ug_layernorm_f32");
+  return UG_OK;
+}
+
 extern "C" int ug_groupnorm_swish(const float* x, const float* gamma, const float* beta, float* y, double* stats_ws,
                                   int64_t B, int64_t HW, int C, int groups, float eps, int apply_swish, hipStream_t st) {
   UG_REQUIRE(B > 0 && HW > 0 && groups > 0 && groups <= 32 && C % groups == 0 && (C / groups) % 4 == 0,
@@ -405,9 +451,9 @@ extern "C" int ug_groupnorm_swish(const float* x, const float* gamma, const floa
   return UG_OK;
 }
 
-extern "C" int ug_softmax_rows_f32(float* x, int64_t rows, int64_t cols, float scale, hipStream_t st) {
-  UG_REQUIRE(rows > 0 && cols > 0, "ug_softmax_rows_f32: empty");
-  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, (int)rows, (int)cols, scale);
+extern "C" int ug_softmax_rows_f32(float* x, int64_t rows, int64_t cols, int64_t ld, float scale, hipStream_t st) {
+  UG_REQUIRE(rows > 0 && cols > 0 && ld >= cols, "ug_softmax_rows_f32: bad shape");
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, (int)rows, (int)cols, ld, scale);
   UG_CHECK_LAUNCH("ug_softmax_rows_f32");
   return UG_OK;
 }

@@ -194,6 +194,25 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restric
   }
 }
 
+// =========================================================================== GELU (erf), bf16
+// torch.nn.GELU() inside UniGen.mm_projector (reference models/unigen.py:119-128) under bf16 autocast
+__global__ __launch_bounds__(256) void gelu_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                   bf16_t* __restrict__ out, int64_t n8) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    const bf16x8_t v = reinterpret_cast<const bf16x8_t*>(x)[i];
+    bf16x8_t g, o;
+    if (dy) g = reinterpret_cast<const bf16x8_t*>(dy)[i];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float f = bf2f((bf16_t)v[k]);
+      const float cdf = 0.5f * (1.f + erff(f * 0.70710678118654752f));
+      if (!dy) o[k] = (short)f2bf(f * cdf);
+      else o[k] = (short)f2bf(bf2f((bf16_t)g[k]) * (cdf + f * 0.3989422804014327f * __expf(-0.5f * f * f)));
+    }
+    reinterpret_cast<bf16x8_t*>(out)[i] = o;
+  }
+}
+
 // =========================================================================== transpose / cast
 // in [R, C] (fp32 or bf16, row stride ld_in)  ->  out bf16 [R, C] (optional, stride ld_out)
 //                                               outT bf16 [C, ldT] with columns R..ldT-1 zeroed
@@ -400,6 +419,14 @@ extern "C" int ug_swiglu_bwd(const void* gate_up, const void* dact, void* dgate_
   dim3 grid(grid_for(tokens * (I / 8))), block(256);
   hipLaunchKernelGGL(swiglu_bwd_kernel, grid, block, 0, st, (const bf16_t*)gate_up, (const bf16_t*)dact, (bf16_t*)dgate_up, tokens, (int)I);
   UG_CHECK_LAUNCH("ug_swiglu_bwd");
+  return UG_OK;
+}
+
+extern "C" int ug_gelu(const void* x, const void* dy_or_null, void* out, int64_t n, hipStream_t st) {
+  UG_REQUIRE(n > 0 && n % 8 == 0 && ug_aligned16(x) && ug_aligned16(out), "ug_gelu: n must be a multiple of 8, 16B-aligned buffers");
+  dim3 grid(grid_for(n / 8)), block(256);
+  hipLaunchKernelGGL(gelu_kernel, grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)dy_or_null, (bf16_t*)out, n / 8);
+  UG_CHECK_LAUNCH("ug_gelu");
   return UG_OK;
 }
 

@@ -166,7 +166,8 @@ class UniGen(ModelMixin, ConfigMixin):
         layers = [torch.nn.Linear(mm_input_dim, hidden)]
         for _ in range(1, mlp_depth):
             layers += [torch.nn.GELU(), torch.nn.Linear(hidden, hidden)]
-        self.mm_projector = torch.nn.Sequential(*layers).to(self.llm.engine.device)
+        from unigen_hip.modules import HipProjector
+        self.mm_projector = HipProjector(*layers).to(self.llm.engine.device)
 
     def get_gen_embed(self, img_tokens):
         raise UniGenHipError("gen_projector path (gen_proj_depth > 0) is not implemented")

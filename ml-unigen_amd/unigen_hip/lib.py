@@ -29,6 +29,7 @@ SIGNATURES = {
     "ug_rope": [P, P, P, I64, I64, I64, I32, I32, I32, P],
     "ug_swiglu_fwd": [P, P, I64, I64, P],
     "ug_swiglu_bwd": [P, P, P, I64, I64, P],
+    "ug_gelu": [P, P, P, I64, P],
     "ug_embed_fwd": [P, P, P, I64, I64, I64, P, P],
     "ug_embed_bwd": [P, P, P, I64, I64, I64, P],
     "ug_gather_rows_bf16": [P, I64, P, P, I64, I64, I64, I32, P],
@@ -48,7 +49,9 @@ SIGNATURES = {
     "ug_conv2d_f32": [P, P, P, P, P, I64, I32, I32, I32, I32, I32, I32, I32, I32, I32, I32, I32, I32, P],
     "ug_gemm_f32": [P, I64, I64, P, I64, I64, I32, P, I64, I64, I64, I64, I64, I64, F32, P],
     "ug_groupnorm_swish": [P, P, P, P, P, I64, I64, I32, I32, F32, I32, P],
-    "ug_softmax_rows_f32": [P, I64, I64, F32, P],
+    "ug_softmax_rows_f32": [P, I64, I64, I64, F32, P],
+    "ug_linear_f32": [P, I64, P, I64, P, P, I64, P, I64, I64, I64, I64, I32, P],
+    "ug_layernorm_f32": [P, P, P, P, I64, I64, F32, P],
     "ug_nchw_to_nhwc": [P, P, I64, I32, I64, I32, P],
     "ug_nhwc_to_nchw": [P, P, I64, I32, I64, I32, P],
     "ug_lfq_pack": [P, I64, P, I64, I32, P],

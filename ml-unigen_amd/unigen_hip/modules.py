@@ -362,3 +362,61 @@ class TrainEngine(Qwen2Engine):
             mb = ops.mask_compress(attention_mask.to(self.device), self.err_flag)
             self._mask_cache = ((attention_mask, attention_mask._version), mb)
         return self._mask_cache[1]
+
+
+# ------------------------------------------------------------------------------------ mm_projector
+class _LinearFn(torch.autograd.Function):
+    """y = x W^T + b with bf16 operands / fp32 accumulate (what nn.Linear does under the reference's bf16
+    autocast), dgrad and wgrad on the same GEMM kernel."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1]).to(torch.bfloat16).contiguous()
+        wb = ops.cast_bf16(w.detach().float().contiguous())
+        bb = ops.cast_bf16(b.detach().float().contiguous()) if b is not None else None
+        y = ops.gemm(x2, wb, bias=bb)
+        ctx.save_for_backward(x2, wb)
+        ctx.shp, ctx.has_bias, ctx.in_dtype = shp, b is not None, x.dtype
+        return y.view(*shp[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, wb = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1]).to(torch.bfloat16).contiguous()
+        dx = ops.gemm(dy2, wb, b_kmajor=True).view(ctx.shp).to(ctx.in_dtype) if ctx.needs_input_grad[0] else None
+        dw = ops.gemm(dy2, x2, a_kmajor=True, b_kmajor=True, epilogue=ops.UG_EPI_F32)
+        db = None
+        if ctx.has_bias:
+            db = torch.zeros(dy2.shape[1], dtype=torch.float32, device=dy2.device)
+            ops.colsum_(dy2, db)
+        return dx, dw, db
+
+
+class _GeluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        xb = x.to(torch.bfloat16).contiguous()
+        ctx.save_for_backward(xb)
+        return ops.gelu(xb)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (xb,) = ctx.saved_tensors
+        return ops.gelu(xb, dy.to(torch.bfloat16).contiguous())
+
+
+class HipProjector(nn.Sequential):
+    """`UniGen.mm_projector` (reference models/unigen.py:119-128): Linear -> (GELU -> Linear)*; an
+    nn.Sequential of ordinary torch modules (state-dict keys `mm_projector.0.weight`, ...) whose forward
+    runs on the HIP GEMM / GELU kernels."""
+
+    def forward(self, x):
+        for m in self:
+            if isinstance(m, nn.Linear):
+                x = _LinearFn.apply(x, m.weight, m.bias)
+            elif isinstance(m, nn.GELU):
+                x = _GeluFn.apply(x)
+            else:
+                raise UniGenHipError(f"unexpected module in mm_projector: {type(m).__name__}")
+        return x

@@ -352,10 +352,15 @@ def conv2d_nhwc(x, wp, cout_pad, bias, cout, ksize, *, stride=1, pad=None, resid
     return y
 
 
-def gemm_f32(a, b, *, b_is_nk, M, N, K, batch=1, lda=None, ldb=None, stride_a=0, stride_b=0, alpha=1.0, out=None):
+def gemm_f32(a, b, *, b_is_nk, M, N, K, batch=1, lda=None, ldb=None, stride_a=0, stride_b=0, alpha=1.0, out=None,
+             ldc=None, stride_c=None):
+    """Batched fp32 GEMM on the f32 matrix cores: C_z[M,N] = alpha * A_z[M,K] @ (B_z as [N,K] if b_is_nk else [K,N]);
+    operand z starts stride_* elements after operand z-1 (heads of a fused projection are z * head_dim apart)."""
     if out is None:
         out = torch.empty((batch, M, N), dtype=torch.float32, device=a.device)
-    _l.check(_l.load().ug_gemm_f32(_p(a), lda, stride_a, _p(b), ldb, stride_b, int(b_is_nk), _p(out), N, M * N, M, N,
+    ldc = N if ldc is None else ldc
+    stride_c = M * N if stride_c is None else stride_c
+    _l.check(_l.load().ug_gemm_f32(_p(a), lda, stride_a, _p(b), ldb, stride_b, int(b_is_nk), _p(out), ldc, stride_c, M, N,
                                    K, batch, alpha, _stream()), "ug_gemm_f32")
     return out
 
@@ -370,10 +375,31 @@ def groupnorm_swish(x, gamma, beta, *, groups=32, eps=1e-6, swish=True):
     return y
 
 
-def softmax_rows_(x2d, scale):
-    _l.check(_l.load().ug_softmax_rows_f32(_p(x2d), x2d.shape[0], x2d.shape[1], scale, _stream()),
+def softmax_rows_(x2d, scale, cols=None):
+    """in-place row softmax of scale*x over the first `cols` columns of a 2-D fp32 tensor (row stride = .stride(0))."""
+    cols = x2d.shape[1] if cols is None else cols
+    _l.check(_l.load().ug_softmax_rows_f32(_p(x2d), x2d.shape[0], cols, x2d.stride(0), scale, _stream()),
              "ug_softmax_rows_f32")
     return x2d
+
+
+def linear_f32(x, W, bias=None, residual=None, act=0, out=None, M=None):
+    """fp32 y = act(x @ W^T + bias) + residual on the f32 matrix cores; x [M,K] (row stride .stride(0)), W [N,K]."""
+    M = x.shape[0] if M is None else M
+    N, K = W.shape
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    _l.check(_l.load().ug_linear_f32(_p(x), x.stride(0), _p(W), W.stride(0), _p(bias), _p(residual),
+                                     residual.stride(0) if residual is not None else 0, _p(out), out.stride(0), M, N, K, act,
+                                     _stream()), "ug_linear_f32")
+    return out
+
+
+def layernorm_f32(x2d, gamma, beta, eps):
+    y = torch.empty_like(x2d)
+    _l.check(_l.load().ug_layernorm_f32(_p(x2d), _p(gamma), _p(beta), _p(y), x2d.shape[0], x2d.shape[1], eps, _stream()),
+             "ug_layernorm_f32")
+    return y
 
 
 def nchw_to_nhwc(x, c_pad):
@@ -407,4 +433,11 @@ def lfq_unpack(idx, nbits, err_flag=None):
 def probe_layouts(device):
     out = torch.zeros((512,), dtype=torch.float32, device=device)
     _l.check(_l.load().ug_probe_layouts(_p(out), 512, _stream()), "ug_probe_layouts")
+    return out
+
+
+def gelu(x, dy=None):
+    """bf16 GELU(erf): forward if dy is None, else the gradient dgelu(x) * dy."""
+    out = torch.empty_like(x)
+    _l.check(_l.load().ug_gelu(_p(x), _p(dy), _p(out), x.numel(), _stream()), "ug_gelu")
     return out

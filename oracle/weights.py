@@ -48,3 +48,20 @@ def synth_images(batch, res, seed):
     """U(-1,1) images, the range the reference's loader normalises to (training/data_loader.py:161-166)."""
     g = torch.Generator().manual_seed(seed)
     return torch.rand(batch, 3, res, res, generator=g) * 2 - 1
+
+
+def synth_siglip_state(named_shapes, seed):
+    """Fan-in scaled projections, mild LayerNorm affine, small biases / position embeddings."""
+    out = {}
+    for name, shape in named_shapes:
+        g = _gen(name, seed)
+        if "layer_norm" in name or "layernorm" in name:
+            out[name] = (1.0 + 0.1 * torch.randn(shape, generator=g)) if name.endswith("weight") else 0.1 * torch.randn(shape, generator=g)
+        elif name.endswith(".bias"):
+            out[name] = 0.05 * torch.randn(shape, generator=g)
+        elif "position_embedding" in name:
+            out[name] = 0.2 * torch.randn(shape, generator=g)
+        else:
+            fan_in = math.prod(shape[1:])
+            out[name] = torch.randn(shape, generator=g) / math.sqrt(fan_in)
+    return out

@@ -300,3 +300,38 @@ if __name__ == "__main__":
         golden_unigen()
     if "magvit" in which:
         golden_magvit()
+
+
+# ------------------------------------------------------------------ G7: SigLIP tower (small config)
+SIGLIP_SMALL = dict(hidden_size=144, intermediate_size=256, num_hidden_layers=4, num_attention_heads=2, num_channels=3,
+                    image_size=56, patch_size=14)
+
+
+def golden_siglip():
+    import importlib
+    from oracle import siglip_ref
+    ref = importlib.import_module("models.multimodal_encoder.siglip_encoder")
+    cfg = ref.SigLipVisionConfig(**SIGLIP_SMALL)
+    torch.manual_seed(0)
+    m = ref.SigLipVisionModel(cfg).eval()
+    shapes = siglip_ref.siglip_param_shapes(144, 256, 4, 3, 14, 56)
+    have = {n: tuple(p.shape) for n, p in m.named_parameters() if not n.startswith("vision_model.head")}
+    assert dict(shapes) == have, set(dict(shapes)) ^ set(have)
+    sd = weights.synth_siglip_state(shapes, seed=41)
+    res = m.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys
+    # what SigLipVisionTower.load_model / forward do (siglip_encoder.py:566-590)
+    del m.vision_model.encoder.layers[-1:]
+    m.vision_model.head = torch.nn.Identity()
+    x = torch.rand(2, 3, 56, 56, generator=torch.Generator().manual_seed(42)) * 2 - 1
+    with torch.no_grad():
+        out = m(x, output_hidden_states=True).hidden_states[-1]
+        mine = siglip_ref.siglip_tower_ref(sd, x, num_layers_total=4, num_heads=2, patch=14)
+    print(f"G7 SigLIP oracle vs reference: {maxdiff(out, mine):.3e}")
+    assert maxdiff(out, mine) < 1e-5
+    torch.save({"cfg": SIGLIP_SMALL, "weight_seed": 41, "image_seed": 42, "out": out}, os.path.join(OUT, "g7_siglip.pt"))
+    print("G7 SigLIP: captured")
+
+
+if __name__ == "__main__" and "siglip" in sys.argv[1:]:
+    golden_siglip()
