@@ -223,9 +223,9 @@ class UniGen(ModelMixin, ConfigMixin):
         else:
             out = self.llm.model(inputs_embeds=input_embeddings, attention_mask=attention_mask)
         hn = out.last_hidden_state                                  # bf16 [B, L, H] (final norm applied)
-        logits = LazyLogits(eng, hn.detach())
         if labels is None:
-            return logits
+            return LazyLogits(eng, hn)          # stays on the autograd graph: DPO differentiates through its slices
+        logits = LazyLogits(eng, hn.detach())
         B, L, _ = hn.shape
         idx, lab_idx, bounds = self._loss_rows(B, L, batch_size_t2i, batch_size_lm, batch_size_mmu, num_vq_tokens,
                                                t2i_mode, hn.device)

@@ -100,17 +100,50 @@ class _HeadLossFn(torch.autograd.Function):
         return None, dhn.view(B, L, H), None, None, None, None
 
 
+class _HeadRowsFn(torch.autograd.Function):
+    """logits[rows, v0:v1] of the tied lm_head for the rows `idx` of hn, differentiable: the gradient goes to hn
+    (dgrad GEMM) and into the flat embedding-gradient rows [v0, v1) (wgrad GEMM)."""
+
+    @staticmethod
+    def forward(ctx, anchor, hn, engine, idx, v0, v1):
+        B, L, H = hn.shape
+        rows = ops.gather_rows(hn.reshape(B * L, H), idx)
+        n = v1 - v0
+        npad = ops.round_up(max(n, 1), 8)
+        out = torch.empty((rows.shape[0], npad), dtype=torch.bfloat16, device=hn.device)
+        ops.gemm(rows, engine.fp.w("embed")[v0:v1], out=out, N=n, K=H)
+        ctx.engine, ctx.rows, ctx.idx, ctx.rng, ctx.shape = engine, rows, idx, (v0, v1), (B, L, H)
+        return out[:, :n]
+
+    @staticmethod
+    def backward(ctx, dout):
+        eng = ctx.engine
+        B, L, H = ctx.shape
+        v0, v1 = ctx.rng
+        n, R = v1 - v0, ctx.rows.shape[0]
+        eng.begin_grad_pass()
+        npad = ops.round_up(n, 8)
+        dl = torch.zeros((R, npad), dtype=torch.bfloat16, device=dout.device)
+        dl[:, :n] = dout
+        ops.gemm(dl, ctx.rows, out=eng.fp.g("embed")[v0:v1], M=n, N=H, K=R, a_kmajor=True, b_kmajor=True,
+                 epilogue=ops.UG_EPI_F32, beta=1)
+        drows = ops.gemm(dl, eng.fp.w("embed")[v0:v1], M=R, N=H, K=n, b_kmajor=True)
+        dhn = torch.zeros((B * L, H), dtype=torch.bfloat16, device=dout.device)
+        ops.scatter_rows_(drows, ctx.idx, dhn)
+        return None, dhn.view(B, L, H), None, None, None, None
+
+
 # ------------------------------------------------------------------------------------ lazy logits
 class LazyLogits:
     """Stand-in for the dense [B, L, V] logits tensor the reference returns (models/unigen.py:287-290).
     Callers only ever slice it (train.py:926-936, unigen.py:416,507, train_dpo.py:602-609); rows are
     produced on demand by the lm_head GEMM for exactly the positions / vocabulary range requested."""
 
-    def __init__(self, engine, hn):
-        self.engine, self.hn = engine, hn      # hn bf16 [B, L, H]
+    def __init__(self, engine, hn, dtype=torch.bfloat16):
+        self.engine, self.hn = engine, hn      # hn bf16 [B, L, H]; attached to the autograd graph when it requires grad
         B, L, _ = hn.shape
         self.shape = torch.Size((B, L, engine.dims.vocab_size))
-        self.dtype, self.device = torch.bfloat16, hn.device
+        self.dtype, self.device = dtype, hn.device
 
     def size(self, dim=None):
         return self.shape if dim is None else self.shape[dim]
@@ -127,12 +160,11 @@ class LazyLogits:
         if vstep != 1:
             raise UniGenHipError("strided vocabulary slices are not supported")
         idx = (torch.tensor(bs, device=self.device)[:, None] * L + torch.tensor(ps, device=self.device)[None, :]).reshape(-1)
-        rows = ops.gather_rows(self.hn.reshape(B * L, -1), idx)
         n = v1 - v0
-        npad = ops.round_up(max(n, 1), 8)
-        out = torch.empty((rows.shape[0], npad), dtype=torch.bfloat16, device=self.device)
-        ops.gemm_nt(rows, eng.fp.w("embed")[v0:v1], out=out, N=n, K=eng.dims.hidden_size)
-        out = out[:, :n].reshape(len(bs), len(ps), n)
+        out = _HeadRowsFn.apply(eng._anchor, self.hn, eng, idx, v0, v1)          # [R, n] bf16, differentiable
+        if self.dtype != torch.bfloat16:
+            out = out.to(self.dtype)
+        out = out.reshape(len(bs), len(ps), n)
         if not isinstance(vsel, slice):
             out = out[..., 0]
         if not isinstance(psel, slice):
@@ -155,10 +187,16 @@ class LazyLogits:
         return self._rows(slice(None), slice(None), slice(None))
 
     def float(self):
-        return self.materialize().float()
+        return self.to(torch.float32)
 
     def to(self, *a, **k):
-        return self.materialize().to(*a, **k)
+        """dtype conversion stays lazy (training/train_dpo.py:602 up-casts the whole tensor before slicing it);
+        device moves are no-ops."""
+        dt = k.get("dtype")
+        for x in a:
+            if isinstance(x, torch.dtype):
+                dt = x
+        return LazyLogits(self.engine, self.hn, dt or self.dtype)
 
     def chunk(self, n, dim=0):
         B = self.shape[0]

@@ -1,0 +1,64 @@
+"""DPO step (BASELINE configs[4], reference training/train_dpo.py:51-90, 573-647) through the drop-in API: the
+reference's own get_batch_logps arithmetic applied to the lazy logits must match the CPU oracle, values and
+gradients."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import additive, golden, oracle_lm
+from test_model_gpu import _tiny_unigen, _rel
+
+pytestmark = pytest.mark.gpu
+
+
+def batch_logps(logits, labels, n):
+    """get_batch_logps, 'mask' mode (train_dpo.py:74-90)."""
+    logits = logits[:, -(n + 1):-1]
+    labels = labels[:, -(n + 1):-1].clone()
+    m = labels != -100
+    labels[labels == -100] = 0
+    per_tok = torch.gather(logits.log_softmax(-1), dim=2, index=labels.unsqueeze(2)).squeeze(2)
+    return (per_tok * m).sum(-1)
+
+
+def test_dpo_loss_and_grads_match_oracle(dev):
+    from oracle import host_ref, qwen2_ref
+    g = golden("g2_tiny_unigen.pt")
+    model, _ = _tiny_unigen(g, dev)
+    lm, _ = oracle_lm(g["cfg"], g["weight_seed"])
+    ids = g["ids"]
+    gen = torch.Generator().manual_seed(11)
+    Bp, L, n = 2, 40, 16
+    seq = torch.randint(0, 290, (2 * Bp, L), generator=gen)
+    seq[:, -(n + 2)] = ids["soi"]; seq[:, -1] = ids["eoi"]
+    seq[0, :4] = ids["pad"]
+    img = torch.randint(312, 332, (2 * Bp, n), generator=gen)
+    msk = torch.rand(2 * Bp, n, generator=gen) < 0.5
+    msk[:, 0] = True
+    seq[:, -(n + 1):-1] = torch.where(msk, ids["mask"], img)
+    labels = torch.full((2 * Bp, L), -100)
+    labels[:, -(n + 1):-1] = torch.where(msk, img, -100)
+    mask = additive(host_ref.mask_predict_next_ref(seq, ids["pad"], ids["soi"], ids["eoi"], rm_pad_in_image=True))
+    ref_lp = torch.randn(2 * Bp, generator=gen)            # frozen reference-model log-probs (any constants)
+    beta = 0.5
+
+    def dpo(lp):
+        pi = lp[:Bp] - lp[Bp:]
+        rf = ref_lp[:Bp].to(lp.device) - ref_lp[Bp:].to(lp.device)
+        return -F.logsigmoid(beta * (pi - rf)).mean()
+
+    lo = qwen2_ref.unigen_forward_ref(lm, seq, mask, None, batch_size_t2i=2 * Bp, autocast=True)
+    lp_ref = batch_logps(lo.float(), labels, n)
+    loss_ref = dpo(lp_ref)
+    loss_ref.backward()
+    all_logits = model(input_ids=seq.to(dev), attention_mask=mask.to(torch.bfloat16).to(dev), batch_size_t2i=2 * Bp)
+    all_logits = all_logits.to(torch.float32)
+    assert tuple(all_logits.shape[:-1]) == tuple(labels.shape)
+    lp = batch_logps(all_logits, labels.to(dev), n)
+    assert _rel(lp, lp_ref) < 2e-3
+    loss = dpo(lp)
+    assert abs(loss.item() - loss_ref.item()) < 2e-3 * max(1.0, abs(loss_ref.item()))
+    loss.backward()
+    ref_g = dict(lm.named_parameters())
+    for nme, p in model.llm.named_parameters():
+        assert _rel(p.grad, ref_g[nme].grad) < 6e-2, (nme, _rel(p.grad, ref_g[nme].grad))
