@@ -33,36 +33,40 @@ struct ConvArgs {
   int act;                                 // 0 none, 1 GELU(tanh) applied before the residual add
 };
 
-// A operand: gather 4 consecutive input channels of one tap for output pixel m (zeros off-image)
-template <bool VEC4>
+// Operand fetches are BRANCH-FREE: an invalid element is loaded from a safe dummy address (the operand's
+// base) and replaced by zero afterwards, so the compiler issues all of a k-tile's global loads back to back
+// (with guarded loads it serialised them behind `s_waitcnt vmcnt(0)`s).
+// MODE 0: convolution (implicit im2col gather);  1: plain GEMM, B as [K][N];  2: plain GEMM, B as [N][K].
+template <bool VEC4, int MODE>
 __device__ __forceinline__ float4 load_a(const ConvArgs& p, const float* xb, int m, bool mvalid, int ob, int oy, int ox,
-                                         int dy, int dx, int c) {
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (!mvalid) return v;
-  if (p.gemm) {
-    const float* a = xb + (int64_t)m * p.lda + c;
-    if (VEC4 && c + 3 < p.Cin) return *reinterpret_cast<const float4*>(a);
-    if (c < p.Cin) v.x = a[0];
-    if (c + 1 < p.Cin) v.y = a[1];
-    if (c + 2 < p.Cin) v.z = a[2];
-    if (c + 3 < p.Cin) v.w = a[3];
-    return v;
+                                         int dy, int dx, int c, bool& keep) {
+  const float* a;
+  bool ok = mvalid;
+  if constexpr (MODE != 0) {
+    a = xb + (int64_t)m * p.lda + c;
+  } else {
+    int iy = oy * p.stride + dy - p.pad_t, ix = ox * p.stride + dx - p.pad_l;
+    const int He = p.ups ? p.Hin * 2 : p.Hin, We = p.ups ? p.Win * 2 : p.Win;
+    ok = ok && iy >= 0 && iy < He && ix >= 0 && ix < We;
+    if (p.ups) { iy >>= 1; ix >>= 1; }
+    a = xb + (((int64_t)ob * p.Hin + iy) * p.Win + ix) * p.Cin + c;
   }
-  int iy = oy * p.stride + dy - p.pad_t, ix = ox * p.stride + dx - p.pad_l;
-  const int He = p.ups ? p.Hin * 2 : p.Hin, We = p.ups ? p.Win * 2 : p.Win;
-  if (iy < 0 || iy >= He || ix < 0 || ix >= We) return v;
-  if (p.ups) { iy >>= 1; ix >>= 1; }
-  const float* a = xb + (((int64_t)ob * p.Hin + iy) * p.Win + ix) * p.Cin + c;
-  if (VEC4 && c + 3 < p.Cin) return *reinterpret_cast<const float4*>(a);
-  if (c < p.Cin) v.x = a[0];
-  if (c + 1 < p.Cin) v.y = a[1];
-  if (c + 2 < p.Cin) v.z = a[2];
-  if (c + 3 < p.Cin) v.w = a[3];
+  float4 v;
+  if constexpr (VEC4) {        // Cin % 4 == 0: the quad is valid or not as a whole
+    ok = ok && (c < p.Cin);
+    v = *reinterpret_cast<const float4*>(ok ? a : xb);
+    keep = ok;                  // zeroing is deferred to the LDS write so the load stays in flight under the MFMAs
+  } else {
+    keep = true;
+    const bool o0 = ok && c < p.Cin, o1 = ok && c + 1 < p.Cin, o2 = ok && c + 2 < p.Cin, o3 = ok && c + 3 < p.Cin;
+    const float t0 = *(o0 ? a : xb), t1 = *(o1 ? a + 1 : xb), t2 = *(o2 ? a + 2 : xb), t3 = *(o3 ? a + 3 : xb);
+    v = make_float4(o0 ? t0 : 0.f, o1 ? t1 : 0.f, o2 ? t2 : 0.f, o3 ? t3 : 0.f);
+  }
   return v;
 }
 
 // BN = 128: waves 2x2, each 64x64 (2x2 MFMA tiles);  BN = 32: waves 4x1, each 32x32
-template <int BN, bool VEC4>
+template <int BN, bool VEC4, int MODE>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs p) {
   constexpr int WN = (BN == 128) ? 2 : 1;          // waves along n
   constexpr int WM = 4 / WN;                       // waves along m
@@ -88,15 +92,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs p) {
   for (int i = 0; i < 2; ++i) {
     const int m = m0 + (tid >> 2) + i * 64;
     am[i] = m; av[i] = m < p.M;
-    if (!p.gemm) {
+    if constexpr (MODE == 0) {
       const int hw = p.Hout * p.Wout;
       const int mm = av[i] ? m : 0;
       ab[i] = mm / hw; const int r = mm % hw; ay[i] = r / p.Wout; ax[i] = r % p.Wout;
     } else { ab[i] = ay[i] = ax[i] = 0; }
   }
-  // B tile loads: BN=128 -> 512 float4 (2/thread): k = (tid>>5)+8i, n4 = tid&31 ; BN=32 -> 128 float4: k = tid>>3, n4 = tid&7
   const int cin_tiles = (p.Cin + CBK - 1) / CBK;
-  const int taps = p.gemm ? 1 : p.KH * p.KW;
+  const int taps = (MODE == 0) ? p.KH * p.KW : 1;
   const int nkt = taps * cin_tiles;
 
   f32x16_t acc[TM][TN];
@@ -108,51 +111,58 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   float4 ra[2], rbv[2];
+  bool ka[2], kb[2];
   auto fetch = [&](int kt) {
     const int tap = kt / cin_tiles, c0 = (kt % cin_tiles) * CBK;
-    const int dy = tap / max(p.KW, 1), dx = tap % max(p.KW, 1);
+    const int dy = (MODE == 0) ? tap / p.KW : 0, dx = (MODE == 0) ? tap % p.KW : 0;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) ra[i] = load_a<VEC4>(p, xb, am[i], av[i], ab[i], ay[i], ax[i], dy, dx, c0 + kc * 4);
-    if constexpr (BN == 128) {
+    for (int i = 0; i < 2; ++i) ra[i] = load_a<VEC4, MODE>(p, xb, am[i], av[i], ab[i], ay[i], ax[i], dy, dx, c0 + kc * 4, ka[i]);
+    if constexpr (MODE != 2) {      // B as [K][ldw]: float4 along n (rows are padded to the N tile by contract)
+      constexpr int NB = (BN == 128) ? 2 : 1;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int k = (tid >> 5) + i * 8, n4 = tid & 31;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!p.b_nk) {
-          if (c0 + k < p.Cin) v = *reinterpret_cast<const float4*>(wb + ((int64_t)tap * p.Cin + c0 + k) * p.ldw + n0 + n4 * 4);
-        }
-        rbv[i] = v;
+      for (int i = 0; i < NB; ++i) {
+        const int k = (BN == 128) ? (tid >> 5) + i * 8 : (tid >> 3);
+        const int n4 = (BN == 128) ? (tid & 31) : (tid & 7);
+        const bool ok = (c0 + k < p.Cin) && (BN == 128 || tid < 128);
+        const float* src = wb + ((int64_t)tap * p.Cin + c0 + k) * p.ldw + n0 + n4 * 4;
+        rbv[i] = *reinterpret_cast<const float4*>(ok ? src : wb);
+        kb[i] = ok;
       }
-    } else {
-      const int k = tid >> 3, n4 = tid & 7;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (tid < 128 && !p.b_nk && c0 + k < p.Cin)
-        v = *reinterpret_cast<const float4*>(wb + ((int64_t)tap * p.Cin + c0 + k) * p.ldw + n0 + n4 * 4);
-      rbv[0] = v;
-    }
-    if (p.b_nk) {   // B given as [N][K]: thread reads 4 consecutive k of one n (same pattern as A)
+    } else {                        // B as [N][K]: thread reads 4 consecutive k of one n (same pattern as A)
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const int n = n0 + (tid >> 2) + i * 64;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n < p.Cout && (tid >> 2) + i * 64 < BN) {
-          const float* b = wb + (int64_t)n * p.ldw + c0 + kc * 4;
-          if (c0 + kc * 4 + 3 < p.Cin) v = *reinterpret_cast<const float4*>(b);
-          else { if (c0 + kc * 4 < p.Cin) v.x = b[0]; if (c0 + kc * 4 + 1 < p.Cin) v.y = b[1]; if (c0 + kc * 4 + 2 < p.Cin) v.z = b[2]; }
+        const int nl = (tid >> 2) + i * 64;
+        const int n = n0 + nl, c = c0 + kc * 4;
+        const bool ok = n < p.Cout && nl < BN;
+        const float* b = wb + (int64_t)n * p.ldw + c;
+        if (VEC4 && (p.ldw & 3) == 0) {
+          const bool o = ok && c < p.Cin;       // K % 4 == 0 whenever the vector path is taken for B
+          rbv[i] = *reinterpret_cast<const float4*>(o ? b : wb);
+          kb[i] = o;
+        } else {
+          kb[i] = true;
+          const bool o0 = ok && c < p.Cin, o1 = ok && c + 1 < p.Cin, o2 = ok && c + 2 < p.Cin, o3 = ok && c + 3 < p.Cin;
+          const float t0 = *(o0 ? b : wb), t1 = *(o1 ? b + 1 : wb), t2 = *(o2 ? b + 2 : wb), t3 = *(o3 ? b + 3 : wb);
+          rbv[i] = make_float4(o0 ? t0 : 0.f, o1 ? t1 : 0.f, o2 ? t2 : 0.f, o3 ? t3 : 0.f);
         }
-        rbv[i] = v;
       }
     }
   };
   auto stash = [&](int buf) {
     float* a = As[buf]; float* b = Bs[buf];
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (!ka[i]) ra[i] = z4;
+      if (i < ((MODE == 2 || BN == 128) ? 2 : 1) && !kb[i]) rbv[i] = z4;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int ml = (tid >> 2) + i * 64;
       a[(kc * 4 + 0) * LDA + ml] = ra[i].x; a[(kc * 4 + 1) * LDA + ml] = ra[i].y;
       a[(kc * 4 + 2) * LDA + ml] = ra[i].z; a[(kc * 4 + 3) * LDA + ml] = ra[i].w;
     }
-    if (p.b_nk) {
+    if constexpr (MODE == 2) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int nl = (tid >> 2) + i * 64;
@@ -356,19 +366,29 @@ __global__ __launch_bounds__(256) void lfq_unpack_kernel(const int64_t* __restri
   for (int c = 0; c < nbits; ++c) z[i * nbits + c] = ((code >> (nbits - 1 - c)) & 1) ? 1.f : -1.f;
 }
 
-int launch_conv(const ConvArgs& a, int nb, hipStream_t st) {
-  const bool vec4 = a.gemm ? (a.lda % 4 == 0 && ug_aligned16(a.x) && a.sa % 4 == 0) : (a.Cin % 4 == 0 && ug_aligned16(a.x));
+template <int MODE>
+void launch_conv_mode(const ConvArgs& a, int nb, bool vec4, hipStream_t st) {
   const bool wide = a.Cout > 32;
   dim3 block(256);
   if (wide) {
     dim3 grid((a.M + CBM - 1) / CBM, (a.Cout + 127) / 128, nb);
-    if (vec4) hipLaunchKernelGGL((conv_igemm_kernel<128, true>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((conv_igemm_kernel<128, false>), grid, block, 0, st, a);
+    if (vec4) hipLaunchKernelGGL((conv_igemm_kernel<128, true, MODE>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((conv_igemm_kernel<128, false, MODE>), grid, block, 0, st, a);
   } else {
     dim3 grid((a.M + CBM - 1) / CBM, 1, nb);
-    if (vec4) hipLaunchKernelGGL((conv_igemm_kernel<32, true>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((conv_igemm_kernel<32, false>), grid, block, 0, st, a);
+    if (vec4) hipLaunchKernelGGL((conv_igemm_kernel<32, true, MODE>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((conv_igemm_kernel<32, false, MODE>), grid, block, 0, st, a);
   }
+}
+
+int launch_conv(const ConvArgs& a, int nb, hipStream_t st) {
+  // vector path: every 4-element A fetch is 16-byte aligned and never straddles the contraction extent
+  const bool vec4 = a.gemm ? (a.lda % 4 == 0 && a.Cin % 4 == 0 && ug_aligned16(a.x) && a.sa % 4 == 0 &&
+                              (!a.b_nk || (a.ldw % 4 == 0 && ug_aligned16(a.w) && a.sb % 4 == 0)))
+                           : (a.Cin % 4 == 0 && ug_aligned16(a.x));
+  if (!a.gemm) launch_conv_mode<0>(a, nb, vec4, st);
+  else if (!a.b_nk) launch_conv_mode<1>(a, nb, vec4, st);
+  else launch_conv_mode<2>(a, nb, vec4, st);
   return UG_OK;
 }
 
