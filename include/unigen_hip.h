@@ -47,7 +47,7 @@ int ug_abi_version(void);
 int ug_gemm_bf16(const void* A, int64_t lda, int a_kmajor, const void* B, int64_t ldb, int b_kmajor,
                  void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int epilogue, const void* bias,
                  const float* resid, int64_t ldr, int beta, const float* alpha_dev, hipStream_t stream);
-int ug_gemm_set_tile_policy(int policy); /* -1 auto (default), 0 = two LDS stages, 2 = one LDS stage: A/B benchmarking */
+int ug_gemm_set_tile_policy(int policy); /* -1 auto (default), 0 = 128x128 two LDS stages, 2 = 128x128 one LDS stage, 3 = staggered 256x256: A/B benchmarking */
 
 /* in [R,C] (fp32 if in_f32 else bf16) -> out bf16 [R,C] (optional) and outT bf16 [C,ldT] with
  * columns R..ldT-1 zero-filled (layout utility; the training path no longer needs it). */

@@ -267,7 +267,168 @@ __global__ __launch_bounds__(256, DBUF ? 2 : 4) void gemm_kernel(GemmArgs p) {
   store_tile<EPI>(p, acc, m0 + wm * 64, n0 + wn * 64, lane, gridDim.y > 1);
 }
 
-int g_tile_policy = -1;   // -1 auto, 0 force two LDS stages, 2 force one LDS stage (ug_gemm_set_tile_policy; A/B runs)
+// =============================================================================================
+// Staggered two-group kernel: 256x256 tile, 8 waves = 2 groups x 4 waves, each wave 128x64
+// (8x4 fragments), k-tiles of 32 in a 4-stage LDS ring (4 x 32 KiB), one workgroup per CU.
+//
+// Why: at 128x128 the LDS-DMA path (L2 -> LDS, ~17 TB/s measured) moves 15.6 B per kFLOP and is
+// as long as the MFMA phase itself; a 256x256 tile halves that.  To keep the matrix pipe fed
+// with one workgroup per CU, the two wave groups run the SAME loop one phase apart:
+//     group 0:        L(t)  |  M(t)  |  L(t+1)  |  M(t+1) | ...          L = 12 ds_read_b128 + 4 LDS-DMA
+//     group 1:   -    |  L(t)  |  M(t)  |  L(t+1)  | ...                 M = 32 MFMA (512 cycles)
+// Every '|' is a workgroup barrier.  A CU's SIMDs each host one wave of either group, so while one
+// runs its 32 MFMAs its partner does LDS reads and issues the DMA of tile t+3; the data it needs
+// is never more than a counted `s_waitcnt vmcnt(8)` away (two newer DMA batches stay in flight).
+// Ring safety: tile t is read in intervals 2t (group 0) and 2t+1 (group 1); its stage is refilled
+// with tile t+4, issued no earlier than interval 2t+2 (inside L(t+1)).
+constexpr int PBM = 256, PBN = 256, PBK = 32;
+constexpr int P_TILE = PBM * PBK * 2;          // 16 KiB per operand per stage
+constexpr int P_STAGE = 2 * P_TILE;            // 32 KiB
+constexpr int P_NST = 4;
+
+__device__ __forceinline__ int swz_rowk32(int row, int chunk) { return chunk ^ ((0 - (row >> 2)) & 3); }
+
+template <bool KMAJOR>
+struct Stager32 {                // 256-row x 32-k operand tile, 8 waves: 2 one-KiB DMA instructions per wave per k-tile
+  const bf16_t* src[2];
+  int64_t step[2];
+  int kofs[2];
+  __device__ __forceinline__ void init(const bf16_t* X, int64_t ld, int row0, int rows_total, int wave, int lane) {
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int inst = i * 8 + wave;
+      if constexpr (!KMAJOR) {                 // [256 rows][4 chunks]: 16 rows per instruction
+        const int row = inst * 16 + (lane >> 2);
+        const int chunk = swz_rowk32(row, lane & 3);
+        const int r = min(row0 + row, rows_total - 1);
+        src[i] = X + (int64_t)r * ld + chunk * 8;
+        step[i] = PBK;
+        kofs[i] = chunk * 8;
+      } else {                                 // [32 k][32 chunks]: 2 k-rows per instruction
+        const int k = inst * 2 + (lane >> 5);
+        const int chunk = swz_krow(k, lane & 31);
+        const int col = row0 + chunk * 8;
+        const bool ok = (col + 8 <= ld);
+        src[i] = ok ? X + (int64_t)k * ld + col : zero;
+        step[i] = ok ? (int64_t)PBK * ld : 0;
+        kofs[i] = k;
+      }
+    }
+  }
+  template <bool CHECK>
+  __device__ __forceinline__ void issue(int kt, int K, char* lds_tile, int wave) const {
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bf16_t* s = src[i] + kt * step[i];
+      if constexpr (CHECK) {
+        const bool past = kt * PBK + kofs[i] >= (KMAJOR ? K : ((K + 7) & ~7));
+        s = reinterpret_cast<const bf16_t*>(past ? reinterpret_cast<uintptr_t>(zero) : reinterpret_cast<uintptr_t>(s));
+      }
+      char* dst = lds_tile + (i * 8 + wave) * 1024;
+      __builtin_amdgcn_global_load_lds((gptr_t)s, (lptr_t)dst, 16, 0, 0);
+    }
+  }
+};
+
+template <bool KMAJOR>
+__device__ __forceinline__ bf16x8_t load_frag32(const char* tile, int r0, int lane) {
+  if constexpr (!KMAJOR) {
+    const int row = r0 + (lane & 15);
+    return *reinterpret_cast<const bf16x8_t*>(tile + row * 64 + swz_rowk32(row, lane >> 4) * 16);
+  } else {
+    const int i16 = lane & 15, g = lane >> 4;
+    const int k = g * 8 + (i16 >> 2);
+    const int chunk = (r0 >> 3) + ((i16 & 3) >> 1);
+    const int sub = (i16 & 1) * 8;
+    const char* p0 = tile + k * (PBM * 2) + swz_krow(k, chunk) * 16 + sub;
+    const char* p1 = tile + (k + 4) * (PBM * 2) + swz_krow(k + 4, chunk) * 16 + sub;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p0);
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p1);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  }
+}
+
+#define P_BARRIER() asm volatile("s_barrier" ::: "memory")
+
+template <int EPI, bool AK, bool BKM>
+__global__ __launch_bounds__(512, 2) void gemm_kernel_p8(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) char lds[P_NST * P_STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, wn = wave & 3;
+
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int pid = xcd_remap(blockIdx.x, nwg);
+  const int per_group = GROUP_M * p.tiles_n;
+  const int gid = pid / per_group, first_m = gid * GROUP_M;
+  const int gsz = min(p.tiles_m - first_m, GROUP_M);
+  const int tm = first_m + (pid % per_group) % gsz;
+  const int tn = (pid % per_group) / gsz;
+  const int m0 = tm * PBM, n0 = tn * PBN;
+
+  Stager32<AK> sa; Stager32<BKM> sb;
+  sa.init(p.A, p.lda, m0, p.M, wave, lane);
+  sb.init(p.B, p.ldb, n0, p.N, wave, lane);
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (p.K + PBK - 1) / PBK;
+  const bool ragged = (p.K % PBK) != 0;
+  auto stage_in = [&](int kt) {                 // 4 DMA instructions per wave
+    char* st = lds + (kt & (P_NST - 1)) * P_STAGE;
+    if (ragged && kt + 1 == nk) { sa.template issue<true>(kt, p.K, st, wave); sb.template issue<true>(kt, p.K, st + P_TILE, wave); }
+    else { sa.template issue<false>(kt, p.K, st, wave); sb.template issue<false>(kt, p.K, st + P_TILE, wave); }
+  };
+  // prologue: tiles 0..2 in flight, tile 0 landed
+  stage_in(0);
+  if (nk > 1) stage_in(1);
+  if (nk > 2) stage_in(2);
+  if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  P_BARRIER();
+  if (grp == 1) P_BARRIER();                    // stagger: group 1 runs one phase behind group 0
+
+  for (int t = 0; t < nk; ++t) {
+    // ---------------- L phase: fragments of tile t into registers, DMA of tile t+3, retire tile t+1's DMA
+    const char* tA = lds + (t & (P_NST - 1)) * P_STAGE;
+    const char* tB = tA + P_TILE;
+    bf16x8_t fa[8], fb[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fa[i] = load_frag32<AK>(tA, grp * 128 + i * 16, lane);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fb[j] = load_frag32<BKM>(tB, wn * 64 + j * 16, lane);
+    if (t + 3 < nk) stage_in(t + 3);
+    // this wave's share of tile t+1 must have landed before the barrier that opens the interval in which
+    // group 0 reads it; newer batches (t+2, t+3) may stay in flight
+    if (t + 3 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    P_BARRIER();
+    // ---------------- M phase
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    P_BARRIER();
+  }
+  if (grp == 0) P_BARRIER();                    // balance the barrier count of the staggered group
+
+  store_tile<EPI>(p, reinterpret_cast<f32x4_t (&)[4][4]>(acc[0]), m0 + grp * 128, n0 + wn * 64, lane, false);
+  store_tile<EPI>(p, reinterpret_cast<f32x4_t (&)[4][4]>(acc[4]), m0 + grp * 128 + 64, n0 + wn * 64, lane, false);
+}
+
+int g_tile_policy = -1;   // -1 auto, 0 two LDS stages, 2 one LDS stage, 3 staggered 256x256 (ug_gemm_set_tile_policy; A/B runs)
 
 template <int EPI, bool AK, bool BKM>
 int launch(GemmArgs a, hipStream_t st) {
@@ -277,6 +438,17 @@ int launch(GemmArgs a, hipStream_t st) {
     const int nk = (a.K + BK - 1) / BK;
     splits = min(32, max(1, 768 / tiles));                         // skinny decode GEMMs (M = 16) get up to 32 slices
     splits = max(1, min(splits, nk / 2));
+  }
+  // Staggered 256x256 kernel when its one-workgroup-per-CU grid quantises well (measured, tools/gemm_bench.py:
+  // +8..17 % on the wide shapes; the 294-tile N=1536 shapes lose a half-empty second round and stay on 128x128).
+  const int tiles_p8 = ((a.M + PBM - 1) / PBM) * ((a.N + PBN - 1) / PBN);
+  const int rounds = (tiles_p8 + 255) / 256;
+  const bool p8_fits = (tiles_p8 <= 256) ? (tiles_p8 >= 200) : (4 * tiles_p8 >= 3 * rounds * 256);
+  if (g_tile_policy == 3 || (g_tile_policy < 0 && p8_fits)) {
+    a.tiles_m = (a.M + PBM - 1) / PBM; a.tiles_n = (a.N + PBN - 1) / PBN;
+    hipLaunchKernelGGL((gemm_kernel_p8<EPI, AK, BKM>), dim3(a.tiles_m * a.tiles_n), dim3(512), 0, st, a);
+    UG_CHECK_LAUNCH("ug_gemm_bf16(p8)");
+    return UG_OK;
   }
   bool dbuf = (!AK && !BKM && a.K >= 4096);
   if (g_tile_policy == 0) dbuf = true;

@@ -41,7 +41,7 @@ def test_probe_layouts(dev):
 
 
 # ------------------------------------------------------------------ GEMM
-@pytest.fixture(params=[0, 2], ids=["two_lds_stages", "one_lds_stage"])
+@pytest.fixture(params=[0, 2, 3], ids=["two_lds_stages", "one_lds_stage", "staggered_256x256"])
 def tile_policy(request):
     ops = _ops()
     ops.set_gemm_tile_policy(request.param)
