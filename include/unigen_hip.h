@@ -126,6 +126,23 @@ int ug_rope_at(void* qkv, const float* cos_tab, const float* sin_tab, int64_t ro
 int ug_attn_decode(const void* q, int64_t ldq, const void* cache_k, const void* cache_v, const uint8_t* key_valid,
                    void* o, int64_t ldo, int64_t rows, int H, int HKV, int head_dim, int64_t Tmax,
                    const int* len_dev, float scale, hipStream_t stream);
+/* weight-streaming GEMV for <= 32 activation rows: acc[r*acc_stride_r + n*acc_stride_n] += sum_k x[r][k] W[n][k]
+ * (fp32 atomics into a zeroed accumulator; the decode-time form of every nn.Linear of the backbone,
+ * models/unigen.py:496-502).  The decode path keeps row-major accumulators (acc_stride_n = 1). */
+int ug_gemv_bf16(const void* x, int64_t ldx, int64_t R, const void* W, int64_t ldw, float* acc, int64_t acc_stride_r,
+                 int64_t acc_stride_n, int64_t N, int64_t K, hipStream_t stream);
+/* fused finishers of one decode step (Qwen2DecoderLayer.forward with a one-token query, transformers
+ * modeling_qwen2.py as driven by models/unigen.py:496-502).  Each consumes a row-major fp32 accumulator
+ * (acc[r*ldacc + n]) filled by ug_gemv_bf16 and leaves it zeroed for the next step.
+ *   qkv:        + bias -> bf16, RoPE at *pos_dev on q and k heads, q -> q_out, k/v -> cache[:, :, *pos_dev]
+ *   resid_norm: x += bf16round(acc);  xn = bf16(rmsnorm(x) * w)   (o_proj / down_proj + the following RMSNorm)
+ *   swiglu:     act = bf16(bf16(silu(bf16 gate)) * bf16 up)       (gate_up projection + SiLU-mul) */
+int ug_decode_finish_qkv(float* acc, int64_t ldacc, const void* bias, const float* cos_tab, const float* sin_tab,
+                         const int* pos_dev, void* q_out, int64_t ldq, void* cache_k, void* cache_v, int64_t rows, int Hq,
+                         int Hkv, int head_dim, int64_t Tmax, int64_t max_pos, hipStream_t stream);
+int ug_decode_finish_resid_norm(float* acc, int64_t ldacc, float* x, const float* w, void* xn, int64_t rows, int64_t cols,
+                                float eps, hipStream_t stream);
+int ug_decode_finish_swiglu(float* acc, int64_t ldacc, void* act, int64_t rows, int64_t I, hipStream_t stream);
 /* finish a split-K fp32 accumulation: mode 0: out_bf16 = bf16(acc + bias); mode 1: resid += bf16round(acc) */
 int ug_skinny_finish(const float* acc, const void* bias, void* out_bf16, float* resid, int64_t M, int64_t N,
                      int mode, hipStream_t stream);

@@ -63,37 +63,53 @@ __global__ __launch_bounds__(256) void rope_at_kernel(bf16_t* __restrict__ qkv, 
   }
 }
 
-// One wave per (row, query head): lane j scores key (chunk*64 + j) against q (fp32 in LDS), online softmax
-// across chunks, then lanes switch to owning two output dims and accumulate p_j * V_j.
+// One workgroup (4 waves) per (row, query head).  Wave w takes key chunks w, w+4, ... of 64 keys: lane j scores
+// key (t0 + j) against q (fp32 in LDS) and the wave keeps its own online-softmax state; for P.V the lanes regroup
+// as (key phase = lane>>4, 8-dim chunk = lane&15) so every V read is a 16-byte load with 16 of them in flight.
+// The four partial (m, l, O) states are merged through LDS (flash-decoding style split over keys).
 // key_valid: optional [rows][Tmax] bytes (0 = padding key, never attended), like HF's 2-D attention_mask.
-__global__ __launch_bounds__(64) void attn_decode_kernel(const bf16_t* __restrict__ q, int64_t ldq, const bf16_t* __restrict__ ck,
-                                                         const bf16_t* __restrict__ cv, const uint8_t* __restrict__ key_valid,
-                                                         bf16_t* __restrict__ o, int64_t ldo, int H, int HKV, int Tmax,
-                                                         const int* __restrict__ len_dev, float scale) {
+constexpr int AD_WAVES = 4;
+__global__ __launch_bounds__(64 * AD_WAVES) void attn_decode_kernel(const bf16_t* __restrict__ q, int64_t ldq, const bf16_t* __restrict__ ck,
+                                                          const bf16_t* __restrict__ cv, const uint8_t* __restrict__ key_valid,
+                                                          bf16_t* __restrict__ o, int64_t ldo, int H, int HKV, int Tmax,
+                                                          const int* __restrict__ len_dev, float scale) {
   __shared__ float qs[DHD];
-  __shared__ float ps[64];
-  const int r = blockIdx.y, h = blockIdx.x, lane = threadIdx.x;
+  __shared__ float om[AD_WAVES][DHD];
+  __shared__ float ml[AD_WAVES][2];
+  const int r = blockIdx.y, h = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int hk = h / (H / HKV);
   const int len = min(*len_dev, Tmax);
   const bf16_t* qp = q + (int64_t)r * ldq + h * DHD;
-  qs[lane * 2] = bf2f(qp[lane * 2]);
-  qs[lane * 2 + 1] = bf2f(qp[lane * 2 + 1]);
+  if (threadIdx.x < DHD) qs[threadIdx.x] = bf2f(qp[threadIdx.x]);
   __syncthreads();
   const bf16_t* kb = ck + ((int64_t)r * HKV + hk) * Tmax * DHD;
   const bf16_t* vb = cv + ((int64_t)r * HKV + hk) * Tmax * DHD;
-  float m = -INFINITY, l = 0.f, acc0 = 0.f, acc1 = 0.f;
-  for (int t0 = 0; t0 < len; t0 += 64) {
+  const int kq = lane >> 4, dc = lane & 15;
+  float m = -INFINITY, l = 0.f;
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  for (int t0 = wave * 64; t0 < len; t0 += 64 * AD_WAVES) {
     const int t = t0 + lane;
     float s = -INFINITY;
+    // K row of this lane's key and the V pieces of its (key phase, dim chunk) all go out before any is consumed
+    bf16x8_t kf[DHD / 8], vf[16];
+    {
+      const bf16_t* kr = kb + (int64_t)min(t, len - 1) * DHD;
+#pragma unroll
+      for (int c = 0; c < DHD / 8; ++c) kf[c] = *reinterpret_cast<const bf16x8_t*>(kr + c * 8);
+#pragma unroll
+      for (int jj = 0; jj < 16; ++jj) {
+        const int tt = min(t0 + jj * 4 + kq, len - 1);
+        vf[jj] = *reinterpret_cast<const bf16x8_t*>(vb + (int64_t)tt * DHD + dc * 8);
+      }
+    }
     if (t < len && (!key_valid || key_valid[(int64_t)r * Tmax + t])) {
-      const bf16_t* kr = kb + (int64_t)t * DHD;
       float d = 0.f;
 #pragma unroll
-      for (int c = 0; c < DHD / 8; ++c) {
-        const bf16x8_t kv = *reinterpret_cast<const bf16x8_t*>(kr + c * 8);
+      for (int c = 0; c < DHD / 8; ++c)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) d += bf2f((bf16_t)kv[e]) * qs[c * 8 + e];
-      }
+        for (int e = 0; e < 8; ++e) d += bf2f((bf16_t)kf[c][e]) * qs[c * 8 + e];
       s = d * scale;
     }
     const float mc = wave_max(s);
@@ -103,21 +119,41 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(const bf16_t* __restric
     const float p = __expf(s - mu);
     l = l * alpha + wave_sum(p);
     m = mn;
-    __syncthreads();
-    ps[lane] = bf2f(f2bf(p));              // P is rounded to bf16 before P.V like the bf16 SDPA paths
-    __syncthreads();
-    acc0 *= alpha; acc1 *= alpha;
-    const int nvalid = min(64, len - t0);
-    for (int j = 0; j < nvalid; ++j) {
-      const float pj = ps[j];
-      const bf16x2_t vv = *reinterpret_cast<const bf16x2_t*>(vb + (int64_t)(t0 + j) * DHD + lane * 2);
-      acc0 += pj * bf2f((bf16_t)vv[0]);
-      acc1 += pj * bf2f((bf16_t)vv[1]);
+    const float pb = bf2f(f2bf(p));          // P is rounded to bf16 before P.V like the bf16 SDPA paths
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] *= alpha;
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+      const float pj = __shfl(pb, jj * 4 + kq, 64);   // 0 for keys past len / masked keys
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += pj * bf2f((bf16_t)vf[jj][e]);
     }
   }
-  const float inv = l > 0.f ? 1.f / l : 0.f;
-  bf16_t* op = o + (int64_t)r * ldo + h * DHD + lane * 2;
-  *reinterpret_cast<uint32_t*>(op) = pack_bf2(acc0 * inv, acc1 * inv);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    acc[e] += __shfl_xor(acc[e], 16, 64);
+    acc[e] += __shfl_xor(acc[e], 32, 64);
+  }
+  if (lane < 16) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) om[wave][dc * 8 + e] = acc[e];
+  }
+  if (lane == 0) { ml[wave][0] = m; ml[wave][1] = l; }
+  __syncthreads();
+  if (threadIdx.x < DHD) {
+    float M = ml[0][0];
+#pragma unroll
+    for (int w = 1; w < AD_WAVES; ++w) M = fmaxf(M, ml[w][0]);
+    float L = 0.f, O = 0.f;
+#pragma unroll
+    for (int w = 0; w < AD_WAVES; ++w) {
+      const float wgt = (ml[w][0] == -INFINITY) ? 0.f : __expf(ml[w][0] - M);
+      L += wgt * ml[w][1];
+      O += wgt * om[w][threadIdx.x];
+    }
+    const float inv = L > 0.f ? 1.f / L : 0.f;
+    o[(int64_t)r * ldo + h * DHD + threadIdx.x] = f2bf(O * inv);
+  }
 }
 
 // Finish a split-K fp32 accumulation of a skinny GEMM:  mode 0: out_bf16 = bf16(acc + bias)
@@ -136,7 +172,346 @@ __global__ __launch_bounds__(256) void skinny_finish_kernel(const float* __restr
   }
 }
 
+// ------------------------------------------------------------------ weight-streaming GEMV for decode
+// acc[r][n] += sum_k x[r][k] W[n][k]   for a handful of rows r (<= 16*RB) and a weight matrix read ONCE.
+// HBM-bound and latency-sensitive (a whole projection is a few MB): the launch is cut into as many waves as
+// it takes for (nearly) the whole matrix to be in flight at once.  One wave owns 16 weight rows x 32*U k,
+// issues its U 16-byte non-temporal loads back to back, then feeds mfma_f32_16x16x32_bf16 with A = activation
+// fragment (a few KiB, L2-resident) and B = weight fragment, so a lane ends up holding 4 rows x 1 column and
+// every atomic instruction of a wave covers 4 rows x 64 contiguous bytes of a ROW-MAJOR accumulator.  The 4 waves of a workgroup
+// take consecutive k-slices of the same 16 columns, reduce through LDS, then one fp32 atomic per output.
+// acc is addressed acc[r*sr + n*sn]; the decode path uses row-major accumulators (sn = 1).
+template <int RB, int U>
+__global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* __restrict__ x, int64_t ldx, int R,
+                                                   const bf16_t* __restrict__ W, int64_t ldw, float* __restrict__ acc,
+                                                   int64_t sr, int64_t sn, int N, int K) {
+  __shared__ float red[3][64][4 * RB];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+  const int n0 = blockIdx.x * 16;
+  const int nrow = min(n0 + (lane & 15), N - 1);
+  const int kbase = (blockIdx.y * 4 + wave) * (32 * U);
+  const bf16_t* wp = W + (int64_t)nrow * ldw + g * 8 + kbase;
+  f32x4_t d[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) d[rb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  bf16x8_t wf[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+    if (kbase + u * 32 < K) wf[u] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(wp + u * 32));
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const bf16_t* xp = x + (int64_t)min(rb * 16 + (lane & 15), R - 1) * ldx + g * 8 + kbase;
+    bf16x8_t xf[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (kbase + u * 32 < K) xf[u] = *reinterpret_cast<const bf16x8_t*>(xp + u * 32);
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (kbase + u * 32 < K) d[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[u], wf[u], d[rb], 0, 0, 0);
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) red[wave - 1][lane][rb * 4 + j] = d[rb][j];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      const int n = n0 + (lane & 15);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = rb * 16 + g * 4 + j;
+        const float v = d[rb][j] + red[0][lane][rb * 4 + j] + red[1][lane][rb * 4 + j] + red[2][lane][rb * 4 + j];
+        if (r < R && n < N) atomicAdd(acc + (int64_t)r * sr + (int64_t)n * sn, v);
+      }
+    }
+  }
+}
+
+// Main form (K >= 256: every projection of the backbone and the lm-head slices).  Per-instruction coalescing
+// decides the achieved HBM rate, and the MFMA operand layout (lane = weight row) only lets a direct load touch
+// 64 bytes per row (measured 2.8 TB/s on gate_up).  So weight tiles go HBM -> LDS with 16-byte LDS-DMA, each
+// instruction covering two rows x 512 contiguous bytes, and the fragments come back out of LDS.  LDS-DMA writes
+// lane-linear, so the bank swizzle (16-byte chunk index ^ row) is applied to the SOURCE address.
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// One wave per workgroup owns ONE 256-wide k-slab and KW consecutive 16-row weight groups.  The
+// activation fragments of the slab are loaded once and stay in registers; the KW weight tiles walk through a
+// two-slot LDS ring (tile t+2's DMA is issued as soon as tile t's fragments are in registers).  No workgroup
+// barrier, no cross-wave reduction; ~10 independent waves per CU keep 16 KiB each in flight.
+template <int RB, int KW>
+__global__ __launch_bounds__(64) void gemv_ring_kernel(const bf16_t* __restrict__ x, int64_t ldx, int R,
+                                                       const bf16_t* __restrict__ W, int64_t ldw, float* __restrict__ acc,
+                                                       int64_t sr, int64_t sn, int N, int K, int nslabs) {
+  __shared__ __attribute__((aligned(1024))) char tile[2][8192];
+  const int lane = threadIdx.x, g = lane >> 4, row = lane & 15;
+  const int grp0 = (blockIdx.x / nslabs) * KW;
+  const int kbase = (blockIdx.x % nslabs) * 256;
+  int roff[8], kc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    roff[i] = 2 * i + (lane >> 5);
+    kc[i] = min(kbase + ((lane & 31) ^ roff[i]) * 8, K - 8);       // chunks past K are never consumed
+  }
+  auto stage = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const bf16_t* src = W + (int64_t)min((grp0 + t) * 16 + roff[i], N - 1) * ldw + kc[i];
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile[t & 1] + i * 1024), 16, 0, 0);
+    }
+  };
+  bf16x8_t xf[RB][8];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const bf16_t* xp = x + (int64_t)min(rb * 16 + row, R - 1) * ldx + g * 8;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) xf[rb][u] = *reinterpret_cast<const bf16x8_t*>(xp + min(kbase + u * 32, K - 32));
+  }
+  stage(0);
+  if constexpr (KW > 1) stage(1);
+#pragma unroll
+  for (int t = 0; t < KW; ++t) {
+    if (t + 1 < KW) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const char* tr = tile[t & 1] + row * 512;
+    bf16x8_t wf[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) wf[u] = *reinterpret_cast<const bf16x8_t*>(tr + (((u * 4 + g) ^ row) << 4));
+    if (t + 2 < KW) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      stage(t + 2);
+    }
+    f32x4_t d[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) d[rb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (kbase + u * 32 < K) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) d[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[rb][u], wf[u], d[rb], 0, 0, 0);
+      }
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      const int n = (grp0 + t) * 16 + row;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = rb * 16 + g * 4 + j;
+        if (r < R && n < N) atomicAdd(acc + (int64_t)r * sr + (int64_t)n * sn, d[rb][j]);
+      }
+    }
+  }
+}
+
+template <int RB>
+void launch_gemv(int U, dim3 grid, hipStream_t st, const bf16_t* x, int64_t ldx, int R, const bf16_t* W, int64_t ldw,
+                 float* acc, int64_t sr, int64_t sn, int N, int K) {
+  const dim3 block(256);
+  switch (U) {
+    case 8: hipLaunchKernelGGL((gemv_kernel<RB, 8>), grid, block, 0, st, x, ldx, R, W, ldw, acc, sr, sn, N, K); break;
+    case 4: hipLaunchKernelGGL((gemv_kernel<RB, 4>), grid, block, 0, st, x, ldx, R, W, ldw, acc, sr, sn, N, K); break;
+    case 2: hipLaunchKernelGGL((gemv_kernel<RB, 2>), grid, block, 0, st, x, ldx, R, W, ldw, acc, sr, sn, N, K); break;
+    default: hipLaunchKernelGGL((gemv_kernel<RB, 1>), grid, block, 0, st, x, ldx, R, W, ldw, acc, sr, sn, N, K); break;
+  }
+}
+
+template <int RB>
+void launch_gemv_ring(int KW, dim3 grid, hipStream_t st, const bf16_t* x, int64_t ldx, int R, const bf16_t* W, int64_t ldw,
+                      float* acc, int64_t sr, int64_t sn, int N, int K, int nslabs) {
+  if (KW == 2) hipLaunchKernelGGL((gemv_ring_kernel<RB, 2>), grid, dim3(64), 0, st, x, ldx, R, W, ldw, acc, sr, sn, N, K, nslabs);
+  else hipLaunchKernelGGL((gemv_ring_kernel<RB, 1>), grid, dim3(64), 0, st, x, ldx, R, W, ldw, acc, sr, sn, N, K, nslabs);
+}
+
+// ------------------------------------------------------------------ fused finishers of the decode step
+// Every finisher consumes a row-major fp32 accumulator filled by the GEMV (acc[r*lda + n]) and leaves it ZEROED
+// for the next step, so the captured graph carries no memset nodes.
+
+// q/k/v projection: + bias -> bf16, RoPE at *pos_dev on the q and k heads, q -> q_out, k/v -> cache[pos].
+// One wave per (head, row); lane i owns dims i and i+64 (the rotary pair).  Same arithmetic as rope_at_kernel.
+__device__ __forceinline__ void finish_qkv_tile(float* __restrict__ acc, int64_t lda, const bf16_t* __restrict__ bias,
+                                                const float* __restrict__ cs, const float* __restrict__ sn_tab, int pos0,
+                                                bf16_t* __restrict__ q_out, int64_t ldq, bf16_t* __restrict__ ck,
+                                                bf16_t* __restrict__ cv, int Hq, int Hk, int Tmax, int max_pos, int hh, int r,
+                                                int i) {
+#pragma clang fp contract(off)
+  const int c1 = hh * DHD + i, c2 = c1 + DHD / 2;
+  float* a = acc + (int64_t)r * lda;
+  float v1 = a[c1], v2 = a[c2];
+  a[c1] = 0.f; a[c2] = 0.f;
+  if (bias) { v1 += bf2f(bias[c1]); v2 += bf2f(bias[c2]); }
+  float x1 = bf2f(f2bf(v1)), x2 = bf2f(f2bf(v2));
+  if (hh < Hq + Hk) {
+    const int pos = min(pos0, max_pos - 1);
+    const float c = cs[(int64_t)pos * (DHD / 2) + i], s = sn_tab[(int64_t)pos * (DHD / 2) + i];
+    const float p1 = x1 * c, p2 = x2 * c;
+    const float q1 = x2 * s, q2 = x1 * s;
+    x1 = bf2f(f2bf(p1 - q1)); x2 = bf2f(f2bf(p2 + q2));
+  }
+  if (hh < Hq) {
+    bf16_t* qp = q_out + (int64_t)r * ldq + hh * DHD;
+    qp[i] = f2bf(x1); qp[i + DHD / 2] = f2bf(x2);
+  } else if (pos0 < Tmax) {
+    const bool is_k = hh < Hq + Hk;
+    const int hk = is_k ? hh - Hq : hh - Hq - Hk;
+    bf16_t* dst = (is_k ? ck : cv) + (((int64_t)r * Hk + hk) * Tmax + pos0) * DHD;
+    dst[i] = f2bf(x1); dst[i + DHD / 2] = f2bf(x2);
+  }
+}
+
+__global__ __launch_bounds__(64) void finish_qkv_kernel(float* __restrict__ acc, int64_t lda, const bf16_t* __restrict__ bias,
+                                                        const float* __restrict__ cs, const float* __restrict__ sn_tab,
+                                                        const int* __restrict__ pos_dev, bf16_t* __restrict__ q_out,
+                                                        int64_t ldq, bf16_t* __restrict__ ck, bf16_t* __restrict__ cv, int Hq,
+                                                        int Hk, int Tmax, int max_pos) {
+  finish_qkv_tile(acc, lda, bias, cs, sn_tab, *pos_dev, q_out, ldq, ck, cv, Hq, Hk, Tmax, max_pos, blockIdx.x, blockIdx.y,
+                  threadIdx.x);
+}
+
+// o / down projection:  x[r] += bf16round(acc[r]);  xn[r] = bf16(rmsnorm(x[r]) * w)   (next sub-block's input).
+// One wave per row, the same per-lane accumulation order as rmsnorm_fwd_kernel so both paths agree bit for bit.
+template <int MAXV>
+__device__ __forceinline__ void finish_resid_norm_row(float* __restrict__ acc, int64_t lda, float* __restrict__ x,
+                                                      const float* __restrict__ w, bf16_t* __restrict__ xn, int cols, float eps,
+                                                      int row, int lane) {
+  float4* xr = reinterpret_cast<float4*>(x + (int64_t)row * cols);
+  float4* ar = reinterpret_cast<float4*>(acc + (int64_t)row * lda);
+  const float4* wr = reinterpret_cast<const float4*>(w);
+  const int nv = cols >> 2;
+  float4 v[MAXV], gw[MAXV], dl[MAXV];
+#pragma unroll
+  for (int c = 0; c < MAXV; ++c) {              // every load of the row in flight at once
+    const int i = lane + c * 64;
+    if (i < nv) { v[c] = xr[i]; gw[c] = wr[i]; dl[c] = ar[i]; }
+  }
+  float ss = 0.f;
+#pragma unroll
+  for (int c = 0; c < MAXV; ++c) {
+    const int i = lane + c * 64;
+    if (i < nv) {
+      ar[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      v[c].x += bf2f(f2bf(dl[c].x)); v[c].y += bf2f(f2bf(dl[c].y));
+      v[c].z += bf2f(f2bf(dl[c].z)); v[c].w += bf2f(f2bf(dl[c].w));
+      xr[i] = v[c];
+      ss += v[c].x * v[c].x + v[c].y * v[c].y + v[c].z * v[c].z + v[c].w * v[c].w;
+    }
+  }
+  ss = wave_sum(ss);
+  const float rs = rsqrtf(ss / (float)cols + eps);
+#pragma unroll
+  for (int c = 0; c < MAXV; ++c) {
+    const int i = lane + c * 64;
+    if (i < nv) {
+      uint2 o;
+      o.x = pack_bf2(gw[c].x * (v[c].x * rs), gw[c].y * (v[c].y * rs));
+      o.y = pack_bf2(gw[c].z * (v[c].z * rs), gw[c].w * (v[c].w * rs));
+      reinterpret_cast<uint2*>(xn + (int64_t)row * cols)[i] = o;
+    }
+  }
+}
+
+template <int MAXV>
+__global__ __launch_bounds__(64) void finish_resid_norm_kernel(float* __restrict__ acc, int64_t lda, float* __restrict__ x,
+                                                               const float* __restrict__ w, bf16_t* __restrict__ xn, int cols,
+                                                               float eps) {
+  finish_resid_norm_row<MAXV>(acc, lda, x, w, xn, cols, eps, blockIdx.x, threadIdx.x);
+}
+
+// gate/up projection:  act = bf16( bf16(silu(bf16 gate)) * bf16 up )  (swiglu_fwd_kernel's arithmetic).
+__device__ __forceinline__ void finish_swiglu_quad(float* __restrict__ acc, int64_t lda, bf16_t* __restrict__ act, int I, int r,
+                                                   int c) {
+  float4* ag = reinterpret_cast<float4*>(acc + (int64_t)r * lda + c);
+  float4* au = reinterpret_cast<float4*>(acc + (int64_t)r * lda + I + c);
+  const float4 gv = *ag, uv = *au;
+  *ag = make_float4(0.f, 0.f, 0.f, 0.f);
+  *au = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float gs[4] = {gv.x, gv.y, gv.z, gv.w}, us[4] = {uv.x, uv.y, uv.z, uv.w};
+  float o[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float g = bf2f(f2bf(gs[e])), u = bf2f(f2bf(us[e]));
+    o[e] = bf2f(f2bf(g / (1.f + __expf(-g)))) * u;
+  }
+  uint2 ov; ov.x = pack_bf2(o[0], o[1]); ov.y = pack_bf2(o[2], o[3]);
+  *reinterpret_cast<uint2*>(act + (int64_t)r * I + c) = ov;
+}
+
+__global__ __launch_bounds__(256) void finish_swiglu_kernel(float* __restrict__ acc, int64_t lda, bf16_t* __restrict__ act,
+                                                            int R, int I) {
+  const int per_row = I >> 2;
+  const int64_t total = (int64_t)R * per_row;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x)
+    finish_swiglu_quad(acc, lda, act, I, (int)(idx / per_row), (int)(idx % per_row) * 4);
+}
+
 }  // namespace
+
+extern "C" int ug_gemv_bf16(const void* x, int64_t ldx, int64_t R, const void* W, int64_t ldw, float* acc, int64_t acc_stride_r,
+                            int64_t acc_stride_n, int64_t N, int64_t K, hipStream_t st) {
+  UG_REQUIRE(R > 0 && R <= 32 && N > 0 && K > 0 && K % 32 == 0, "ug_gemv_bf16: need 1 <= rows <= 32 and K %% 32 == 0 (rows=%ld K=%ld)", (long)R, (long)K);
+  UG_REQUIRE(ldx % 8 == 0 && ldw % 8 == 0 && ug_aligned16(x) && ug_aligned16(W), "ug_gemv_bf16: 16-byte aligned rows required");
+  const int64_t groups = (N + 15) / 16;
+  const bf16_t* xb = (const bf16_t*)x;
+  const bf16_t* wb = (const bf16_t*)W;
+  if (K >= 256) {
+    // measured on MI355X (tools/gemv_bench.py): two row groups per wave once there are >= 3000 tiles, else one
+    const int nslabs = (int)((K + 255) / 256);
+    const int KW = groups * nslabs >= 3000 ? 2 : 1;
+    dim3 grid((unsigned)(((groups + KW - 1) / KW) * nslabs));
+    if (R <= 16) launch_gemv_ring<1>(KW, grid, st, xb, ldx, (int)R, wb, ldw, acc, acc_stride_r, acc_stride_n, (int)N, (int)K, nslabs);
+    else launch_gemv_ring<2>(KW, grid, st, xb, ldx, (int)R, wb, ldw, acc, acc_stride_r, acc_stride_n, (int)N, (int)K, nslabs);
+    UG_CHECK_LAUNCH("ug_gemv_bf16");
+    return UG_OK;
+  }
+  // short contractions: direct loads, deepest per-wave unroll that still leaves >= 2048 waves
+  int U = 8;
+  while (U > 1 && groups * ((K + 32 * U - 1) / (32 * U)) < 2048) U >>= 1;
+  const int64_t nslices = (K + 32 * U - 1) / (32 * U);
+  dim3 grid((unsigned)groups, (unsigned)((nslices + 3) / 4));
+  if (R <= 16) launch_gemv<1>(U, grid, st, xb, ldx, (int)R, wb, ldw, acc, acc_stride_r, acc_stride_n, (int)N, (int)K);
+  else launch_gemv<2>(U, grid, st, xb, ldx, (int)R, wb, ldw, acc, acc_stride_r, acc_stride_n, (int)N, (int)K);
+  UG_CHECK_LAUNCH("ug_gemv_bf16");
+  return UG_OK;
+}
+
+extern "C" int ug_decode_finish_qkv(float* acc, int64_t ldacc, const void* bias, const float* cos_tab, const float* sin_tab,
+                                    const int* pos_dev, void* q_out, int64_t ldq, void* cache_k, void* cache_v, int64_t rows,
+                                    int Hq, int Hkv, int head_dim, int64_t Tmax, int64_t max_pos, hipStream_t st) {
+  UG_REQUIRE(rows > 0 && head_dim == DHD && Hq > 0 && Hkv > 0 && pos_dev && acc && q_out && cache_k && cache_v,
+             "ug_decode_finish_qkv: bad args");
+  hipLaunchKernelGGL(finish_qkv_kernel, dim3(Hq + 2 * Hkv, (unsigned)rows), dim3(64), 0, st, acc, ldacc, (const bf16_t*)bias,
+                     cos_tab, sin_tab, pos_dev, (bf16_t*)q_out, ldq, (bf16_t*)cache_k, (bf16_t*)cache_v, Hq, Hkv, (int)Tmax,
+                     (int)max_pos);
+  UG_CHECK_LAUNCH("ug_decode_finish_qkv");
+  return UG_OK;
+}
+
+extern "C" int ug_decode_finish_resid_norm(float* acc, int64_t ldacc, float* x, const float* w, void* xn, int64_t rows,
+                                           int64_t cols, float eps, hipStream_t st) {
+  UG_REQUIRE(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= 4096 && ldacc % 4 == 0 && acc && x && w && xn,
+             "ug_decode_finish_resid_norm: bad args (cols=%ld, multiple of 4 and <= 4096)", (long)cols);
+  UG_REQUIRE(ug_aligned16(x) && ug_aligned16(w) && ug_aligned16(acc) && ((uintptr_t)xn & 7) == 0,
+             "ug_decode_finish_resid_norm: alignment");
+  if (cols <= 2048)
+    hipLaunchKernelGGL(finish_resid_norm_kernel<8>, dim3((unsigned)rows), dim3(64), 0, st, acc, ldacc, x, w, (bf16_t*)xn,
+                       (int)cols, eps);
+  else
+    hipLaunchKernelGGL(finish_resid_norm_kernel<16>, dim3((unsigned)rows), dim3(64), 0, st, acc, ldacc, x, w, (bf16_t*)xn,
+                       (int)cols, eps);
+  UG_CHECK_LAUNCH("ug_decode_finish_resid_norm");
+  return UG_OK;
+}
+
+extern "C" int ug_decode_finish_swiglu(float* acc, int64_t ldacc, void* act, int64_t rows, int64_t I, hipStream_t st) {
+  UG_REQUIRE(rows > 0 && I > 0 && I % 4 == 0 && ldacc % 4 == 0 && acc && act && ug_aligned16(acc) && ((uintptr_t)act & 7) == 0,
+             "ug_decode_finish_swiglu: bad args");
+  const int64_t total = rows * (I / 4);
+  int64_t g = (total + 255) / 256; if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(finish_swiglu_kernel, dim3((unsigned)g), dim3(256), 0, st, acc, ldacc, (bf16_t*)act, (int)rows, (int)I);
+  UG_CHECK_LAUNCH("ug_decode_finish_swiglu");
+  return UG_OK;
+}
 
 extern "C" int ug_kv_store(const void* qkv, int64_t ldq, int64_t k_col, int64_t v_col, void* cache_k, void* cache_v,
                            int64_t rows, int64_t L, int HKV, int head_dim, int64_t Tmax, const int* pos_dev, int pos_host,
@@ -165,7 +540,7 @@ extern "C" int ug_attn_decode(const void* q, int64_t ldq, const void* cache_k, c
                               void* o, int64_t ldo, int64_t rows, int H, int HKV, int head_dim, int64_t Tmax,
                               const int* len_dev, float scale, hipStream_t st) {
   UG_REQUIRE(rows > 0 && head_dim == DHD && H % HKV == 0 && len_dev, "ug_attn_decode: bad args");
-  hipLaunchKernelGGL(attn_decode_kernel, dim3(H, (unsigned)rows), dim3(64), 0, st, (const bf16_t*)q, ldq, (const bf16_t*)cache_k,
+  hipLaunchKernelGGL(attn_decode_kernel, dim3(H, (unsigned)rows), dim3(64 * AD_WAVES), 0, st, (const bf16_t*)q, ldq, (const bf16_t*)cache_k,
                      (const bf16_t*)cache_v, key_valid, (bf16_t*)o, ldo, H, HKV, (int)Tmax, len_dev, scale);
   UG_CHECK_LAUNCH("ug_attn_decode");
   return UG_OK;

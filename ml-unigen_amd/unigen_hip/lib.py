@@ -42,6 +42,10 @@ SIGNATURES = {
     "ug_kv_store": [P, I64, I64, I64, P, P, I64, I64, I32, I32, I64, P, I32, P],
     "ug_rope_at": [P, P, P, I64, I64, I32, I32, P, I64, P],
     "ug_attn_decode": [P, I64, P, P, P, P, I64, I64, I32, I32, I32, I64, P, F32, P],
+    "ug_gemv_bf16": [P, I64, I64, P, I64, P, I64, I64, I64, I64, P],
+    "ug_decode_finish_qkv": [P, I64, P, P, P, P, P, I64, P, P, I64, I32, I32, I32, I64, I64, P],
+    "ug_decode_finish_resid_norm": [P, I64, P, P, P, I64, I64, F32, P],
+    "ug_decode_finish_swiglu": [P, I64, P, I64, I64, P],
     "ug_skinny_finish": [P, P, P, P, I64, I64, I32, P],
     "ug_ce_fwd": [P, I64, I64, I64, P, I64, P, P, P, P, P],
     "ug_ce_bwd": [P, I64, I64, I64, P, I64, P, P, P, P],

@@ -97,10 +97,10 @@ def cast_bf16(x, out=None):
 
 
 # ------------------------------------------------------------------------------------ row ops
-def rmsnorm_fwd(x, w, eps, out_f32=False, want_rstd=True):
+def rmsnorm_fwd(x, w, eps, out_f32=False, want_rstd=True, out=None):
     _need_cuda(x, w)
     rows, cols = x.shape
-    y = torch.empty((rows, cols), dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
+    y = out if out is not None else torch.empty((rows, cols), dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
     rstd = torch.empty((rows,), dtype=torch.float32, device=x.device) if want_rstd else None
     _l.check(_l.load().ug_rmsnorm_fwd(_p(x), _p(w), _p(y), _p(rstd), rows, cols, eps, int(out_f32), _stream()),
              "ug_rmsnorm_fwd")
@@ -276,10 +276,10 @@ def rope_at_(qkv, cos, sin, nheads, hd, pos_dev):
     return qkv
 
 
-def attn_decode(qkv, cache_k, cache_v, key_valid, H, HKV, hd, Tmax, len_dev, scale=None):
+def attn_decode(qkv, cache_k, cache_v, key_valid, H, HKV, hd, Tmax, len_dev, scale=None, out=None):
     rows = qkv.shape[0]
     scale = 1.0 / math.sqrt(hd) if scale is None else scale
-    o = torch.empty((rows, H * hd), dtype=torch.bfloat16, device=qkv.device)
+    o = out if out is not None else torch.empty((rows, H * hd), dtype=torch.bfloat16, device=qkv.device)
     _l.check(_l.load().ug_attn_decode(_p(qkv), qkv.stride(0), _p(cache_k), _p(cache_v), _p(key_valid), _p(o), o.stride(0),
                                       rows, H, HKV, hd, Tmax, _p(len_dev), scale, _stream()), "ug_attn_decode")
     return o
@@ -290,11 +290,42 @@ def skinny_linear(x, w, bias=None, resid=None):
     stream once) + a finishing pass.  resid given -> in-place residual update, else bf16 output."""
     M, N = x.shape[0], w.shape[0]
     acc = torch.zeros((M, N), dtype=torch.float32, device=x.device)
-    gemm(x, w, out=acc, epilogue=UG_EPI_F32, beta=1)
+    K = w.shape[1]
+    if M <= 32 and K % 32 == 0:
+        _l.check(_l.load().ug_gemv_bf16(_p(x), x.stride(0), M, _p(w), w.stride(0), _p(acc), N, 1, N, K, _stream()), "ug_gemv_bf16")
+    else:
+        gemm(x, w, out=acc, epilogue=UG_EPI_F32, beta=1)
     out = None if resid is not None else torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
     _l.check(_l.load().ug_skinny_finish(_p(acc), _p(bias), _p(out), _p(resid), M, N, 0 if resid is None else 1, _stream()),
              "ug_skinny_finish")
     return resid if resid is not None else out
+
+
+def gemv_acc_(x, w, acc):
+    """acc[r, n] += sum_k x[r, k] w[n, k]; acc fp32 [rows, N] row-major (the decode accumulators)."""
+    M, N, K = x.shape[0], w.shape[0], w.shape[1]
+    _l.check(_l.load().ug_gemv_bf16(_p(x), x.stride(0), M, _p(w), w.stride(0), _p(acc), acc.stride(0), 1, N, K, _stream()),
+             "ug_gemv_bf16")
+    return acc
+
+
+def decode_finish_qkv_(acc, bias, cos, sin, pos_dev, q_out, cache_k, cache_v, rows, H, HKV, hd, Tmax):
+    _l.check(_l.load().ug_decode_finish_qkv(_p(acc), acc.stride(0), _p(bias), _p(cos), _p(sin), _p(pos_dev), _p(q_out),
+                                            q_out.stride(0), _p(cache_k), _p(cache_v), rows, H, HKV, hd, Tmax, cos.shape[0],
+                                            _stream()), "ug_decode_finish_qkv")
+    return q_out
+
+
+def decode_finish_resid_norm_(acc, x, w, xn, eps):
+    _l.check(_l.load().ug_decode_finish_resid_norm(_p(acc), acc.stride(0), _p(x), _p(w), _p(xn), x.shape[0], x.shape[1], eps,
+                                                   _stream()), "ug_decode_finish_resid_norm")
+    return xn
+
+
+def decode_finish_swiglu_(acc, act):
+    _l.check(_l.load().ug_decode_finish_swiglu(_p(acc), acc.stride(0), _p(act), act.shape[0], act.shape[1], _stream()),
+             "ug_decode_finish_swiglu")
+    return act
 
 
 # ------------------------------------------------------------------------------------ loss

@@ -253,6 +253,15 @@ class DecodeState:
         self.pos.add_(1)
         self.len.add_(1)
 
+    def ensure_accumulators(self, dims):
+        """fp32 accumulators of the decode GEMVs, row-major [rows][N], zero between uses (the finishers re-zero)."""
+        if getattr(self, "acc_qkv", None) is None:
+            dev = self.pos.device
+            nqkv = (dims.num_attention_heads + 2 * dims.num_key_value_heads) * dims.head_dim
+            self.acc_qkv = torch.zeros((self.rows, nqkv), dtype=torch.float32, device=dev)
+            self.acc_h = torch.zeros((self.rows, dims.hidden_size), dtype=torch.float32, device=dev)
+            self.acc_gu = torch.zeros((self.rows, 2 * dims.intermediate_size), dtype=torch.float32, device=dev)
+
 
 def _decode_methods(cls):
     def prefill(self, st, embeds, key_valid=None):
@@ -275,7 +284,37 @@ def _decode_methods(cls):
     def decode_step(self, st, x):
         """x fp32 [rows, H] = embedding of the newest token (updated in place as the residual stream);
         appends its K/V at st.pos and returns the final-norm hidden bf16 [rows, H].  No host sync, no
-        shape depends on the step: capturable."""
+        shape depends on the step: capturable.  Nine launches per layer: four weight-streaming GEMVs into
+        persistent fp32 accumulators, their four fused finishers, and the cache attention."""
+        d, fp = self.dims, self.fp
+        Hq, Hk, hd = d.num_attention_heads, d.num_key_value_heads, d.head_dim
+        R, H, I = st.rows, d.hidden_size, d.intermediate_size
+        if R > 32:
+            return self._decode_step_wide(st, x)
+        cos, sin = self.rope(st.Tmax)
+        st.ensure_accumulators(d)
+        dev = x.device
+        xn = torch.empty((R, H), dtype=torch.bfloat16, device=dev)
+        q = torch.empty((R, Hq * hd), dtype=torch.bfloat16, device=dev)
+        o = torch.empty((R, Hq * hd), dtype=torch.bfloat16, device=dev)
+        act = torch.empty((R, I), dtype=torch.bfloat16, device=dev)
+        ops.rmsnorm_fwd(x, fp.p("l0.ln1"), d.rms_norm_eps, want_rstd=False, out=xn)
+        n = d.num_hidden_layers
+        for i in range(n):
+            ops.gemv_acc_(xn, fp.w(f"l{i}.wqkv"), st.acc_qkv)
+            ops.decode_finish_qkv_(st.acc_qkv, fp.w(f"l{i}.bqkv"), cos, sin, st.pos, q, st.k[i], st.v[i], R, Hq, Hk, hd, st.Tmax)
+            ops.attn_decode(q, st.k[i], st.v[i], st.key_valid, Hq, Hk, hd, st.Tmax, st.len, out=o)
+            ops.gemv_acc_(o, fp.w(f"l{i}.wo"), st.acc_h)
+            ops.decode_finish_resid_norm_(st.acc_h, x, fp.p(f"l{i}.ln2"), xn, d.rms_norm_eps)
+            ops.gemv_acc_(xn, fp.w(f"l{i}.wgu"), st.acc_gu)
+            ops.decode_finish_swiglu_(st.acc_gu, act)
+            ops.gemv_acc_(act, fp.w(f"l{i}.wdown"), st.acc_h)
+            nxt = fp.p(f"l{i + 1}.ln1") if i + 1 < n else fp.p("norm")
+            ops.decode_finish_resid_norm_(st.acc_h, x, nxt, xn, d.rms_norm_eps)
+        return xn
+
+    def _decode_step_wide(self, st, x):
+        """> 32 rows: the GEMV kernel does not apply; split-K GEMMs + separate finishing kernels."""
         d, fp = self.dims, self.fp
         Hq, Hk, hd = d.num_attention_heads, d.num_key_value_heads, d.head_dim
         cos, sin = self.rope(st.Tmax)
@@ -301,6 +340,7 @@ def _decode_methods(cls):
         return out[:, :n]
 
     cls.prefill, cls.decode_step, cls.head_slice = prefill, decode_step, head_slice
+    cls._decode_step_wide = _decode_step_wide
     return cls
 
 

@@ -397,3 +397,102 @@ def test_lfq_and_layout(dev):
     nhwc = ops.nchw_to_nhwc(img.to(dev), 4)
     assert torch.equal(nhwc[..., :3].cpu(), img.permute(0, 2, 3, 1)) and nhwc[..., 3].abs().max().item() == 0
     assert torch.equal(ops.nhwc_to_nchw(nhwc, 3).cpu(), img)
+
+
+@pytest.mark.parametrize("R,N,K", [(16, 2048, 1536), (5, 333, 256), (20, 1536, 8960), (32, 17920, 1536), (1, 64, 32)])
+def test_decode_gemv_and_skinny_linear(dev, R, N, K):
+    ops = _ops()
+    g = torch.Generator().manual_seed(R * 31 + N + K)
+    x = torch.randn(R, K, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16)
+    b = torch.randn(N, generator=g).to(torch.bfloat16)
+    ref = x.float() @ w.float().t()
+    y = ops.skinny_linear(x.to(dev), w.to(dev), bias=b.to(dev))
+    assert _rel(y, ref + b.float()) < 4e-3
+    res = torch.randn(R, N, generator=g)
+    r2 = res.clone().to(dev)
+    ops.skinny_linear(x.to(dev), w.to(dev), resid=r2)
+    assert _rel(r2, res + ref.to(torch.bfloat16).float()) < 4e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,Tmax,length", [(16, 400, 331), (3, 96, 64), (5, 130, 1), (16, 1100, 1027)])
+def test_attn_decode_matches_reference(dev, R, Tmax, length):
+    """one-token query over the static KV cache == softmax(q K^T / sqrt(d)) V with GQA and a key-validity mask"""
+    ops = _ops()
+    H, HK, hd = 12, 2, 128
+    g = torch.Generator().manual_seed(R + Tmax + length)
+    q = torch.randn(R, H * hd, generator=g).to(torch.bfloat16)
+    ck = torch.randn(R, HK, Tmax, hd, generator=g).to(torch.bfloat16)
+    cv = torch.randn(R, HK, Tmax, hd, generator=g).to(torch.bfloat16)
+    valid = (torch.rand(R, Tmax, generator=g) > 0.2).to(torch.uint8)
+    valid[:, length - 1] = 1
+    ln = torch.tensor([length], dtype=torch.int32)
+    for kvd in (None, valid):
+        o = ops.attn_decode(q.to(dev), ck.to(dev), cv.to(dev), None if kvd is None else kvd.to(dev), H, HK, hd, Tmax, ln.to(dev))
+        qf = q.float().view(R, H, hd)
+        kf = ck.float()[:, :, :length].repeat_interleave(H // HK, dim=1)
+        vf = cv.float()[:, :, :length].repeat_interleave(H // HK, dim=1)
+        s = torch.einsum("rhd,rhtd->rht", qf, kf) / math.sqrt(hd)
+        if kvd is not None:
+            s = s.masked_fill(kvd[:, None, :length] == 0, float("-inf"))
+        ref = torch.einsum("rht,rhtd->rhd", torch.softmax(s, -1), vf).reshape(R, H * hd)
+        assert _rel(o, ref) < 1e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R", [16, 5, 24])
+def test_decode_fused_finishers_match_unfused_kernels(dev, R):
+    """the fused decode finishers are bit-identical to the separate kernels they replace and re-zero the accumulator"""
+    ops = _ops()
+    Hq, Hk, hd, H, I, Tmax, pos = 12, 2, 128, 1536, 8960, 40, 17
+    g = torch.Generator().manual_seed(R)
+    cos, sin = ops.rope_tables(Tmax, hd, 1e6, dev)
+    pos_dev = torch.tensor([pos], dtype=torch.int32, device=dev)
+    # ---- qkv
+    nq = (Hq + 2 * Hk) * hd
+    a = torch.randn(R, nq, generator=g) * 3
+    bias = torch.randn(nq, generator=g).to(torch.bfloat16).to(dev)
+    acc = a.clone().to(dev)
+    q = torch.empty(R, Hq * hd, dtype=torch.bfloat16, device=dev)
+    ck = torch.zeros(R, Hk, Tmax, hd, dtype=torch.bfloat16, device=dev); cv = torch.zeros_like(ck)
+    ops.decode_finish_qkv_(acc, bias, cos, sin, pos_dev, q, ck, cv, R, Hq, Hk, hd, Tmax)
+    qkv = torch.empty(R, nq, dtype=torch.bfloat16, device=dev)
+    lib = ops._l.load()
+    ops._l.check(lib.ug_skinny_finish(ops._p(a.to(dev).contiguous()), ops._p(bias), ops._p(qkv), None, R, nq, 0, ops._stream()), "fin")
+    ops.rope_at_(qkv, cos, sin, Hq + Hk, hd, pos_dev)
+    ck2 = torch.zeros_like(ck); cv2 = torch.zeros_like(cv)
+    ops.kv_store(qkv, ck2, cv2, R, 1, Hq, Hk, hd, Tmax, pos_dev, 0)
+    assert torch.equal(q, qkv[:, :Hq * hd]) and torch.equal(ck, ck2) and torch.equal(cv, cv2)
+    assert float(acc.abs().max()) == 0.0
+    # ---- residual + rmsnorm
+    a = torch.randn(R, H, generator=g)
+    x0 = torch.randn(R, H, generator=g)
+    w = (1 + 0.1 * torch.randn(H, generator=g)).to(dev)
+    acc = a.clone().to(dev)
+    x = x0.clone().to(dev)
+    xn = torch.empty(R, H, dtype=torch.bfloat16, device=dev)
+    ops.decode_finish_resid_norm_(acc, x, w, xn, 1e-6)
+    x2 = x0.clone().to(dev)
+    ops._l.check(lib.ug_skinny_finish(ops._p(a.to(dev).contiguous()), None, None, ops._p(x2), R, H, 1, ops._stream()), "fin")
+    xn2, _ = ops.rmsnorm_fwd(x2, w, 1e-6, want_rstd=False)
+    assert torch.equal(x, x2) and torch.equal(xn, xn2) and float(acc.abs().max()) == 0.0
+    # ---- swiglu
+    a = torch.randn(R, 2 * I, generator=g) * 2
+    acc = a.clone().to(dev)
+    act = torch.empty(R, I, dtype=torch.bfloat16, device=dev)
+    ops.decode_finish_swiglu_(acc, act)
+    assert torch.equal(act, ops.swiglu_fwd(a.to(torch.bfloat16).to(dev))) and float(acc.abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,N,K", [(16, 2048, 1536), (16, 17920, 1536), (16, 1536, 8960), (7, 1000, 160), (20, 520, 96)])
+def test_gemv_row_major_accumulator(dev, R, N, K):
+    ops = _ops()
+    g = torch.Generator().manual_seed(N + K)
+    x = torch.randn(R, K, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16)
+    acc = torch.zeros(R, N, device=dev)
+    ops.gemv_acc_(x.to(dev), w.to(dev), acc)
+    ref = x.float() @ w.float().t()
+    assert _rel(acc, ref) < 1e-3
