@@ -143,6 +143,31 @@ int ug_decode_finish_qkv(float* acc, int64_t ldacc, const void* bias, const floa
 int ug_decode_finish_resid_norm(float* acc, int64_t ldacc, float* x, const float* w, void* xn, int64_t rows, int64_t cols,
                                 float eps, hipStream_t stream);
 int ug_decode_finish_swiglu(float* acc, int64_t ldacc, void* act, int64_t rows, int64_t I, hipStream_t stream);
+/* Five-launch decode layer (what UniGen.t2i_generate_ar's per-token forward, models/unigen.py:496-502, runs).  A decode
+ * step is bound by the ~4 us floor of every launch, so all finishing work moves to the CONSUMER of each accumulator
+ * and kernel boundaries are the only synchronisation:
+ *   ug_decode_gemv_resid_norm  q/k/v and gate/up projections.  Operand = bf16(norm_w[k] * xnew[r][k]) with
+ *        xnew = x_in + bf16round(pending) (the previous projection's residual add); writes xnew to x_out (!= x_in) and
+ *        adds sum_k xnew^2 into ss_out[r].  RMSNorm's per-row rsqrt factor is applied by the accumulator's consumer.
+ *   ug_attn_decode_fused       builds the new token's q/k/v from the raw qkv accumulator (rstd, bias, RoPE), appends k/v
+ *        to the cache at *pos_dev, attends to cache keys [0, *pos_dev) + the new token.
+ *   ug_decode_gemv             o projection (bf16 operand).
+ *   ug_decode_gemv_swiglu      down projection.  Operand = bf16(bf16(silu(g)) * u), g, u = bf16(rstd[r] * gate/up acc).
+ * Each GEMV also clears up to two fully-consumed accumulators (zero0/zero1, n floats each, multiples of 4) and one
+ * 32-float statistics slot, so a captured step has no memset nodes. */
+int ug_decode_gemv(const void* x, int64_t ldx, int64_t R, const void* W, int64_t ldw, float* acc, int64_t ldacc, int64_t N,
+                   int64_t K, float* zero0, int64_t n0, float* zero1, int64_t n1, float* ss_zero, hipStream_t stream);
+int ug_decode_gemv_resid_norm(const float* x_in, const float* pending, int64_t ld_pending, const float* norm_w, float* x_out,
+                              float* ss_out, int64_t R, const void* W, int64_t ldw, float* acc, int64_t ldacc, int64_t N,
+                              int64_t K, float* zero0, int64_t n0, float* zero1, int64_t n1, float* ss_zero,
+                              hipStream_t stream);
+int ug_decode_gemv_swiglu(const float* gate_up_acc, int64_t ld_gu, const float* ss_in, float eps, int64_t norm_cols, int64_t R,
+                          const void* W, int64_t ldw, float* acc, int64_t ldacc, int64_t N, int64_t K, float* zero0, int64_t n0,
+                          float* zero1, int64_t n1, float* ss_zero, hipStream_t stream);
+int ug_attn_decode_fused(const float* acc_qkv, int64_t ldacc, const float* ss_in, float eps, int64_t norm_cols, const void* bias,
+                         const float* cos_tab, const float* sin_tab, const int* pos_dev, void* cache_k, void* cache_v,
+                         const uint8_t* key_valid, void* o, int64_t ldo, int64_t rows, int H, int HKV, int head_dim,
+                         int64_t Tmax, int64_t max_pos, float scale, hipStream_t stream);
 /* finish a split-K fp32 accumulation: mode 0: out_bf16 = bf16(acc + bias); mode 1: resid += bf16round(acc) */
 int ug_skinny_finish(const float* acc, const void* bias, void* out_bf16, float* resid, int64_t M, int64_t N,
                      int mode, hipStream_t stream);

@@ -156,6 +156,130 @@ __global__ __launch_bounds__(64 * AD_WAVES) void attn_decode_kernel(const bf16_t
   }
 }
 
+// The new token's q / k / v head slices straight from the raw qkv accumulator (consumer-side finishing of the qkv
+// projection): x = bf16(rstd * acc + bias), RoPE at `pos` on q and k.  Thread i of a 64-thread group owns the
+// rotary pair (i, i+64).  Same arithmetic as finish_qkv_tile / rope_at_kernel.
+__device__ __forceinline__ void new_token_pair(const float* __restrict__ arow, const bf16_t* __restrict__ bias, float rs,
+                                               int col0, int i, bool rot, const float* __restrict__ cs,
+                                               const float* __restrict__ sn, int pos, float& x1, float& x2) {
+#pragma clang fp contract(off)
+  const int c1 = col0 + i, c2 = c1 + DHD / 2;
+  float v1 = rs * arow[c1], v2 = rs * arow[c2];
+  if (bias) { v1 += bf2f(bias[c1]); v2 += bf2f(bias[c2]); }
+  x1 = bf2f(f2bf(v1)); x2 = bf2f(f2bf(v2));
+  if (rot) {
+    const float c = cs[(int64_t)pos * (DHD / 2) + i], s = sn[(int64_t)pos * (DHD / 2) + i];
+    const float p1 = x1 * c, p2 = x2 * c;
+    const float q1 = x2 * s, q2 = x1 * s;
+    x1 = bf2f(f2bf(p1 - q1)); x2 = bf2f(f2bf(p2 + q2));
+  }
+}
+
+// Cache attention of one decode step fed by the RAW qkv accumulator: every (row, query head) workgroup rebuilds
+// q and its kv head's new k / v row itself (no dependency between workgroups; the first query head of each kv head
+// also appends the row to the cache), attends to cache keys [0, pos) exactly like attn_decode_kernel, and merges
+// the new token as one more (m, l, O) partial.
+__global__ __launch_bounds__(64 * AD_WAVES) void attn_decode_fused_kernel(
+    const float* __restrict__ acc_qkv, int64_t lda, const float* __restrict__ ss, float eps, int norm_cols,
+    const bf16_t* __restrict__ bias, const float* __restrict__ cs, const float* __restrict__ sn, const int* __restrict__ pos_dev,
+    bf16_t* __restrict__ ck, bf16_t* __restrict__ cv, const uint8_t* __restrict__ key_valid, bf16_t* __restrict__ o, int64_t ldo,
+    int H, int HKV, int Tmax, int max_pos, float scale) {
+  __shared__ float qs[DHD], kn[DHD], vn[DHD];
+  __shared__ float om[AD_WAVES][DHD];
+  __shared__ float ml[AD_WAVES][2];
+  const int r = blockIdx.y, h = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int hk = h / (H / HKV);
+  const int pos0 = *pos_dev;
+  const int len = min(pos0, Tmax);                         // cache keys visible to the new token
+  const float rs = rsqrtf(ss[r] / (float)norm_cols + eps);
+  const float* arow = acc_qkv + (int64_t)r * lda;
+  if (wave < 3) {
+    const int col0 = wave == 0 ? h * DHD : wave == 1 ? (H + hk) * DHD : (H + HKV + hk) * DHD;
+    float x1, x2;
+    new_token_pair(arow, bias, rs, col0, lane, wave < 2, cs, sn, min(pos0, max_pos - 1), x1, x2);
+    float* dst = wave == 0 ? qs : wave == 1 ? kn : vn;
+    dst[lane] = x1; dst[lane + DHD / 2] = x2;
+    if (wave > 0 && h % (H / HKV) == 0 && pos0 < Tmax) {
+      bf16_t* row = (wave == 1 ? ck : cv) + (((int64_t)r * HKV + hk) * Tmax + pos0) * DHD;
+      row[lane] = f2bf(x1); row[lane + DHD / 2] = f2bf(x2);
+    }
+  }
+  __syncthreads();
+  const bf16_t* kb = ck + ((int64_t)r * HKV + hk) * Tmax * DHD;
+  const bf16_t* vb = cv + ((int64_t)r * HKV + hk) * Tmax * DHD;
+  const int kq = lane >> 4, dc = lane & 15;
+  float m = -INFINITY, l = 0.f;
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  for (int t0 = wave * 64; t0 < len; t0 += 64 * AD_WAVES) {
+    const int t = t0 + lane;
+    float s = -INFINITY;
+    bf16x8_t kf[DHD / 8], vf[16];
+    {
+      const bf16_t* kr = kb + (int64_t)min(t, len - 1) * DHD;
+#pragma unroll
+      for (int c = 0; c < DHD / 8; ++c) kf[c] = *reinterpret_cast<const bf16x8_t*>(kr + c * 8);
+#pragma unroll
+      for (int jj = 0; jj < 16; ++jj) {
+        const int tt = min(t0 + jj * 4 + kq, len - 1);
+        vf[jj] = *reinterpret_cast<const bf16x8_t*>(vb + (int64_t)tt * DHD + dc * 8);
+      }
+    }
+    if (t < len && (!key_valid || key_valid[(int64_t)r * Tmax + t])) {
+      float d = 0.f;
+#pragma unroll
+      for (int c = 0; c < DHD / 8; ++c)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d += bf2f((bf16_t)kf[c][e]) * qs[c * 8 + e];
+      s = d * scale;
+    }
+    const float mc = wave_max(s);
+    const float mn = fmaxf(m, mc);
+    const float mu = (mn == -INFINITY) ? 0.f : mn;
+    const float alpha = __expf(m - mu);
+    const float p = __expf(s - mu);
+    l = l * alpha + wave_sum(p);
+    m = mn;
+    const float pb = bf2f(f2bf(p));
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] *= alpha;
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+      const float pj = __shfl(pb, jj * 4 + kq, 64);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += pj * bf2f((bf16_t)vf[jj][e]);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    acc[e] += __shfl_xor(acc[e], 16, 64);
+    acc[e] += __shfl_xor(acc[e], 32, 64);
+  }
+  if (lane < 16) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) om[wave][dc * 8 + e] = acc[e];
+  }
+  if (lane == 0) { ml[wave][0] = m; ml[wave][1] = l; }
+  // the new token's own score (every wave computes it; no extra barrier)
+  const float s_new = wave_sum(qs[lane] * kn[lane] + qs[lane + DHD / 2] * kn[lane + DHD / 2]) * scale;
+  __syncthreads();
+  if (threadIdx.x < DHD) {
+    float M = s_new;
+#pragma unroll
+    for (int w = 0; w < AD_WAVES; ++w) M = fmaxf(M, ml[w][0]);
+    const float wn = __expf(s_new - M);
+    float L = wn, O = wn * vn[threadIdx.x];
+#pragma unroll
+    for (int w = 0; w < AD_WAVES; ++w) {
+      const float wgt = (ml[w][0] == -INFINITY) ? 0.f : __expf(ml[w][0] - M);
+      L += wgt * ml[w][1];
+      O += wgt * om[w][threadIdx.x];
+    }
+    o[(int64_t)r * ldo + h * DHD + threadIdx.x] = f2bf(O / L);
+  }
+}
+
 // Finish a split-K fp32 accumulation of a skinny GEMM:  mode 0: out_bf16 = bf16(acc + bias)
 //                                                      mode 1: resid_f32 += bf16round(acc)      (in place)
 __global__ __launch_bounds__(256) void skinny_finish_kernel(const float* __restrict__ acc, const bf16_t* __restrict__ bias,
@@ -237,92 +361,6 @@ __global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* __restrict__ x,
 // lane-linear, so the bank swizzle (16-byte chunk index ^ row) is applied to the SOURCE address.
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
-
-// One wave per workgroup owns ONE 256-wide k-slab and KW consecutive 16-row weight groups.  The
-// activation fragments of the slab are loaded once and stay in registers; the KW weight tiles walk through a
-// two-slot LDS ring (tile t+2's DMA is issued as soon as tile t's fragments are in registers).  No workgroup
-// barrier, no cross-wave reduction; ~10 independent waves per CU keep 16 KiB each in flight.
-template <int RB, int KW>
-__global__ __launch_bounds__(64) void gemv_ring_kernel(const bf16_t* __restrict__ x, int64_t ldx, int R,
-                                                       const bf16_t* __restrict__ W, int64_t ldw, float* __restrict__ acc,
-                                                       int64_t sr, int64_t sn, int N, int K, int nslabs) {
-  __shared__ __attribute__((aligned(1024))) char tile[2][8192];
-  const int lane = threadIdx.x, g = lane >> 4, row = lane & 15;
-  const int grp0 = (blockIdx.x / nslabs) * KW;
-  const int kbase = (blockIdx.x % nslabs) * 256;
-  int roff[8], kc[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    roff[i] = 2 * i + (lane >> 5);
-    kc[i] = min(kbase + ((lane & 31) ^ roff[i]) * 8, K - 8);       // chunks past K are never consumed
-  }
-  auto stage = [&](int t) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const bf16_t* src = W + (int64_t)min((grp0 + t) * 16 + roff[i], N - 1) * ldw + kc[i];
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile[t & 1] + i * 1024), 16, 0, 0);
-    }
-  };
-  bf16x8_t xf[RB][8];
-#pragma unroll
-  for (int rb = 0; rb < RB; ++rb) {
-    const bf16_t* xp = x + (int64_t)min(rb * 16 + row, R - 1) * ldx + g * 8;
-#pragma unroll
-    for (int u = 0; u < 8; ++u) xf[rb][u] = *reinterpret_cast<const bf16x8_t*>(xp + min(kbase + u * 32, K - 32));
-  }
-  stage(0);
-  if constexpr (KW > 1) stage(1);
-#pragma unroll
-  for (int t = 0; t < KW; ++t) {
-    if (t + 1 < KW) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const char* tr = tile[t & 1] + row * 512;
-    bf16x8_t wf[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) wf[u] = *reinterpret_cast<const bf16x8_t*>(tr + (((u * 4 + g) ^ row) << 4));
-    if (t + 2 < KW) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      stage(t + 2);
-    }
-    f32x4_t d[RB];
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb) d[rb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int u = 0; u < 8; ++u)
-      if (kbase + u * 32 < K) {
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb) d[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[rb][u], wf[u], d[rb], 0, 0, 0);
-      }
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb) {
-      const int n = (grp0 + t) * 16 + row;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int r = rb * 16 + g * 4 + j;
-        if (r < R && n < N) atomicAdd(acc + (int64_t)r * sr + (int64_t)n * sn, d[rb][j]);
-      }
-    }
-  }
-}
-
-template <int RB>
-void launch_gemv(int U, dim3 grid, hipStream_t st, const bf16_t* x, int64_t ldx, int R, const bf16_t* W, int64_t ldw,
-                 float* acc, int64_t sr, int64_t sn, int N, int K) {
-  const dim3 block(256);
-  switch (U) {
-    case 8: hipLaunchKernelGGL((gemv_kernel<RB, 8>), grid, block, 0, st, x, ldx, R, W, ldw, acc, sr, sn, N, K); break;
-    case 4: hipLaunchKernelGGL((gemv_kernel<RB, 4>), grid, block, 0, st, x, ldx, R, W, ldw, acc, sr, sn, N, K); break;
-    case 2: hipLaunchKernelGGL((gemv_kernel<RB, 2>), grid, block, 0, st, x, ldx, R, W, ldw, acc, sr, sn, N, K); break;
-    default: hipLaunchKernelGGL((gemv_kernel<RB, 1>), grid, block, 0, st, x, ldx, R, W, ldw, acc, sr, sn, N, K); break;
-  }
-}
-
-template <int RB>
-void launch_gemv_ring(int KW, dim3 grid, hipStream_t st, const bf16_t* x, int64_t ldx, int R, const bf16_t* W, int64_t ldw,
-                      float* acc, int64_t sr, int64_t sn, int N, int K, int nslabs) {
-  if (KW == 2) hipLaunchKernelGGL((gemv_ring_kernel<RB, 2>), grid, dim3(64), 0, st, x, ldx, R, W, ldw, acc, sr, sn, N, K, nslabs);
-  else hipLaunchKernelGGL((gemv_ring_kernel<RB, 1>), grid, dim3(64), 0, st, x, ldx, R, W, ldw, acc, sr, sn, N, K, nslabs);
-}
 
 // ------------------------------------------------------------------ fused finishers of the decode step
 // Every finisher consumes a row-major fp32 accumulator filled by the GEMV (acc[r*lda + n]) and leaves it ZEROED
@@ -445,6 +483,296 @@ __global__ __launch_bounds__(256) void finish_swiglu_kernel(float* __restrict__ 
     finish_swiglu_quad(acc, lda, act, I, (int)(idx / per_row), (int)(idx % per_row) * 4);
 }
 
+// One wave per workgroup owns ONE 256-wide k-slab and KW consecutive 16-row weight groups.  The
+// activation fragments of the slab are built once and stay in registers; the KW weight tiles walk through a
+// two-slot LDS ring (tile t+2's DMA is issued as soon as tile t's fragments are in registers).  No workgroup
+// barrier, no cross-wave reduction; ~10 independent waves per CU keep 16 KiB each in flight.
+//
+// Decode fusion.  A decode step is bound by the ~4 us floor of every launch, not by bytes, and on this multi-XCD
+// part any in-kernel cross-wave hand-off costs several trips to the device coherence point (a completion-counter
+// "last wave finishes" variant was measured SLOWER than separate finishing kernels).  So all finishing work moves
+// to the CONSUMER side: a projection leaves its raw fp32 accumulator behind and the next kernel applies the
+// finisher while building its own operand fragments; kernel boundaries are the only synchronisation.
+//   XIN_BF16        operand = bf16 activations (o_proj after attention)
+//   XIN_RESID_NORM  operand = bf16(w[k] * xnew[r][k]),  xnew = x_in + bf16round(pending accumulator)
+//                   (residual add of the previous projection + the elementwise half of RMSNorm; the per-row
+//                   rsqrt(mean(xnew^2)) factor is a scalar of the output row, so it is applied by the consumer of
+//                   THIS projection's accumulator).  The waves of weight group 0 also write xnew to x_out and add
+//                   their slab's sum of squares to ss_out[r].
+//   XIN_SWIGLU      operand = bf16( bf16(silu(g)) * u ),  g, u = bf16(rstd[r] * gate/up accumulator)
+// Every launch also clears up to two accumulators that earlier kernels have fully consumed and one 32-float
+// statistics slot (spread over all waves), so the captured graph carries no memset nodes.
+enum { XIN_BF16 = 0, XIN_RESID_NORM = 1, XIN_SWIGLU = 2 };
+
+struct DecodeIn {
+  const float* x_in; const float* pend; int64_t ld_pend; const float* norm_w; float* x_out; float* ss_out;   // RESID_NORM
+  const float* gu; int64_t ld_gu; const float* ss_in; float eps; int norm_cols;                              // SWIGLU
+  float* zero0; int64_t n0; float* zero1; int64_t n1; float* ss_zero;                                        // clears
+};
+
+__device__ __forceinline__ void decode_clear(const DecodeIn& f, int tid, int bid, int nblocks) {
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int nt = blockDim.x;
+  if (f.zero0) {
+    const int64_t n4 = f.n0 >> 2, per = (n4 + nblocks - 1) / nblocks, lo = bid * per, hi = min(n4, lo + per);
+    for (int64_t i = lo + tid; i < hi; i += nt) reinterpret_cast<float4*>(f.zero0)[i] = z;
+  }
+  if (f.zero1) {
+    const int64_t n4 = f.n1 >> 2, per = (n4 + nblocks - 1) / nblocks, lo = bid * per, hi = min(n4, lo + per);
+    for (int64_t i = lo + tid; i < hi; i += nt) reinterpret_cast<float4*>(f.zero1)[i] = z;
+  }
+  if (f.ss_zero && bid == 0 && tid < 32) f.ss_zero[tid] = 0.f;
+}
+
+__device__ __forceinline__ float silu_bf(float g) { return bf2f(f2bf(g / (1.f + __expf(-g)))); }
+
+// Build this lane's operand fragment (row `ar`, 8 k-values at k0) for the fp32-operand modes.
+template <int XIN>
+__device__ __forceinline__ void decode_operand_load(const DecodeIn& f, int ar, int k0, int K, float4 (&a)[2], float4 (&b)[2],
+                                                    float4 (&w)[2]) {
+  if constexpr (XIN == XIN_RESID_NORM) {
+    const float* xp = f.x_in + (int64_t)ar * K + k0;
+    const float* pp = f.pend + (int64_t)ar * f.ld_pend + k0;
+    a[0] = *reinterpret_cast<const float4*>(xp); a[1] = *reinterpret_cast<const float4*>(xp + 4);
+    b[0] = *reinterpret_cast<const float4*>(pp); b[1] = *reinterpret_cast<const float4*>(pp + 4);
+    w[0] = *reinterpret_cast<const float4*>(f.norm_w + k0); w[1] = *reinterpret_cast<const float4*>(f.norm_w + k0 + 4);
+  } else {
+    const float* gp = f.gu + (int64_t)ar * f.ld_gu + k0;
+    a[0] = *reinterpret_cast<const float4*>(gp); a[1] = *reinterpret_cast<const float4*>(gp + 4);
+    b[0] = *reinterpret_cast<const float4*>(gp + K); b[1] = *reinterpret_cast<const float4*>(gp + K + 4);
+  }
+}
+
+template <int XIN>
+__device__ __forceinline__ bf16x8_t decode_operand_make(const DecodeIn& f, const float4 (&a)[2], const float4 (&b)[2],
+                                                        const float4 (&w)[2], float rs, bool store, float* __restrict__ op,
+                                                        float& ssq) {
+  const float av[8] = {a[0].x, a[0].y, a[0].z, a[0].w, a[1].x, a[1].y, a[1].z, a[1].w};
+  const float bv[8] = {b[0].x, b[0].y, b[0].z, b[0].w, b[1].x, b[1].y, b[1].z, b[1].w};
+  bf16x8_t o;
+  if constexpr (XIN == XIN_RESID_NORM) {
+    const float wv[8] = {w[0].x, w[0].y, w[0].z, w[0].w, w[1].x, w[1].y, w[1].z, w[1].w};
+    float xn[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      xn[e] = av[e] + bf2f(f2bf(bv[e]));
+      o[e] = (short)f2bf(wv[e] * xn[e]);
+      ssq += xn[e] * xn[e];
+    }
+    if (store) {
+      *reinterpret_cast<float4*>(op) = make_float4(xn[0], xn[1], xn[2], xn[3]);
+      *reinterpret_cast<float4*>(op + 4) = make_float4(xn[4], xn[5], xn[6], xn[7]);
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (short)f2bf(silu_bf(bf2f(f2bf(rs * av[e]))) * bf2f(f2bf(rs * bv[e])));
+  }
+  return o;
+}
+
+// XIN_BF16: one wave per workgroup (see above).
+template <int RB, int KW>
+__global__ __launch_bounds__(64) void gemv_ring_kernel(const bf16_t* __restrict__ x, int64_t ldx, int R,
+                                                       const bf16_t* __restrict__ W, int64_t ldw, float* __restrict__ acc,
+                                                       int64_t sr, int64_t sn, int N, int K, int nslabs, DecodeIn f) {
+  __shared__ __attribute__((aligned(1024))) char tile[2][8192];
+  const int lane = threadIdx.x, g = lane >> 4, row = lane & 15;
+  const int grp0 = (blockIdx.x / nslabs) * KW;
+  const int kbase = (blockIdx.x % nslabs) * 256;
+  int roff[8], kc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    roff[i] = 2 * i + (lane >> 5);
+    kc[i] = min(kbase + ((lane & 31) ^ roff[i]) * 8, K - 8);       // chunks past K are never consumed
+  }
+  auto stage = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const bf16_t* src = W + (int64_t)min((grp0 + t) * 16 + roff[i], N - 1) * ldw + kc[i];
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile[t & 1] + i * 1024), 16, 0, 0);
+    }
+  };
+  stage(0);
+  if constexpr (KW > 1) stage(1);
+  bf16x8_t xf[RB][8];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const bf16_t* xp = x + (int64_t)min(rb * 16 + row, R - 1) * ldx + g * 8;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) xf[rb][u] = *reinterpret_cast<const bf16x8_t*>(xp + min(kbase + u * 32, K - 32));
+  }
+  decode_clear(f, lane, blockIdx.x, gridDim.x);
+#pragma unroll
+  for (int t = 0; t < KW; ++t) {
+    if (t + 1 < KW) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const char* tr = tile[t & 1] + row * 512;
+    bf16x8_t wf[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) wf[u] = *reinterpret_cast<const bf16x8_t*>(tr + (((u * 4 + g) ^ row) << 4));
+    if (t + 2 < KW) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      stage(t + 2);
+    }
+    f32x4_t d[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) d[rb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (kbase + u * 32 < K) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) d[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[rb][u], wf[u], d[rb], 0, 0, 0);
+      }
+    const int grp = grp0 + t;
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      const int n = grp * 16 + row;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = rb * 16 + g * 4 + j;
+        if (r < R && n < N) atomicAdd(acc + (int64_t)r * sr + (int64_t)n * sn, d[rb][j]);
+      }
+    }
+  }
+}
+
+// fp32-operand modes: FOUR waves per workgroup share one k-slab (each owns KW weight groups and its own LDS ring).
+// The operand fragments are built cooperatively -- wave w converts k-steps 2w, 2w+1 for all rows and parks them in
+// LDS -- because every wave re-reading the fp32 slab itself costs more L2 bandwidth than the weights cost HBM
+// (measured: gate_up 14.5 -> 28.8 us).
+template <int RB, int KW, int XIN>
+__global__ __launch_bounds__(256) void gemv_ring4_kernel(int R, const bf16_t* __restrict__ W, int64_t ldw,
+                                                         float* __restrict__ acc, int64_t sr, int64_t sn, int N, int K,
+                                                         int nslabs, DecodeIn f) {
+  __shared__ __attribute__((aligned(1024))) char tile[4][2][8192];
+  __shared__ __attribute__((aligned(16))) bf16x8_t frag[RB][8][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, row = lane & 15;
+  const int chunk = blockIdx.x / nslabs;
+  const int grp0 = (chunk * 4 + wave) * KW;
+  const int kbase = (blockIdx.x % nslabs) * 256;
+  int roff[8], kc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    roff[i] = 2 * i + (lane >> 5);
+    kc[i] = min(kbase + ((lane & 31) ^ roff[i]) * 8, K - 8);
+  }
+  auto stage = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const bf16_t* src = W + (int64_t)min((grp0 + t) * 16 + roff[i], N - 1) * ldw + kc[i];
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile[wave][t & 1] + i * 1024), 16, 0, 0);
+    }
+  };
+  // operand loads of this wave's two k-steps go out first, then the weight DMA
+  float4 a[RB][2][2], b[RB][2][2], w[RB][2][2];
+  float rs[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const int ar = min(rb * 16 + row, R - 1);
+    rs[rb] = 0.f;
+    if constexpr (XIN == XIN_SWIGLU) rs[rb] = f.ss_in[ar];
+#pragma unroll
+    for (int uu = 0; uu < 2; ++uu)
+      decode_operand_load<XIN>(f, ar, min(kbase + (wave * 2 + uu) * 32, K - 32) + g * 8, K, a[rb][uu], b[rb][uu], w[rb][uu]);
+  }
+  stage(0);
+  if constexpr (KW > 1) stage(1);
+  decode_clear(f, threadIdx.x, blockIdx.x, gridDim.x);
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const int ar = min(rb * 16 + row, R - 1);
+    const bool live = rb * 16 + row < R;
+    if constexpr (XIN == XIN_SWIGLU) rs[rb] = rsqrtf(rs[rb] / (float)f.norm_cols + f.eps);
+    float ssq = 0.f;
+#pragma unroll
+    for (int uu = 0; uu < 2; ++uu) {
+      const int u = wave * 2 + uu;
+      const bool in_k = kbase + u * 32 < K;                          // clamped (re-read) steps carry no new data
+      float part = 0.f;
+      float* op = XIN == XIN_RESID_NORM ? f.x_out + (int64_t)ar * K + kbase + u * 32 + g * 8 : nullptr;
+      frag[rb][u][lane] = decode_operand_make<XIN>(f, a[rb][uu], b[rb][uu], w[rb][uu], rs[rb], chunk == 0 && live && in_k, op, part);
+      if (in_k) ssq += part;
+    }
+    if constexpr (XIN == XIN_RESID_NORM) {
+      ssq += __shfl_xor(ssq, 16, 64);
+      ssq += __shfl_xor(ssq, 32, 64);
+      if (chunk == 0 && live && g == 0 && f.ss_out) atomicAdd(f.ss_out + rb * 16 + row, ssq);
+    }
+  }
+  __syncthreads();
+  bf16x8_t xf[RB][8];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) xf[rb][u] = frag[rb][u][lane];
+#pragma unroll
+  for (int t = 0; t < KW; ++t) {
+    if (t + 1 < KW) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const char* tr = tile[wave][t & 1] + row * 512;
+    bf16x8_t wf[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) wf[u] = *reinterpret_cast<const bf16x8_t*>(tr + (((u * 4 + g) ^ row) << 4));
+    if (t + 2 < KW) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      stage(t + 2);
+    }
+    f32x4_t d[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) d[rb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (kbase + u * 32 < K) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) d[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[rb][u], wf[u], d[rb], 0, 0, 0);
+      }
+    const int grp = grp0 + t;
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      const int n = grp * 16 + row;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = rb * 16 + g * 4 + j;
+        if (r < R && n < N) atomicAdd(acc + (int64_t)r * sr + (int64_t)n * sn, d[rb][j]);
+      }
+    }
+  }
+}
+
+template <int RB>
+void launch_gemv(int U, dim3 grid, hipStream_t st, const bf16_t* x, int64_t ldx, int R, const bf16_t* W, int64_t ldw,
+                 float* acc, int64_t sr, int64_t sn, int N, int K) {
+  const dim3 block(256);
+  switch (U) {
+    case 8: hipLaunchKernelGGL((gemv_kernel<RB, 8>), grid, block, 0, st, x, ldx, R, W, ldw, acc, sr, sn, N, K); break;
+    case 4: hipLaunchKernelGGL((gemv_kernel<RB, 4>), grid, block, 0, st, x, ldx, R, W, ldw, acc, sr, sn, N, K); break;
+    case 2: hipLaunchKernelGGL((gemv_kernel<RB, 2>), grid, block, 0, st, x, ldx, R, W, ldw, acc, sr, sn, N, K); break;
+    default: hipLaunchKernelGGL((gemv_kernel<RB, 1>), grid, block, 0, st, x, ldx, R, W, ldw, acc, sr, sn, N, K); break;
+  }
+}
+
+// measured on MI355X (tools/gemv_bench.py): two row groups per wave once there are >= 3000 tiles, else one
+template <int XIN>
+void launch_ring_auto(hipStream_t st, const bf16_t* x, int64_t ldx, int R, const bf16_t* W, int64_t ldw, float* acc, int64_t sr,
+                      int64_t sn, int N, int K, const DecodeIn& f) {
+  const int64_t groups = (N + 15) / 16;
+  const int nslabs = (K + 255) / 256;
+  const int KW = groups * nslabs >= 3000 ? 2 : 1;
+  if constexpr (XIN == XIN_BF16) {
+    dim3 grid((unsigned)(((groups + KW - 1) / KW) * nslabs));
+#define UG_RING1(RBV, KWV) hipLaunchKernelGGL((gemv_ring_kernel<RBV, KWV>), grid, dim3(64), 0, st, x, ldx, R, W, ldw, acc, sr, sn, N, K, nslabs, f)
+    if (R <= 16) { if (KW == 2) UG_RING1(1, 2); else UG_RING1(1, 1); }
+    else { if (KW == 2) UG_RING1(2, 2); else UG_RING1(2, 1); }
+#undef UG_RING1
+  } else {
+    dim3 grid((unsigned)(((groups + 4 * KW - 1) / (4 * KW)) * nslabs));
+#define UG_RING4(RBV, KWV) hipLaunchKernelGGL((gemv_ring4_kernel<RBV, KWV, XIN>), grid, dim3(256), 0, st, R, W, ldw, acc, sr, sn, N, K, nslabs, f)
+    if (R <= 16) { if (KW == 2) UG_RING4(1, 2); else UG_RING4(1, 1); }
+    else { if (KW == 2) UG_RING4(2, 2); else UG_RING4(2, 1); }
+#undef UG_RING4
+  }
+}
+
 }  // namespace
 
 extern "C" int ug_gemv_bf16(const void* x, int64_t ldx, int64_t R, const void* W, int64_t ldw, float* acc, int64_t acc_stride_r,
@@ -455,12 +783,7 @@ extern "C" int ug_gemv_bf16(const void* x, int64_t ldx, int64_t R, const void* W
   const bf16_t* xb = (const bf16_t*)x;
   const bf16_t* wb = (const bf16_t*)W;
   if (K >= 256) {
-    // measured on MI355X (tools/gemv_bench.py): two row groups per wave once there are >= 3000 tiles, else one
-    const int nslabs = (int)((K + 255) / 256);
-    const int KW = groups * nslabs >= 3000 ? 2 : 1;
-    dim3 grid((unsigned)(((groups + KW - 1) / KW) * nslabs));
-    if (R <= 16) launch_gemv_ring<1>(KW, grid, st, xb, ldx, (int)R, wb, ldw, acc, acc_stride_r, acc_stride_n, (int)N, (int)K, nslabs);
-    else launch_gemv_ring<2>(KW, grid, st, xb, ldx, (int)R, wb, ldw, acc, acc_stride_r, acc_stride_n, (int)N, (int)K, nslabs);
+    launch_ring_auto<XIN_BF16>(st, xb, ldx, (int)R, wb, ldw, acc, acc_stride_r, acc_stride_n, (int)N, (int)K, DecodeIn{});
     UG_CHECK_LAUNCH("ug_gemv_bf16");
     return UG_OK;
   }
@@ -472,6 +795,53 @@ extern "C" int ug_gemv_bf16(const void* x, int64_t ldx, int64_t R, const void* W
   if (R <= 16) launch_gemv<1>(U, grid, st, xb, ldx, (int)R, wb, ldw, acc, acc_stride_r, acc_stride_n, (int)N, (int)K);
   else launch_gemv<2>(U, grid, st, xb, ldx, (int)R, wb, ldw, acc, acc_stride_r, acc_stride_n, (int)N, (int)K);
   UG_CHECK_LAUNCH("ug_gemv_bf16");
+  return UG_OK;
+}
+
+#define UG_DECODE_COMMON(name)                                                                                              \
+  UG_REQUIRE(R > 0 && R <= 32 && K >= 256 && K % 32 == 0 && N > 0 && ldw % 8 == 0 && ug_aligned16(W) && acc &&              \
+                 ug_aligned16(acc) && ldacc % 4 == 0 && n0 % 4 == 0 && n1 % 4 == 0 && ug_aligned16(zero0) && ug_aligned16(zero1), \
+             name ": need 1 <= rows <= 32, K >= 256, K %% 32 == 0, 16-byte aligned operands (rows=%ld K=%ld)", (long)R, (long)K)
+
+extern "C" int ug_decode_gemv(const void* x, int64_t ldx, int64_t R, const void* W, int64_t ldw, float* acc, int64_t ldacc,
+                              int64_t N, int64_t K, float* zero0, int64_t n0, float* zero1, int64_t n1, float* ss_zero,
+                              hipStream_t st) {
+  UG_DECODE_COMMON("ug_decode_gemv");
+  UG_REQUIRE(x && ldx % 8 == 0 && ug_aligned16(x), "ug_decode_gemv: activations must be 16-byte aligned rows");
+  DecodeIn f{};
+  f.zero0 = zero0; f.n0 = n0; f.zero1 = zero1; f.n1 = n1; f.ss_zero = ss_zero;
+  launch_ring_auto<XIN_BF16>(st, (const bf16_t*)x, ldx, (int)R, (const bf16_t*)W, ldw, acc, ldacc, 1, (int)N, (int)K, f);
+  UG_CHECK_LAUNCH("ug_decode_gemv");
+  return UG_OK;
+}
+
+extern "C" int ug_decode_gemv_resid_norm(const float* x_in, const float* pending, int64_t ld_pending, const float* norm_w,
+                                         float* x_out, float* ss_out, int64_t R, const void* W, int64_t ldw, float* acc,
+                                         int64_t ldacc, int64_t N, int64_t K, float* zero0, int64_t n0, float* zero1, int64_t n1,
+                                         float* ss_zero, hipStream_t st) {
+  UG_DECODE_COMMON("ug_decode_gemv_resid_norm");
+  UG_REQUIRE(x_in && pending && norm_w && x_out && ss_out && x_in != x_out && ld_pending % 4 == 0 && ug_aligned16(x_in) &&
+                 ug_aligned16(pending) && ug_aligned16(norm_w) && ug_aligned16(x_out),
+             "ug_decode_gemv_resid_norm: bad args (x_in and x_out must be distinct, 16-byte aligned fp32 buffers)");
+  DecodeIn f{};
+  f.x_in = x_in; f.pend = pending; f.ld_pend = ld_pending; f.norm_w = norm_w; f.x_out = x_out; f.ss_out = ss_out;
+  f.zero0 = zero0; f.n0 = n0; f.zero1 = zero1; f.n1 = n1; f.ss_zero = ss_zero;
+  launch_ring_auto<XIN_RESID_NORM>(st, nullptr, 0, (int)R, (const bf16_t*)W, ldw, acc, ldacc, 1, (int)N, (int)K, f);
+  UG_CHECK_LAUNCH("ug_decode_gemv_resid_norm");
+  return UG_OK;
+}
+
+extern "C" int ug_decode_gemv_swiglu(const float* gate_up_acc, int64_t ld_gu, const float* ss_in, float eps, int64_t norm_cols,
+                                     int64_t R, const void* W, int64_t ldw, float* acc, int64_t ldacc, int64_t N, int64_t K,
+                                     float* zero0, int64_t n0, float* zero1, int64_t n1, float* ss_zero, hipStream_t st) {
+  UG_DECODE_COMMON("ug_decode_gemv_swiglu");
+  UG_REQUIRE(gate_up_acc && ss_in && norm_cols > 0 && ld_gu % 4 == 0 && K % 4 == 0 && ug_aligned16(gate_up_acc),
+             "ug_decode_gemv_swiglu: bad args");
+  DecodeIn f{};
+  f.gu = gate_up_acc; f.ld_gu = ld_gu; f.ss_in = ss_in; f.eps = eps; f.norm_cols = (int)norm_cols;
+  f.zero0 = zero0; f.n0 = n0; f.zero1 = zero1; f.n1 = n1; f.ss_zero = ss_zero;
+  launch_ring_auto<XIN_SWIGLU>(st, nullptr, 0, (int)R, (const bf16_t*)W, ldw, acc, ldacc, 1, (int)N, (int)K, f);
+  UG_CHECK_LAUNCH("ug_decode_gemv_swiglu");
   return UG_OK;
 }
 
@@ -543,6 +913,19 @@ extern "C" int ug_attn_decode(const void* q, int64_t ldq, const void* cache_k, c
   hipLaunchKernelGGL(attn_decode_kernel, dim3(H, (unsigned)rows), dim3(64 * AD_WAVES), 0, st, (const bf16_t*)q, ldq, (const bf16_t*)cache_k,
                      (const bf16_t*)cache_v, key_valid, (bf16_t*)o, ldo, H, HKV, (int)Tmax, len_dev, scale);
   UG_CHECK_LAUNCH("ug_attn_decode");
+  return UG_OK;
+}
+
+extern "C" int ug_attn_decode_fused(const float* acc_qkv, int64_t ldacc, const float* ss_in, float eps, int64_t norm_cols,
+                                    const void* bias, const float* cos_tab, const float* sin_tab, const int* pos_dev,
+                                    void* cache_k, void* cache_v, const uint8_t* key_valid, void* o, int64_t ldo, int64_t rows,
+                                    int H, int HKV, int head_dim, int64_t Tmax, int64_t max_pos, float scale, hipStream_t st) {
+  UG_REQUIRE(rows > 0 && head_dim == DHD && H % HKV == 0 && acc_qkv && ss_in && norm_cols > 0 && pos_dev && cache_k && cache_v && o,
+             "ug_attn_decode_fused: bad args");
+  hipLaunchKernelGGL(attn_decode_fused_kernel, dim3(H, (unsigned)rows), dim3(64 * AD_WAVES), 0, st, acc_qkv, ldacc, ss_in, eps,
+                     (int)norm_cols, (const bf16_t*)bias, cos_tab, sin_tab, pos_dev, (bf16_t*)cache_k, (bf16_t*)cache_v, key_valid,
+                     (bf16_t*)o, ldo, H, HKV, (int)Tmax, (int)max_pos, scale);
+  UG_CHECK_LAUNCH("ug_attn_decode_fused");
   return UG_OK;
 }
 

@@ -43,6 +43,10 @@ SIGNATURES = {
     "ug_rope_at": [P, P, P, I64, I64, I32, I32, P, I64, P],
     "ug_attn_decode": [P, I64, P, P, P, P, I64, I64, I32, I32, I32, I64, P, F32, P],
     "ug_gemv_bf16": [P, I64, I64, P, I64, P, I64, I64, I64, I64, P],
+    "ug_decode_gemv": [P, I64, I64, P, I64, P, I64, I64, I64, P, I64, P, I64, P, P],
+    "ug_decode_gemv_resid_norm": [P, P, I64, P, P, P, I64, P, I64, P, I64, I64, I64, P, I64, P, I64, P, P],
+    "ug_decode_gemv_swiglu": [P, I64, P, F32, I64, I64, P, I64, P, I64, I64, I64, P, I64, P, I64, P, P],
+    "ug_attn_decode_fused": [P, I64, P, F32, I64, P, P, P, P, P, P, P, P, I64, I64, I32, I32, I32, I64, I64, F32, P],
     "ug_decode_finish_qkv": [P, I64, P, P, P, P, P, I64, P, P, I64, I32, I32, I32, I64, I64, P],
     "ug_decode_finish_resid_norm": [P, I64, P, P, P, I64, I64, F32, P],
     "ug_decode_finish_swiglu": [P, I64, P, I64, I64, P],

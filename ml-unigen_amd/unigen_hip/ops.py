@@ -328,6 +328,45 @@ def decode_finish_swiglu_(acc, act):
     return act
 
 
+def _clr(t):
+    return (_p(t), t.numel()) if t is not None else (None, 0)
+
+
+def decode_gemv_(x, w, acc, zero0=None, zero1=None, ss_zero=None):
+    """acc[r, n] += sum_k x[r, k] w[n, k] (bf16 operand) + the clears this launch carries."""
+    _l.check(_l.load().ug_decode_gemv(_p(x), x.stride(0), x.shape[0], _p(w), w.stride(0), _p(acc), acc.stride(0), w.shape[0],
+                                      w.shape[1], *_clr(zero0), *_clr(zero1), _p(ss_zero), _stream()), "ug_decode_gemv")
+    return acc
+
+
+def decode_gemv_resid_norm_(x_in, pending, norm_w, x_out, ss_out, w, acc, zero0=None, zero1=None, ss_zero=None):
+    """Projection whose operand is bf16(norm_w * (x_in + bf16round(pending))); x_out / ss_out receive the updated
+    residual stream and its row sums of squares."""
+    _l.check(_l.load().ug_decode_gemv_resid_norm(_p(x_in), _p(pending), pending.stride(0), _p(norm_w), _p(x_out), _p(ss_out),
+                                                 x_in.shape[0], _p(w), w.stride(0), _p(acc), acc.stride(0), w.shape[0],
+                                                 w.shape[1], *_clr(zero0), *_clr(zero1), _p(ss_zero), _stream()),
+             "ug_decode_gemv_resid_norm")
+    return acc
+
+
+def decode_gemv_swiglu_(gu_acc, ss_in, eps, norm_cols, w, acc, zero0=None, zero1=None, ss_zero=None):
+    """Projection whose operand is SwiGLU of the raw gate/up accumulator scaled by the row's RMSNorm factor."""
+    _l.check(_l.load().ug_decode_gemv_swiglu(_p(gu_acc), gu_acc.stride(0), _p(ss_in), eps, norm_cols, gu_acc.shape[0], _p(w),
+                                             w.stride(0), _p(acc), acc.stride(0), w.shape[0], w.shape[1], *_clr(zero0),
+                                             *_clr(zero1), _p(ss_zero), _stream()), "ug_decode_gemv_swiglu")
+    return acc
+
+
+def attn_decode_fused(acc_qkv, ss_in, eps, norm_cols, bias, cos, sin, pos_dev, cache_k, cache_v, key_valid, out, H, HKV, hd, Tmax,
+                      scale=None):
+    scale = 1.0 / math.sqrt(hd) if scale is None else scale
+    _l.check(_l.load().ug_attn_decode_fused(_p(acc_qkv), acc_qkv.stride(0), _p(ss_in), eps, norm_cols, _p(bias), _p(cos), _p(sin),
+                                            _p(pos_dev), _p(cache_k), _p(cache_v), _p(key_valid), _p(out), out.stride(0),
+                                            acc_qkv.shape[0], H, HKV, hd, Tmax, cos.shape[0], scale, _stream()),
+             "ug_attn_decode_fused")
+    return out
+
+
 # ------------------------------------------------------------------------------------ loss
 def ce_fwd(logits, V, labels, ignore_index=-100, want_logp=False):
     """logits bf16 [R, ld>=V]; -> (loss_and_count [2], lse [R], loss_row [R], logp|None)"""

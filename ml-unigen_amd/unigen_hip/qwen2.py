@@ -254,13 +254,17 @@ class DecodeState:
         self.len.add_(1)
 
     def ensure_accumulators(self, dims):
-        """fp32 accumulators of the decode GEMVs, row-major [rows][N], zero between uses (the finishers re-zero)."""
+        """Persistent scratch of the five-launch decode layer: one raw fp32 accumulator per projection (row-major
+        [rows][N]; each is cleared by a later launch once fully consumed), the second residual-stream buffer, and
+        the two row sum-of-squares slots that carry the RMSNorm statistics to the accumulators' consumers."""
         if getattr(self, "acc_qkv", None) is None:
             dev = self.pos.device
             nqkv = (dims.num_attention_heads + 2 * dims.num_key_value_heads) * dims.head_dim
-            self.acc_qkv = torch.zeros((self.rows, nqkv), dtype=torch.float32, device=dev)
-            self.acc_h = torch.zeros((self.rows, dims.hidden_size), dtype=torch.float32, device=dev)
-            self.acc_gu = torch.zeros((self.rows, 2 * dims.intermediate_size), dtype=torch.float32, device=dev)
+            z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
+            self.acc_qkv, self.acc_gu = z(self.rows, nqkv), z(self.rows, 2 * dims.intermediate_size)
+            self.acc_o, self.acc_down = z(self.rows, dims.hidden_size), z(self.rows, dims.hidden_size)
+            self.x_mid = z(self.rows, dims.hidden_size)
+            self.ss_attn, self.ss_mlp = z(32), z(32)
 
 
 def _decode_methods(cls):
@@ -284,34 +288,32 @@ def _decode_methods(cls):
     def decode_step(self, st, x):
         """x fp32 [rows, H] = embedding of the newest token (updated in place as the residual stream);
         appends its K/V at st.pos and returns the final-norm hidden bf16 [rows, H].  No host sync, no
-        shape depends on the step: capturable.  Nine launches per layer: four weight-streaming GEMVs into
-        persistent fp32 accumulators, their four fused finishers, and the cache attention."""
+        shape depends on the step: capturable.  Five launches per layer (see include/unigen_hip.h): each
+        projection leaves its raw fp32 accumulator behind and the NEXT kernel applies bias / RoPE / residual add /
+        RMSNorm / SiLU-mul while it builds its own operand, so kernel boundaries are the only synchronisation."""
         d, fp = self.dims, self.fp
         Hq, Hk, hd = d.num_attention_heads, d.num_key_value_heads, d.head_dim
         R, H, I = st.rows, d.hidden_size, d.intermediate_size
-        if R > 32:
+        if not getattr(self, "decode_fused", True) or R > 32 or hd != 128 or min(H, I, Hq * hd) < 256 or H % 32 or I % 32:
             return self._decode_step_wide(st, x)
         cos, sin = self.rope(st.Tmax)
         st.ensure_accumulators(d)
-        dev = x.device
-        xn = torch.empty((R, H), dtype=torch.bfloat16, device=dev)
-        q = torch.empty((R, Hq * hd), dtype=torch.bfloat16, device=dev)
-        o = torch.empty((R, Hq * hd), dtype=torch.bfloat16, device=dev)
-        act = torch.empty((R, I), dtype=torch.bfloat16, device=dev)
-        ops.rmsnorm_fwd(x, fp.p("l0.ln1"), d.rms_norm_eps, want_rstd=False, out=xn)
-        n = d.num_hidden_layers
-        for i in range(n):
-            ops.gemv_acc_(xn, fp.w(f"l{i}.wqkv"), st.acc_qkv)
-            ops.decode_finish_qkv_(st.acc_qkv, fp.w(f"l{i}.bqkv"), cos, sin, st.pos, q, st.k[i], st.v[i], R, Hq, Hk, hd, st.Tmax)
-            ops.attn_decode(q, st.k[i], st.v[i], st.key_valid, Hq, Hk, hd, st.Tmax, st.len, out=o)
-            ops.gemv_acc_(o, fp.w(f"l{i}.wo"), st.acc_h)
-            ops.decode_finish_resid_norm_(st.acc_h, x, fp.p(f"l{i}.ln2"), xn, d.rms_norm_eps)
-            ops.gemv_acc_(xn, fp.w(f"l{i}.wgu"), st.acc_gu)
-            ops.decode_finish_swiglu_(st.acc_gu, act)
-            ops.gemv_acc_(act, fp.w(f"l{i}.wdown"), st.acc_h)
-            nxt = fp.p(f"l{i + 1}.ln1") if i + 1 < n else fp.p("norm")
-            ops.decode_finish_resid_norm_(st.acc_h, x, nxt, xn, d.rms_norm_eps)
-        return xn
+        eps = d.rms_norm_eps
+        o = torch.empty((R, Hq * hd), dtype=torch.bfloat16, device=x.device)
+        for i in range(d.num_hidden_layers):
+            # x (+ pending down_proj of the previous layer) -> x_mid ; q/k/v accumulator ; clears gate_up acc
+            ops.decode_gemv_resid_norm_(x, st.acc_down, fp.p(f"l{i}.ln1"), st.x_mid, st.ss_attn, fp.w(f"l{i}.wqkv"), st.acc_qkv,
+                                        zero0=st.acc_gu, ss_zero=st.ss_mlp)
+            ops.attn_decode_fused(st.acc_qkv, st.ss_attn, eps, H, fp.w(f"l{i}.bqkv"), cos, sin, st.pos, st.k[i], st.v[i],
+                                  st.key_valid, o, Hq, Hk, hd, st.Tmax)
+            ops.decode_gemv_(o, fp.w(f"l{i}.wo"), st.acc_o, zero0=st.acc_qkv, zero1=st.acc_down, ss_zero=st.ss_attn)
+            # x_mid + pending o_proj -> x ; gate/up accumulator
+            ops.decode_gemv_resid_norm_(st.x_mid, st.acc_o, fp.p(f"l{i}.ln2"), x, st.ss_mlp, fp.w(f"l{i}.wgu"), st.acc_gu)
+            ops.decode_gemv_swiglu_(st.acc_gu, st.ss_mlp, eps, H, fp.w(f"l{i}.wdown"), st.acc_down, zero0=st.acc_o)
+        # pending down_proj of the last layer + final RMSNorm (also clears acc_down for the next step)
+        hn = torch.empty((R, H), dtype=torch.bfloat16, device=x.device)
+        ops.decode_finish_resid_norm_(st.acc_down, x, fp.p("norm"), hn, eps)
+        return hn
 
     def _decode_step_wide(self, st, x):
         """> 32 rows: the GEMV kernel does not apply; split-K GEMMs + separate finishing kernels."""

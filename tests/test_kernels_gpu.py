@@ -496,3 +496,64 @@ def test_gemv_row_major_accumulator(dev, R, N, K):
     ops.gemv_acc_(x.to(dev), w.to(dev), acc)
     ref = x.float() @ w.float().t()
     assert _rel(acc, ref) < 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R", [16, 5, 24])
+def test_decode_consumer_side_finishing_matches_separate_kernels(dev, R):
+    """The five-launch decode layer (raw accumulators finished by their consumers) against the separate kernels, on
+    Qwen2.5-1.5B layer shapes; the scratch buffers are reused across iterations like in a captured step."""
+    ops = _ops()
+    Hq, Hk, hd, H, I, Tmax, pos = 12, 2, 128, 1536, 8960, 40, 17
+    g = torch.Generator().manual_seed(100 + R)
+    cos, sin = ops.rope_tables(Tmax, hd, 1e6, dev)
+    pos_dev = torch.tensor([pos], dtype=torch.int32, device=dev)
+    len_dev = torch.tensor([pos + 1], dtype=torch.int32, device=dev)
+    nq = (Hq + 2 * Hk) * hd
+    mk = lambda n, k: (torch.randn(n, k, generator=g) / math.sqrt(k)).to(torch.bfloat16).to(dev)
+    wqkv, wo, wgu, wdown = mk(nq, H), mk(H, Hq * hd), mk(2 * I, H), mk(H, I)
+    bias = torch.randn(nq, generator=g).to(torch.bfloat16).to(dev)
+    ln1 = (1 + 0.1 * torch.randn(H, generator=g)).to(dev)
+    ln2 = (1 + 0.1 * torch.randn(H, generator=g)).to(dev)
+    z = lambda *shape: torch.zeros(shape, device=dev)
+    acc_qkv, acc_o, acc_gu, acc_down, x_mid = z(R, nq), z(R, H), z(R, 2 * I), z(R, H), z(R, H)
+    ss_attn, ss_mlp = z(32), z(32)
+    ck0 = torch.randn(R, Hk, Tmax, hd, generator=g).to(torch.bfloat16).to(dev)
+    cv0 = torch.randn(R, Hk, Tmax, hd, generator=g).to(torch.bfloat16).to(dev)
+    valid = (torch.rand(R, Tmax, generator=g) > 0.2).to(torch.uint8).to(dev)
+    valid[:, pos] = 1
+    for it in range(4):
+        x0 = torch.randn(R, H, generator=g).to(dev)
+        pend = (0.3 * torch.randn(R, H, generator=g)).to(dev) if it else z(R, H)
+        # ---- reference: separate kernels (the > 32-row decode path)
+        xr = x0 + pend.to(torch.bfloat16).float()
+        xn, _ = ops.rmsnorm_fwd(xr, ln1, 1e-6, want_rstd=False)
+        qkv = ops.skinny_linear(xn, wqkv, bias=bias)
+        ops.rope_at_(qkv, cos, sin, Hq + Hk, hd, pos_dev)
+        ck2, cv2 = ck0.clone(), cv0.clone()
+        ops.kv_store(qkv, ck2, cv2, R, 1, Hq, Hk, hd, Tmax, pos_dev, 0)
+        o2 = ops.attn_decode(qkv, ck2, cv2, valid, Hq, Hk, hd, Tmax, len_dev)
+        xr2 = xr.clone()
+        ops.skinny_linear(o2, wo, resid=xr2)
+        xn2, _ = ops.rmsnorm_fwd(xr2, ln2, 1e-6, want_rstd=False)
+        act2 = ops.swiglu_fwd(ops.skinny_linear(xn2, wgu))
+        xr3 = xr2.clone()
+        ops.skinny_linear(act2, wdown, resid=xr3)
+        # ---- five launches
+        x = x0.clone()
+        acc_down.copy_(pend)
+        ck, cv = ck0.clone(), cv0.clone()
+        o = torch.empty(R, Hq * hd, dtype=torch.bfloat16, device=dev)
+        ops.decode_gemv_resid_norm_(x, acc_down, ln1, x_mid, ss_attn, wqkv, acc_qkv, zero0=acc_gu, ss_zero=ss_mlp)
+        assert _rel(x_mid, xr) < 1e-6 and _rel(ss_attn[:R], (xr * xr).sum(-1)) < 1e-5
+        ops.attn_decode_fused(acc_qkv, ss_attn, 1e-6, H, bias, cos, sin, pos_dev, ck, cv, valid, o, Hq, Hk, hd, Tmax)
+        assert _rel(ck, ck2) < 1e-2 and _rel(cv, cv2) < 1e-2 and _rel(o, o2) < 2e-2
+        ops.decode_gemv_(o, wo, acc_o, zero0=acc_qkv, zero1=acc_down, ss_zero=ss_attn)
+        ops.decode_gemv_resid_norm_(x_mid, acc_o, ln2, x, ss_mlp, wgu, acc_gu)
+        assert _rel(x, xr2) < 5e-3
+        ops.decode_gemv_swiglu_(acc_gu, ss_mlp, 1e-6, H, wdown, acc_down, zero0=acc_o)
+        hn = torch.empty(R, H, dtype=torch.bfloat16, device=dev)
+        ops.decode_finish_resid_norm_(acc_down, x, ln1, hn, 1e-6)
+        assert _rel(x, xr3) < 1e-2
+        for t in (acc_qkv, acc_o, acc_down, ss_attn):
+            assert float(t.abs().max()) == 0.0

@@ -176,7 +176,8 @@ def test_ar_generation_kv_cache_matches_oracle(dev):
     with torch.no_grad():
         ce, ue = lm.model.embed_tokens(cond[:, :P]), lm.model.embed_tokens(uncond[:, :P])
     want, margin = qwen2_ref.ar_generate_ref(lm, ce, ue, n, 3.0, ids["text_vocab"], key_valid=am[:, :P])
-    for use_graph in (False, True):
+    for use_graph, fused in ((False, True), (True, True), (True, False)):
+        model.llm.engine.decode_fused = fused        # one-launch projections vs the separate-kernel path
         got = model.t2i_generate_ar(input_ids=cond.to(dev), uncond_input_ids=uncond.to(dev), attention_mask=am.to(dev),
                                     guidance_scale=3.0, temperature=1.0, text_vocab_size=ids["text_vocab"],
                                     image_token_num_per_image=n, greedy=True, use_graph=use_graph).cpu()
@@ -187,6 +188,6 @@ def test_ar_generation_kv_cache_matches_oracle(dev):
             for i in range(n):
                 if margin[b, i] < 0.05:
                     break                      # an oracle near-tie: later tokens may legitimately diverge
-                assert got[b, i].item() == want[b, i].item(), (use_graph, b, i, got[b], want[b])
+                assert got[b, i].item() == want[b, i].item(), (use_graph, fused, b, i, got[b], want[b])
                 compared += 1
         assert compared >= 8, compared
