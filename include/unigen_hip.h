@@ -107,12 +107,14 @@ int ug_attn_transpose(const void* in, int64_t ld, void* out, int64_t B, int64_t 
 int ug_attn_fwd(const void* q, const void* k, const void* v, int64_t ldq, const void* vT, void* o,
                 int64_t ldo, float* lse, const uint64_t* bits, const uint8_t* tileany, int64_t B, int64_t L,
                 int64_t Lp, int H, int HKV, int head_dim, float scale, hipStream_t stream);
-/* dq/dk/dv written with row stride ldg (heads laid out like q/k/v); delta: [B][H][L] workspace */
+/* dq/dk/dv written with row stride ldg (heads laid out like q/k/v); delta: [B][H][L] workspace.
+ * dkv_ws: optional fp32 [B*L][2*HKV*128] workspace, ZERO on entry and left zero: dK/dV are then accumulated per query
+ * head (6x the workgroups, balanced under causal masks) with fp32 atomics; null -> per-kv-head kernel, no atomics. */
 int ug_attn_bwd(const void* q, const void* k, const void* v, int64_t ldq, const void* qT, const void* kT,
                 const void* o, const void* dout, int64_t ldo, const void* doT, const float* lse,
                 float* delta, void* dq, void* dk, void* dv, int64_t ldg, const uint64_t* bits,
                 const uint8_t* tileany, int64_t B, int64_t L, int64_t Lp, int H, int HKV, int head_dim,
-                float scale, hipStream_t stream);
+                float scale, float* dkv_ws, hipStream_t stream);
 
 /* ---- autoregressive decode (static KV cache, graph-capturable) -------------------------------- */
 /* replaces: transformers DynamicCache.update + SDPA on one new token per row inside

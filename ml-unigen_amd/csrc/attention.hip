@@ -165,6 +165,7 @@ struct AttnArgs {
   const bf16_t* qT; const bf16_t* doT;                 // [B][H*128][Lp]
   bf16_t* o; const bf16_t* dout;                       // [tokens, ldo]
   bf16_t* dq; bf16_t* dk; bf16_t* dv;                  // row stride ldg
+  float* dkv_ws;                                       // [tokens][2*HKV*128] fp32, split-head dK/dV accumulation (or null)
   float* lse; const float* delta;                      // [B][H][L]
   const uint64_t* bits; const uint8_t* tileany;
   int64_t ldq, ldo, ldg;
@@ -348,16 +349,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
 // ================================================================== backward: dK, dV
 // grid (nKVtiles, HKV, B); each wave owns 16 keys (a lane owns key column kv = lane&15), walks the
 // H/HKV query heads of its group and all query tiles; dK^T/dV^T accumulate in registers, no atomics.
+// SPLIT: grid (nKVtiles, H, B) -- one query head per workgroup, 6x the workgroups (a causal mask makes key tile 0
+// thirteen times the work of the last one, and nKV*HKV*B = 416 workgroups do not even fill the 512 slots once);
+// partial dK/dV go to an fp32 workspace with row-contiguous atomics (transposed through LDS), finished by
+// dkv_finish_kernel.
+template <bool SPLIT>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
-  __shared__ __attribute__((aligned(16))) bf16_t Qs[64 * RM_LD];
-  __shared__ __attribute__((aligned(16))) bf16_t Ds[64 * RM_LD];     // dO rows
+  __shared__ __attribute__((aligned(16))) bf16_t QD[2 * 64 * RM_LD];  // Q rows | dO rows (one array: reused as the
+  bf16_t* Qs = QD;                                                    // SPLIT epilogue's fp32 transpose scratch)
+  bf16_t* Ds = QD + 64 * RM_LD;
   __shared__ __attribute__((aligned(16))) bf16_t Qt[128 * TR_LD];
   __shared__ __attribute__((aligned(16))) bf16_t Dt[128 * TR_LD];    // dO^T
   __shared__ float lse_s[64], dl_s[64];
   __shared__ uint64_t word_s[64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
-  const int t = blockIdx.x, hk = blockIdx.y, b = blockIdx.z;
+  const int t = blockIdx.x, b = blockIdx.z;
   const int grp = p.H / p.HKV;
+  const int hk = SPLIT ? blockIdx.y / grp : blockIdx.y;
   const int krow = t * 64 + wave * 16 + (lane & 15);
   const int krow_c = min(krow, p.L - 1);
   const bf16_t* kseq = p.k + (int64_t)b * p.L * p.ldq + hk * HD;
@@ -373,7 +381,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
   for (int d = 0; d < 8; ++d) { dkt[d] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dvt[d] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
   const int kbit = wave * 16 + (lane & 15);
 
-  for (int hh = 0; hh < grp; ++hh) {
+  for (int hh = SPLIT ? blockIdx.y % grp : 0; hh < (SPLIT ? blockIdx.y % grp + 1 : grp); ++hh) {
     const int h = hk * grp + hh;
     const bf16_t* qseq = p.q + (int64_t)b * p.L * p.ldq + h * HD;
     const bf16_t* doseq = p.dout + (int64_t)b * p.L * p.ldo + h * HD;
@@ -424,6 +432,35 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
       }
     }
   }
+  if constexpr (SPLIT) {
+    // wave-private transpose through LDS (the staging tiles are dead): [16 keys][128 d] fp32 per tensor, then every
+    // atomic instruction covers 64 consecutive floats of one key row
+    __syncthreads();
+    static_assert(4 * 16 * 132 * 4 <= 2 * 64 * RM_LD * 2, "transpose scratch must fit in QD");
+    float* tw = reinterpret_cast<float*>(QD) + wave * (16 * 132);
+    const int ldws = 2 * p.HKV * HD;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+      for (int d = 0; d < 8; ++d)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tw[(lane & 15) * 132 + d * 16 + g * 4 + r] = pass == 0 ? dkt[d][r] : dvt[d][r];
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int kr = t * 64 + wave * 16 + i;
+        if (kr < p.L) {
+          float* dst = p.dkv_ws + ((int64_t)b * p.L + kr) * ldws + (pass * p.HKV + hk) * HD;
+          atomicAdd(dst + lane, tw[i * 132 + lane]);
+          atomicAdd(dst + 64 + lane, tw[i * 132 + 64 + lane]);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    return;
+  }
   if (krow < p.L) {
     bf16_t* dkrow = p.dk + ((int64_t)b * p.L + krow) * p.ldg + hk * HD;
     bf16_t* dvrow = p.dv + ((int64_t)b * p.L + krow) * p.ldg + hk * HD;
@@ -434,6 +471,22 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
       uint2 u; u.x = pack_bf2(dvt[d][0], dvt[d][1]); u.y = pack_bf2(dvt[d][2], dvt[d][3]);
       *reinterpret_cast<uint2*>(dvrow + d * 16 + g * 4) = u;
     }
+  }
+}
+
+// workspace -> bf16 dK | dV (row stride ldg) and re-zero the workspace for the next layer
+__global__ __launch_bounds__(256) void dkv_finish_kernel(float* __restrict__ ws, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv,
+                                                         int64_t ldg, int64_t tokens, int kvw) {
+  const int per_row = 2 * kvw / 4;
+  const int64_t total = tokens * per_row;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = idx / per_row; const int c = (int)(idx % per_row) * 4;
+    float4* src = reinterpret_cast<float4*>(ws + row * 2 * kvw + c);
+    const float4 v = *src;
+    *src = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint2 w; w.x = pack_bf2(v.x, v.y); w.y = pack_bf2(v.z, v.w);
+    bf16_t* dst = c < kvw ? dk + row * ldg + c : dv + row * ldg + (c - kvw);
+    *reinterpret_cast<uint2*>(dst) = w;
   }
 }
 
@@ -513,8 +566,9 @@ extern "C" int ug_attn_bwd(const void* q, const void* k, const void* v, int64_t 
                            const void* o, const void* dout, int64_t ldo, const void* doT, const float* lse,
                            float* delta, void* dq, void* dk, void* dv, int64_t ldg, const uint64_t* bits,
                            const uint8_t* tileany, int64_t B, int64_t L, int64_t Lp, int H, int HKV, int head_dim,
-                           float scale, hipStream_t st) {
+                           float scale, float* dkv_ws, hipStream_t st) {
   if (int rc = check_common("ug_attn_bwd", B, L, Lp, H, HKV, head_dim, ldq)) return rc;
+  UG_REQUIRE(ug_aligned16(dkv_ws), "ug_attn_bwd: workspace alignment");
   UG_REQUIRE(ug_aligned16(q) && ug_aligned16(k) && ug_aligned16(v) && ug_aligned16(qT) && ug_aligned16(kT) &&
                  ug_aligned16(doT) && ug_aligned16(dout) && ldo % 8 == 0 && ldg % 4 == 0,
              "ug_attn_bwd: alignment");
@@ -522,7 +576,7 @@ extern "C" int ug_attn_bwd(const void* q, const void* k, const void* v, int64_t 
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v;
   a.qT = (const bf16_t*)qT; a.kT = (const bf16_t*)kT; a.doT = (const bf16_t*)doT;
   a.dout = (const bf16_t*)dout; a.lse = const_cast<float*>(lse); a.delta = delta;
-  a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv;
+  a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.dkv_ws = dkv_ws;
   a.bits = bits; a.tileany = tileany;
   a.ldq = ldq; a.ldo = ldo; a.ldg = ldg; a.B = (int)B; a.L = (int)L; a.Lp = (int)Lp; a.nW = (int)((L + 63) / 64);
   a.H = H; a.HKV = HKV; a.scale = scale;
@@ -532,7 +586,16 @@ extern "C" int ug_attn_bwd(const void* q, const void* k, const void* v, int64_t 
   UG_CHECK_LAUNCH("ug_attn_bwd(delta)");
   hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(a.nW, H, (unsigned)B), dim3(256), 0, st, a);
   UG_CHECK_LAUNCH("ug_attn_bwd(dq)");
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(a.nW, HKV, (unsigned)B), dim3(256), 0, st, a);
-  UG_CHECK_LAUNCH("ug_attn_bwd(dkv)");
+  if (dkv_ws) {
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, dim3(a.nW, H, (unsigned)B), dim3(256), 0, st, a);
+    UG_CHECK_LAUNCH("ug_attn_bwd(dkv split)");
+    const int64_t total = B * L * (2 * HKV * HD / 4);
+    int64_t gsz = (total + 255) / 256; if (gsz > 4096) gsz = 4096;
+    hipLaunchKernelGGL(dkv_finish_kernel, dim3((unsigned)gsz), dim3(256), 0, st, dkv_ws, a.dk, a.dv, ldg, B * L, HKV * HD);
+    UG_CHECK_LAUNCH("ug_attn_bwd(dkv finish)");
+  } else {
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, dim3(a.nW, HKV, (unsigned)B), dim3(256), 0, st, a);
+    UG_CHECK_LAUNCH("ug_attn_bwd(dkv)");
+  }
   return UG_OK;
 }

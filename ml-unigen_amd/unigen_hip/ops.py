@@ -243,7 +243,19 @@ def attn_fwd(qkv, mb, H, HKV, hd, scale=None):
     return o, lse
 
 
-def attn_bwd(qkv, o, lse, dout, mb, H, HKV, hd, scale=None):
+_DKV_WS = {}
+
+
+def _dkv_workspace(tokens, width, device):
+    """zeroed fp32 [tokens, width] scratch for the split-head dK/dV accumulation (the kernels leave it zeroed)"""
+    key = (device, tokens, width)
+    if key not in _DKV_WS:
+        _DKV_WS.clear()
+        _DKV_WS[key] = torch.zeros((tokens, width), dtype=torch.float32, device=device)
+    return _DKV_WS[key]
+
+
+def attn_bwd(qkv, o, lse, dout, mb, H, HKV, hd, scale=None, split_heads=True):
     """-> dqkv bf16 [B*L, (H+2*HKV)*hd] (gradient w.r.t. the post-RoPE q/k and v)."""
     B, L, Lp = mb.B, mb.L, mb.Lp
     scale = 1.0 / math.sqrt(hd) if scale is None else scale
@@ -258,9 +270,10 @@ def attn_bwd(qkv, o, lse, dout, mb, H, HKV, hd, scale=None):
     dk = dqkv[:, H * hd: (H + HKV) * hd]
     dv = dqkv[:, (H + HKV) * hd:]
     delta = torch.empty((B, H, L), dtype=torch.float32, device=qkv.device)
+    ws = _dkv_workspace(B * L, 2 * HKV * hd, qkv.device) if split_heads and H > HKV else None
     _l.check(_l.load().ug_attn_bwd(_p(q), _p(k), _p(v), qkv.stride(0), _p(qT), _p(kT), _p(o), _p(dout), o.stride(0),
                                    _p(doT), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), dqkv.stride(0), _p(mb.bits),
-                                   _p(mb.tileany), B, L, Lp, H, HKV, hd, scale, _stream()), "ug_attn_bwd")
+                                   _p(mb.tileany), B, L, Lp, H, HKV, hd, scale, _p(ws), _stream()), "ug_attn_bwd")
     return dqkv
 
 

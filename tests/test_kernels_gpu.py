@@ -300,7 +300,10 @@ def test_attention_fwd_bwd(dev, kind, B, L, H, HKV):
     assert _rel(got, ref) < 8e-3, f"fwd rel {_rel(got, ref)}"
     dout = torch.randn(B * L, H * hd, generator=gen).to(torch.bfloat16)
     ref.backward(dout.float().view(B, L, H, hd).permute(0, 2, 1, 3))
-    dqkv = ops.attn_bwd(qkv.to(dev), o, lse, dout.to(dev), mb, H, HKV, hd).float().cpu()
+    dqkv_det = ops.attn_bwd(qkv.to(dev), o, lse, dout.to(dev), mb, H, HKV, hd, split_heads=False).float().cpu()
+    dqkv = ops.attn_bwd(qkv.to(dev), o, lse, dout.to(dev), mb, H, HKV, hd).float().cpu()      # split-head dK/dV (atomics)
+    assert _rel(dqkv, dqkv_det) < 4e-3
+    assert float(ops._dkv_workspace(B * L, 2 * HKV * hd, dev).abs().max()) == 0.0
     dq = dqkv[:, : H * hd].view(B, L, H, hd).permute(0, 2, 1, 3)
     dk = dqkv[:, H * hd:(H + HKV) * hd].view(B, L, HKV, hd).permute(0, 2, 1, 3)
     dv = dqkv[:, (H + HKV) * hd:].view(B, L, HKV, hd).permute(0, 2, 1, 3)
