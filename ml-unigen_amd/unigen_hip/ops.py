@@ -401,6 +401,30 @@ def ce_bwd_(logits, V, labels, lse, lc, gscale=None, ignore_index=-100):
     return logits
 
 
+# flat fp32 master buffers that keep a bf16 compute mirror (FlatParams registers itself); FusedAdamW writes the
+# mirror in the same pass so no separate cast pass follows an optimizer step
+BF16_MIRRORS = []
+
+
+def register_bf16_mirror(owner):
+    """owner: object with .master (fp32 flat), .bf16 (same layout) and ._seen_version"""
+    import weakref
+    BF16_MIRRORS.append(weakref.ref(owner))
+
+
+def find_bf16_mirror(ptr, numel):
+    """-> (owner, bf16 address of the element at fp32 address `ptr`) if [ptr, ptr+4*numel) lies in a registered master"""
+    for ref in list(BF16_MIRRORS):
+        o = ref()
+        if o is None:
+            BF16_MIRRORS.remove(ref)
+            continue
+        base = o.master.data_ptr()
+        if base <= ptr and ptr + 4 * numel <= base + 4 * o.master.numel():
+            return o, o.bf16.data_ptr() + (ptr - base) // 2
+    return None, 0
+
+
 # ------------------------------------------------------------------------------------ optimizer
 def adamw_flat_(p, g, m, v, p_bf16, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
     _l.check(_l.load().ug_adamw_flat(_p(p), _p(g), _p(m), _p(v), _p(p_bf16), p.numel(), lr, beta1, beta2, eps, wd,

@@ -51,6 +51,8 @@ class FusedAdamW(torch.optim.Optimizer):
             self._build_runs()
         self._step += 1
         lib = ops._l.load()
+        # masters whose bf16 compute mirror is in sync right now stay in sync: the kernel writes the mirror too
+        synced = {}
         for r in self._runs:
             g = self.param_groups[r.group]
             first = r.params[0]
@@ -63,10 +65,19 @@ class FusedAdamW(torch.optim.Optimizer):
                 if p.grad is None or p.grad.data_ptr() - g_ptr != p.data_ptr() - r.p_ptr:
                     raise ops._l.UniGenHipError("FusedAdamW: gradient views do not mirror the parameter layout")
             b1, b2 = g["betas"]
-            rc = lib.ug_adamw_flat(r.p_ptr, g_ptr, r.m.data_ptr(), r.v.data_ptr(), 0, r.numel, float(g["lr"]), b1, b2,
+            owner, mirror = ops.find_bf16_mirror(r.p_ptr, r.numel)
+            if owner is not None:
+                if id(owner) not in synced:
+                    synced[id(owner)] = (owner, owner._seen_version == owner.master._version)
+                if not synced[id(owner)][1]:
+                    mirror = 0
+            rc = lib.ug_adamw_flat(r.p_ptr, g_ptr, r.m.data_ptr(), r.v.data_ptr(), mirror, r.numel, float(g["lr"]), b1, b2,
                                    g["eps"], g["weight_decay"], self._step, float(grad_scale), ops._stream())
             ops._l.check(rc, "ug_adamw_flat")
             # the kernel wrote through a raw pointer: bump the (shared) version counter so the engine
             # knows its bf16 compute copies are stale
             torch.autograd.graph.increment_version(first)
+        for owner, ok in synced.values():
+            if ok:
+                owner._seen_version = owner.master._version
         return loss

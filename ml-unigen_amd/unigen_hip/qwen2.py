@@ -66,6 +66,7 @@ class FlatParams:
         self.grad = torch.zeros(n, dtype=torch.float32, device=device)
         self.bf16 = torch.zeros(n, dtype=torch.bfloat16, device=device)
         self._seen_version = -1
+        ops.register_bf16_mirror(self)
 
     def view(self, buf, key):
         o, shp = self.off[key]

@@ -70,6 +70,10 @@ def test_tiny_unigen_step_matches_reference_golden(dev):
     opt = FusedAdamW([{"params": decay, "weight_decay": 0.01}, {"params": nodecay, "weight_decay": 0.0}], lr=1e-3,
                      betas=(0.9, 0.999), eps=1e-8)
     opt.step()
+    # the optimizer pass also refreshed the bf16 compute mirror of the flat master weights (no cast pass follows)
+    fp = model.llm.engine.fp
+    assert fp._seen_version == fp.master._version
+    assert torch.equal(fp.bf16, fp.master.to(torch.bfloat16))
     a = want["adamw"]
     # first Adam step moves every weight by ~lr*sign(g): compare the update, not the weight
     q0 = params["model.layers.0.self_attn.q_proj.weight"][:4].detach().cpu()
