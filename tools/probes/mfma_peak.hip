@@ -1,0 +1,27 @@
+// Achievable bf16 MFMA rate of the whole chip with nothing but MFMAs in flight (no memory traffic):
+// the practical ceiling the GEMM kernels should be judged against next to the 2.5 PFLOP/s datasheet figure.
+//   hipcc --offload-arch=gfx950 -O3 -shared -fPIC tools/probes/mfma_peak.hip -o gpurun_out/mfma_peak.so
+#include <hip/hip_runtime.h>
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+template <int NACC>
+__global__ __launch_bounds__(256) void mfma_burn(const short* __restrict__ seed, float* __restrict__ out, int iters) {
+  bf16x8_t a, b;
+  for (int e = 0; e < 8; ++e) { a[e] = seed[(threadIdx.x * 8 + e) & 4095]; b[e] = seed[(threadIdx.x * 8 + e + 1777) & 4095]; }
+  f32x4_t acc[NACC];
+  for (int i = 0; i < NACC; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+extern "C" int mfma_burn_launch(const void* seed, void* out, int blocks, int threads, int iters, int nacc, hipStream_t st) {
+  if (nacc == 64) hipLaunchKernelGGL(mfma_burn<64>, dim3(blocks), dim3(threads), 0, st, (const short*)seed, (float*)out, iters);
+  else hipLaunchKernelGGL(mfma_burn<16>, dim3(blocks), dim3(threads), 0, st, (const short*)seed, (float*)out, iters);
+  return (int)hipGetLastError();
+}
