@@ -174,6 +174,20 @@ int ug_attn_decode_fused(const float* acc_qkv, int64_t ldacc, const float* ss_in
 int ug_skinny_finish(const float* acc, const void* bias, void* out_bf16, float* resid, int64_t M, int64_t N,
                      int mode, hipStream_t stream);
 
+/* ---- MaskGIT parallel decoding step ------------------------------------------------------------ */
+/* replaces, per round of UniGen.t2i_generate (models/unigen.py:404-451): the CFG mix of the code-book logits, softmax,
+ * torch.multinomial, the gather of the drawn token's probability and models/sampling.py:41-46 mask_by_random_topk.
+ * logits: bf16 [(cfg ? 2 : 1) * N * n][ld], row (b*n + i) = image b / position i, the N*n unconditional rows after the
+ * conditional ones; V code-book columns.  u_sample / u_conf: uniforms in [0,1) [N*n] from the caller's generator
+ * (token = inverse CDF in index order; Gumbel = -log(-log(u))).  cur_ids: code ids or mask_id [N*n].
+ * mask_len_sched = floor(n * schedule(ratio)); temperature = the already-compounded Gumbel temperature.
+ * Outputs [N*n]: sampled (known tokens kept), next_cur (mask_id where re-masked), next_ids (+ id_offset unless masked),
+ * masking_out (optional bytes).  sel_ws: fp32 [N*n] scratch. */
+int ug_maskgit_step(const void* logits, int64_t ld, int64_t V, int64_t N, int64_t n, int cfg, float guidance_scale,
+                    const float* u_sample, const float* u_conf, const int64_t* cur_ids, int64_t mask_id, int64_t id_offset,
+                    int64_t mask_len_sched, float temperature, int64_t* sampled, float* sel_ws, int64_t* next_cur,
+                    int64_t* next_ids, uint8_t* masking_out, hipStream_t stream);
+
 /* ---- loss ------------------------------------------------------------------------------------ */
 /* replaces: F.cross_entropy(ignore_index=-100) x3 in UniGen.forward (models/unigen.py:310-338) and
  * get_batch_logps (training/train_dpo.py:51-90).  logits bf16 [R, ld], ld % 8 == 0.

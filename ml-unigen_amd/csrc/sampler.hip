@@ -1,0 +1,135 @@
+// MaskGIT parallel-decoding step (UniGen.t2i_generate, reference models/unigen.py:404-451 with
+// models/sampling.py:24-46): classifier-free-guidance mix of the code-book logits, softmax, one categorical draw
+// per image position, the confidence of the drawn token, and the re-masking of the least confident positions.
+// Randomness is SUPPLIED as uniforms (drawn by the caller's generator), so a step is a deterministic function of
+// its inputs: token = first index whose running sum of exp(logit - max) exceeds u * total (inverse CDF over the
+// code book in index order); Gumbel noise = -log(-log(u2)).  torch.multinomial draws from the same distribution
+// with a different use of the stream; the oracle restates this rule (oracle/qwen2_ref.py: InverseCdfSampler).
+#include "common.h"
+#include "unigen_hip.h"
+
+namespace {
+
+constexpr int SMP_T = 256;
+
+// one workgroup per (image, position); thread t owns code-book indices [t*C, (t+1)*C)
+__global__ __launch_bounds__(SMP_T) void maskgit_sample_kernel(const bf16_t* __restrict__ logits, int64_t ld, int V, int N, int n,
+                                                              int cfg, float scale, const float* __restrict__ u_sample,
+                                                              const int64_t* __restrict__ cur_ids, int64_t mask_id,
+                                                              int64_t* __restrict__ sampled, float* __restrict__ sel) {
+  __shared__ float red[SMP_T / 64];
+  __shared__ float part[SMP_T];
+  __shared__ int hit;
+  const int bi = blockIdx.x, t = threadIdx.x;
+  const int64_t cur = cur_ids[bi];
+  if (cur != mask_id) {                      // known token: kept, never re-masked (confidence = float max)
+    if (t == 0) { sampled[bi] = cur; sel[bi] = 3.402823466e+38f; }
+    return;
+  }
+  const int C = (V + SMP_T - 1) / SMP_T;
+  const bf16_t* c = logits + (int64_t)bi * ld;
+  const bf16_t* u = logits + ((int64_t)N * n + bi) * ld;
+  const int lo = t * C, hi = min(V, lo + C);
+  float mx = -INFINITY;
+  for (int e = lo; e < hi; ++e) {
+    const float cv = bf2f(c[e]);
+    float v = cv;
+    if (cfg) { const float uv = bf2f(u[e]); v = scale * (cv - uv) + uv; }
+    mx = fmaxf(mx, v);
+  }
+  mx = block_max<SMP_T / 64>(mx, red);
+  float local = 0.f;
+  for (int e = lo; e < hi; ++e) {
+    const float cv = bf2f(c[e]);
+    float v = cv;
+    if (cfg) { const float uv = bf2f(u[e]); v = scale * (cv - uv) + uv; }
+    local += expf(v - mx);
+  }
+  part[t] = local;
+  if (t == 0) hit = SMP_T - 1;
+  __syncthreads();
+  // exclusive prefix over the 256 chunk sums: every thread sums its predecessors (256 LDS reads, negligible)
+  float excl = 0.f, total = 0.f;
+  for (int j = 0; j < SMP_T; ++j) { const float pj = part[j]; if (j < t) excl += pj; total += pj; }
+  const float target = u_sample[bi] * total;
+  if (excl <= target && target < excl + local) atomicMin(&hit, t);      // first chunk whose range holds the target
+  __syncthreads();
+  if (t == hit) {
+    float run = excl, ex = 0.f;
+    int idx = hi - 1;
+    for (int e = lo; e < hi; ++e) {
+      const float cv = bf2f(c[e]);
+      float v = cv;
+      if (cfg) { const float uv = bf2f(u[e]); v = scale * (cv - uv) + uv; }
+      ex = expf(v - mx);
+      run += ex;
+      if (run > target) { idx = e; break; }
+    }
+    if (idx == hi - 1 && !(run > target)) {       // rounding pushed the target past the end of the chunk / vocabulary
+      const float cv = bf2f(c[idx]);
+      float v = cv;
+      if (cfg) { const float uv = bf2f(u[idx]); v = scale * (cv - uv) + uv; }
+      ex = expf(v - mx);
+    }
+    sampled[bi] = idx;
+    sel[bi] = ex / total;
+  }
+}
+
+// one workgroup per image: confidence, rank of every position, threshold = (mask_len)-th smallest, re-mask below it
+__global__ __launch_bounds__(1024) void maskgit_remask_kernel(const float* __restrict__ sel, const float* __restrict__ u_conf,
+                                                              const int64_t* __restrict__ cur_ids, const int64_t* __restrict__ sampled,
+                                                              int64_t mask_id, int64_t id_offset, int mask_len_sched,
+                                                              float temperature, int n, int64_t* __restrict__ next_cur,
+                                                              int64_t* __restrict__ next_ids, uint8_t* __restrict__ masking_out) {
+  extern __shared__ float conf_s[];
+  __shared__ int unknown_cnt;
+  __shared__ float thr_s;
+  const int b = blockIdx.x, i = threadIdx.x;
+  if (i == 0) unknown_cnt = 0;
+  __syncthreads();
+  float conf = INFINITY;
+  if (i < n) {
+    const int64_t g = (int64_t)b * n + i;
+    const float uu = fmaxf(u_conf[g], 1e-20f);
+    const float gum = -logf(fmaxf(-logf(uu), 1e-20f));
+    conf = logf(fmaxf(sel[g], 1e-20f)) + temperature * gum;
+    conf_s[i] = conf;
+    if (cur_ids[g] == mask_id) atomicAdd(&unknown_cnt, 1);
+  }
+  __syncthreads();
+  const int k = max(1, min(unknown_cnt - 1, mask_len_sched));
+  if (i < n) {
+    int less = 0, eq = 0;
+    for (int j = 0; j < n; ++j) { const float cj = conf_s[j]; less += cj < conf; eq += cj == conf; }
+    if (less <= k && k < less + eq) thr_s = conf;        // sorted[k] (all writers hold the same value)
+  }
+  __syncthreads();
+  if (i < n) {
+    const int64_t g = (int64_t)b * n + i;
+    const bool m = (k < n) && conf < thr_s;
+    const int64_t s = sampled[g];
+    next_cur[g] = m ? mask_id : s;
+    next_ids[g] = m ? mask_id : s + id_offset;
+    if (masking_out) masking_out[g] = m;
+  }
+}
+
+}  // namespace
+
+extern "C" int ug_maskgit_step(const void* logits, int64_t ld, int64_t V, int64_t N, int64_t n, int cfg, float guidance_scale,
+                               const float* u_sample, const float* u_conf, const int64_t* cur_ids, int64_t mask_id,
+                               int64_t id_offset, int64_t mask_len_sched, float temperature, int64_t* sampled, float* sel_ws,
+                               int64_t* next_cur, int64_t* next_ids, uint8_t* masking_out, hipStream_t st) {
+  UG_REQUIRE(logits && u_sample && u_conf && cur_ids && sampled && sel_ws && next_cur && next_ids, "ug_maskgit_step: null argument");
+  UG_REQUIRE(N > 0 && n > 0 && n <= 1024 && V > 0 && ld >= V, "ug_maskgit_step: bad sizes (N=%ld n=%ld V=%ld ld=%ld; n <= 1024)",
+             (long)N, (long)n, (long)V, (long)ld);
+  hipLaunchKernelGGL(maskgit_sample_kernel, dim3((unsigned)(N * n)), dim3(SMP_T), 0, st, (const bf16_t*)logits, ld, (int)V, (int)N,
+                     (int)n, cfg, guidance_scale, u_sample, cur_ids, mask_id, sampled, sel_ws);
+  UG_CHECK_LAUNCH("ug_maskgit_step(sample)");
+  const int threads = (int)((n + 63) / 64 * 64);
+  hipLaunchKernelGGL(maskgit_remask_kernel, dim3((unsigned)N), dim3(threads), n * sizeof(float), st, sel_ws, u_conf, cur_ids, sampled,
+                     mask_id, id_offset, (int)mask_len_sched, temperature, (int)n, next_cur, next_ids, masking_out);
+  UG_CHECK_LAUNCH("ug_maskgit_step(remask)");
+  return UG_OK;
+}

@@ -22,6 +22,7 @@ from typing import Optional
 
 import torch
 
+from unigen_hip import ops
 from unigen_hip.lib import UniGenHipError
 from unigen_hip.modules import HipQwen2ForCausalLM, LazyLogits, _HeadLossFn
 from unigen_hip.qwen2 import Qwen2Dims
@@ -291,27 +292,17 @@ class UniGen(ModelMixin, ConfigMixin):
             seq = torch.cat([prefix, img, suffix], 1)
             out = self(input_ids=input_ids, input_embeddings=seq, attention_mask=attention_mask)
             # only the image positions x codebook columns are ever read (reference slices the dense logits)
-            lg = out[:, -(n + 1):-1, text_vocab_size:-1].float()
-            if cfg:
-                cond, uncond = lg[:bsz], lg[bsz:]
-                lg = guidance_scale * (cond - uncond[:bsz]) + uncond[:bsz]
-            probs = lg.softmax(dim=-1)
-            flat = probs.reshape(-1, lg.size(-1))
-            sampled_ids = torch.multinomial(flat, 1, generator=generator)[:, 0].view(*lg.shape[:-1])
-            unknown = cur_ids == mask_token_id
-            sampled_ids = torch.where(unknown, sampled_ids, cur_ids)
+            lg = out[:, -(n + 1):-1, text_vocab_size:-1]
             ratio = 1.0 * (step + 1) / timesteps
-            mask_ratio = noise_schedule(torch.tensor(ratio))
-            sel = torch.gather(probs, -1, sampled_ids.long()[..., None]).squeeze(-1)
-            sel = torch.where(unknown, sel, torch.finfo(sel.dtype).max)
-            mask_len = (n * mask_ratio).floor().unsqueeze(0).to(lg.device)
-            mask_len = torch.max(torch.tensor([1], device=lg.device),
-                                 torch.min(unknown.sum(dim=-1, keepdim=True) - 1, mask_len))
+            mask_len = int(torch.floor(n * noise_schedule(torch.tensor(ratio))).item())
             temperature = temperature * (1.0 - ratio)
-            masking = mask_by_random_topk(mask_len, sel, temperature, generator=generator)
-            next_ids = torch.where(masking, mask_token_id, sampled_ids + text_vocab_size)
+            # one fused step on the device: CFG mix, softmax, categorical draw (inverse CDF on uniforms from `generator`),
+            # confidence + Gumbel noise, re-masking of the max(1, min(#unknown - 1, mask_len)) least confident positions
+            u_dev = lg.device if generator is None else generator.device
+            u = torch.rand((2, bsz, n), device=u_dev, generator=generator).to(lg.device)
+            sampled_ids, cur_ids, next_ids = ops.maskgit_step(lg.contiguous(), bsz, n, cfg, guidance_scale, u[0], u[1], cur_ids,
+                                                              mask_token_id, text_vocab_size, mask_len, temperature)
             image_embeddings = embed(next_ids)
-            cur_ids = torch.where(masking, mask_token_id, sampled_ids)
         return sampled_ids
 
     # ------------------------------------------------------------------ autoregressive generation

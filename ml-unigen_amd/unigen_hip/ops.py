@@ -380,6 +380,28 @@ def attn_decode_fused(acc_qkv, ss_in, eps, norm_cols, bias, cos, sin, pos_dev, c
     return out
 
 
+# ------------------------------------------------------------------------------------ MaskGIT sampler
+def maskgit_step(logits, N, n, cfg, guidance_scale, u_sample, u_conf, cur_ids, mask_id, id_offset, mask_len_sched, temperature,
+                 want_masking=False):
+    """One parallel-decoding round on bf16 code-book logits [(2 if cfg else 1)*N*n, V(+pad)] -> (sampled, next_cur,
+    next_ids[, masking]) int64 [N, n]; see include/unigen_hip.h."""
+    V = logits.shape[-1]
+    logits = logits.reshape(-1, V)
+    if logits.dtype != torch.bfloat16 or logits.stride(1) != 1:
+        raise _l.UniGenHipError("maskgit_step: logits must be bf16 with contiguous rows")
+    dev = logits.device
+    sampled = torch.empty((N, n), dtype=torch.int64, device=dev)
+    next_cur, next_ids = torch.empty_like(sampled), torch.empty_like(sampled)
+    sel = torch.empty((N, n), dtype=torch.float32, device=dev)
+    masking = torch.empty((N, n), dtype=torch.uint8, device=dev) if want_masking else None
+    cur_ids = cur_ids.to(torch.int64).contiguous()
+    _l.check(_l.load().ug_maskgit_step(_p(logits), logits.stride(0), V, N, n, int(bool(cfg)), float(guidance_scale),
+                                       _p(u_sample.contiguous()), _p(u_conf.contiguous()), _p(cur_ids), int(mask_id),
+                                       int(id_offset), int(mask_len_sched), float(temperature), _p(sampled), _p(sel), _p(next_cur),
+                                       _p(next_ids), _p(masking), _stream()), "ug_maskgit_step")
+    return (sampled, next_cur, next_ids, masking.bool()) if want_masking else (sampled, next_cur, next_ids)
+
+
 # ------------------------------------------------------------------------------------ loss
 def ce_fwd(logits, V, labels, ignore_index=-100, want_logp=False):
     """logits bf16 [R, ld>=V]; -> (loss_and_count [2], lse [R], loss_row [R], logp|None)"""

@@ -255,3 +255,87 @@ def ar_generate_ref(lm, cond_embeds, uncond_embeds, n_tokens, guidance_scale, te
             pos = total
             x = lm.model.embed_tokens(torch.cat([nxt, nxt]) + text_vocab)
     return torch.cat(toks, 1), torch.stack(margins, 1)
+
+
+# ------------------------------------------------------------------ MaskGIT parallel decoding
+class TorchSampler:
+    """The reference's randomness: torch.multinomial + uniform_()-based Gumbel noise on one generator
+    (models/unigen.py:418-420, models/sampling.py:24-26,41-46).  Used to pin maskgit_generate_ref to the real
+    reference's trajectory (tests/golden/g2_tiny_unigen.pt['maskgit'])."""
+
+    def __init__(self, generator=None):
+        self.generator = generator
+
+    def sample(self, probs_flat):
+        return torch.multinomial(probs_flat, 1, generator=self.generator)[:, 0]
+
+    def gumbel(self, like):
+        u = torch.zeros_like(like).uniform_(0, 1, generator=self.generator)
+        return -torch.log((-torch.log(u.clamp(min=1e-20))).clamp(min=1e-20))
+
+
+class InverseCdfSampler:
+    """The product kernel's sampling rule (ug_maskgit_step): token = first index whose running sum of
+    UNNORMALISED exp(logit - max) exceeds u * total, Gumbel noise = -log(-log(u2)), both from supplied uniforms
+    u_sample[step] / u_conf[step] of shape [N, n]."""
+
+    def __init__(self, u_sample, u_conf):
+        self.u_sample, self.u_conf, self.step = u_sample, u_conf, 0
+
+    def sample(self, probs_flat):
+        u = self.u_sample[self.step].reshape(-1, 1).to(probs_flat.dtype)
+        cdf = probs_flat.cumsum(-1)
+        idx = (cdf <= u * cdf[:, -1:]).sum(-1)
+        return idx.clamp(max=probs_flat.shape[-1] - 1)
+
+    def gumbel(self, like):
+        u = self.u_conf[self.step].to(like.dtype).reshape(like.shape)
+        self.step += 1
+        return -torch.log((-torch.log(u.clamp(min=1e-20))).clamp(min=1e-20))
+
+
+def maskgit_generate_ref(lm, input_ids, uncond_input_ids, attention_mask, guidance_scale, temperature, timesteps,
+                         schedule, n, text_vocab, mask_token_id, sampler, autocast=False, trace=None):
+    """UniGen.t2i_generate (models/unigen.py:344-455): T rounds of {full forward on [cond; uncond], CFG on the
+    code-book slice of the image positions, sample every position, keep known tokens, re-mask the
+    max(1, min(#unknown - 1, floor(n * schedule((step+1)/T)))) least confident ones with Gumbel noise whose
+    temperature is COMPOUNDED (temperature *= 1 - ratio)}; returns the last round's sampled ids."""
+    embed = lm.model.embed_tokens
+    cur_ids = input_ids[:, -(n + 1):-1].clone()
+    emb = embed(input_ids)
+    image_emb = emb[:, -(n + 1):-1]
+    bsz = emb.shape[0]
+    prefix, suffix = emb[:, :-(n + 1)], emb[:, -1:]
+    cfg = guidance_scale > 1
+    if cfg:
+        prefix = torch.cat([prefix, embed(uncond_input_ids[:, :-(n + 1)])])
+        suffix = torch.cat([suffix, suffix])
+    sampled = None
+    with torch.no_grad():
+        for step in range(timesteps):
+            img = torch.cat([image_emb, image_emb]) if cfg else image_emb
+            seq = torch.cat([prefix, img, suffix], 1)
+            with autocast_ctx(autocast):
+                logits = lm(None, seq, attention_mask)
+            lg = logits.float()[:, -(n + 1):-1, text_vocab:-1]
+            if cfg:
+                cond, uncond = lg[:bsz], lg[bsz:]
+                lg = guidance_scale * (cond - uncond) + uncond
+            probs = lg.softmax(-1)
+            sampled = sampler.sample(probs.reshape(-1, probs.shape[-1])).view(bsz, n)
+            unknown = cur_ids == mask_token_id
+            sampled = torch.where(unknown, sampled, cur_ids)
+            ratio = (step + 1) / timesteps
+            sel = probs.gather(-1, sampled[..., None]).squeeze(-1)
+            sel = torch.where(unknown, sel, torch.finfo(sel.dtype).max)
+            mask_len = (n * schedule(torch.tensor(ratio))).floor().reshape(1, 1)
+            mask_len = torch.max(torch.tensor([1]), torch.min(unknown.sum(-1, keepdim=True) - 1, mask_len))
+            temperature = temperature * (1.0 - ratio)
+            conf = torch.log(sel.clamp(min=1e-20)) + temperature * sampler.gumbel(sel)
+            thr = torch.gather(torch.sort(conf, -1).values, 1, mask_len.long())
+            masking = conf < thr
+            if trace is not None:
+                trace.append(dict(mixed=lg, sampled=sampled.clone(), masking=masking.clone(), conf=conf))
+            image_emb = embed(torch.where(masking, mask_token_id, sampled + text_vocab))
+            cur_ids = torch.where(masking, mask_token_id, sampled)
+    return sampled

@@ -560,3 +560,45 @@ def test_decode_consumer_side_finishing_matches_separate_kernels(dev, R):
         assert _rel(x, xr3) < 1e-2
         for t in (acc_qkv, acc_o, acc_down, ss_attn):
             assert float(t.abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,n,V,cfg", [(3, 256, 8192, True), (2, 16, 20, True), (4, 64, 1000, False)])
+def test_maskgit_step_kernel_matches_restatement(dev, N, n, V, cfg):
+    """ug_maskgit_step against a float64 restatement of its rule (CFG mix, inverse-CDF draw from supplied uniforms,
+    confidence + Gumbel, re-mask the k least confident); draws whose target lies within rounding distance of a CDF
+    step are excluded from the exact comparison."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(N * 1000 + n)
+    rows = (2 if cfg else 1) * N * n
+    logits = (2.0 * torch.randn(rows, V, generator=g)).to(torch.bfloat16)
+    u1, u2 = torch.rand(N, n, generator=g), torch.rand(N, n, generator=g)
+    mask_id, off, scale, temp, sched = V + 7, 300, 3.0, 0.6, n // 3
+    cur = torch.full((N, n), mask_id, dtype=torch.int64)
+    known = torch.rand(N, n, generator=g) < 0.3
+    cur[known] = torch.randint(0, V, (int(known.sum()),), generator=g)
+    s, nc, ni, mk = ops.maskgit_step(logits.to(dev), N, n, cfg, scale, u1.to(dev), u2.to(dev), cur.to(dev), mask_id, off, sched,
+                                     temp, want_masking=True)
+    s, nc, ni, mk = s.cpu(), nc.cpu(), ni.cpu(), mk.cpu()
+    lf = logits.float()
+    mixed = (scale * (lf[:N * n] - lf[N * n:]) + lf[N * n:]) if cfg else lf
+    ex = torch.exp((mixed - mixed.max(-1, keepdim=True).values).double())
+    cdf = ex.cumsum(-1)
+    target = u1.reshape(-1, 1).double() * cdf[:, -1:]
+    want = (cdf <= target).sum(-1).clamp(max=V - 1).view(N, n)
+    gap = ((cdf - target).abs().min(-1).values / cdf[:, -1]).view(N, n)
+    sure = (gap > 1e-4) & ~known
+    assert sure.float().mean() > 0.5
+    assert torch.equal(s[sure], want[sure]) and torch.equal(s[known], cur[known])
+    # confidence / re-masking, teacher-forced on the kernel's own draws
+    p = (ex / cdf[:, -1:]).view(N, n, V).gather(-1, s[..., None]).squeeze(-1)
+    p = torch.where(known, torch.full_like(p, 3.4e38), p)
+    conf = torch.log(p.clamp(min=1e-20)) + temp * -torch.log((-torch.log(u2.double().clamp(min=1e-20))).clamp(min=1e-20))
+    k = torch.clamp(torch.minimum((~known).sum(-1, keepdim=True) - 1, torch.tensor(sched)), min=1)
+    srt = conf.sort(-1).values
+    thr = srt.gather(1, k)
+    want_mask = conf < thr
+    margin = (conf - thr).abs() > 1e-4
+    assert torch.equal(mk[margin], want_mask[margin])
+    assert torch.equal(nc, torch.where(mk, torch.tensor(mask_id), s)) and torch.equal(ni, torch.where(mk, torch.tensor(mask_id), s + off))
+    assert int(mk.sum(-1).min()) >= 1 and not bool((mk & known).any())

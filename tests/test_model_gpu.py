@@ -195,3 +195,39 @@ def test_ar_generation_kv_cache_matches_oracle(dev):
                 assert got[b, i].item() == want[b, i].item(), (use_graph, fused, b, i, got[b], want[b])
                 compared += 1
         assert compared >= 8, compared
+
+
+def test_maskgit_generation_first_round_matches_oracle(dev):
+    """UniGen.t2i_generate (fused sampler step) vs oracle.maskgit_generate_ref fed the same uniforms: one round must
+    agree wherever the oracle's draw is not within bf16 noise of a CDF step; a full 4-round run keeps the contract
+    (every position decoded, ids inside the code book)."""
+    import math
+    from oracle import qwen2_ref
+    g = golden("g2_tiny_unigen.pt")
+    model, _ = _tiny_unigen(g, dev)
+    model.eval()
+    lm, _ = oracle_lm(g["cfg"], g["weight_seed"])
+    m, ids = g["maskgit"], g["ids"]
+    n, N = 16, m["input_ids"].shape[0]
+    sched = lambda t: torch.cos(t * math.pi * 0.5)
+    am = additive(m["mask_allow"])
+    gen = torch.Generator(device=dev).manual_seed(77)
+    state = gen.get_state()
+    u = torch.rand((2, N, n), device=dev, generator=gen).cpu()
+    gen.set_state(state)
+    got = model.t2i_generate(input_ids=m["input_ids"].to(dev), uncond_input_ids=m["uncond_ids"].to(dev), attention_mask=am.to(dev),
+                             guidance_scale=m["scale"], temperature=1.0, timesteps=1, noise_schedule=sched, generator=gen,
+                             image_token_num_per_image=n, text_vocab_size=ids["text_vocab"]).cpu()
+    trace = []
+    want = qwen2_ref.maskgit_generate_ref(lm, m["input_ids"], m["uncond_ids"], am, m["scale"], 1.0, 1, sched, n, ids["text_vocab"],
+                                          ids["mask"], qwen2_ref.InverseCdfSampler(u[0:1], u[1:2]), autocast=True, trace=trace)
+    probs = trace[0]["mixed"].softmax(-1)
+    cdf = probs.cumsum(-1)
+    gap = (cdf - u[0].reshape(N, n, 1)).abs().min(-1).values
+    sure = gap > 0.004
+    assert sure.float().mean() > 0.6 and torch.equal(got[sure], want[sure])
+    full = model.t2i_generate(input_ids=m["input_ids"].to(dev), uncond_input_ids=m["uncond_ids"].to(dev), attention_mask=am.to(dev),
+                              guidance_scale=m["scale"], temperature=1.0, timesteps=4, noise_schedule=sched,
+                              generator=torch.Generator().manual_seed(3), image_token_num_per_image=n,
+                              text_vocab_size=ids["text_vocab"]).cpu()
+    assert full.shape == (N, n) and int(full.min()) >= 0 and int(full.max()) < 20

@@ -69,3 +69,18 @@ def test_magvit_oracle_vs_reference():
     assert torch.equal(bits[safe], bits_ref[safe])
     assert (idx != g["indices"][:1]).float().mean().item() <= (~safe).float().mean().item() * 13 + 1e-9
     assert torch.equal(lfq_indices_ref(g["z"]), g["indices"])
+
+
+def test_maskgit_oracle_reproduces_reference_trajectory():
+    """oracle.maskgit_generate_ref with the reference's own randomness (torch.multinomial + uniform_ Gumbel on one
+    CPU generator) returns exactly what the real UniGen.t2i_generate returned when the fixture was made."""
+    import math
+    from oracle import qwen2_ref
+    g = golden("g2_tiny_unigen.pt")
+    lm, _ = oracle_lm(g["cfg"], g["weight_seed"])
+    m = g["maskgit"]
+    mask = additive(m["mask_allow"])
+    out = qwen2_ref.maskgit_generate_ref(lm, m["input_ids"], m["uncond_ids"], mask, m["scale"], 1.0, m["steps"],
+                                         lambda t: torch.cos(t * math.pi * 0.5), 16, g["ids"]["text_vocab"], g["ids"]["mask"],
+                                         qwen2_ref.TorchSampler(torch.Generator().manual_seed(m["seed"])))
+    assert torch.equal(out, m["result"])
