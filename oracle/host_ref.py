@@ -93,3 +93,26 @@ def t2i_layout_ref(text_ids, image_ids, labels, max_seq_len, pad_id, soi_id, eoi
         lab = torch.where(lab == pad_id, ignore_id, lab)
         seqs.append(ids); masks.append(torch.tensor(m)); labs.append(lab)
     return torch.stack(seqs), torch.stack(masks), torch.stack(labs)
+
+
+def batch_logps_ref(logits, labels, num_vq_tokens, average_log_prob=False, label_pad_token_id=-100, t2i_gen_mode="mask"):
+    """get_batch_logps (training/train_dpo.py:51-90): log-softmax over V at the image positions [-(n+1):-1], gather the
+    label's log-prob, sum (or mean) over positions whose label is not the pad id; 'ar' mode shifts by one."""
+    n = num_vq_tokens
+    lg = logits[:, -(n + 1):-1]
+    lb = labels[:, -(n + 1):-1].clone()
+    keep = lb != label_pad_token_id
+    lb[~keep] = 0
+    if t2i_gen_mode == "ar":
+        per = torch.gather(lg[:, :-1].log_softmax(-1), 2, lb[:, 1:].unsqueeze(2)).squeeze(2)
+        keep = keep[:, 1:]
+    else:
+        per = torch.gather(lg.log_softmax(-1), 2, lb.unsqueeze(2)).squeeze(2)
+    tot = (per * keep).sum(-1)
+    return tot / keep.sum(-1) if average_log_prob else tot
+
+
+def dpo_loss_ref(policy_chosen, policy_rejected, ref_chosen, ref_rejected, beta, coef=1.0):
+    """training/train_dpo.py:640-647: coef * mean(-logsigmoid(beta * ((pi_c - pi_r) - (ref_c - ref_r))))."""
+    import torch.nn.functional as F
+    return coef * (-F.logsigmoid(beta * ((policy_chosen - policy_rejected) - (ref_chosen - ref_rejected)))).mean()

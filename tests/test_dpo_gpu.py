@@ -12,13 +12,10 @@ pytestmark = pytest.mark.gpu
 
 
 def batch_logps(logits, labels, n):
-    """get_batch_logps, 'mask' mode (train_dpo.py:74-90)."""
-    logits = logits[:, -(n + 1):-1]
-    labels = labels[:, -(n + 1):-1].clone()
-    m = labels != -100
-    labels[labels == -100] = 0
-    per_tok = torch.gather(logits.log_softmax(-1), dim=2, index=labels.unsqueeze(2)).squeeze(2)
-    return (per_tok * m).sum(-1)
+    """get_batch_logps, 'mask' mode (train_dpo.py:74-90): the oracle's restatement, pinned bit-exactly to the real
+    function by tests/golden/g8_dpo_logps.pt (tests/test_oracle_golden.py)."""
+    from oracle import host_ref
+    return host_ref.batch_logps_ref(logits, labels, n)
 
 
 def test_dpo_loss_and_grads_match_oracle(dev):

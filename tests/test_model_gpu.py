@@ -231,3 +231,75 @@ def test_maskgit_generation_first_round_matches_oracle(dev):
                               generator=torch.Generator().manual_seed(3), image_token_num_per_image=n,
                               text_vocab_size=ids["text_vocab"]).cpu()
     assert full.shape == (N, n) and int(full.min()) >= 0 and int(full.max()) < 20
+
+
+def test_wide_layer_matches_reference_golden(dev):
+    """G3: the real reference's forward + backward through one decoder layer of the 1.5B model's width at L = 387
+    (left padding, MaskGIT labels) vs the HIP path: loss, image-position logits, every parameter's gradient."""
+    from models import UniGen
+    from oracle import weights
+    g = golden("g3_wide_layer.pt")
+    cfg, ids = g["cfg"], g["ids"]
+    m = UniGen(w_und_encoder=False, vocab_size=cfg["vocab_size"], llm_vocab_size=ids["text_vocab"], llm_model_path=llm_config_dir(cfg),
+               codebook_size=g["codebook"], num_vq_tokens=256, load_from_pretrained=True, device=dev, init_seed=1)
+    names = [(n, tuple(p.shape)) for n, p in m.llm.named_parameters()]
+    m.llm.load_state_dict(weights.synth_llm_state(names, seed=g["weight_seed"]), strict=False)
+    m.train()
+    logits, l1, _, _ = m(input_ids=g["input_ids"].to(dev), attention_mask=additive(g["mask_allow"]).to(dev), labels=g["labels"].to(dev),
+                         **g["kw"])
+    assert abs(l1.item() - g["loss"].item()) < 1e-3 * g["loss"].item(), (l1.item(), g["loss"].item())
+    got = logits[:, -257:-1, :].float().cpu()[:, ::8]
+    assert _rel(got, g["logits_rows"]) < 1e-2
+    l1.backward()
+    params = dict(m.llm.named_parameters())
+    for n, v in g["grad_norms"].items():
+        gn = params[n].grad.norm().item()
+        assert abs(gn - v) <= 2e-2 * max(v, 1e-8), (n, gn, v)
+    assert _rel(params["model.layers.0.self_attn.o_proj.weight"].grad[:2], g["grad_o_rows"]) < 3e-2
+    assert _rel(params["model.layers.0.mlp.gate_proj.weight"].grad[:2], g["grad_gate_rows"]) < 3e-2
+
+
+def test_loss_curve_20_steps_matches_oracle(dev):
+    """SURVEY.md section 8d parity gate: the same 20 optimizer steps (fresh synthetic t2i batch each step, fused AdamW vs
+    torch.optim.AdamW on the CPU oracle, bf16 autocast) give the same loss curve within 1e-3 relative."""
+    from oracle import host_ref, qwen2_ref
+    from unigen_hip.optim import FusedAdamW
+    g = golden("g2_tiny_unigen.pt")
+    model, _ = _tiny_unigen(g, dev)
+    model.train()
+    lm, _ = oracle_lm(g["cfg"], g["weight_seed"])
+    ids = g["ids"]
+    B, L, n = 4, 40, 16
+    gen = torch.Generator().manual_seed(123)
+
+    def groups(named):
+        named = list(named)
+        return [{"params": [p for k, p in named if "bias" not in k], "weight_decay": 0.01},
+                {"params": [p for k, p in named if "bias" in k], "weight_decay": 0.0}]
+    opt = FusedAdamW(groups(model.named_parameters()), lr=3e-4, betas=(0.9, 0.999), eps=1e-8)
+    opt_ref = torch.optim.AdamW(groups(lm.named_parameters()), lr=3e-4, betas=(0.9, 0.999), eps=1e-8)
+    got, want = [], []
+    for step in range(20):
+        seq = torch.randint(0, 290, (B, L), generator=gen)
+        seq[:, -(n + 2)] = ids["soi"]; seq[:, -1] = ids["eoi"]
+        seq[0, :step % 7] = ids["pad"]
+        img = torch.randint(312, 332, (B, n), generator=gen)
+        msk = torch.rand(B, n, generator=gen) < 0.6
+        msk[:, 0] = True
+        seq[:, -(n + 1):-1] = torch.where(msk, ids["mask"], img)
+        labels = torch.full((B, L), -100)
+        labels[:, -(n + 1):-1] = torch.where(msk, img, -100)
+        mask = additive(host_ref.mask_predict_next_ref(seq, ids["pad"], ids["soi"], ids["eoi"], rm_pad_in_image=True))
+        _, r1, _, _ = qwen2_ref.unigen_forward_ref(lm, seq, mask, labels, autocast=True, batch_size_t2i=B, num_vq_tokens=n)
+        opt_ref.zero_grad(set_to_none=True)
+        r1.backward()
+        opt_ref.step()
+        _, l1, _, _ = model(input_ids=seq.to(dev), attention_mask=mask.to(dev), labels=labels.to(dev), batch_size_t2i=B,
+                            max_seq_length=L - n - 3, num_vq_tokens=n)
+        opt.zero_grad(set_to_none=True)
+        l1.backward()
+        opt.step()
+        got.append(l1.item()); want.append(r1.item())
+    got, want = torch.tensor(got), torch.tensor(want)
+    assert ((got - want).abs() / want).max().item() < 1e-3, (got, want)
+    assert want[-5:].mean() < want[:5].mean()          # and it is actually training

@@ -84,3 +84,26 @@ def test_maskgit_oracle_reproduces_reference_trajectory():
                                          lambda t: torch.cos(t * math.pi * 0.5), 16, g["ids"]["text_vocab"], g["ids"]["mask"],
                                          qwen2_ref.TorchSampler(torch.Generator().manual_seed(m["seed"])))
     assert torch.equal(out, m["result"])
+
+
+def test_dpo_logps_oracle_matches_reference():
+    from oracle import host_ref
+    g = golden("g8_dpo_logps.pt")
+    for mode in ("mask", "ar"):
+        for avg in (False, True):
+            got = host_ref.batch_logps_ref(g["logits"], g["labels"], g["n"], average_log_prob=avg, t2i_gen_mode=mode)
+            assert torch.equal(got, g[f"{mode}_{int(avg)}"]), (mode, avg)
+
+
+def test_wide_layer_oracle_bit_exact_vs_reference():
+    """One decoder layer at the 1.5B model's width (1536 / 8960 / 12:2 heads) on the pt1 sequence shape L = 387."""
+    from oracle import qwen2_ref
+    g = golden("g3_wide_layer.pt")
+    lm, _ = oracle_lm(g["cfg"], g["weight_seed"])
+    logits, l1, _, _ = qwen2_ref.unigen_forward_ref(lm, g["input_ids"], additive(g["mask_allow"], torch.float32), g["labels"],
+                                                    autocast=True, batch_size_t2i=2, num_vq_tokens=256)
+    assert torch.equal(l1, g["loss"])
+    assert torch.equal(logits[:, -257:-1:8].to(torch.bfloat16), g["logits_rows"])
+    l1.backward()
+    for n, p in lm.named_parameters():
+        assert abs(p.grad.norm().item() - g["grad_norms"][n]) <= 1e-6 * max(1.0, g["grad_norms"][n]), n

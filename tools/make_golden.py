@@ -335,3 +335,85 @@ def golden_siglip():
 
 if __name__ == "__main__" and "siglip" in sys.argv[1:]:
     golden_siglip()
+
+
+# ------------------------------------------------------------------ G8: DPO log-probs (training/train_dpo.py:51-90)
+def golden_dpo():
+    mod = ref_shims.import_with_stubs("training.train_dpo")
+    g = torch.Generator().manual_seed(8)
+    B, L, V, n = 4, 24, 50, 16
+    logits = 3.0 * torch.randn(B, L, V, generator=g)
+    labels = torch.randint(0, V, (B, L), generator=g)
+    labels[torch.rand(B, L, generator=g) < 0.4] = -100
+    labels[:, -(n + 1)] = 7                      # at least one kept position per row
+    out = {"logits": logits, "labels": labels, "n": n}
+    for mode in ("mask", "ar"):
+        for avg in (False, True):
+            want = mod.get_batch_logps(logits, labels, average_log_prob=avg, num_vq_tokens=n, t2i_gen_mode=mode)
+            mine = host_ref.batch_logps_ref(logits, labels, n, average_log_prob=avg, t2i_gen_mode=mode)
+            assert torch.equal(want, mine), (mode, avg)
+            out[f"{mode}_{int(avg)}"] = want
+    torch.save(out, os.path.join(OUT, "g8_dpo_logps.pt"))
+    print("G8 DPO log-probs: captured (oracle bit-identical)")
+
+
+# ------------------------------------------------------------------ G3: one Qwen2.5-1.5B-width decoder layer at L = 387
+WIDE = dict(hidden_size=1536, intermediate_size=8960, num_hidden_layers=1, num_attention_heads=12, num_key_value_heads=2,
+            rope_theta=1e6, rms_norm_eps=1e-6)
+
+
+def golden_wide():
+    """The real reference UniGen (transformers Qwen2 under it) with ONE decoder layer of the 1.5B model's width on the
+    pt1 sequence shape (128 text + 256 image + 3 = 387, left padding), bf16 autocast, forward + backward."""
+    import math
+    from models import UniGen
+    from training.prompting_utils import UniversalPromptingQwen2, create_attention_mask_predict_next
+    tok = FakeTok()
+    NVQ, CODEBOOK, MAXTXT = 256, 64, 128
+    up = UniversalPromptingQwen2(tok, max_seq_len=MAXTXT + NVQ + 3, cond_dropout_prob=0.0, ignore_id=-100)
+    V = len(tok) + CODEBOOK + 1
+    mask_id = V - 1
+    cfg = qwen2_ref.Qwen2Cfg(vocab_size=V, **WIDE)
+    d = ref_shims.write_llm_config_dir(cfg.to_hf_dict())
+    torch.manual_seed(0)
+    model = UniGen(w_und_encoder=False, vocab_size=V, llm_vocab_size=len(tok), llm_model_path=d, codebook_size=CODEBOOK,
+                   num_vq_tokens=NVQ, load_from_pretrained=True)
+    model.train()
+    names = [(n, tuple(p.shape)) for n, p in model.llm.named_parameters()]
+    sd = weights.synth_llm_state(names, seed=33)
+    model.llm.load_state_dict(sd, strict=False)
+    g = torch.Generator().manual_seed(5)
+    img = torch.randint(0, CODEBOOK, (2, NVQ), generator=g) + len(tok)
+    ts, sc = torch.tensor([0.15, 0.8]), torch.rand(2, NVQ, generator=g)
+    in_img, lab_img, _ = host_ref.maskgit_train_mask_ref(img, mask_id, ts, sc, lambda x: torch.cos(x * math.pi * 0.5))
+    texts = ["".join(chr(97 + v) for v in torch.randint(0, 26, (k,), generator=g).tolist()) for k in (37, 101)]
+    ids, _, labels = up((list(texts), in_img, lab_img), 't2i')
+    PAD, SOI, EOI = int(up.sptids_dict['<|pad|>']), int(up.sptids_dict['<|soi|>']), int(up.sptids_dict['<|eoi|>'])
+    mask = create_attention_mask_predict_next(ids, pad_id=PAD, soi_id=SOI, eoi_id=EOI, rm_pad_in_image=True).to(torch.float32)
+    assert ids.shape == (2, 387)
+    kw = dict(batch_size_t2i=2, batch_size_lm=0, batch_size_mmu=0, max_seq_length=MAXTXT, num_vq_tokens=NVQ)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        logits, l1, _, _ = model(input_ids=ids, attention_mask=mask, labels=labels, **kw)
+    l1.float().backward()
+    grads = {n: p.grad.detach().clone() for n, p in model.llm.named_parameters()}
+    lm_ref = qwen2_ref.RefCausalLM(cfg)
+    lm_ref.load_state_dict(sd, strict=False)
+    lo, r1, _, _ = qwen2_ref.unigen_forward_ref(lm_ref, ids, mask, labels, autocast=True, batch_size_t2i=2, num_vq_tokens=NVQ)
+    r1.backward()
+    gd = max(maxdiff(grads[n], p.grad) for n, p in lm_ref.named_parameters())
+    print(f"G3 oracle vs reference: logits {maxdiff(lo, logits):.3e} loss {abs(r1.item() - l1.item()):.2e} grads {gd:.3e}")
+    assert maxdiff(lo, logits) == 0 and gd == 0, "oracle is not bit-identical to the reference on CPU"
+    out = {"cfg": dict(WIDE, vocab_size=V), "weight_seed": 33, "input_ids": ids, "labels": labels, "mask_allow": (mask[:, 0] == 0),
+           "kw": kw, "ids": dict(pad=PAD, soi=SOI, eoi=EOI, mask=mask_id, text_vocab=len(tok)), "codebook": CODEBOOK,
+           "loss": l1.detach().float(), "logits_rows": logits.detach()[:, -(NVQ + 1):-1:8].to(torch.bfloat16),
+           "grad_norms": {n: gg.norm().item() for n, gg in grads.items()},
+           "grad_o_rows": grads["model.layers.0.self_attn.o_proj.weight"][:2].clone(),
+           "grad_gate_rows": grads["model.layers.0.mlp.gate_proj.weight"][:2].clone()}
+    torch.save(out, os.path.join(OUT, "g3_wide_layer.pt"))
+    print("G3 wide layer: captured")
+
+
+if __name__ == "__main__" and "dpo" in sys.argv[1:]:
+    golden_dpo()
+if __name__ == "__main__" and "wide" in sys.argv[1:]:
+    golden_wide()

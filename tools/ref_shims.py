@@ -111,3 +111,63 @@ def write_llm_config_dir(cfg_dict):
     with open(os.path.join(d, "config.json"), "w") as f:
         json.dump(cfg_dict, f)
     return d
+
+
+class _Anything:
+    """Attribute sink for modules the reference imports at file scope but the captured function never touches."""
+
+    def __init__(self, *a, **k):
+        pass
+
+    def __call__(self, *a, **k):
+        return _Anything()
+
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return _Anything()
+
+    def __iter__(self):
+        return iter(())
+
+    def __mro_entries__(self, bases):
+        return (object,)
+
+
+class _StubModule(types.ModuleType):
+    __path__ = []
+
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        return _Anything()
+
+
+def import_with_stubs(module_name, max_stubs=40):
+    """Import a reference module whose file-scope imports need packages this container lacks (wandb, omegaconf, ...):
+    every missing top-level package is replaced by a names-only stub and the import retried.  Only used to reach plain
+    functions (e.g. training/train_dpo.py:get_batch_logps) whose own body needs none of them."""
+    import importlib
+    for _ in range(max_stubs):
+        try:
+            return importlib.import_module(module_name)
+        except ModuleNotFoundError as e:
+            missing = e.name
+            if missing is None or missing.split(".")[0] in ("training", "models"):
+                raise
+            parts = missing.split(".")
+            import importlib.machinery
+            for i in range(1, len(parts) + 1):
+                nm = ".".join(parts[:i])
+                if nm not in sys.modules:
+                    st = _StubModule(nm)
+                    st.__spec__ = importlib.machinery.ModuleSpec(nm, None)
+                    sys.modules[nm] = st
+        except ImportError as e:          # a names-only shim installed earlier lacks this name: add it
+            import re
+            m = re.match(r"cannot import name '(\w+)' from '([\w.]+)'", str(e))
+            if m and m.group(2) in sys.modules:
+                setattr(sys.modules[m.group(2)], m.group(1), _Anything())
+            else:
+                raise
+    raise RuntimeError(f"too many missing modules importing {module_name}")
