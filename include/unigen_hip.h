@@ -174,6 +174,19 @@ int ug_attn_decode_fused(const float* acc_qkv, int64_t ldacc, const float* ss_in
 int ug_skinny_finish(const float* acc, const void* bias, void* out_bf16, float* resid, int64_t M, int64_t N,
                      int mode, hipStream_t stream);
 
+/* ---- device-side prompt / mask assembly --------------------------------- */
+/* replaces the per-sample Python loops of UniversalPromptingQwen2.t2i_prompt (training/prompting_utils.py:59-111, prompt
+ * dropout excluded) and the dense [B,1,L,L] masks of create_attention_mask_predict_next / _for_mmu (:975-1036): the
+ * compressed mask is built straight from the token ids.  text_ids: all prompts back to back, text_offsets [B+1].
+ * mode: 0 = predict_next with rm_pad_in_image (t2i), 1 = predict_next (lm), 2 = mmu (eoi of the first match in the batch).
+ * meta_ws: int32 [4*B], flags_ws: bytes [B*L]. */
+int ug_t2i_assemble(const int64_t* text_ids, const int64_t* text_offsets, const int64_t* conv_start, int64_t n_start,
+                    const int64_t* conv_end, int64_t n_end, const int64_t* image_in, const int64_t* image_labels, int64_t B,
+                    int64_t n_image, int64_t max_seq_len, int64_t pad_id, int64_t soi_id, int64_t eoi_id, int64_t ignore_id,
+                    int64_t* input_ids, int64_t* labels, uint8_t* attn01, hipStream_t stream);
+int ug_attn_mask_from_ids(const int64_t* ids, int64_t B, int64_t L, int64_t pad_id, int64_t soi_id, int64_t eoi_id, int mode,
+                          int* meta_ws, uint8_t* flags_ws, uint64_t* bits, uint8_t* tileany, hipStream_t stream);
+
 /* ---- MaskGIT parallel decoding step ------------------------------------------------------------ */
 /* replaces, per round of UniGen.t2i_generate (models/unigen.py:404-451): the CFG mix of the code-book logits, softmax,
  * torch.multinomial, the gather of the drawn token's probability and models/sampling.py:41-46 mask_by_random_topk.

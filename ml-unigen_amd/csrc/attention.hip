@@ -74,6 +74,65 @@ __global__ __launch_bounds__(256) void mask_causal_kernel(uint64_t* __restrict__
   if (lane == 0) bits[wid] = word;
 }
 
+// ---- masks straight from token ids (no dense [B,1,L,L] tensor on the way) ----------------------------------------
+// Reference builders (training/prompting_utils.py:975-1036; verified semantics in SURVEY.md section 8a):
+//   mode 0  create_attention_mask_predict_next(rm_pad_in_image=True)  (t2i rows)
+//   mode 1  create_attention_mask_predict_next()                      (lm rows)
+//   mode 2  create_attention_mask_for_mmu                             (eoi position of the FIRST match in the batch)
+// meta[b] = {last_pad, soi_pos, first_eoi_of_batch(+1, 0 = none), unused}; flags[b][t]: bit0 = pad, bit1 = inside <soi>..<eoi>
+__global__ __launch_bounds__(64) void mask_ids_meta_kernel(const int64_t* __restrict__ ids, int L, int64_t pad_id, int64_t soi_id,
+                                                           int64_t eoi_id, int* __restrict__ meta, uint8_t* __restrict__ flags) {
+  const int b = blockIdx.x;
+  if (threadIdx.x != 0) return;                      // L is a few hundred tokens: one serial walk per row
+  const int64_t* row = ids + (int64_t)b * L;
+  int starts = 0, ends = 0, last_pad = -1, soi_pos = -1, eoi_first = -1;
+  for (int t = 0; t < L; ++t) {
+    const int64_t v = row[t];
+    const bool st = v == soi_id, en = v == eoi_id, pd = v == pad_id;
+    starts += st;
+    ends += en;
+    const bool in_img = (starts > ends) || st || en;   // inclusive cumsum(start) > cumsum(end), or a delimiter itself
+    flags[(int64_t)b * L + t] = (uint8_t)((pd ? 1 : 0) | (in_img ? 2 : 0));
+    if (pd) last_pad = t;
+    if (st && soi_pos < 0) soi_pos = t;
+    if (en && eoi_first < 0) eoi_first = t;
+  }
+  meta[b * 4 + 0] = last_pad;
+  meta[b * 4 + 1] = soi_pos < 0 ? 0 : soi_pos;        // argmax of an all-zero row is 0
+  meta[b * 4 + 2] = eoi_first;
+}
+
+__global__ __launch_bounds__(256) void mask_ids_kernel(uint64_t* __restrict__ bits, const int* __restrict__ meta,
+                                                       const uint8_t* __restrict__ flags, int B, int L, int nW, int mode) {
+  const int64_t wid = blockIdx.x * 4LL + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int64_t total = (int64_t)B * L * nW;
+  if (wid >= total) return;
+  const int w = (int)(wid % nW);
+  const int row = (int)((wid / nW) % L);
+  const int b = (int)(wid / ((int64_t)nW * L));
+  const int col = w * 64 + lane;
+  bool a = false;
+  if (col < L) {
+    if (mode == 2) {
+      int eoi = -1;
+      for (int bb = 0; bb < B && eoi < 0; ++bb) eoi = meta[bb * 4 + 2];       // first match in row-major order
+      a = (col <= row) || (col <= eoi);
+    } else {
+      const uint8_t fr = flags[(int64_t)b * L + row], fc = flags[(int64_t)b * L + col];
+      const bool img_row = fr & 2;
+      a = img_row || (col <= row);
+      if (mode == 0) {
+        const int last_pad = meta[b * 4 + 0], soi_pos = meta[b * 4 + 1];
+        if (!img_row && row > last_pad && col <= last_pad) a = false;        // text after the padding never looks at it
+        if (img_row && row >= soi_pos && (fc & 1)) a = false;                // image rows never look at pad columns
+      }
+    }
+  }
+  const uint64_t word = __ballot(a);
+  if (lane == 0) bits[wid] = word;
+}
+
 // tileany[b, qt, w] = OR over the 64 rows of q-tile qt of bits[b, row, w] != 0 ; one wave each
 __global__ __launch_bounds__(256) void mask_tiles_kernel(const uint64_t* __restrict__ bits, uint8_t* __restrict__ tileany,
                                                          int B, int L, int nW) {
@@ -534,6 +593,22 @@ extern "C" int ug_attn_mask_causal(const uint8_t* key_valid, uint64_t* bits, uin
   const int64_t ntile = B * nW * nW;
   hipLaunchKernelGGL(mask_tiles_kernel, dim3((unsigned)((ntile + 3) / 4)), block, 0, st, bits, tileany, (int)B, (int)L, nW);
   UG_CHECK_LAUNCH("ug_attn_mask_causal(tiles)");
+  return UG_OK;
+}
+
+extern "C" int ug_attn_mask_from_ids(const int64_t* ids, int64_t B, int64_t L, int64_t pad_id, int64_t soi_id, int64_t eoi_id,
+                                     int mode, int* meta_ws, uint8_t* flags_ws, uint64_t* bits, uint8_t* tileany, hipStream_t st) {
+  UG_REQUIRE(ids && bits && tileany && meta_ws && flags_ws && B > 0 && L > 0 && mode >= 0 && mode <= 2,
+             "ug_attn_mask_from_ids: bad args");
+  const int nW = (int)((L + 63) / 64);
+  hipLaunchKernelGGL(mask_ids_meta_kernel, dim3((unsigned)B), dim3(64), 0, st, ids, (int)L, pad_id, soi_id, eoi_id, meta_ws, flags_ws);
+  UG_CHECK_LAUNCH("ug_attn_mask_from_ids(meta)");
+  const int64_t nwaves = B * L * nW;
+  hipLaunchKernelGGL(mask_ids_kernel, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, st, bits, meta_ws, flags_ws, (int)B, (int)L, nW, mode);
+  UG_CHECK_LAUNCH("ug_attn_mask_from_ids");
+  const int64_t ntile = B * nW * nW;
+  hipLaunchKernelGGL(mask_tiles_kernel, dim3((unsigned)((ntile + 3) / 4)), dim3(256), 0, st, bits, tileany, (int)B, (int)L, nW);
+  UG_CHECK_LAUNCH("ug_attn_mask_from_ids(tiles)");
   return UG_OK;
 }
 

@@ -387,9 +387,55 @@ class UniGen(ModelMixin, ConfigMixin):
     # ------------------------------------------------------------------ text decoding for understanding
     @torch.no_grad()
     def mmu_generate(self, idx=None, input_embeddings=None, attention_mask=None, max_new_tokens=100, temperature=1.0,
-                     top_k=None, eot_token=None):
-        """Greedy / top-k text continuation (reference models/unigen.py:523-581): the whole growing
-        sequence is re-run each step and the additive mask is extended by one causal row/column."""
+                     top_k=None, eot_token=None, use_cache=True):
+        """Greedy / top-k text continuation (reference models/unigen.py:523-581).  The reference re-runs the whole
+        growing sequence every step and extends the additive mask by one row that copies the previous last row;
+        here the prompt is prefilled once under its mask into the static KV cache and every new token is one decode
+        step that attends to the keys the prompt's last row could see plus everything generated since (the same
+        function of the inputs; `use_cache=False` keeps the step-by-step recomputation for comparison)."""
+        if use_cache and attention_mask is not None and attention_mask.shape[0] == 1:
+            return self._mmu_generate_cached(idx, input_embeddings, attention_mask, max_new_tokens, temperature, top_k, eot_token)
+        return self._mmu_generate_recompute(idx, input_embeddings, attention_mask, max_new_tokens, temperature, top_k, eot_token)
+
+    @staticmethod
+    def _pick_next(last, temperature, top_k):
+        if temperature > 0:
+            last = last / temperature
+            if top_k is not None:
+                v, _ = torch.topk(last, min(top_k, last.size(-1)))
+                last[last < v[:, [-1]]] = -float('Inf')
+            return torch.multinomial(torch.softmax(last, dim=-1), num_samples=1)
+        return torch.argmax(last, dim=-1).reshape(-1, 1)
+
+    @torch.no_grad()
+    def _mmu_generate_cached(self, idx, input_embeddings, attention_mask, max_new_tokens, temperature, top_k, eot_token):
+        from unigen_hip.qwen2 import DecodeState
+        eng = self.llm.engine
+        embed = self.llm.model.embed_tokens
+        prompt = (embed(idx) if input_embeddings is None else input_embeddings).float()
+        dev = prompt.device
+        L = prompt.shape[1]
+        mb = eng.mask_bits(attention_mask, 1, L)
+        eng.check_errors()
+        key_valid = (attention_mask.reshape(L, L)[-1] == 0).view(1, L)
+        st = DecodeState(eng.dims, 1, L + max_new_tokens, dev, key_valid=key_valid)
+        hn = eng.prefill(st, prompt, mask_bits=mb)
+        V = self.config.vocab_size
+        x = torch.empty((1, eng.dims.hidden_size), dtype=torch.float32, device=dev)
+        result = []
+        for i in range(max_new_tokens):
+            last = eng.head_slice(hn, 0, V).float()
+            idx_next = self._pick_next(last, temperature, top_k)
+            result.append(idx_next[0][0])
+            if eot_token is not None and idx_next.cpu() == eot_token:
+                break
+            if i + 1 < max_new_tokens:
+                x.copy_(embed(idx_next)[:, 0])
+                hn = eng.decode_step(st, x)
+                st.advance()
+        return result
+
+    def _mmu_generate_recompute(self, idx, input_embeddings, attention_mask, max_new_tokens, temperature, top_k, eot_token):
         device = idx.device if idx is not None else input_embeddings.device
         result = []
         neg = torch.finfo(torch.bfloat16).min

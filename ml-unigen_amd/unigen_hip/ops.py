@@ -221,6 +221,48 @@ def mask_causal(B, L, device, key_valid=None):
     return MaskBits(bits, tileany, B, L)
 
 
+MASK_T2I, MASK_LM, MASK_MMU = 0, 1, 2
+
+
+def mask_from_ids(ids, pad_id, soi_id, eoi_id, mode=MASK_T2I):
+    """Compressed attention mask straight from token ids [B, L] (no dense [B,1,L,L] tensor): the reference's
+    create_attention_mask_predict_next (mode MASK_T2I = rm_pad_in_image, MASK_LM) / create_attention_mask_for_mmu."""
+    _need_cuda(ids)
+    B, L = ids.shape
+    ids = ids.to(torch.int64).contiguous()
+    bits, tileany = _alloc_mask(B, L, ids.device)
+    meta = torch.empty((B, 4), dtype=torch.int32, device=ids.device)
+    flags = torch.empty((B, L), dtype=torch.uint8, device=ids.device)
+    _l.check(_l.load().ug_attn_mask_from_ids(_p(ids), B, L, int(pad_id), int(soi_id), int(eoi_id), int(mode), _p(meta), _p(flags),
+                                             _p(bits), _p(tileany), _stream()), "ug_attn_mask_from_ids")
+    return MaskBits(bits, tileany, B, L)
+
+
+def t2i_assemble(text_ids, image_in, image_labels, max_seq_len, pad_id, soi_id, eoi_id, conv_start, conv_end, ignore_id=-100):
+    """t2i training rows on the device: text_ids = list of per-sample id lists (or (flat int64 tensor, offsets [B+1]));
+    image_in / image_labels int64 [B, n] on the GPU.  -> (input_ids [B, L], attention01 [B, L] uint8, labels [B, L])."""
+    dev = image_in.device
+    if isinstance(text_ids, tuple):
+        flat, offs = text_ids
+    else:
+        offs = [0]
+        for t in text_ids:
+            offs.append(offs[-1] + len(t))
+        flat = torch.tensor([v for t in text_ids for v in t] or [0], dtype=torch.int64)
+        offs = torch.tensor(offs, dtype=torch.int64)
+    flat, offs = flat.to(dev), offs.to(dev)
+    cs = torch.as_tensor(list(conv_start), dtype=torch.int64).to(dev)
+    ce = torch.as_tensor(list(conv_end), dtype=torch.int64).to(dev)
+    B, n = image_in.shape
+    ids = torch.empty((B, max_seq_len), dtype=torch.int64, device=dev)
+    labels = torch.empty_like(ids)
+    attn = torch.empty((B, max_seq_len), dtype=torch.uint8, device=dev)
+    _l.check(_l.load().ug_t2i_assemble(_p(flat), _p(offs), _p(cs), cs.numel(), _p(ce), ce.numel(), _p(image_in.to(torch.int64).contiguous()),
+                                       _p(image_labels.to(torch.int64).contiguous()), B, n, max_seq_len, int(pad_id), int(soi_id),
+                                       int(eoi_id), int(ignore_id), _p(ids), _p(labels), _p(attn), _stream()), "ug_t2i_assemble")
+    return ids, attn, labels
+
+
 def attn_transpose(x, B, L, Lp, C):
     """x: rows (b*L+t), C columns starting at x's first column (row stride x.stride(0)) -> [B, C, Lp]."""
     out = torch.empty((B, C, Lp), dtype=torch.bfloat16, device=x.device)

@@ -269,13 +269,14 @@ class DecodeState:
 
 
 def _decode_methods(cls):
-    def prefill(self, st, embeds, key_valid=None):
-        """embeds fp32 [rows, P, H] -> final-norm hidden of the LAST position, bf16 [rows, H]; fills the cache."""
+    def prefill(self, st, embeds, key_valid=None, mask_bits=None):
+        """embeds fp32 [rows, P, H] -> final-norm hidden of the LAST position, bf16 [rows, H]; fills the cache.
+        mask_bits: compressed [rows, P, P] mask of the prompt (default: causal with `key_valid` columns)."""
         d = self.dims
         R, P, H = embeds.shape
         Hq, Hk, hd = d.num_attention_heads, d.num_key_value_heads, d.head_dim
         self.fp.refresh_compute_copies()
-        mb = ops.mask_causal(R, P, self.device, key_valid=key_valid)
+        mb = mask_bits if mask_bits is not None else ops.mask_causal(R, P, self.device, key_valid=key_valid)
         h = embeds.reshape(R * P, H).float().contiguous()
         for i in range(d.num_hidden_layers):
             saved = []

@@ -602,3 +602,64 @@ def test_maskgit_step_kernel_matches_restatement(dev, N, n, V, cfg):
     assert torch.equal(mk[margin], want_mask[margin])
     assert torch.equal(nc, torch.where(mk, torch.tensor(mask_id), s)) and torch.equal(ni, torch.where(mk, torch.tensor(mask_id), s + off))
     assert int(mk.sum(-1).min()) >= 1 and not bool((mk & known).any())
+
+
+def _unpack_bits(mb):
+    """MaskBits -> bool [B, L, L]"""
+    w = mb.bits.cpu()
+    B, L, nW = w.shape
+    cols = torch.arange(nW * 64)
+    allow = ((w[:, :, cols // 64] >> (cols % 64)) & 1).bool()
+    return allow[:, :, :L]
+
+
+@pytest.mark.gpu
+def test_masks_from_ids_match_reference_builders(dev):
+    """ug_attn_mask_from_ids (no dense mask) against the reference builders' outputs (golden G4) and, on longer random
+    sequences with pads / several tiles, against the oracle restatement that G4 pins."""
+    from helpers import golden
+    from oracle import host_ref
+    ops = _ops()
+    g = golden("g4_masks.pt")
+    ids = g["ids"]
+    for seq, want, mode in ((g["t2i_seq"], g["t2i_allow"], ops.MASK_T2I), (g["lm_seq"], g["lm_allow"], ops.MASK_LM),
+                            (g["mmu_seq"], g["mmu_allow"], ops.MASK_MMU)):
+        mb = ops.mask_from_ids(seq.to(dev), ids["pad"], ids["soi"], ids["eoi"], mode)
+        assert torch.equal(_unpack_bits(mb), want), mode
+    gen = torch.Generator().manual_seed(4)
+    B, L, n = 5, 203, 64
+    seq = torch.randint(0, 290, (B, L), generator=gen)
+    seq[:, -(n + 2)] = ids["soi"]; seq[:, -1] = ids["eoi"]
+    for b, npad in enumerate((0, 1, 70, 130, 136)):
+        seq[b, :npad] = ids["pad"]
+    for mode, ref in ((ops.MASK_T2I, host_ref.mask_predict_next_ref(seq, ids["pad"], ids["soi"], ids["eoi"], rm_pad_in_image=True)),
+                      (ops.MASK_LM, host_ref.mask_predict_next_ref(seq, ids["pad"], ids["soi"], ids["eoi"])),
+                      (ops.MASK_MMU, host_ref.mask_mmu_ref(seq, ids["eoi"]))):
+        mb = ops.mask_from_ids(seq.to(dev), ids["pad"], ids["soi"], ids["eoi"], mode)
+        assert torch.equal(_unpack_bits(mb), ref), mode
+        dense = ops.mask_compress(host_ref.to_additive(ref).to(dev))
+        assert torch.equal(mb.bits.cpu(), dense.bits.cpu()) and torch.equal(mb.tileany.cpu(), dense.tileany.cpu())
+
+
+@pytest.mark.gpu
+def test_t2i_assemble_matches_reference_layout(dev):
+    """ug_t2i_assemble against the ids / labels the real UniversalPromptingQwen2.t2i_prompt produced (golden G2 layout)
+    and against the oracle layout on ragged / truncated prompts."""
+    from helpers import golden
+    from oracle import host_ref
+    ops = _ops()
+    g = golden("g2_tiny_unigen.pt")
+    lay, ids = g["layout"], g["ids"]
+    got_ids, attn, got_lab = ops.t2i_assemble(lay["t2i_texts"], lay["t2i_in"].to(dev), lay["t2i_lab"].to(dev), lay["max_seq_len"],
+                                              ids["pad"], ids["soi"], ids["eoi"], lay["conv_start"], lay["conv_end"])
+    assert torch.equal(got_ids.cpu(), lay["ids_t2i"]) and torch.equal(got_lab.cpu(), lay["lab_t2i"])
+    gen = torch.Generator().manual_seed(6)
+    texts = [torch.randint(0, 290, (k,), generator=gen).tolist() for k in (0, 3, 40, 95, 200)]      # the last two are truncated
+    n, L = 32, 96
+    img = torch.randint(312, 332, (5, n), generator=gen)
+    lab = torch.where(torch.rand(5, n, generator=gen) < 0.5, img, torch.full_like(img, -100))
+    lab[0, 0] = ids["pad"]                                                # a label equal to the pad id becomes ignore
+    want = host_ref.t2i_layout_ref(texts, img, lab, L, ids["pad"], ids["soi"], ids["eoi"], lay["conv_start"], lay["conv_end"])
+    got = ops.t2i_assemble(texts, img.to(dev), lab.to(dev), L, ids["pad"], ids["soi"], ids["eoi"], lay["conv_start"], lay["conv_end"])
+    for a, b in zip(got, want):
+        assert torch.equal(a.cpu().long(), b.long())

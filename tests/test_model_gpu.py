@@ -303,3 +303,23 @@ def test_loss_curve_20_steps_matches_oracle(dev):
     got, want = torch.tensor(got), torch.tensor(want)
     assert ((got - want).abs() / want).max().item() < 1e-3, (got, want)
     assert want[-5:].mean() < want[:5].mean()          # and it is actually training
+
+
+def test_mmu_generate_kv_cache_matches_recompute(dev):
+    """mmu_generate with the static KV cache (one prefill under the prompt's mmu mask + one decode step per token) returns
+    the tokens the reference procedure (whole sequence re-run per token, mask grown by one row) returns, greedy."""
+    g = golden("g2_tiny_unigen.pt")
+    model, _ = _tiny_unigen(g, dev)
+    model.eval()
+    P = 30
+    idx = g["input_ids"][-1:, :P].to(dev)                       # the mmu row of the fixture: image tokens, then text
+    mask = additive(g["mask_allow"][-1:, :P, :P]).to(torch.float32).to(dev)
+    slow = model.mmu_generate(idx=idx, attention_mask=mask, max_new_tokens=12, temperature=0.0, use_cache=False)
+    fast = model.mmu_generate(idx=idx, attention_mask=mask, max_new_tokens=12, temperature=0.0, use_cache=True)
+    slow, fast = [int(t) for t in slow], [int(t) for t in fast]
+    assert len(fast) == 12 and fast[:8] == slow[:8], (fast, slow)
+    # sampling path and early stop on the end-of-turn token
+    out = model.mmu_generate(idx=idx, attention_mask=mask, max_new_tokens=6, temperature=1.0, top_k=5, eot_token=fast[2])
+    assert 1 <= len(out) <= 6
+    stop = model.mmu_generate(idx=idx, attention_mask=mask, max_new_tokens=12, temperature=0.0, eot_token=fast[2])
+    assert [int(t) for t in stop] == fast[:fast.index(fast[2]) + 1]
