@@ -3,6 +3,7 @@ the C ABI) against (a) the golden vectors captured from the real reference and (
 the same seeded inputs.  Tolerances: bit-exact for integer outputs (token indices, argmax decode),
 <= 1e-3 relative for bf16 logits / losses (BASELINE.json north_star), stated per assert."""
 import math
+import os
 
 import pytest
 import torch
@@ -323,3 +324,34 @@ def test_mmu_generate_kv_cache_matches_recompute(dev):
     assert 1 <= len(out) <= 6
     stop = model.mmu_generate(idx=idx, attention_mask=mask, max_new_tokens=12, temperature=0.0, eot_token=fast[2])
     assert [int(t) for t in stop] == fast[:fast.index(fast[2]) + 1]
+
+
+def test_checkpoint_round_trip_and_hf_llm_loading(dev, tmp_path):
+    """save_pretrained -> from_pretrained keeps every tensor (reference key names, tied head written once per name) and
+    the logits; a HF-layout Qwen2 directory (config.json + *.safetensors) loads through llm_model_path with the
+    embedding resized to the UniGen vocabulary (models/unigen.py:58-69)."""
+    from models import UniGen
+    from safetensors.torch import save_file
+    g = golden("g2_tiny_unigen.pt")
+    model, sd = _tiny_unigen(g, dev)
+    model.eval()
+    ids, mask = g["input_ids"].to(dev), additive(g["mask_allow"]).to(dev)
+    ref = model(input_ids=ids, attention_mask=mask)[:, -5:, :].float().cpu()
+    model.save_pretrained(str(tmp_path / "ckpt"))
+    again, info = UniGen.from_pretrained(str(tmp_path / "ckpt"), device=dev, output_loading_info=True)
+    assert not info["unexpected_keys"] and not info["missing_keys"], info
+    a, b = model.state_dict(), again.state_dict()
+    assert sorted(a) == sorted(b) and all(torch.equal(a[k].cpu(), b[k].cpu()) for k in a)
+    assert torch.equal(again(input_ids=ids, attention_mask=mask)[:, -5:, :].float().cpu(), ref)
+    # HF Qwen2 directory with a SMALLER vocabulary than UniGen's (text tokens only)
+    cfg = dict(g["cfg"]); text_v = g["ids"]["text_vocab"]
+    hf_dir = llm_config_dir(dict(cfg, vocab_size=text_v))
+    hf_sd = {k: v.clone() for k, v in sd.items() if k != "lm_head.weight"}
+    hf_sd["model.embed_tokens.weight"] = hf_sd["model.embed_tokens.weight"][:text_v].clone()
+    save_file(hf_sd, os.path.join(hf_dir, "model.safetensors"))
+    m2 = UniGen(w_und_encoder=False, vocab_size=cfg["vocab_size"], llm_vocab_size=text_v, llm_model_path=hf_dir, codebook_size=20,
+                num_vq_tokens=16, load_from_pretrained=False, device=dev, init_seed=5)
+    own = m2.llm.state_dict()
+    assert torch.equal(own["model.embed_tokens.weight"][:text_v].cpu(), sd["model.embed_tokens.weight"][:text_v])
+    assert torch.equal(own["model.layers.1.mlp.down_proj.weight"].cpu(), sd["model.layers.1.mlp.down_proj.weight"])
+    assert own["model.embed_tokens.weight"].shape[0] == cfg["vocab_size"]
