@@ -20,6 +20,29 @@ __global__ __launch_bounds__(256) void mfma_burn(const short* __restrict__ seed,
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+// fp32-input matrix cores (the tokenizer's convolutions): v_mfma_f32_32x32x2_f32
+template <int NACC>
+__global__ __launch_bounds__(256) void mfma_burn_f32(const short* __restrict__ seed, float* __restrict__ out, int iters) {
+  const float a = (float)seed[threadIdx.x & 4095] * 1e-4f, b = (float)seed[(threadIdx.x + 977) & 4095] * 1e-4f;
+  f32x16_t acc[NACC];
+  for (int i = 0; i < NACC; ++i)
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int i = 0; i < NACC; ++i)
+    for (int r = 0; r < 16; ++r) s += acc[i][r];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+extern "C" int mfma_burn_f32_launch(const void* seed, void* out, int blocks, int threads, int iters, hipStream_t st) {
+  hipLaunchKernelGGL(mfma_burn_f32<4>, dim3(blocks), dim3(threads), 0, st, (const short*)seed, (float*)out, iters);
+  return (int)hipGetLastError();
+}
+
 extern "C" int mfma_burn_launch(const void* seed, void* out, int blocks, int threads, int iters, int nacc, hipStream_t st) {
   if (nacc == 64) hipLaunchKernelGGL(mfma_burn<64>, dim3(blocks), dim3(threads), 0, st, (const short*)seed, (float*)out, iters);
   else hipLaunchKernelGGL(mfma_burn<16>, dim3(blocks), dim3(threads), 0, st, (const short*)seed, (float*)out, iters);

@@ -14,7 +14,7 @@ dev = torch.device("cuda:0")
 out = torch.empty(1 << 20, device=dev)
 for data in ("zeros", "randn"):
     seed = (torch.zeros(4096) if data == "zeros" else torch.randn(4096)).to(torch.bfloat16).view(torch.int16).to(dev)
-    for threads, blocks_per_cu in ((256, 1), (256, 2), (512, 1)):
+    for threads, blocks_per_cu in ((256, 1), (256, 2)):
         for nacc in (64, 16):
             blocks, iters = 256 * blocks_per_cu, 20000 if nacc == 16 else 5000
             args = (ctypes.c_void_p(seed.data_ptr()), ctypes.c_void_p(out.data_ptr()), blocks, threads, iters, nacc,
@@ -29,3 +29,20 @@ for data in ("zeros", "randn"):
             ms = e0.elapsed_time(e1)
             flops = blocks * (threads // 64) * iters * nacc * 2.0 * 16 * 16 * 32
             print(f"{data:6s} threads={threads} blocks/CU={blocks_per_cu} nacc={nacc}: {flops / ms / 1e9:8.1f} TF/s ({ms:.2f} ms)", flush=True)
+
+# fp32-input MFMA (32x32x2): 1, 2 and 4 waves per SIMD
+seed = torch.randn(4096).mul(1000).to(torch.int16).to(dev)
+for blocks_per_cu in (1, 2, 4):
+    blocks, iters = 256 * blocks_per_cu, 20000
+    args = (ctypes.c_void_p(seed.data_ptr()), ctypes.c_void_p(out.data_ptr()), blocks, 256, iters,
+            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    lib.mfma_burn_f32_launch(*args)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    lib.mfma_burn_f32_launch(*args)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    flops = blocks * 4 * iters * 4 * 2.0 * 32 * 32 * 2
+    print(f"fp32 32x32x2 blocks/CU={blocks_per_cu}: {flops / ms / 1e9:8.1f} TF/s ({ms:.2f} ms)", flush=True)
