@@ -201,6 +201,14 @@ int ug_maskgit_step(const void* logits, int64_t ld, int64_t V, int64_t N, int64_
                     int64_t mask_len_sched, float temperature, int64_t* sampled, float* sel_ws, int64_t* next_cur,
                     int64_t* next_ids, uint8_t* masking_out, hipStream_t stream);
 
+/* one autoregressive sampling step (models/unigen.py:503-519) on the raw fp32 lm-head accumulator acc [2*bsz][ldacc]
+ * (conditional rows, then unconditional; rounded to bf16 like the head's output; cleared on exit): CFG mix, /temperature,
+ * softmax + inverse-CDF draw on uniforms[step*bsz + b] (or argmax if greedy), step = *pos_dev - pos0.  Writes tok[b],
+ * out_tokens[b*nsteps + step] and the next input x[b], x[bsz+b] = embed[token + id_offset] (fp32 rows of ld_embed). */
+int ug_ar_sample(float* acc, int64_t ldacc, int64_t bsz, int64_t V, float guidance_scale, float temperature, int greedy,
+                 const float* uniforms, const int* pos_dev, int64_t pos0, int64_t nsteps, const float* embed, int64_t ld_embed,
+                 int64_t H, int64_t id_offset, int64_t* tok, int* out_tokens, float* x, hipStream_t stream);
+
 /* ---- loss ------------------------------------------------------------------------------------ */
 /* replaces: F.cross_entropy(ignore_index=-100) x3 in UniGen.forward (models/unigen.py:310-338) and
  * get_batch_logps (training/train_dpo.py:51-90).  logits bf16 [R, ld], ld % 8 == 0.

@@ -115,6 +115,82 @@ __global__ __launch_bounds__(1024) void maskgit_remask_kernel(const float* __res
   }
 }
 
+// ------------------------------------------------------------------ autoregressive image-token sampling
+// One decode step of UniGen.t2i_generate_ar after the backbone (reference models/unigen.py:503-519): code-book logits
+// of the conditional / unconditional rows (raw fp32 accumulator of the lm-head GEMV, rounded to bf16 like the head's
+// output), CFG mix, temperature, softmax, one categorical draw (inverse CDF on a supplied uniform) or argmax, then the
+// next step's input: the embedding row of (token + id_offset) for both halves.  One workgroup per image; the
+// accumulator rows are cleared for the next step.
+__global__ __launch_bounds__(SMP_T) void ar_sample_kernel(float* __restrict__ acc, int64_t lda, int bsz, int V, float scale,
+                                                         float inv_temp, int greedy, const float* __restrict__ uniforms,
+                                                         const int* __restrict__ pos_dev, int pos0, int nsteps,
+                                                         const float* __restrict__ embed, int64_t lde, int H, int64_t id_offset,
+                                                         int64_t* __restrict__ tok, int* __restrict__ out_tokens,
+                                                         float* __restrict__ x) {
+  __shared__ float red[SMP_T / 64];
+  __shared__ float part[SMP_T];
+  __shared__ int hit;
+  __shared__ int best_i[SMP_T / 64];
+  __shared__ int chosen;
+  const int b = blockIdx.x, t = threadIdx.x;
+  const int step = min(max(*pos_dev - pos0, 0), nsteps - 1);
+  float* c = acc + (int64_t)b * lda;
+  float* u = acc + (int64_t)(bsz + b) * lda;
+  const int C = (V + SMP_T - 1) / SMP_T;
+  const int lo = t * C, hi = min(V, lo + C);
+  auto mixed = [&](int e) {
+    const float cv = bf2f(f2bf(c[e])), uv = bf2f(f2bf(u[e]));
+    return (uv + scale * (cv - uv)) * inv_temp;
+  };
+  float mx = -INFINITY;
+  int arg = lo;
+  for (int e = lo; e < hi; ++e) { const float v = mixed(e); if (v > mx) { mx = v; arg = e; } }
+  if (greedy) {
+    // block argmax, first index on ties (threads own ascending index ranges)
+    float wm = mx; int wi = arg;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float om = __shfl_xor(wm, o, 64); const int oi = __shfl_xor(wi, o, 64);
+      if (om > wm || (om == wm && oi < wi)) { wm = om; wi = oi; }
+    }
+    if ((t & 63) == 0) { red[t >> 6] = wm; best_i[t >> 6] = wi; }
+    __syncthreads();
+    if (t == 0) {
+      float bm = red[0]; int bi = best_i[0];
+      for (int w = 1; w < SMP_T / 64; ++w) if (red[w] > bm || (red[w] == bm && best_i[w] < bi)) { bm = red[w]; bi = best_i[w]; }
+      chosen = bi;
+    }
+    __syncthreads();
+  } else {
+    const float bmx = block_max<SMP_T / 64>(mx, red);
+    float local = 0.f;
+    for (int e = lo; e < hi; ++e) local += expf(mixed(e) - bmx);
+    part[t] = local;
+    if (t == 0) hit = SMP_T - 1;
+    __syncthreads();
+    float excl = 0.f, total = 0.f;
+    for (int j = 0; j < SMP_T; ++j) { const float pj = part[j]; if (j < t) excl += pj; total += pj; }
+    const float target = uniforms[(int64_t)step * bsz + b] * total;
+    if (excl <= target && target < excl + local) atomicMin(&hit, t);
+    __syncthreads();
+    if (t == hit) {
+      float run = excl;
+      int idx = max(hi - 1, lo);
+      for (int e = lo; e < hi; ++e) { run += expf(mixed(e) - bmx); if (run > target) { idx = e; break; } }
+      chosen = min(idx, V - 1);
+    }
+    __syncthreads();
+  }
+  const int token = chosen;
+  __syncthreads();
+  for (int e = t; e < V; e += SMP_T) { c[e] = 0.f; u[e] = 0.f; }          // accumulator ready for the next step
+  if (t == 0) { tok[b] = token; out_tokens[(int64_t)b * nsteps + step] = token; }
+  const float4* er = reinterpret_cast<const float4*>(embed + (token + id_offset) * lde);
+  float4* x0 = reinterpret_cast<float4*>(x + (int64_t)b * H);
+  float4* x1 = reinterpret_cast<float4*>(x + (int64_t)(bsz + b) * H);
+  for (int i = t; i < (H >> 2); i += SMP_T) { const float4 v = er[i]; x0[i] = v; x1[i] = v; }
+}
+
 }  // namespace
 
 extern "C" int ug_maskgit_step(const void* logits, int64_t ld, int64_t V, int64_t N, int64_t n, int cfg, float guidance_scale,
@@ -131,5 +207,19 @@ extern "C" int ug_maskgit_step(const void* logits, int64_t ld, int64_t V, int64_
   hipLaunchKernelGGL(maskgit_remask_kernel, dim3((unsigned)N), dim3(threads), n * sizeof(float), st, sel_ws, u_conf, cur_ids, sampled,
                      mask_id, id_offset, (int)mask_len_sched, temperature, (int)n, next_cur, next_ids, masking_out);
   UG_CHECK_LAUNCH("ug_maskgit_step(remask)");
+  return UG_OK;
+}
+
+extern "C" int ug_ar_sample(float* acc, int64_t ldacc, int64_t bsz, int64_t V, float guidance_scale, float temperature, int greedy,
+                            const float* uniforms, const int* pos_dev, int64_t pos0, int64_t nsteps, const float* embed,
+                            int64_t ld_embed, int64_t H, int64_t id_offset, int64_t* tok, int* out_tokens, float* x, hipStream_t st) {
+  UG_REQUIRE(acc && pos_dev && embed && tok && out_tokens && x && (greedy || uniforms), "ug_ar_sample: null argument");
+  UG_REQUIRE(bsz > 0 && V > 0 && ldacc >= V && nsteps > 0 && H > 0 && H % 4 == 0 && ld_embed % 4 == 0 && temperature > 0.f &&
+                 ug_aligned16(embed) && ug_aligned16(x),
+             "ug_ar_sample: bad sizes (bsz=%ld V=%ld H=%ld temperature=%g)", (long)bsz, (long)V, (long)H, (double)temperature);
+  hipLaunchKernelGGL(ar_sample_kernel, dim3((unsigned)bsz), dim3(SMP_T), 0, st, acc, ldacc, (int)bsz, (int)V, guidance_scale,
+                     1.f / temperature, greedy, uniforms, pos_dev, (int)pos0, (int)nsteps, embed, ld_embed, (int)H, id_offset, tok,
+                     out_tokens, x);
+  UG_CHECK_LAUNCH("ug_ar_sample");
   return UG_OK;
 }

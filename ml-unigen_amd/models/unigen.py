@@ -348,20 +348,36 @@ class UniGen(ModelMixin, ConfigMixin):
         out_tokens = torch.zeros((bsz, n), dtype=torch.int, device=dev)
         x = torch.empty((R, eng.dims.hidden_size), dtype=torch.float32, device=dev)      # static: next token's embedding
         tok = torch.zeros((bsz, 1), dtype=torch.long, device=dev)                        # static: last sampled token
+        V = code_hi - code_lo
+        fused = R <= 32 and eng.dims.hidden_size >= 256 and eng.dims.hidden_size % 32 == 0 and not kwargs.get("torch_sampler", False)
+        if fused:
+            # lm-head as a weight-streaming GEMV into a raw fp32 accumulator + ONE sampling kernel per step (CFG mix,
+            # temperature, softmax, inverse-CDF draw on uniforms taken from `generator` up front, next input embedding)
+            acc_head = torch.zeros((R, V), dtype=torch.float32, device=dev)
+            u_dev = dev if generator is None else generator.device
+            uniforms = None if greedy else torch.rand((n, bsz), device=u_dev, generator=generator).to(dev)
+            w_head = eng.fp.w("embed")[code_lo:code_hi]
+            w_embed = eng.fp.p("embed")
 
-        def sample(hn):
-            lg = eng.head_slice(hn, code_lo, code_hi).float()
-            cond, uncond = lg[:bsz], lg[bsz:]
-            lg = uncond + guidance_scale * (cond - uncond)
-            if greedy:
-                nxt = lg.argmax(-1, keepdim=True)
-            else:
-                nxt = torch.multinomial(torch.softmax(lg / temperature, dim=-1), num_samples=1, generator=generator)
-            tok.copy_(nxt)
-            x.copy_(embed(torch.cat([nxt, nxt]) + text_vocab_size)[:, 0])
+            def sample(hn):
+                ops.decode_gemv_(hn, w_head, acc_head)
+                ops.ar_sample_(acc_head, bsz, V, guidance_scale, temperature, greedy, uniforms, st.pos, P, n, w_embed,
+                               text_vocab_size, tok, out_tokens, x)
+        else:
+            def sample(hn):
+                lg = eng.head_slice(hn, code_lo, code_hi).float()
+                cond, uncond = lg[:bsz], lg[bsz:]
+                lg = uncond + guidance_scale * (cond - uncond)
+                if greedy:
+                    nxt = lg.argmax(-1, keepdim=True)
+                else:
+                    nxt = torch.multinomial(torch.softmax(lg / temperature, dim=-1), num_samples=1, generator=generator)
+                tok.copy_(nxt)
+                x.copy_(embed(torch.cat([nxt, nxt]) + text_vocab_size)[:, 0])
 
         sample(eng.prefill(st, prefix, key_valid))
-        out_tokens[:, 0] = tok[:, 0]
+        if not fused:
+            out_tokens[:, 0] = tok[:, 0]
 
         def step():
             hn = eng.decode_step(st, x)
@@ -370,17 +386,19 @@ class UniGen(ModelMixin, ConfigMixin):
 
         graph = None
         for i in range(1, n):
-            if use_graph and generator is None and i == 2:
+            if use_graph and (generator is None or fused) and i == 2:
                 # step 1 ran eagerly (warm-up: allocations, lazy inits); capture step 2 and replay it from then on
                 torch.cuda.synchronize()
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
                     step()
+                graph.replay()                      # capture only records: this replay IS step 2
             elif graph is not None:
                 graph.replay()
             else:
                 step()
-            out_tokens[:, i] = tok[:, 0]
+            if not fused:
+                out_tokens[:, i] = tok[:, 0]
         eng.last_decode_graph = graph is not None
         return out_tokens
 

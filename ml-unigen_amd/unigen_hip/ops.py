@@ -444,6 +444,15 @@ def maskgit_step(logits, N, n, cfg, guidance_scale, u_sample, u_conf, cur_ids, m
     return (sampled, next_cur, next_ids, masking.bool()) if want_masking else (sampled, next_cur, next_ids)
 
 
+def ar_sample_(acc, bsz, V, guidance_scale, temperature, greedy, uniforms, pos_dev, pos0, nsteps, embed_master, id_offset, tok,
+               out_tokens, x):
+    """Fused AR sampling step on the raw lm-head accumulator (see include/unigen_hip.h: ug_ar_sample)."""
+    _l.check(_l.load().ug_ar_sample(_p(acc), acc.stride(0), bsz, V, float(guidance_scale), float(temperature), int(bool(greedy)),
+                                    _p(uniforms), _p(pos_dev), int(pos0), int(nsteps), _p(embed_master), embed_master.stride(0),
+                                    embed_master.shape[1], int(id_offset), _p(tok), _p(out_tokens), _p(x), _stream()),
+             "ug_ar_sample")
+
+
 # ------------------------------------------------------------------------------------ loss
 def ce_fwd(logits, V, labels, ignore_index=-100, want_logp=False):
     """logits bf16 [R, ld>=V]; -> (loss_and_count [2], lse [R], loss_row [R], logp|None)"""

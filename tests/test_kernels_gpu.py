@@ -663,3 +663,40 @@ def test_t2i_assemble_matches_reference_layout(dev):
     got = ops.t2i_assemble(texts, img.to(dev), lab.to(dev), L, ids["pad"], ids["soi"], ids["eoi"], lay["conv_start"], lay["conv_end"])
     for a, b in zip(got, want):
         assert torch.equal(a.cpu().long(), b.long())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("greedy", [True, False])
+def test_ar_sample_kernel_matches_restatement(dev, greedy):
+    """ug_ar_sample: CFG mix of bf16-rounded head logits, temperature, argmax / inverse-CDF draw, next-input embedding
+    rows, accumulator cleared; against a float64 restatement (draws within rounding of a CDF step excluded)."""
+    ops = _ops()
+    bsz, V, H, n, P, off = 6, 8192, 256, 10, 40, 100
+    g = torch.Generator().manual_seed(17 + greedy)
+    acc = 3.0 * torch.randn(2 * bsz, V, generator=g)
+    emb = torch.randn(off + V, H, generator=g)
+    u = torch.rand(n, bsz, generator=g)
+    step = 3
+    pos = torch.tensor([P + step], dtype=torch.int32)
+    tok = torch.zeros(bsz, 1, dtype=torch.long, device=dev)
+    out = torch.zeros(bsz, n, dtype=torch.int32, device=dev)
+    x = torch.zeros(2 * bsz, H, device=dev)
+    acc_d = acc.clone().to(dev)
+    ops.ar_sample_(acc_d, bsz, V, 4.0, 0.7, greedy, None if greedy else u.to(dev), pos.to(dev), P, n, emb.to(dev), off, tok, out, x)
+    lf = acc.to(torch.bfloat16).float()
+    mixed = ((lf[bsz:] + 4.0 * (lf[:bsz] - lf[bsz:])) / 0.7).double()
+    got = tok[:, 0].cpu()
+    if greedy:
+        want = mixed.argmax(-1)
+        top2 = mixed.topk(2, -1).values
+        sure = (top2[:, 0] - top2[:, 1]) > 1e-4
+    else:
+        ex = torch.exp(mixed - mixed.max(-1, keepdim=True).values)
+        cdf = ex.cumsum(-1)
+        target = u[step].double().reshape(-1, 1) * cdf[:, -1:]
+        want = (cdf <= target).sum(-1).clamp(max=V - 1)
+        sure = ((cdf - target).abs().min(-1).values / cdf[:, -1]) > 1e-4
+    assert sure.sum() >= bsz - 1 and torch.equal(got[sure], want[sure])
+    assert torch.equal(out[:, step].cpu().long(), got) and int(out.cpu().abs().sum()) == int(got.sum())
+    assert torch.equal(x[:bsz].cpu(), emb[got + off]) and torch.equal(x[bsz:].cpu(), emb[got + off])
+    assert float(acc_d.abs().max()) == 0.0
