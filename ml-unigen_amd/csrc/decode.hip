@@ -191,6 +191,23 @@ __global__ __launch_bounds__(64 * AD_WAVES) void attn_decode_fused_kernel(
   const int hk = h / (H / HKV);
   const int pos0 = *pos_dev;
   const int len = min(pos0, Tmax);                         // cache keys visible to the new token
+  const bf16_t* kb = ck + ((int64_t)r * HKV + hk) * Tmax * DHD;
+  const bf16_t* vb = cv + ((int64_t)r * HKV + hk) * Tmax * DHD;
+  const int kq = lane >> 4, dc = lane & 15;
+  // the first key chunk's K row / V pieces do not depend on the new token: request them before the prologue's own
+  // round trip (accumulator, bias, RoPE table) so the two latencies overlap
+  bf16x8_t kf[DHD / 8], vf[16];
+  auto load_chunk = [&](int t0) {
+    const bf16_t* kr = kb + (int64_t)min(t0 + lane, len - 1) * DHD;
+#pragma unroll
+    for (int c = 0; c < DHD / 8; ++c) kf[c] = *reinterpret_cast<const bf16x8_t*>(kr + c * 8);
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+      const int tt = min(t0 + jj * 4 + kq, len - 1);
+      vf[jj] = *reinterpret_cast<const bf16x8_t*>(vb + (int64_t)tt * DHD + dc * 8);
+    }
+  };
+  if (wave * 64 < len) load_chunk(wave * 64);
   const float rs = rsqrtf(ss[r] / (float)norm_cols + eps);
   const float* arow = acc_qkv + (int64_t)r * lda;
   if (wave < 3) {
@@ -205,9 +222,6 @@ __global__ __launch_bounds__(64 * AD_WAVES) void attn_decode_fused_kernel(
     }
   }
   __syncthreads();
-  const bf16_t* kb = ck + ((int64_t)r * HKV + hk) * Tmax * DHD;
-  const bf16_t* vb = cv + ((int64_t)r * HKV + hk) * Tmax * DHD;
-  const int kq = lane >> 4, dc = lane & 15;
   float m = -INFINITY, l = 0.f;
   float acc[8];
 #pragma unroll
@@ -215,17 +229,7 @@ __global__ __launch_bounds__(64 * AD_WAVES) void attn_decode_fused_kernel(
   for (int t0 = wave * 64; t0 < len; t0 += 64 * AD_WAVES) {
     const int t = t0 + lane;
     float s = -INFINITY;
-    bf16x8_t kf[DHD / 8], vf[16];
-    {
-      const bf16_t* kr = kb + (int64_t)min(t, len - 1) * DHD;
-#pragma unroll
-      for (int c = 0; c < DHD / 8; ++c) kf[c] = *reinterpret_cast<const bf16x8_t*>(kr + c * 8);
-#pragma unroll
-      for (int jj = 0; jj < 16; ++jj) {
-        const int tt = min(t0 + jj * 4 + kq, len - 1);
-        vf[jj] = *reinterpret_cast<const bf16x8_t*>(vb + (int64_t)tt * DHD + dc * 8);
-      }
-    }
+    if (t0 != wave * 64) load_chunk(t0);                 // later chunks (contexts beyond 256 keys)
     if (t < len && (!key_valid || key_valid[(int64_t)r * Tmax + t])) {
       float d = 0.f;
 #pragma unroll

@@ -121,12 +121,16 @@ __global__ __launch_bounds__(1024) void maskgit_remask_kernel(const float* __res
 // output), CFG mix, temperature, softmax, one categorical draw (inverse CDF on a supplied uniform) or argmax, then the
 // next step's input: the embedding row of (token + id_offset) for both halves.  One workgroup per image; the
 // accumulator rows are cleared for the next step.
+constexpr int AR_MAXV = 8192;          // code-book slice staged in LDS (33 KiB incl. padding)
+__device__ __forceinline__ int ar_pad(int e) { return e + (e >> 5); }      // chunk starts land on different banks
+
 __global__ __launch_bounds__(SMP_T) void ar_sample_kernel(float* __restrict__ acc, int64_t lda, int bsz, int V, float scale,
                                                          float inv_temp, int greedy, const float* __restrict__ uniforms,
                                                          const int* __restrict__ pos_dev, int pos0, int nsteps,
                                                          const float* __restrict__ embed, int64_t lde, int H, int64_t id_offset,
                                                          int64_t* __restrict__ tok, int* __restrict__ out_tokens,
                                                          float* __restrict__ x) {
+  __shared__ float mix[AR_MAXV + AR_MAXV / 32];
   __shared__ float red[SMP_T / 64];
   __shared__ float part[SMP_T];
   __shared__ int hit;
@@ -136,37 +140,50 @@ __global__ __launch_bounds__(SMP_T) void ar_sample_kernel(float* __restrict__ ac
   const int step = min(max(*pos_dev - pos0, 0), nsteps - 1);
   float* c = acc + (int64_t)b * lda;
   float* u = acc + (int64_t)(bsz + b) * lda;
-  const int C = (V + SMP_T - 1) / SMP_T;
-  const int lo = t * C, hi = min(V, lo + C);
-  auto mixed = [&](int e) {
-    const float cv = bf2f(f2bf(c[e])), uv = bf2f(f2bf(u[e]));
-    return (uv + scale * (cv - uv)) * inv_temp;
-  };
+  // pass 1 (coalesced): mixed logits into LDS, accumulator rows cleared, running max / first argmax per thread
   float mx = -INFINITY;
-  int arg = lo;
-  for (int e = lo; e < hi; ++e) { const float v = mixed(e); if (v > mx) { mx = v; arg = e; } }
-  if (greedy) {
-    // block argmax, first index on ties (threads own ascending index ranges)
-    float wm = mx; int wi = arg;
+  int arg = 0x7fffffff;
+  {
+    constexpr int PER = AR_MAXV / SMP_T;                     // every load of the two rows in flight at once
+    float cr[PER], ur[PER];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float om = __shfl_xor(wm, o, 64); const int oi = __shfl_xor(wi, o, 64);
-      if (om > wm || (om == wm && oi < wi)) { wm = om; wi = oi; }
+    for (int j = 0; j < PER; ++j) {
+      const int e = min(t + j * SMP_T, V - 1);
+      cr[j] = c[e]; ur[j] = u[e];
     }
-    if ((t & 63) == 0) { red[t >> 6] = wm; best_i[t >> 6] = wi; }
-    __syncthreads();
-    if (t == 0) {
-      float bm = red[0]; int bi = best_i[0];
-      for (int w = 1; w < SMP_T / 64; ++w) if (red[w] > bm || (red[w] == bm && best_i[w] < bi)) { bm = red[w]; bi = best_i[w]; }
-      chosen = bi;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int e = t + j * SMP_T;
+      if (e < V) {
+        c[e] = 0.f; u[e] = 0.f;
+        const float cv = bf2f(f2bf(cr[j])), uv = bf2f(f2bf(ur[j]));
+        const float v = (uv + scale * (cv - uv)) * inv_temp;
+        mix[ar_pad(e)] = v;
+        if (v > mx) { mx = v; arg = e; }
+      }
     }
-    __syncthreads();
+  }
+  // block max + smallest index attaining it
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float om = __shfl_xor(mx, o, 64); const int oi = __shfl_xor(arg, o, 64);
+    if (om > mx || (om == mx && oi < arg)) { mx = om; arg = oi; }
+  }
+  if ((t & 63) == 0) { red[t >> 6] = mx; best_i[t >> 6] = arg; }
+  if (t == 0) hit = SMP_T - 1;
+  __syncthreads();
+  float bmx = red[0]; int bi = best_i[0];
+#pragma unroll
+  for (int w = 1; w < SMP_T / 64; ++w) if (red[w] > bmx || (red[w] == bmx && best_i[w] < bi)) { bmx = red[w]; bi = best_i[w]; }
+  if (greedy) {
+    if (t == 0) chosen = bi;
   } else {
-    const float bmx = block_max<SMP_T / 64>(mx, red);
+    // inverse CDF in index order: thread t owns the contiguous chunk [t*C, (t+1)*C)
+    const int C = (V + SMP_T - 1) / SMP_T;
+    const int lo = t * C, hi = min(V, lo + C);
     float local = 0.f;
-    for (int e = lo; e < hi; ++e) local += expf(mixed(e) - bmx);
+    for (int e = lo; e < hi; ++e) local += expf(mix[ar_pad(e)] - bmx);
     part[t] = local;
-    if (t == 0) hit = SMP_T - 1;
     __syncthreads();
     float excl = 0.f, total = 0.f;
     for (int j = 0; j < SMP_T; ++j) { const float pj = part[j]; if (j < t) excl += pj; total += pj; }
@@ -176,14 +193,12 @@ __global__ __launch_bounds__(SMP_T) void ar_sample_kernel(float* __restrict__ ac
     if (t == hit) {
       float run = excl;
       int idx = max(hi - 1, lo);
-      for (int e = lo; e < hi; ++e) { run += expf(mixed(e) - bmx); if (run > target) { idx = e; break; } }
+      for (int e = lo; e < hi; ++e) { run += expf(mix[ar_pad(e)] - bmx); if (run > target) { idx = e; break; } }
       chosen = min(idx, V - 1);
     }
-    __syncthreads();
   }
-  const int token = chosen;
   __syncthreads();
-  for (int e = t; e < V; e += SMP_T) { c[e] = 0.f; u[e] = 0.f; }          // accumulator ready for the next step
+  const int token = chosen;
   if (t == 0) { tok[b] = token; out_tokens[(int64_t)b * nsteps + step] = token; }
   const float4* er = reinterpret_cast<const float4*>(embed + (token + id_offset) * lde);
   float4* x0 = reinterpret_cast<float4*>(x + (int64_t)b * H);
@@ -214,6 +229,7 @@ extern "C" int ug_ar_sample(float* acc, int64_t ldacc, int64_t bsz, int64_t V, f
                             const float* uniforms, const int* pos_dev, int64_t pos0, int64_t nsteps, const float* embed,
                             int64_t ld_embed, int64_t H, int64_t id_offset, int64_t* tok, int* out_tokens, float* x, hipStream_t st) {
   UG_REQUIRE(acc && pos_dev && embed && tok && out_tokens && x && (greedy || uniforms), "ug_ar_sample: null argument");
+  UG_REQUIRE(V <= AR_MAXV, "ug_ar_sample: code-book slice of %ld columns exceeds the %d this build stages in LDS", (long)V, AR_MAXV);
   UG_REQUIRE(bsz > 0 && V > 0 && ldacc >= V && nsteps > 0 && H > 0 && H % 4 == 0 && ld_embed % 4 == 0 && temperature > 0.f &&
                  ug_aligned16(embed) && ug_aligned16(x),
              "ug_ar_sample: bad sizes (bsz=%ld V=%ld H=%ld temperature=%g)", (long)bsz, (long)V, (long)H, (double)temperature);
