@@ -56,6 +56,10 @@ struct GemmArgs {
   int64_t lda, ldb, ldc, ldr;
   int beta;                // EPI_F32: 1 => C += acc
   int tiles_m, tiles_n;
+  // staggered kernel, partial last round: the first `full_tiles` tiles run whole, every remaining tile is cut into
+  // `tail_split` k-slices that add into the fp32 scratch tail_ws[tile - full_tiles][256][256] (finished by tail_finish)
+  int full_tiles, tail_split;
+  float* tail_ws;
 };
 
 __device__ __forceinline__ int swz_rowk(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
@@ -360,7 +364,10 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p8(GemmArgs p) {
   const int grp = wave >> 2, wn = wave & 3;
 
   const int nwg = p.tiles_m * p.tiles_n;
-  const int pid = xcd_remap(blockIdx.x, nwg);
+  const bool tail = p.tail_split > 1 && (int)blockIdx.x >= p.full_tiles;
+  const int tail_j = tail ? (int)blockIdx.x - p.full_tiles : 0;
+  const int tile_lin = tail ? p.full_tiles + tail_j / p.tail_split : (int)blockIdx.x;
+  const int pid = xcd_remap(tile_lin, nwg);
   const int per_group = GROUP_M * p.tiles_n;
   const int gid = pid / per_group, first_m = gid * GROUP_M;
   const int gsz = min(p.tiles_m - first_m, GROUP_M);
@@ -378,11 +385,16 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p8(GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = (p.K + PBK - 1) / PBK;
+  const int nk_all = (p.K + PBK - 1) / PBK;
+  const int per_split = tail ? (nk_all + p.tail_split - 1) / p.tail_split : nk_all;
+  const int kt0 = tail ? (tail_j % p.tail_split) * per_split : 0;
+  const int nk = min(nk_all, kt0 + per_split) - kt0;                // local k-tile count (ring slots are local indices)
+  if (nk <= 0) return;
   const bool ragged = (p.K % PBK) != 0;
-  auto stage_in = [&](int kt) {                 // 4 DMA instructions per wave
-    char* st = lds + (kt & (P_NST - 1)) * P_STAGE;
-    if (ragged && kt + 1 == nk) { sa.template issue<true>(kt, p.K, st, wave); sb.template issue<true>(kt, p.K, st + P_TILE, wave); }
+  auto stage_in = [&](int lt) {                 // 4 DMA instructions per wave
+    const int kt = kt0 + lt;
+    char* st = lds + (lt & (P_NST - 1)) * P_STAGE;
+    if (ragged && kt + 1 == nk_all) { sa.template issue<true>(kt, p.K, st, wave); sb.template issue<true>(kt, p.K, st + P_TILE, wave); }
     else { sa.template issue<false>(kt, p.K, st, wave); sb.template issue<false>(kt, p.K, st + P_TILE, wave); }
   };
   // prologue: tiles 0..2 in flight, tile 0 landed
@@ -424,8 +436,73 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p8(GemmArgs p) {
   }
   if (grp == 0) P_BARRIER();                    // balance the barrier count of the staggered group
 
+  if (tail) {
+    float* ws = p.tail_ws + (int64_t)(tile_lin - p.full_tiles) * (PBM * PBN);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int ml = grp * 128 + i * 16 + (lane & 15);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float* dst = ws + ml * PBN + wn * 64 + j * 16 + (lane >> 4) * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(dst + r, acc[i][j][r]);
+      }
+    }
+    return;
+  }
   store_tile<EPI>(p, reinterpret_cast<f32x4_t (&)[4][4]>(acc[0]), m0 + grp * 128, n0 + wn * 64, lane, false);
   store_tile<EPI>(p, reinterpret_cast<f32x4_t (&)[4][4]>(acc[4]), m0 + grp * 128 + 64, n0 + wn * 64, lane, false);
+}
+
+// Epilogue of the k-sliced tail tiles: scratch -> C with the launch's epilogue, scratch re-zeroed.
+template <int EPI>
+__global__ __launch_bounds__(256) void tail_finish_kernel(GemmArgs p, int ntail) {
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int per_tile = PBM * PBN / 4;
+  const int64_t total = (int64_t)ntail * per_tile;
+  float alpha = 1.f;
+  if constexpr (EPI == EPI_F32) { if (p.alpha_dev) alpha = *p.alpha_dev; }
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int tl = (int)(idx / per_tile), q = (int)(idx % per_tile);
+    const int pid = xcd_remap(p.full_tiles + tl, nwg);
+    const int per_group = GROUP_M * p.tiles_n;
+    const int gid = pid / per_group, first_m = gid * GROUP_M;
+    const int gsz = min(p.tiles_m - first_m, GROUP_M);
+    const int tm = first_m + (pid % per_group) % gsz;
+    const int tn = (pid % per_group) / gsz;
+    const int ml = q / (PBN / 4), nl = (q % (PBN / 4)) * 4;
+    float4* src = reinterpret_cast<float4*>(p.tail_ws + (int64_t)tl * (PBM * PBN) + ml * PBN + nl);
+    const float4 v4 = *src;
+    *src = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int m = tm * PBM + ml, n = tn * PBN + nl;
+    if (m >= p.M || n >= p.N) continue;
+    float v[4] = {v4.x, v4.y, v4.z, v4.w};
+    for (int r = 0; r < 4 && n + r < p.N; ++r) {
+      if constexpr (EPI == EPI_BF16) {
+        float o = v[r];
+        if (p.bias) o += bf2f(p.bias[n + r]);
+        reinterpret_cast<bf16_t*>(p.C)[(int64_t)m * p.ldc + n + r] = f2bf(o);
+      } else if constexpr (EPI == EPI_F32) {
+        float* c = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n + r;
+        *c = (p.beta ? *c : 0.f) + v[r] * alpha;
+      } else {
+        reinterpret_cast<float*>(p.C)[(int64_t)m * p.ldc + n + r] = p.resid[(int64_t)m * p.ldr + n + r] + bf2f(f2bf(v[r]));
+      }
+    }
+  }
+}
+
+// scratch of the k-sliced tail tiles: up to 128 tiles x 256 KiB, allocated on first use (zeroed; the finisher re-zeroes)
+float* g_tail_ws = nullptr;
+bool ensure_tail_ws(int ntiles) {
+  if (ntiles > 128) return false;
+  if (!g_tail_ws) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipMalloc(&g_tail_ws, (size_t)128 * PBM * PBN * sizeof(float)) != hipSuccess) { g_tail_ws = nullptr; (void)hipGetLastError(); return false; }
+    if (hipMemset(g_tail_ws, 0, (size_t)128 * PBM * PBN * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return false; }
+    (void)cs;
+  }
+  return true;
 }
 
 int g_tile_policy = -1;   // -1 auto, 0 two LDS stages, 2 one LDS stage, 3 staggered 256x256 (ug_gemm_set_tile_policy; A/B runs)
@@ -444,10 +521,24 @@ int launch(GemmArgs a, hipStream_t st) {
   const int tiles_p8 = ((a.M + PBM - 1) / PBM) * ((a.N + PBN - 1) / PBN);
   const int rounds = (tiles_p8 + 255) / 256;
   const bool p8_fits = (tiles_p8 <= 256) ? (tiles_p8 >= 200) : (4 * tiles_p8 >= 3 * rounds * 256);
-  if (g_tile_policy == 3 || (g_tile_policy < 0 && p8_fits)) {
+  // A partial last round of 256x256 tiles is cut along K instead: r = tiles mod 256 leftover tiles x s slices fill
+  // the chip once more for 1/s of a tile time (fp32 atomics into a scratch, then tail_finish applies the epilogue).
+  int tail_r = 0, tail_s = 1;
+  if (!p8_fits && tiles_p8 > 256 && (tiles_p8 % 256) <= 128 && g_tile_policy != 5) {
+    const int r = tiles_p8 % 256, nk32 = (a.K + PBK - 1) / PBK;
+    int sp = 256 / r;
+    while (sp > 1 && nk32 / sp < 64) --sp;       // measured: slices shorter than ~2048 of K lose to the 128x128 kernel
+    if ((sp >= 5 || g_tile_policy == 6) && sp >= 2 && ensure_tail_ws(r)) { tail_r = r; tail_s = sp; }
+  }
+  if (g_tile_policy == 3 || g_tile_policy == 6 || (g_tile_policy < 0 && (p8_fits || tail_s > 1))) {
     a.tiles_m = (a.M + PBM - 1) / PBM; a.tiles_n = (a.N + PBN - 1) / PBN;
-    hipLaunchKernelGGL((gemm_kernel_p8<EPI, AK, BKM>), dim3(a.tiles_m * a.tiles_n), dim3(512), 0, st, a);
+    a.full_tiles = tiles_p8 - tail_r; a.tail_split = tail_s; a.tail_ws = g_tail_ws;
+    hipLaunchKernelGGL((gemm_kernel_p8<EPI, AK, BKM>), dim3(a.full_tiles + tail_r * tail_s), dim3(512), 0, st, a);
     UG_CHECK_LAUNCH("ug_gemm_bf16(p8)");
+    if (tail_s > 1) {
+      hipLaunchKernelGGL((tail_finish_kernel<EPI>), dim3(tail_r * 16), dim3(256), 0, st, a, tail_r);
+      UG_CHECK_LAUNCH("ug_gemm_bf16(tail finish)");
+    }
     return UG_OK;
   }
   bool dbuf = (!AK && !BKM && a.K >= 4096);

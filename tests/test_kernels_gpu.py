@@ -92,6 +92,37 @@ def test_gemm_bf16_layouts(dev, tile_policy, mode, M, N, K):
         assert ((r32[:, :N].cpu() - want).abs() <= ref.abs() * 2.0 ** -7 + 1e-3).all()
 
 
+@pytest.mark.parametrize("mode", ["nt", "dgrad", "wgrad"])
+def test_gemm_bf16_partial_last_round(dev, mode):
+    """288 tiles of 256x256 = one full round + 32 leftover tiles: the leftovers are cut along K into fp32-scratch slices
+    and finished by a second kernel (auto policy); all three epilogues, ragged M / N / K, scratch left zeroed (re-run)."""
+    ops = _ops()
+    ops.set_gemm_tile_policy(6)          # staggered kernel with the k-sliced tail forced on (auto needs K >= ~10k)
+    ak, bk = {"nt": (False, False), "dgrad": (False, True), "wgrad": (True, True)}[mode]
+    M, N, K = 4400, 4000, 3104
+    g = torch.Generator().manual_seed(99)
+    a = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16)
+    b = (torch.randn(N, K, generator=g) * 0.5).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g).to(torch.bfloat16)
+    ref = a.float() @ b.float().t()
+    A = (a.t().contiguous() if ak else a).to(dev)
+    B = (b.t().contiguous() if bk else b).to(dev)
+    for rep in range(2):
+        cbuf = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
+        ops.gemm(A, B, out=cbuf, M=M, N=N, K=K, a_kmajor=ak, b_kmajor=bk, bias=bias.to(dev))
+        assert _rel(cbuf, ref + bias.float()) < 4e-3, rep
+    c32 = torch.ones(M, N, dtype=torch.float32, device=dev)
+    ops.gemm(A, B, out=c32, M=M, N=N, K=K, a_kmajor=ak, b_kmajor=bk, epilogue=ops.UG_EPI_F32, beta=1)
+    assert _rel(c32, ref + 1.0) < 1e-5 * math.sqrt(K) + 1e-6
+    if mode == "nt":
+        res = torch.randn(M, N, generator=g)
+        r32 = torch.empty(M, N, dtype=torch.float32, device=dev)
+        ops.gemm(A, B, out=r32, M=M, N=N, K=K, epilogue=ops.UG_EPI_RESID, resid=res.to(dev))
+        want = res + ref.to(torch.bfloat16).float()
+        assert ((r32.cpu() - want).abs() <= ref.abs() * 2.0 ** -7 + 1e-3).all()
+    ops.set_gemm_tile_policy(-1)
+
+
 def test_gemm_rejects_bad_args(dev):
     ops = _ops()
     from unigen_hip.lib import UniGenHipError
