@@ -287,12 +287,34 @@ class UniGen(ModelMixin, ConfigMixin):
             prefix = torch.cat([prefix, un_prefix])
             suffix = torch.cat([suffix, suffix])
         sampled_ids = None
+        eng = self.llm.engine
+        L = prefix.shape[1] + n + 1
+        seg_start = L - n - 2                        # <soi> | n image tokens | <eoi>
+        # Prefix rows (padding + text) must not see the image segment for their keys / values to be round-invariant;
+        # true for every mask the reference builds (create_attention_mask_predict_next), checked on the mask given.
+        incremental = bool(kwargs.get("incremental", True)) and not torch.is_grad_enabled() and attention_mask is not None \
+            and torch.is_tensor(attention_mask) and attention_mask.dim() == 4 \
+            and not bool((attention_mask[:, 0, :seg_start, seg_start:] == 0).any())
+        sess = None
         for step in range(timesteps):
             img = torch.cat([image_embeddings, image_embeddings]) if cfg else image_embeddings
-            seq = torch.cat([prefix, img, suffix], 1)
-            out = self(input_ids=input_ids, input_embeddings=seq, attention_mask=attention_mask)
-            # only the image positions x codebook columns are ever read (reference slices the dense logits)
-            lg = out[:, -(n + 1):-1, text_vocab_size:-1]
+            if incremental:
+                R = img.shape[0]
+                if sess is None:
+                    seq = torch.cat([prefix, img, suffix], 1).float()
+                    mb = eng.mask_bits(attention_mask, R, L)
+                    sess, hn = eng.maskgit_begin(seq.reshape(R * L, -1).contiguous(), mb, L, seg_start)
+                    eng.check_errors()
+                else:
+                    seg = torch.cat([prefix[:, -1:], img, suffix], 1).float()
+                    hn = eng.maskgit_step(sess, seg.reshape(R * (n + 2), -1).contiguous())
+                rows = hn.view(R, n + 2, -1)[:, 1:n + 1].reshape(R * n, -1).contiguous()
+                lg = eng.head_slice(rows, text_vocab_size, self.vocab_size - 1).reshape(R, n, -1)
+            else:
+                seq = torch.cat([prefix, img, suffix], 1)
+                out = self(input_ids=input_ids, input_embeddings=seq, attention_mask=attention_mask)
+                # only the image positions x codebook columns are ever read (reference slices the dense logits)
+                lg = out[:, -(n + 1):-1, text_vocab_size:-1]
             ratio = 1.0 * (step + 1) / timesteps
             mask_len = int(torch.floor(n * noise_schedule(torch.tensor(ratio))).item())
             temperature = temperature * (1.0 - ratio)

@@ -13,6 +13,8 @@ Memory plan (sized for 288 GB HBM3E, no activation recompute):
 """
 import math
 
+import types
+
 import torch
 import torch.nn as nn
 
@@ -172,6 +174,49 @@ class Qwen2Engine:
             h = self.layer_fwd(i, h, mb, L, save)
         hn, rstd = ops.rmsnorm_fwd(h, self.fp.p("norm"), self.dims.rms_norm_eps)
         return h, hn, rstd
+
+    # ---------------------------------------------------------------- incremental MaskGIT rounds
+    def maskgit_begin(self, h0, mb, L, seg_start):
+        """First round of UniGen.t2i_generate: a full forward that keeps every layer's (post-RoPE) q/k/v.  The rows before
+        `seg_start` (padding + text) are causal and never see the image segment, so their keys / values are the same in
+        every later round; only the segment rows [seg_start, L) are recomputed by maskgit_step.
+        h0 fp32 [B*L, H] -> (session, final-norm hidden of the segment rows bf16 [B*S, H])."""
+        self.fp.refresh_compute_copies()
+        B = h0.shape[0] // L
+        saved, h = [], h0
+        for i in range(self.dims.num_hidden_layers):
+            h = self.layer_fwd(i, h, mb, L, saved)
+        sess = types.SimpleNamespace()
+        sess.qkv = [s.qkv for s in saved]
+        sess.mb, sess.B, sess.L, sess.P, sess.S = mb, B, L, seg_start, L - seg_start
+        r = torch.arange(seg_start, L, device=self.device)
+        sess.rows = (torch.arange(B, device=self.device)[:, None] * L + r[None, :]).reshape(-1).contiguous()
+        cos, sin = self.rope(L)
+        sess.cos, sess.sin = cos[seg_start:].contiguous(), sin[seg_start:].contiguous()
+        hn, _ = ops.rmsnorm_fwd(h.view(B, L, -1)[:, seg_start:].reshape(B * sess.S, -1).contiguous(), self.fp.p("norm"),
+                                self.dims.rms_norm_eps, want_rstd=False)
+        return sess, hn
+
+    def maskgit_step(self, sess, seg):
+        """seg fp32 [B*S, H] = embeddings of the segment rows this round -> final-norm hidden bf16 [B*S, H].  All GEMMs and
+        norms run on the B*S segment rows only; attention runs over the full sequence from the per-layer q/k/v buffers
+        (prefix rows cached, segment rows refreshed in place)."""
+        d, fp = self.dims, self.fp
+        Hq, Hk, hd = d.num_attention_heads, d.num_key_value_heads, d.head_dim
+        h = seg
+        for i in range(d.num_hidden_layers):
+            xn1, _ = ops.rmsnorm_fwd(h, fp.p(f"l{i}.ln1"), d.rms_norm_eps, want_rstd=False)
+            qkv_s = ops.gemm_nt(xn1, fp.w(f"l{i}.wqkv"), bias=fp.w(f"l{i}.bqkv"))
+            ops.rope_(qkv_s, sess.cos, sess.sin, sess.S, Hq + Hk, hd)          # row r sits at position seg_start + r % S
+            ops.scatter_rows_(qkv_s, sess.rows, sess.qkv[i])
+            o, _ = ops.attn_fwd(sess.qkv[i], sess.mb, Hq, Hk, hd)
+            o_s = ops.gather_rows(o, sess.rows)
+            h_mid = ops.gemm_nt(o_s, fp.w(f"l{i}.wo"), epilogue=ops.UG_EPI_RESID, resid=h)
+            xn2, _ = ops.rmsnorm_fwd(h_mid, fp.p(f"l{i}.ln2"), d.rms_norm_eps, want_rstd=False)
+            act = ops.swiglu_fwd(ops.gemm_nt(xn2, fp.w(f"l{i}.wgu")))
+            h = ops.gemm_nt(act, fp.w(f"l{i}.wdown"), epilogue=ops.UG_EPI_RESID, resid=h_mid)
+        hn, _ = ops.rmsnorm_fwd(h, fp.p("norm"), d.rms_norm_eps, want_rstd=False)
+        return hn
 
     # ---------------------------------------------------------------- backward
     def layer_bwd(self, i, s, dh, mb, L):

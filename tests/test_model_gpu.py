@@ -355,3 +355,28 @@ def test_checkpoint_round_trip_and_hf_llm_loading(dev, tmp_path):
     assert torch.equal(own["model.embed_tokens.weight"][:text_v].cpu(), sd["model.embed_tokens.weight"][:text_v])
     assert torch.equal(own["model.layers.1.mlp.down_proj.weight"].cpu(), sd["model.layers.1.mlp.down_proj.weight"])
     assert own["model.embed_tokens.weight"].shape[0] == cfg["vocab_size"]
+
+
+def test_maskgit_incremental_rounds_match_full_recompute(dev):
+    """t2i_generate with the prefix keys / values cached across rounds (only the <soi>..<eoi> rows recomputed) returns
+    the tokens of the round-by-round full forward, same uniforms."""
+    import math
+    g = golden("g2_tiny_unigen.pt")
+    model, _ = _tiny_unigen(g, dev)
+    model.eval()
+    m, ids = g["maskgit"], g["ids"]
+    sched = lambda t: torch.cos(t * math.pi * 0.5)
+    am = additive(m["mask_allow"]).to(dev)
+    outs = []
+    for inc in (False, True):
+        gen = torch.Generator(device=dev).manual_seed(2024)
+        outs.append(model.t2i_generate(input_ids=m["input_ids"].to(dev), uncond_input_ids=m["uncond_ids"].to(dev), attention_mask=am,
+                                       guidance_scale=m["scale"], temperature=1.0, timesteps=6, noise_schedule=sched, generator=gen,
+                                       image_token_num_per_image=16, text_vocab_size=ids["text_vocab"], incremental=inc).cpu())
+    assert torch.equal(outs[0], outs[1]), (outs[0], outs[1])
+    # a mask whose prefix rows can see the image segment disables the cache (falls back to full recompute, no error)
+    bad = am.clone(); bad[:, :, 0, -3] = 0
+    out = model.t2i_generate(input_ids=m["input_ids"].to(dev), uncond_input_ids=m["uncond_ids"].to(dev), attention_mask=bad,
+                             guidance_scale=m["scale"], temperature=1.0, timesteps=2, noise_schedule=sched,
+                             image_token_num_per_image=16, text_vocab_size=ids["text_vocab"])
+    assert out.shape == outs[0].shape
