@@ -60,9 +60,10 @@ int ug_cast_f32_bf16(const float* in, void* out, int64_t n, hipStream_t stream);
  * of the following Linear's input.  x fp32 [rows,cols]; y bf16 (or fp32 if out_f32); rstd optional. */
 int ug_rmsnorm_fwd(const float* x, const float* w, void* y, float* rstd, int64_t rows, int64_t cols,
                    float eps, int out_f32, hipStream_t stream);
-/* dres += d(rmsnorm)/dx . dy ; dw += sum_rows dy * xhat      (dy bf16) */
+/* dres += d(rmsnorm)/dx . dy ; dw += sum_rows dy * xhat      (dy bf16); dres_bf16 (optional): bf16 copy of the
+ * updated dres = the next GEMM's operand, written here instead of by a separate cast pass */
 int ug_rmsnorm_bwd(const void* dy, const float* x, const float* rstd, const float* w, float* dres,
-                   float* dw, int64_t rows, int64_t cols, hipStream_t stream);
+                   float* dw, void* dres_bf16, int64_t rows, int64_t cols, hipStream_t stream);
 /* replaces: apply_rotary_pos_emb (modeling_qwen2.py:113-135); in place on `nheads` consecutive heads of
  * width head_dim starting at qkv (row stride ldq); position of row t is t % L; cos/sin [L, head_dim/2]. */
 int ug_rope(void* qkv, const float* cos_tab, const float* sin_tab, int64_t tokens, int64_t L, int64_t ldq,

@@ -50,7 +50,8 @@ constexpr int RN_MAXV = 8;   // supports cols <= 2048
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ x,
                                                           const float* __restrict__ rstd, const float* __restrict__ w,
                                                           float* __restrict__ dres, float* __restrict__ dw,
-                                                          int rows, int cols, int rows_per_block) {
+                                                          bf16_t* __restrict__ dres_bf16, int rows, int cols,
+                                                          int rows_per_block) {
   __shared__ float red[4][64 * 4];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int nv = cols >> 2;
@@ -88,6 +89,10 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
         o.x += r * (g[k].x - xh[k].x * dot); o.y += r * (g[k].y - xh[k].y * dot);
         o.z += r * (g[k].z - xh[k].z * dot); o.w += r * (g[k].w - xh[k].w * dot);
         dr[i] = o;
+        if (dres_bf16) {          // the next GEMM's bf16 operand, written here instead of by a cast pass over dres
+          uint2 ob; ob.x = pack_bf2(o.x, o.y); ob.y = pack_bf2(o.z, o.w);
+          reinterpret_cast<uint2*>(dres_bf16 + (int64_t)row * cols)[i] = ob;
+        }
       }
     }
   }
@@ -377,15 +382,16 @@ extern "C" int ug_rmsnorm_fwd(const float* x, const float* w, void* y, float* rs
 }
 
 extern "C" int ug_rmsnorm_bwd(const void* dy, const float* x, const float* rstd, const float* w, float* dres,
-                              float* dw, int64_t rows, int64_t cols, hipStream_t st) {
+                              float* dw, void* dres_bf16, int64_t rows, int64_t cols, hipStream_t st) {
   UG_REQUIRE(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= 64 * 4 * RN_MAXV,
              "ug_rmsnorm_bwd: cols=%ld unsupported (multiple of 4, <= %d)", (long)cols, 64 * 4 * RN_MAXV);
   UG_REQUIRE(ug_aligned16(x) && ug_aligned16(w) && ug_aligned16(dres) && ((uintptr_t)dy & 7) == 0,
              "ug_rmsnorm_bwd: pointers must be aligned");
   const int rpb = 32;
   dim3 grid((unsigned)((rows + rpb - 1) / rpb)), block(256);
-  hipLaunchKernelGGL(rmsnorm_bwd_kernel, grid, block, 0, st, (const bf16_t*)dy, x, rstd, w, dres, dw, (int)rows,
-                     (int)cols, rpb);
+  UG_REQUIRE(((uintptr_t)dres_bf16 & 7) == 0, "ug_rmsnorm_bwd: dres_bf16 must be 8-byte aligned");
+  hipLaunchKernelGGL(rmsnorm_bwd_kernel, grid, block, 0, st, (const bf16_t*)dy, x, rstd, w, dres, dw, (bf16_t*)dres_bf16,
+                     (int)rows, (int)cols, rpb);
   UG_CHECK_LAUNCH("ug_rmsnorm_bwd");
   return UG_OK;
 }

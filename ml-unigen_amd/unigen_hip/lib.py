@@ -25,7 +25,7 @@ SIGNATURES = {
     "ug_transpose_cast": [P, I32, I64, P, I64, P, I64, I64, I64, P],
     "ug_cast_f32_bf16": [P, P, I64, P],
     "ug_rmsnorm_fwd": [P, P, P, P, I64, I64, F32, I32, P],
-    "ug_rmsnorm_bwd": [P, P, P, P, P, P, I64, I64, P],
+    "ug_rmsnorm_bwd": [P, P, P, P, P, P, P, I64, I64, P],
     "ug_rope": [P, P, P, I64, I64, I64, I32, I32, I32, P],
     "ug_swiglu_fwd": [P, P, I64, I64, P],
     "ug_swiglu_bwd": [P, P, P, I64, I64, P],

@@ -107,11 +107,14 @@ def rmsnorm_fwd(x, w, eps, out_f32=False, want_rstd=True, out=None):
     return y, rstd
 
 
-def rmsnorm_bwd(dy, x, rstd, w, dres, dw):
-    """dres (fp32 [rows,cols]) += dx ; dw (fp32 [cols]) += sum dy*xhat."""
+def rmsnorm_bwd(dy, x, rstd, w, dres, dw, want_bf16=False):
+    """dres (fp32 [rows,cols]) += dx ; dw (fp32 [cols]) += sum dy*xhat.  want_bf16: also return bf16(dres) (the operand of
+    the GEMMs that consume the updated gradient), written by the same kernel."""
     rows, cols = x.shape
-    _l.check(_l.load().ug_rmsnorm_bwd(_p(dy), _p(x), _p(rstd), _p(w), _p(dres), _p(dw), rows, cols, _stream()),
+    out = torch.empty((rows, cols), dtype=torch.bfloat16, device=x.device) if want_bf16 else None
+    _l.check(_l.load().ug_rmsnorm_bwd(_p(dy), _p(x), _p(rstd), _p(w), _p(dres), _p(dw), _p(out), rows, cols, _stream()),
              "ug_rmsnorm_bwd")
+    return out
 
 
 def rope_tables(L, head_dim, theta, device):

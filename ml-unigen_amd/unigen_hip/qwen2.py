@@ -219,23 +219,23 @@ class Qwen2Engine:
         return hn
 
     # ---------------------------------------------------------------- backward
-    def layer_bwd(self, i, s, dh, mb, L):
+    def layer_bwd(self, i, s, dh, mb, L, dh_bf16=None):
         """dh fp32 [M,H]: grad w.r.t. the layer output on entry, w.r.t. the layer input on exit (in place).
-        Weight gradients accumulate into the flat fp32 grad buffer."""
+        Weight gradients accumulate into the flat fp32 grad buffer.  dh_bf16: bf16(dh) if the producer already has it.
+        Returns (dh, bf16(dh)): every RMSNorm backward also emits the bf16 operand of the GEMMs that follow."""
         d, fp = self.dims, self.fp
         Hq, Hk, hd = d.num_attention_heads, d.num_key_value_heads, d.head_dim
         cos, sin = self.rope(L)
         F32 = ops.UG_EPI_F32
         # ---- MLP   (wgrad: both operands k-major over the token axis; dgrad: weight read k-major)
-        dyd = ops.cast_bf16(dh)
+        dyd = dh_bf16 if dh_bf16 is not None else ops.cast_bf16(dh)
         ops.gemm(dyd, s.act, out=fp.g(f"l{i}.wdown"), a_kmajor=True, b_kmajor=True, epilogue=F32, beta=1)
         dact = ops.gemm(dyd, fp.w(f"l{i}.wdown"), b_kmajor=True)
         dgu = ops.swiglu_bwd(s.gu, dact)
         ops.gemm(dgu, s.xn2, out=fp.g(f"l{i}.wgu"), a_kmajor=True, b_kmajor=True, epilogue=F32, beta=1)
         dxn2 = ops.gemm(dgu, fp.w(f"l{i}.wgu"), b_kmajor=True)
-        ops.rmsnorm_bwd(dxn2, s.h_mid, s.rstd2, fp.p(f"l{i}.ln2"), dh, fp.g(f"l{i}.ln2"))
+        dyo = ops.rmsnorm_bwd(dxn2, s.h_mid, s.rstd2, fp.p(f"l{i}.ln2"), dh, fp.g(f"l{i}.ln2"), want_bf16=True)
         # ---- attention
-        dyo = ops.cast_bf16(dh)
         ops.gemm(dyo, s.o, out=fp.g(f"l{i}.wo"), a_kmajor=True, b_kmajor=True, epilogue=F32, beta=1)
         do = ops.gemm(dyo, fp.w(f"l{i}.wo"), b_kmajor=True)
         dqkv = ops.attn_bwd(s.qkv, s.o, s.lse, do, mb, Hq, Hk, hd)
@@ -243,17 +243,17 @@ class Qwen2Engine:
         ops.colsum_(dqkv, fp.g(f"l{i}.bqkv"))
         ops.gemm(dqkv, s.xn1, out=fp.g(f"l{i}.wqkv"), a_kmajor=True, b_kmajor=True, epilogue=F32, beta=1)
         dxn1 = ops.gemm(dqkv, fp.w(f"l{i}.wqkv"), b_kmajor=True)
-        ops.rmsnorm_bwd(dxn1, s.h, s.rstd1, fp.p(f"l{i}.ln1"), dh, fp.g(f"l{i}.ln1"))
-        return dh
+        dnext = ops.rmsnorm_bwd(dxn1, s.h, s.rstd1, fp.p(f"l{i}.ln1"), dh, fp.g(f"l{i}.ln1"), want_bf16=True)
+        return dh, dnext
 
     def stack_bwd(self, saved, h_last, rstd_last, dhn, mb, L):
         """dhn bf16 [M,H] (grad of the final-norm output) -> dh0 fp32 [M,H]."""
         dh = torch.zeros_like(h_last)
-        ops.rmsnorm_bwd(dhn, h_last, rstd_last, self.fp.p("norm"), dh, self.fp.g("norm"))
+        dh16 = ops.rmsnorm_bwd(dhn, h_last, rstd_last, self.fp.p("norm"), dh, self.fp.g("norm"), want_bf16=True)
         if self.grad_ready_hook:
             self.grad_ready_hook("norm")
         for i in reversed(range(self.dims.num_hidden_layers)):
-            dh = self.layer_bwd(i, saved[i], dh, mb, L)
+            dh, dh16 = self.layer_bwd(i, saved[i], dh, mb, L, dh16)
             saved[i] = None                       # release this layer's activations
             if self.grad_ready_hook:
                 self.grad_ready_hook(i)

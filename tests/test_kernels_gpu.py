@@ -160,10 +160,11 @@ def test_rmsnorm_fwd_bwd(dev):
         dres0 = torch.randn(rows, cols)
         dres = dres0.clone().to(dev)
         dw = torch.zeros(cols, device=dev)
-        ops.rmsnorm_bwd(dy.to(dev), x.to(dev), rstd, w.to(dev), dres, dw)
+        d16 = ops.rmsnorm_bwd(dy.to(dev), x.to(dev), rstd, w.to(dev), dres, dw, want_bf16=True)
         dx_ref, dw_ref = rmsnorm_bwd_ref(dy.float(), x, w, 1e-6)
         assert _rel(dres, dres0 + dx_ref) < 1e-5
         assert _rel(dw, dw_ref) < 1e-5
+        assert torch.equal(d16, dres.to(torch.bfloat16))          # the fused bf16 copy == a cast of the updated gradient
 
 
 def test_rope_fwd_bwd(dev):
