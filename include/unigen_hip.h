@@ -217,10 +217,12 @@ int ug_ar_sample(float* acc, int64_t ldacc, int64_t bsz, int64_t V, float guidan
 int ug_ce_fwd(const void* logits, int64_t ld, int64_t R, int64_t V, const int64_t* labels,
               int64_t ignore_index, float* lse, float* loss_row, float* logp_label, float* loss_and_count,
               hipStream_t stream);
-/* in place: logits <- (softmax - onehot) * (*gscale / count) (valid rows), 0 elsewhere incl. pad cols */
+/* in place: logits <- (softmax - onehot) * (*gscale / count) (valid rows), 0 elsewhere incl. pad cols.
+ * row_scale (optional, fp32 [R]): per-row factor instead of *gscale / count -- the backward of per-row label
+ * log-probabilities (get_batch_logps, training/train_dpo.py:51-90: pass minus the upstream gradient of each row's logp) */
 int ug_ce_bwd(void* logits_inout, int64_t ld, int64_t R, int64_t V, const int64_t* labels,
               int64_t ignore_index, const float* lse, const float* loss_and_count, const float* gscale,
-              hipStream_t stream);
+              const float* row_scale, hipStream_t stream);
 
 /* ---- optimizer ------------------------------------------------------------------------------- */
 /* replaces: torch.optim.AdamW.step (training/train.py:324-330,780) over one flat fp32 segment; also

@@ -67,12 +67,13 @@ __global__ __launch_bounds__(256) void ce_reduce_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void ce_bwd_kernel(bf16_t* __restrict__ logits, int64_t ld, int V,
                                                      const int64_t* __restrict__ labels, int64_t ignore_index,
                                                      const float* __restrict__ lse, const float* __restrict__ loss_cnt,
-                                                     const float* __restrict__ gscale) {
+                                                     const float* __restrict__ gscale, const float* __restrict__ row_scale) {
   const int row = blockIdx.x;
   bf16_t* x = logits + (int64_t)row * ld;
   const int64_t lab = labels[row];
   const bool valid = (lab != ignore_index);
-  const float sc = valid ? (gscale ? *gscale : 1.f) / loss_cnt[1] : 0.f;
+  // mean-CE gradient (*gscale / count) or, with row_scale, an arbitrary upstream gradient per row (log-prob sums of DPO)
+  const float sc = !valid ? 0.f : row_scale ? row_scale[row] : (gscale ? *gscale : 1.f) / loss_cnt[1];
   const float l = lse[row];
   const int nvp = (int)(ld >> 3);
   for (int i = threadIdx.x; i < nvp; i += 256) {
@@ -108,11 +109,11 @@ extern "C" int ug_ce_fwd(const void* logits, int64_t ld, int64_t R, int64_t V, c
 
 extern "C" int ug_ce_bwd(void* logits_inout, int64_t ld, int64_t R, int64_t V, const int64_t* labels,
                          int64_t ignore_index, const float* lse, const float* loss_and_count, const float* gscale,
-                         hipStream_t st) {
+                         const float* row_scale, hipStream_t st) {
   UG_REQUIRE(R > 0 && V > 0 && ld >= V && ld % 8 == 0, "ug_ce_bwd: need ld>=V and ld%%8==0");
-  UG_REQUIRE(ug_aligned16(logits_inout) && labels && lse && loss_and_count, "ug_ce_bwd: bad pointers");
+  UG_REQUIRE(ug_aligned16(logits_inout) && labels && lse && (loss_and_count || row_scale), "ug_ce_bwd: bad pointers");
   hipLaunchKernelGGL(ce_bwd_kernel, dim3((unsigned)R), dim3(256), 0, st, (bf16_t*)logits_inout, ld, (int)V, labels,
-                     ignore_index, lse, loss_and_count, gscale);
+                     ignore_index, lse, loss_and_count, gscale, row_scale);
   UG_CHECK_LAUNCH("ug_ce_bwd");
   return UG_OK;
 }

@@ -470,10 +470,10 @@ def ce_fwd(logits, V, labels, ignore_index=-100, want_logp=False):
     return lc, lse, loss_row, logp
 
 
-def ce_bwd_(logits, V, labels, lse, lc, gscale=None, ignore_index=-100):
+def ce_bwd_(logits, V, labels, lse, lc, gscale=None, ignore_index=-100, row_scale=None):
     R, ld = logits.shape[0], logits.stride(0)
     _l.check(_l.load().ug_ce_bwd(_p(logits), ld, R, V, _p(labels), ignore_index, _p(lse), _p(lc), _p(gscale),
-                                 _stream()), "ug_ce_bwd")
+                                 _p(row_scale), _stream()), "ug_ce_bwd")
     return logits
 
 

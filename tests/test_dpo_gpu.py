@@ -59,3 +59,44 @@ def test_dpo_loss_and_grads_match_oracle(dev):
     ref_g = dict(lm.named_parameters())
     for nme, p in model.llm.named_parameters():
         assert _rel(p.grad, ref_g[nme].grad) < 6e-2, (nme, _rel(p.grad, ref_g[nme].grad))
+
+
+def test_fused_batch_logps_matches_reference_function(dev):
+    """unigen_hip.dpo.get_batch_logps (head on the image rows only + one CE pass, per-row backward) == the reference
+    function applied to the lazy logits: values in both modes / with averaging, and the gradients it sends back."""
+    from unigen_hip.dpo import get_batch_logps
+    from oracle import host_ref
+    g = golden("g2_tiny_unigen.pt")
+    model, _ = _tiny_unigen(g, dev)
+    ids = g["ids"]
+    gen = torch.Generator().manual_seed(12)
+    B, L, n = 4, 40, 16
+    seq = torch.randint(0, 290, (B, L), generator=gen)
+    seq[:, -(n + 2)] = ids["soi"]; seq[:, -1] = ids["eoi"]
+    img = torch.randint(312, 332, (B, n), generator=gen)
+    msk = torch.rand(B, n, generator=gen) < 0.5
+    msk[:, 0] = True
+    seq[:, -(n + 1):-1] = torch.where(msk, ids["mask"], img)
+    labels = torch.full((B, L), -100)
+    labels[:, -(n + 1):-1] = torch.where(msk, img, -100)
+    mask = additive(host_ref.mask_predict_next_ref(seq, ids["pad"], ids["soi"], ids["eoi"], rm_pad_in_image=True)).to(dev)
+    up = torch.randn(B, generator=gen).to(dev)
+    grads = []
+    for fused in (False, True):
+        model.zero_grad(set_to_none=True)
+        lz = model(input_ids=seq.to(dev), attention_mask=mask, batch_size_t2i=B)
+        if fused:
+            lp = get_batch_logps(lz, labels.to(dev), num_vq_tokens=n)
+        else:
+            lp = host_ref.batch_logps_ref(lz.to(torch.float32), labels.to(dev), n)
+        (lp * up).sum().backward()
+        grads.append((lp.detach().float().cpu(), {k: p.grad.clone() for k, p in model.llm.named_parameters()}))
+    assert _rel(grads[1][0], grads[0][0]) < 1e-4
+    for k in grads[0][1]:
+        assert _rel(grads[1][1][k], grads[0][1][k]) < 2e-2, (k, _rel(grads[1][1][k], grads[0][1][k]))
+    lz = model(input_ids=seq.to(dev), attention_mask=mask, batch_size_t2i=B)
+    for mode in ("mask", "ar"):
+        for avg in (False, True):
+            a = get_batch_logps(lz, labels.to(dev), average_log_prob=avg, num_vq_tokens=n, t2i_gen_mode=mode)
+            b = host_ref.batch_logps_ref(lz.to(torch.float32), labels.to(dev), n, average_log_prob=avg, t2i_gen_mode=mode)
+            assert _rel(a, b) < 1e-4, (mode, avg)
