@@ -175,18 +175,19 @@ __device__ __forceinline__ void new_token_pair(const float* __restrict__ arow, c
   }
 }
 
+constexpr int ADF_WAVES = 8;            // one 64-key chunk per wave up to 512 keys: no serialized second chunk
 // Cache attention of one decode step fed by the RAW qkv accumulator: every (row, query head) workgroup rebuilds
 // q and its kv head's new k / v row itself (no dependency between workgroups; the first query head of each kv head
 // also appends the row to the cache), attends to cache keys [0, pos) exactly like attn_decode_kernel, and merges
 // the new token as one more (m, l, O) partial.
-__global__ __launch_bounds__(64 * AD_WAVES) void attn_decode_fused_kernel(
+__global__ __launch_bounds__(64 * ADF_WAVES) void attn_decode_fused_kernel(
     const float* __restrict__ acc_qkv, int64_t lda, const float* __restrict__ ss, float eps, int norm_cols,
     const bf16_t* __restrict__ bias, const float* __restrict__ cs, const float* __restrict__ sn, const int* __restrict__ pos_dev,
     bf16_t* __restrict__ ck, bf16_t* __restrict__ cv, const uint8_t* __restrict__ key_valid, bf16_t* __restrict__ o, int64_t ldo,
     int H, int HKV, int Tmax, int max_pos, float scale) {
   __shared__ float qs[DHD], kn[DHD], vn[DHD];
-  __shared__ float om[AD_WAVES][DHD];
-  __shared__ float ml[AD_WAVES][2];
+  __shared__ float om[ADF_WAVES][DHD];
+  __shared__ float ml[ADF_WAVES][2];
   const int r = blockIdx.y, h = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int hk = h / (H / HKV);
   const int pos0 = *pos_dev;
@@ -226,16 +227,22 @@ __global__ __launch_bounds__(64 * AD_WAVES) void attn_decode_fused_kernel(
   float acc[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) acc[e] = 0.f;
-  for (int t0 = wave * 64; t0 < len; t0 += 64 * AD_WAVES) {
+#pragma unroll 1
+  for (int t0 = wave * 64; t0 < len; t0 += 64 * ADF_WAVES) {
     const int t = t0 + lane;
     float s = -INFINITY;
     if (t0 != wave * 64) load_chunk(t0);                 // later chunks (contexts beyond 256 keys)
     if (t < len && (!key_valid || key_valid[(int64_t)r * Tmax + t])) {
       float d = 0.f;
+      asm volatile("" ::: "memory");           // keep the q reads below inside the chunk loop
 #pragma unroll
-      for (int c = 0; c < DHD / 8; ++c)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) d += bf2f((bf16_t)kf[c][e]) * qs[c * 8 + e];
+      for (int c = 0; c < DHD / 8; ++c) {
+        // q is re-read from LDS (broadcast) where it is used: hoisting all 128 values would not fit 8 waves' registers
+        const float4 q0 = *reinterpret_cast<const float4*>(&qs[c * 8]);
+        const float4 q1 = *reinterpret_cast<const float4*>(&qs[c * 8 + 4]);
+        d += bf2f((bf16_t)kf[c][0]) * q0.x + bf2f((bf16_t)kf[c][1]) * q0.y + bf2f((bf16_t)kf[c][2]) * q0.z + bf2f((bf16_t)kf[c][3]) * q0.w;
+        d += bf2f((bf16_t)kf[c][4]) * q1.x + bf2f((bf16_t)kf[c][5]) * q1.y + bf2f((bf16_t)kf[c][6]) * q1.z + bf2f((bf16_t)kf[c][7]) * q1.w;
+      }
       s = d * scale;
     }
     const float mc = wave_max(s);
@@ -271,11 +278,11 @@ __global__ __launch_bounds__(64 * AD_WAVES) void attn_decode_fused_kernel(
   if (threadIdx.x < DHD) {
     float M = s_new;
 #pragma unroll
-    for (int w = 0; w < AD_WAVES; ++w) M = fmaxf(M, ml[w][0]);
+    for (int w = 0; w < ADF_WAVES; ++w) M = fmaxf(M, ml[w][0]);
     const float wn = __expf(s_new - M);
     float L = wn, O = wn * vn[threadIdx.x];
 #pragma unroll
-    for (int w = 0; w < AD_WAVES; ++w) {
+    for (int w = 0; w < ADF_WAVES; ++w) {
       const float wgt = (ml[w][0] == -INFINITY) ? 0.f : __expf(ml[w][0] - M);
       L += wgt * ml[w][1];
       O += wgt * om[w][threadIdx.x];
@@ -926,7 +933,7 @@ extern "C" int ug_attn_decode_fused(const float* acc_qkv, int64_t ldacc, const f
                                     int H, int HKV, int head_dim, int64_t Tmax, int64_t max_pos, float scale, hipStream_t st) {
   UG_REQUIRE(rows > 0 && head_dim == DHD && H % HKV == 0 && acc_qkv && ss_in && norm_cols > 0 && pos_dev && cache_k && cache_v && o,
              "ug_attn_decode_fused: bad args");
-  hipLaunchKernelGGL(attn_decode_fused_kernel, dim3(H, (unsigned)rows), dim3(64 * AD_WAVES), 0, st, acc_qkv, ldacc, ss_in, eps,
+  hipLaunchKernelGGL(attn_decode_fused_kernel, dim3(H, (unsigned)rows), dim3(64 * ADF_WAVES), 0, st, acc_qkv, ldacc, ss_in, eps,
                      (int)norm_cols, (const bf16_t*)bias, cos_tab, sin_tab, pos_dev, (bf16_t*)cache_k, (bf16_t*)cache_v, key_valid,
                      (bf16_t*)o, ldo, H, HKV, (int)Tmax, (int)max_pos, scale);
   UG_CHECK_LAUNCH("ug_attn_decode_fused");
