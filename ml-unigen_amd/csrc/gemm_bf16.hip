@@ -60,6 +60,7 @@ struct GemmArgs {
   // `tail_split` k-slices that add into the fp32 scratch tail_ws[tile - full_tiles][256][256] (finished by tail_finish)
   int full_tiles, tail_split;
   float* tail_ws;
+  int tail_private;        // 1: every k-slice stores its own [256][256] partial (no atomics); the finisher sums them
 };
 
 __device__ __forceinline__ int swz_rowk(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
@@ -437,15 +438,21 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p8(GemmArgs p) {
   if (grp == 0) P_BARRIER();                    // balance the barrier count of the staggered group
 
   if (tail) {
-    float* ws = p.tail_ws + (int64_t)(tile_lin - p.full_tiles) * (PBM * PBN);
+    const int64_t slot = p.tail_private ? (int64_t)(tile_lin - p.full_tiles) * p.tail_split + tail_j % p.tail_split
+                                        : (int64_t)(tile_lin - p.full_tiles);
+    float* ws = p.tail_ws + slot * (PBM * PBN);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int ml = grp * 128 + i * 16 + (lane & 15);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float* dst = ws + ml * PBN + wn * 64 + j * 16 + (lane >> 4) * 4;
+        if (p.tail_private) {
+          *reinterpret_cast<float4*>(dst) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) atomicAdd(dst + r, acc[i][j][r]);
+          for (int r = 0; r < 4; ++r) atomicAdd(dst + r, acc[i][j][r]);
+        }
       }
     }
     return;
@@ -471,9 +478,19 @@ __global__ __launch_bounds__(256) void tail_finish_kernel(GemmArgs p, int ntail)
     const int tm = first_m + (pid % per_group) % gsz;
     const int tn = (pid % per_group) / gsz;
     const int ml = q / (PBN / 4), nl = (q % (PBN / 4)) * 4;
-    float4* src = reinterpret_cast<float4*>(p.tail_ws + (int64_t)tl * (PBM * PBN) + ml * PBN + nl);
-    const float4 v4 = *src;
-    *src = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 v4;
+    if (p.tail_private) {      // sum of the k-slices' private partials (a slice past K wrote nothing: skipped)
+      const int nk_all = (p.K + PBK - 1) / PBK, per_split = (nk_all + p.tail_split - 1) / p.tail_split;
+      v4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int sp = 0; sp < p.tail_split && sp * per_split < nk_all; ++sp) {
+        const float4 t = *reinterpret_cast<const float4*>(p.tail_ws + ((int64_t)tl * p.tail_split + sp) * (PBM * PBN) + ml * PBN + nl);
+        v4.x += t.x; v4.y += t.y; v4.z += t.z; v4.w += t.w;
+      }
+    } else {
+      float4* src = reinterpret_cast<float4*>(p.tail_ws + (int64_t)tl * (PBM * PBN) + ml * PBN + nl);
+      v4 = *src;
+      *src = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     const int m = tm * PBM + ml, n = tn * PBN + nl;
     if (m >= p.M || n >= p.N) continue;
     float v[4] = {v4.x, v4.y, v4.z, v4.w};
@@ -492,14 +509,17 @@ __global__ __launch_bounds__(256) void tail_finish_kernel(GemmArgs p, int ntail)
   }
 }
 
-// scratch of the k-sliced tail tiles: up to 128 tiles x 256 KiB, allocated on first use (zeroed; the finisher re-zeroes)
+// scratch of the k-sliced tiles: 128 zeroed slots of 256 KiB for the atomically accumulated tail (the finisher re-zeroes
+// them) followed by 256 slots for private partials; allocated on first use
+constexpr int WS_ATOMIC_SLOTS = 128, WS_PRIVATE_SLOTS = 256;
 float* g_tail_ws = nullptr;
 bool ensure_tail_ws(int ntiles) {
-  if (ntiles > 128) return false;
+  if (ntiles > WS_PRIVATE_SLOTS) return false;
   if (!g_tail_ws) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipMalloc(&g_tail_ws, (size_t)128 * PBM * PBN * sizeof(float)) != hipSuccess) { g_tail_ws = nullptr; (void)hipGetLastError(); return false; }
-    if (hipMemset(g_tail_ws, 0, (size_t)128 * PBM * PBN * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return false; }
+    const size_t slots = WS_ATOMIC_SLOTS + WS_PRIVATE_SLOTS;
+    if (hipMalloc(&g_tail_ws, slots * PBM * PBN * sizeof(float)) != hipSuccess) { g_tail_ws = nullptr; (void)hipGetLastError(); return false; }
+    if (hipMemset(g_tail_ws, 0, slots * PBM * PBN * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return false; }
     (void)cs;
   }
   return true;
@@ -528,7 +548,27 @@ int launch(GemmArgs a, hipStream_t st) {
     const int r = tiles_p8 % 256, nk32 = (a.K + PBK - 1) / PBK;
     int sp = 256 / r;
     while (sp > 1 && nk32 / sp < 64) --sp;       // measured: slices shorter than ~2048 of K lose to the 128x128 kernel
-    if ((sp >= 5 || g_tile_policy == 6) && sp >= 2 && ensure_tail_ws(r)) { tail_r = r; tail_s = sp; }
+    if ((sp >= 5 || g_tile_policy == 6) && sp >= 2 && r <= WS_ATOMIC_SLOTS && ensure_tail_ws(r)) { tail_r = r; tail_s = sp; }
+  }
+  // Small accumulating fp32 outputs (weight gradients of the attention projections: 48 / 36 tiles): cut EVERY tile
+  // along K so one round fills the chip, each slice storing a private partial that a finishing pass sums into C.
+  // (The same cut with fp32 atomics was 118-316 TF/s, the 128x128 kernel's 4 atomic slices 353: atomics cost more
+  // than the GEMM itself at these sizes.)
+  if (EPI == EPI_F32 && a.beta == 1 && tiles_p8 >= 24 && tiles_p8 <= 128 && a.M >= 512 && a.N >= 512 &&
+      (g_tile_policy < 0 || g_tile_policy == 8)) {
+    const int nk32 = (a.K + PBK - 1) / PBK;
+    int sp = 256 / tiles_p8;
+    while (sp > 1 && nk32 / sp < 32) --sp;
+    if (sp >= 2 && tiles_p8 * sp <= WS_PRIVATE_SLOTS && ensure_tail_ws(1)) {
+      a.tiles_m = (a.M + PBM - 1) / PBM; a.tiles_n = (a.N + PBN - 1) / PBN;
+      a.full_tiles = 0; a.tail_split = sp; a.tail_private = 1;
+      a.tail_ws = g_tail_ws + (size_t)WS_ATOMIC_SLOTS * PBM * PBN;
+      hipLaunchKernelGGL((gemm_kernel_p8<EPI, AK, BKM>), dim3(tiles_p8 * sp), dim3(512), 0, st, a);
+      UG_CHECK_LAUNCH("ug_gemm_bf16(p8 k-sliced)");
+      hipLaunchKernelGGL((tail_finish_kernel<EPI>), dim3(tiles_p8 * 16), dim3(256), 0, st, a, tiles_p8);
+      UG_CHECK_LAUNCH("ug_gemm_bf16(partial sum)");
+      return UG_OK;
+    }
   }
   if (g_tile_policy == 3 || g_tile_policy == 6 || (g_tile_policy < 0 && (p8_fits || tail_s > 1))) {
     a.tiles_m = (a.M + PBM - 1) / PBM; a.tiles_n = (a.N + PBN - 1) / PBN;

@@ -123,6 +123,23 @@ def test_gemm_bf16_partial_last_round(dev, mode):
     ops.set_gemm_tile_policy(-1)
 
 
+def test_gemm_bf16_small_weight_gradient_private_partials(dev):
+    """Attention-projection-sized weight gradient (48 tiles of 256x256): every tile is cut along K, each slice stores a
+    private fp32 partial, a finishing pass sums them into the accumulating output (auto policy); ragged K, twice in a row."""
+    ops = _ops()
+    ops.set_gemm_tile_policy(-1)
+    M, N, K = 2048, 1536, 5000
+    g = torch.Generator().manual_seed(321)
+    a = (torch.randn(M, K, generator=g) * 0.5).to(torch.bfloat16)
+    b = (torch.randn(N, K, generator=g) * 0.5).to(torch.bfloat16)
+    ref = a.float() @ b.float().t()
+    c32 = torch.full((M, N), 1.5, dtype=torch.float32, device=dev)
+    A, B = a.t().contiguous().to(dev), b.t().contiguous().to(dev)
+    for rep in (1, 2):
+        ops.gemm(A, B, out=c32, M=M, N=N, K=K, a_kmajor=True, b_kmajor=True, epilogue=ops.UG_EPI_F32, beta=1)
+        assert _rel(c32, rep * ref + 1.5) < 1e-5 * math.sqrt(K) + 1e-6, rep
+
+
 def test_gemm_rejects_bad_args(dev):
     ops = _ops()
     from unigen_hip.lib import UniGenHipError
