@@ -547,8 +547,10 @@ int launch(GemmArgs a, hipStream_t st) {
   if (!p8_fits && tiles_p8 > 256 && (tiles_p8 % 256) <= 128 && g_tile_policy != 5) {
     const int r = tiles_p8 % 256, nk32 = (a.K + PBK - 1) / PBK;
     int sp = 256 / r;
-    while (sp > 1 && nk32 / sp < 64) --sp;       // measured: slices shorter than ~2048 of K lose to the 128x128 kernel
-    if ((sp >= 5 || g_tile_policy == 6) && sp >= 2 && r <= WS_ATOMIC_SLOTS && ensure_tail_ws(r)) { tail_r = r; tail_s = sp; }
+    // measured with private partials (tools/gemm_bench.py): slices of >= 40 k-tiles and >= 3 slices win (down fwd
+    // 856 -> 1073, gate_up dgrad 748 -> ~1000 TF/s); the K = 1536 shapes (<= 24 k-tiles per slice) lose to 128x128
+    while (sp > 1 && nk32 / sp < 40) --sp;
+    if ((sp >= 3 || g_tile_policy == 6) && sp >= 2 && r * sp <= WS_PRIVATE_SLOTS && ensure_tail_ws(r)) { tail_r = r; tail_s = sp; }
   }
   // Small accumulating fp32 outputs (weight gradients of the attention projections: 48 / 36 tiles): cut EVERY tile
   // along K so one round fills the chip, each slice storing a private partial that a finishing pass sums into C.
@@ -572,7 +574,9 @@ int launch(GemmArgs a, hipStream_t st) {
   }
   if (g_tile_policy == 3 || g_tile_policy == 6 || (g_tile_policy < 0 && (p8_fits || tail_s > 1))) {
     a.tiles_m = (a.M + PBM - 1) / PBM; a.tiles_n = (a.N + PBN - 1) / PBN;
-    a.full_tiles = tiles_p8 - tail_r; a.tail_split = tail_s; a.tail_ws = g_tail_ws;
+    a.full_tiles = tiles_p8 - tail_r; a.tail_split = tail_s;
+    a.tail_private = 1;                          // private partials beat atomics here too (gate_up dgrad 886 -> see DESIGN)
+    a.tail_ws = g_tail_ws ? g_tail_ws + (size_t)WS_ATOMIC_SLOTS * PBM * PBN : nullptr;
     hipLaunchKernelGGL((gemm_kernel_p8<EPI, AK, BKM>), dim3(a.full_tiles + tail_r * tail_s), dim3(512), 0, st, a);
     UG_CHECK_LAUNCH("ug_gemm_bf16(p8)");
     if (tail_s > 1) {
