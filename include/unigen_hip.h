@@ -10,8 +10,9 @@
  *     a hipStream_t.  No torch types.  bf16 tensors are passed as void* (raw 16-bit storage).
  *   - every function returns 0 on success or a negative error class (UG_ERR_*); the message is
  *     available from ug_last_error() (thread-local).  Nothing throws or aborts across the boundary.
- *   - every tensor is owned by the caller; the library allocates nothing, never frees caller memory,
- *     never synchronises the device, and launches only on the stream it is given (so every entry is
+ *   - every tensor is owned by the caller; the library never frees caller memory, allocates only one lazily
+ *     created device scratch (k-sliced GEMM partials), never synchronises the device, and launches only on the
+ *     stream it is given (so every entry is
  *     legal inside a hipGraph capture).
  *   - shape / alignment requirements are checked at entry and fail loudly (UG_ERR_ARG).
  */
