@@ -556,7 +556,7 @@ int launch(GemmArgs a, hipStream_t st) {
   // along K so one round fills the chip, each slice storing a private partial that a finishing pass sums into C.
   // (The same cut with fp32 atomics was 118-316 TF/s, the 128x128 kernel's 4 atomic slices 353: atomics cost more
   // than the GEMM itself at these sizes.)
-  if (EPI == EPI_F32 && a.beta == 1 && tiles_p8 >= 24 && tiles_p8 <= 128 && a.M >= 512 && a.N >= 512 &&
+  if (EPI == EPI_F32 && tiles_p8 >= 24 && tiles_p8 <= 128 && a.M >= 512 && a.N >= 512 &&
       (g_tile_policy < 0 || g_tile_policy == 8)) {
     const int nk32 = (a.K + PBK - 1) / PBK;
     int sp = 256 / tiles_p8;

@@ -379,7 +379,7 @@ class TrainEngine(Qwen2Engine):
         views = self.__dict__.get("_grad_views", {})
         probe = views.get("model.norm.weight")
         if probe is not None and probe[0].grad is None:
-            self.fp.grad.zero_()
+            self.fp.clear_grads()
             for p, g in views.values():
                 p.grad = g
 
