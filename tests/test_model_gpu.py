@@ -380,3 +380,30 @@ def test_maskgit_incremental_rounds_match_full_recompute(dev):
                              guidance_scale=m["scale"], temperature=1.0, timesteps=2, noise_schedule=sched,
                              image_token_num_per_image=16, text_vocab_size=ids["text_vocab"])
     assert out.shape == outs[0].shape
+
+
+def test_gradient_accumulation_and_fresh_write_semantics(dev):
+    """Weight gradients: the first backward after zero_grad(set_to_none=True) OVERWRITES the big matrices (no zero fill),
+    a second backward without zero_grad ACCUMULATES, and stale values from an earlier step never leak through."""
+    g = golden("g2_tiny_unigen.pt")
+    model, _ = _tiny_unigen(g, dev)
+    model.train()
+    mask = additive(g["mask_allow"]).to(dev)
+    ids, labels = g["input_ids"].to(dev), g["labels"].to(dev)
+
+    def run():
+        _, l1, l2, l3 = model(input_ids=ids, attention_mask=mask, labels=labels, **g["kw"])
+        (l1 + 0.1 * l2 + l3).backward()
+    params = dict(model.llm.named_parameters())
+    names = ["model.layers.0.self_attn.q_proj.weight", "model.layers.1.mlp.down_proj.weight", "model.layers.1.mlp.gate_proj.weight",
+             "model.layers.0.self_attn.o_proj.weight", "model.norm.weight", "model.embed_tokens.weight", "model.layers.0.self_attn.k_proj.bias"]
+    run()
+    once = {n: params[n].grad.clone() for n in names}
+    run()                                                   # accumulate
+    for n in names:
+        assert _rel(params[n].grad, 2 * once[n]) < 2e-3, n
+    model.zero_grad(set_to_none=True)
+    model.llm.engine.fp.grad.fill_(123.0)                   # poison: anything not rewritten or cleared would show
+    run()
+    for n in names:
+        assert _rel(params[n].grad, once[n]) < 2e-3, n
