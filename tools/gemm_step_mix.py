@@ -1,0 +1,30 @@
+"""Every distinct bf16 GEMM of one training step exactly once (the 12 per-layer launches at M = 12336 tokens + the
+lm-head trio on 4096 label rows), for rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes: HBM-side traffic per launch."""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ml-unigen_amd"))
+import torch
+from unigen_hip import ops
+dev = torch.device("cuda:0")
+M = 12336
+shapes = {"qkv": (2048, 1536), "o": (1536, 1536), "gu": (17920, 1536), "down": (1536, 8960)}
+bufs = []
+for name, (N, K) in shapes.items():
+    x = torch.randn(M, K, device=dev).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=dev) * 0.02).to(torch.bfloat16)
+    dy = torch.randn(M, N, device=dev).to(torch.bfloat16)
+    gw = torch.zeros(N, K, device=dev)
+    bufs.append((x, w, dy, gw))
+R, V, H = 4096, 159867, 1536
+hn = torch.randn(R, H, device=dev).to(torch.bfloat16)
+emb = (torch.randn(V, H, device=dev) * 0.02).to(torch.bfloat16)
+logits = torch.empty(R, 159872, dtype=torch.bfloat16, device=dev)
+gemb = torch.zeros(V, H, device=dev)
+torch.cuda.synchronize()
+for x, w, dy, gw in bufs:
+    ops.gemm(x, w)
+    ops.gemm(dy, w, b_kmajor=True)
+    ops.gemm(dy, x, out=gw, a_kmajor=True, b_kmajor=True, epilogue=ops.UG_EPI_F32, beta=1)
+ops.gemm(hn, emb, out=logits, N=V, K=H)
+ops.gemm(logits, hn, out=gemb, M=V, N=H, K=R, a_kmajor=True, b_kmajor=True, epilogue=ops.UG_EPI_F32, beta=1)
+ops.gemm(logits, emb, M=R, N=H, K=V, b_kmajor=True)
+torch.cuda.synchronize()
