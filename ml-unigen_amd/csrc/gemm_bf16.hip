@@ -509,9 +509,8 @@ __global__ __launch_bounds__(256) void tail_finish_kernel(GemmArgs p, int ntail)
   }
 }
 
-// scratch of the k-sliced tiles: 128 zeroed slots of 256 KiB for the atomically accumulated tail (the finisher re-zeroes
-// them) followed by 256 slots for private partials; allocated on first use
-constexpr int WS_ATOMIC_SLOTS = 128, WS_PRIVATE_SLOTS = 256;
+// scratch of the k-sliced tiles: 768 slots of 256 KiB for private partials; allocated on first use
+constexpr int WS_ATOMIC_SLOTS = 0, WS_PRIVATE_SLOTS = 768;     // 192 MiB: room for 3 rounds of k-slices
 float* g_tail_ws = nullptr;
 bool ensure_tail_ws(int ntiles) {
   if (ntiles > WS_PRIVATE_SLOTS) return false;
@@ -556,12 +555,23 @@ int launch(GemmArgs a, hipStream_t st) {
   // along K so one round fills the chip, each slice storing a private partial that a finishing pass sums into C.
   // (The same cut with fp32 atomics was 118-316 TF/s, the 128x128 kernel's 4 atomic slices 353: atomics cost more
   // than the GEMM itself at these sizes.)
-  if (EPI == EPI_F32 && tiles_p8 >= 24 && tiles_p8 <= 128 && a.M >= 512 && a.N >= 512 &&
-      (g_tile_policy < 0 || g_tile_policy == 8)) {
+  {
     const int nk32 = (a.K + PBK - 1) / PBK;
-    int sp = 256 / tiles_p8;
-    while (sp > 1 && nk32 / sp < 32) --sp;
-    if (sp >= 2 && tiles_p8 * sp <= WS_PRIVATE_SLOTS && ensure_tail_ws(1)) {
+    int sp = 0;
+    if (EPI == EPI_F32 && tiles_p8 >= 24 && tiles_p8 <= 128 && a.M >= 512 && a.N >= 512) {
+      sp = 256 / tiles_p8;                               // one round
+      while (sp > 1 && nk32 / sp < 32) --sp;
+    } else if (tiles_p8 >= 24 && tiles_p8 <= 128 && nk32 >= 2048) {
+      // few output tiles, very long contraction (lm-head dgrad: 96 tiles, K = 159 867): up to three rounds of slices,
+      // the count that fills whole rounds best (632 -> 1094 TF/s)
+      float best = 0.f;
+      for (int c = 2; c <= 8 && tiles_p8 * c <= WS_PRIVATE_SLOTS; ++c) {
+        const int items = tiles_p8 * c, r = (items + 255) / 256;
+        const float eff = (float)items / (float)(r * 256);
+        if (eff > best + 0.01f) { best = eff; sp = c; }
+      }
+    }
+    if (sp >= 2 && tiles_p8 * sp <= WS_PRIVATE_SLOTS && (g_tile_policy < 0 || g_tile_policy == 8) && ensure_tail_ws(1)) {
       a.tiles_m = (a.M + PBM - 1) / PBM; a.tiles_n = (a.N + PBN - 1) / PBN;
       a.full_tiles = 0; a.tail_split = sp; a.tail_private = 1;
       a.tail_ws = g_tail_ws + (size_t)WS_ATOMIC_SLOTS * PBM * PBN;

@@ -140,6 +140,22 @@ def test_gemm_bf16_small_weight_gradient_private_partials(dev):
         assert _rel(c32, rep * ref + 1.5) < 1e-5 * math.sqrt(K) + 1e-6, rep
 
 
+def test_gemm_bf16_long_contraction_few_tiles(dev):
+    """lm-head dgrad shape class: 48 output tiles, K = 70 000 -- every tile is cut along K over several rounds with private
+    partials and a summing pass that applies the bf16 epilogue (auto policy).  Reference: fp32 matmul on the same device
+    (210 GFLOP is too much for the CPU oracle; the k-sliced path is also covered against the CPU on smaller shapes above)."""
+    ops = _ops()
+    ops.set_gemm_tile_policy(-1)
+    M, N, K = 2000, 1500, 70000
+    g = torch.Generator(device=dev).manual_seed(5)
+    a = (torch.randn(M, K, device=dev, generator=g) * 0.1).to(torch.bfloat16)
+    bt = (torch.randn(K, N + 4, device=dev, generator=g) * 0.1).to(torch.bfloat16)        # B k-major, ld = N + 4
+    ref = a.float() @ bt[:, :N].float()
+    out = torch.zeros(M, N + 4, dtype=torch.bfloat16, device=dev)
+    ops.gemm(a, bt, out=out, M=M, N=N, K=K, b_kmajor=True)
+    assert _rel(out[:, :N], ref) < 4e-3 and float(out[:, N:].abs().max()) == 0.0
+
+
 def test_gemm_rejects_bad_args(dev):
     ops = _ops()
     from unigen_hip.lib import UniGenHipError
