@@ -317,24 +317,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   }
 }
 
-// ================================================================== delta = rowsum(dO * O)
-// one wave per (token, head)
-__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
-                                                         float* __restrict__ delta, int64_t ldo, int B, int L, int H) {
-  const int64_t wid = blockIdx.x * 4LL + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (wid >= (int64_t)B * L * H) return;
-  const int h = (int)(wid % H);
-  const int64_t tok = wid / H;
-  const bf16x2_t a = *reinterpret_cast<const bf16x2_t*>(o + tok * ldo + h * HD + lane * 2);
-  const bf16x2_t d = *reinterpret_cast<const bf16x2_t*>(dout + tok * ldo + h * HD + lane * 2);
-  float s = bf2f((bf16_t)a[0]) * bf2f((bf16_t)d[0]) + bf2f((bf16_t)a[1]) * bf2f((bf16_t)d[1]);
-  s = wave_sum(s);
-  if (lane == 0) { const int b = (int)(tok / L), t = (int)(tok % L); delta[((int64_t)b * H + h) * L + t] = s; }
-}
-
-// ================================================================== backward: dQ
-// grid (nQtiles, H, B); same walk as the forward, recomputing P^T from the saved log-sum-exp
+// ================================================================== backward: dQ  (also delta = rowsum(dO * O))
+// grid (nQtiles, H, B)
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
   __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * RM_LD];
   __shared__ __attribute__((aligned(16))) bf16_t Vs[64 * RM_LD];
@@ -357,7 +341,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
     dof[ks] = *reinterpret_cast<const bf16x8_t*>(doseq + (int64_t)qrow_c * p.ldo + ks * 32 + g * 8);
   }
   const float lse = p.lse[((int64_t)b * p.H + h) * p.L + qrow_c];
-  const float dl = p.delta[((int64_t)b * p.H + h) * p.L + qrow_c];
+  // delta = rowsum(dO * O) of this lane's query row, computed here (the four lanes g = 0..3 of a row hold its 128 dims)
+  // and published for the dK/dV kernel that runs next: no separate pass over O and dO
+  float dl = 0.f;
+  {
+    const bf16_t* oseq = p.o + (int64_t)b * p.L * p.ldo + h * HD;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const bf16x8_t of = *reinterpret_cast<const bf16x8_t*>(oseq + (int64_t)qrow_c * p.ldo + ks * 32 + g * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dl += bf2f((bf16_t)of[e]) * bf2f((bf16_t)dof[ks][e]);
+    }
+    dl += __shfl_xor(dl, 16, 64);
+    dl += __shfl_xor(dl, 32, 64);
+    if (g == 0 && qrow < p.L) const_cast<float*>(p.delta)[((int64_t)b * p.H + h) * p.L + qrow] = dl;
+  }
   f32x4_t dqt[8];
 #pragma unroll
   for (int d = 0; d < 8; ++d) dqt[d] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -651,14 +649,11 @@ extern "C" int ug_attn_bwd(const void* q, const void* k, const void* v, int64_t 
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v;
   a.qT = (const bf16_t*)qT; a.kT = (const bf16_t*)kT; a.doT = (const bf16_t*)doT;
   a.dout = (const bf16_t*)dout; a.lse = const_cast<float*>(lse); a.delta = delta;
+  a.o = const_cast<bf16_t*>((const bf16_t*)o);
   a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.dkv_ws = dkv_ws;
   a.bits = bits; a.tileany = tileany;
   a.ldq = ldq; a.ldo = ldo; a.ldg = ldg; a.B = (int)B; a.L = (int)L; a.Lp = (int)Lp; a.nW = (int)((L + 63) / 64);
   a.H = H; a.HKV = HKV; a.scale = scale;
-  const int64_t nwaves = B * L * H;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, st, (const bf16_t*)o,
-                     (const bf16_t*)dout, delta, ldo, (int)B, (int)L, H);
-  UG_CHECK_LAUNCH("ug_attn_bwd(delta)");
   hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(a.nW, H, (unsigned)B), dim3(256), 0, st, a);
   UG_CHECK_LAUNCH("ug_attn_bwd(dq)");
   if (dkv_ws) {
