@@ -765,3 +765,39 @@ def test_ar_sample_kernel_matches_restatement(dev, greedy):
     assert torch.equal(out[:, step].cpu().long(), got) and int(out.cpu().abs().sum()) == int(got.sum())
     assert torch.equal(x[:bsz].cpu(), emb[got + off]) and torch.equal(x[bsz:].cpu(), emb[got + off])
     assert float(acc_d.abs().max()) == 0.0
+
+
+@pytest.mark.gpu
+def test_gemm_bf16_randomised_shapes_against_device_fp32(dev):
+    """Seeded sweep over shapes that land on every dispatch path (128x128 single / two-stage, staggered 256x256, k-sliced
+    tail, k-sliced small outputs), all layouts and epilogues, ragged M / N / K; reference = fp32 matmul on the device."""
+    ops = _ops()
+    ops.set_gemm_tile_policy(-1)
+    rng = torch.Generator().manual_seed(2718)
+    cases = [(4400, 4000, 3104), (2048, 1536, 5000), (1536, 1536, 4104), (2300, 1800, 2600), (5000, 2100, 1288), (12336, 1536, 2048),
+             (777, 333, 1000), (3100, 3000, 640), (4608, 5120, 1296), (1200, 2500, 9000)]
+    gen = torch.Generator(device=dev).manual_seed(1)
+    for (M, N, K) in cases:
+        mode = int(torch.randint(0, 3, (1,), generator=rng))
+        ak, bk = [(False, False), (False, True), (True, True)][mode]
+        if not ak and not bk:
+            K = K // 8 * 8
+        a = (torch.randn(M, K, device=dev, generator=gen) * 0.3).to(torch.bfloat16)
+        b = (torch.randn(N, K, device=dev, generator=gen) * 0.3).to(torch.bfloat16)
+        ref = a.float() @ b.float().t()
+        A = a.t().contiguous() if ak else a
+        B = b.t().contiguous() if bk else b
+        if ak:       # k-major leading dimensions must be multiples of 8
+            A = torch.nn.functional.pad(A, (0, (-M) % 8))
+        if bk:
+            B = torch.nn.functional.pad(B, (0, (-N) % 8))
+        ldc = (N + 7) // 8 * 8
+        out = torch.zeros(M, ldc, dtype=torch.bfloat16, device=dev)
+        ops.gemm(A, B, out=out, M=M, N=N, K=K, a_kmajor=ak, b_kmajor=bk)
+        assert _rel(out[:, :N], ref) < 4e-3, (M, N, K, mode)
+        c32 = torch.full((M, ldc), 0.5, dtype=torch.float32, device=dev)
+        for beta in (1, 0):
+            ops.gemm(A, B, out=c32, M=M, N=N, K=K, a_kmajor=ak, b_kmajor=bk, epilogue=ops.UG_EPI_F32, beta=beta)
+            want = ref + 0.5 if beta else ref
+            assert _rel(c32[:, :N], want) < 1e-5 * math.sqrt(K) + 1e-6, (M, N, K, mode, beta)
+            c32.fill_(0.5)
