@@ -651,15 +651,16 @@ __global__ __launch_bounds__(64) void gemv_ring_kernel(const bf16_t* __restrict_
 // The operand fragments are built cooperatively -- wave w converts k-steps 2w, 2w+1 for all rows and parks them in
 // LDS -- because every wave re-reading the fp32 slab itself costs more L2 bandwidth than the weights cost HBM
 // (measured: gate_up 14.5 -> 28.8 us).
-template <int RB, int KW, int XIN>
-__global__ __launch_bounds__(256) void gemv_ring4_kernel(int R, const bf16_t* __restrict__ W, int64_t ldw,
-                                                         float* __restrict__ acc, int64_t sr, int64_t sn, int N, int K,
-                                                         int nslabs, DecodeIn f) {
-  __shared__ __attribute__((aligned(1024))) char tile[4][2][8192];
+template <int RB, int KW, int XIN, int NW>
+__global__ __launch_bounds__(64 * NW) void gemv_ring4_kernel(int R, const bf16_t* __restrict__ W, int64_t ldw,
+                                                             float* __restrict__ acc, int64_t sr, int64_t sn, int N, int K,
+                                                             int nslabs, DecodeIn f) {
+  __shared__ __attribute__((aligned(1024))) char tile[NW][2][8192];
   __shared__ __attribute__((aligned(16))) bf16x8_t frag[RB][8][64];
+  constexpr int UPW = (8 + NW - 1) / NW;           // k-steps of the operand each wave converts
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, row = lane & 15;
   const int chunk = blockIdx.x / nslabs;
-  const int grp0 = (chunk * 4 + wave) * KW;
+  const int grp0 = (chunk * NW + wave) * KW;
   const int kbase = (blockIdx.x % nslabs) * 256;
   int roff[8], kc[8];
 #pragma unroll
@@ -674,8 +675,8 @@ __global__ __launch_bounds__(256) void gemv_ring4_kernel(int R, const bf16_t* __
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile[wave][t & 1] + i * 1024), 16, 0, 0);
     }
   };
-  // operand loads of this wave's two k-steps go out first, then the weight DMA
-  float4 a[RB][2][2], b[RB][2][2], w[RB][2][2];
+  // operand loads of this wave's k-steps go out first, then the weight DMA
+  float4 a[RB][UPW][2], b[RB][UPW][2], w[RB][UPW][2];
   float rs[RB];
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
@@ -683,8 +684,10 @@ __global__ __launch_bounds__(256) void gemv_ring4_kernel(int R, const bf16_t* __
     rs[rb] = 0.f;
     if constexpr (XIN == XIN_SWIGLU) rs[rb] = f.ss_in[ar];
 #pragma unroll
-    for (int uu = 0; uu < 2; ++uu)
-      decode_operand_load<XIN>(f, ar, min(kbase + (wave * 2 + uu) * 32, K - 32) + g * 8, K, a[rb][uu], b[rb][uu], w[rb][uu]);
+    for (int uu = 0; uu < UPW; ++uu) {
+      const int u = min(wave + uu * NW, 7);
+      decode_operand_load<XIN>(f, ar, min(kbase + u * 32, K - 32) + g * 8, K, a[rb][uu], b[rb][uu], w[rb][uu]);
+    }
   }
   stage(0);
   if constexpr (KW > 1) stage(1);
@@ -696,18 +699,20 @@ __global__ __launch_bounds__(256) void gemv_ring4_kernel(int R, const bf16_t* __
     if constexpr (XIN == XIN_SWIGLU) rs[rb] = rsqrtf(rs[rb] / (float)f.norm_cols + f.eps);
     float ssq = 0.f;
 #pragma unroll
-    for (int uu = 0; uu < 2; ++uu) {
-      const int u = wave * 2 + uu;
-      const bool in_k = kbase + u * 32 < K;                          // clamped (re-read) steps carry no new data
-      float part = 0.f;
-      float* op = XIN == XIN_RESID_NORM ? f.x_out + (int64_t)ar * K + kbase + u * 32 + g * 8 : nullptr;
-      frag[rb][u][lane] = decode_operand_make<XIN>(f, a[rb][uu], b[rb][uu], w[rb][uu], rs[rb], chunk == 0 && live && in_k, op, part);
-      if (in_k) ssq += part;
+    for (int uu = 0; uu < UPW; ++uu) {
+      const int u = wave + uu * NW;
+      if (u < 8) {
+        const bool in_k = kbase + u * 32 < K;                        // clamped (re-read) steps carry no new data
+        float part = 0.f;
+        float* op = XIN == XIN_RESID_NORM ? f.x_out + (int64_t)ar * K + kbase + u * 32 + g * 8 : nullptr;
+        frag[rb][u][lane] = decode_operand_make<XIN>(f, a[rb][uu], b[rb][uu], w[rb][uu], rs[rb], chunk == 0 && live && in_k, op, part);
+        if (in_k) ssq += part;
+      }
     }
     if constexpr (XIN == XIN_RESID_NORM) {
       ssq += __shfl_xor(ssq, 16, 64);
       ssq += __shfl_xor(ssq, 32, 64);
-      if (chunk == 0 && live && g == 0 && f.ss_out) atomicAdd(f.ss_out + rb * 16 + row, ssq);
+      if (chunk == 0 && live && g == 0 && f.ss_out && ssq != 0.f) atomicAdd(f.ss_out + rb * 16 + row, ssq);
     }
   }
   __syncthreads();
@@ -776,10 +781,24 @@ void launch_ring_auto(hipStream_t st, const bf16_t* x, int64_t ldx, int R, const
     else { if (KW == 2) UG_RING1(2, 2); else UG_RING1(2, 1); }
 #undef UG_RING1
   } else {
-    dim3 grid((unsigned)(((groups + 4 * KW - 1) / (4 * KW)) * nslabs));
-#define UG_RING4(RBV, KWV) hipLaunchKernelGGL((gemv_ring4_kernel<RBV, KWV, XIN>), grid, dim3(256), 0, st, R, W, ldw, acc, sr, sn, N, K, nslabs, f)
-    if (R <= 16) { if (KW == 2) UG_RING4(1, 2); else UG_RING4(1, 1); }
-    else { if (KW == 2) UG_RING4(2, 2); else UG_RING4(2, 1); }
+    // workgroup shape (waves, tiles per wave) by the tile count the busiest CU ends up with: one 9-wave x 3-tile workgroup
+    // per CU for gate_up (27 tile slots for 26.25 tiles per CU), 7 x 2 for down (14 for 13.1), 4 x 1|2 otherwise
+    struct Cand { int nw, kw; };
+    const Cand cands[4] = {{4, 1}, {4, 2}, {7, 2}, {9, 3}};
+    int best = 0;
+    int64_t best_cost = INT64_MAX;
+    for (int c = 0; c < 4; ++c) {
+      if (R > 16 && cands[c].nw != 4) continue;                    // two row blocks: the operand image needs the LDS
+      const int64_t blocks = ((groups + cands[c].nw * cands[c].kw - 1) / (cands[c].nw * cands[c].kw)) * nslabs;
+      const int64_t cost = ((blocks + 255) / 256) * cands[c].nw * cands[c].kw;
+      if (cost < best_cost) { best_cost = cost; best = c; }
+    }
+    const int NWc = cands[best].nw, KWc = cands[best].kw;
+    dim3 grid((unsigned)(((groups + NWc * KWc - 1) / (NWc * KWc)) * nslabs));
+#define UG_RING4(RBV, KWV, NWV) hipLaunchKernelGGL((gemv_ring4_kernel<RBV, KWV, XIN, NWV>), grid, dim3(64 * NWV), 0, st, R, W, ldw, acc, sr, sn, N, K, nslabs, f)
+    if (R <= 16) {
+      if (NWc == 9) UG_RING4(1, 3, 9); else if (NWc == 7) UG_RING4(1, 2, 7); else if (KWc == 2) UG_RING4(1, 2, 4); else UG_RING4(1, 1, 4);
+    } else { if (KWc == 2) UG_RING4(2, 2, 4); else UG_RING4(2, 1, 4); }
 #undef UG_RING4
   }
 }
