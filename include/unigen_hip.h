@@ -239,6 +239,16 @@ int ug_adamw_flat(float* p, const float* g, float* m, float* v, void* p_bf16, in
 int ug_conv2d_f32(const float* x, const float* w_packed, const float* bias, const float* residual, float* y,
                   int64_t B, int Hin, int Win, int Cin, int Cout, int cout_pad, int ksize, int stride,
                   int pad_top, int pad_left, int Hout, int Wout, int upsample2x, hipStream_t stream);
+/* The same convolution at fp32 accuracy on the bf16 matrix cores: every fp32 operand is split into three bf16 terms
+ * (a = a1 + a2 + a3 exactly) and the product summed from its six leading partial products in fp32 accumulators --
+ * error per product <= 3 * 2^-26 |a.b|, below the fp32 rounding of the sum; 6/16 the MFMA cost of ug_conv2d_f32.
+ * ug_conv_split_weights turns ug_conv2d_f32's packed weights into the split tile image once per weight version:
+ * w_split holds 3 * taps * Cin * cout_pad bf16.  Needs Cin % 32 == 0, Cout % 4 == 0, cout_pad % 128 == 0; same
+ * geometry arguments and the same reference call sites as ug_conv2d_f32. */
+int ug_conv_split_weights(const float* w_packed, uint16_t* w_split, int taps, int Cin, int cout_pad, hipStream_t stream);
+int ug_conv2d_split3(const float* x, const uint16_t* w_split, const float* bias, const float* residual, float* y,
+                     int64_t B, int Hin, int Win, int Cin, int Cout, int cout_pad, int ksize, int stride,
+                     int pad_top, int pad_left, int Hout, int Wout, int upsample2x, hipStream_t stream);
 /* batched fp32 GEMM on the same kernel (AttnBlock bmm's, common_modules.py:190-214) */
 int ug_gemm_f32(const float* A, int64_t lda, int64_t stride_a, const float* B, int64_t ldb, int64_t stride_b,
                 int b_is_nk, float* C, int64_t ldc, int64_t stride_c, int64_t M, int64_t N, int64_t K,

@@ -15,6 +15,7 @@ conv's gather.  torch modules below only HOLD parameters (names/shapes/initialis
 their forward()s is ever called.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -28,6 +29,7 @@ _CH = 128
 _ENC_MULT, _ENC_BLOCKS = (1, 2, 2, 4, 4), (4, 3, 4, 3, 4)
 _DEC_MULT, _DEC_BLOCKS = (1, 1, 2, 2, 4), (4, 4, 3, 4, 3)
 _ZC = 13
+_SPLIT_CONV = os.environ.get("UNIGEN_CONV_FP32_MFMA", "0") != "1"
 
 
 def _gn(c):
@@ -131,7 +133,7 @@ class LFQuantizer(nn.Module):
 
 class _Packed:
     """Per-conv packed weights [k*k][Cin][cout_pad] + bias, built once per weight version."""
-    __slots__ = ("w", "cpad", "bias", "cout", "cin", "k")
+    __slots__ = ("w", "cpad", "bias", "cout", "cin", "k", "ws")
 
 
 class MAGVITv2(ModelMixin, ConfigMixin):
@@ -168,13 +170,16 @@ class MAGVITv2(ModelMixin, ConfigMixin):
         p.w, p.cpad = ops.pack_conv_weight(w)
         p.bias = conv.bias.detach().float().contiguous()
         p.cout, p.cin, p.k = w.shape[0], w.shape[1], w.shape[2]
+        # wide convs run on the bf16 matrix cores with three-way split operands (fp32-accurate, 16/6 the MFMA rate);
+        # UNIGEN_CONV_FP32_MFMA=1 keeps every conv on the exact fp32 MFMA chain
+        p.ws = ops.split_conv_weight(p.w) if (_SPLIT_CONV and ops.conv_split_eligible(p.cin, p.cout, p.cpad)) else None
         self._packed[key] = (ver, p)
         return p
 
     def _conv(self, x, conv, residual=None, upsample=False, asym=False, pad_cin_to=None):
         p = self._pk(conv, pad_cin_to)
         return ops.conv2d_nhwc(x, p.w, p.cpad, p.bias, p.cout, p.k, stride=2 if asym else 1, asym_pad=asym,
-                               upsample=upsample, residual=residual)
+                               upsample=upsample, residual=residual, w_split=p.ws)
 
     @staticmethod
     def _norm(x, gn, swish=True):

@@ -517,10 +517,24 @@ def pack_conv_weight(w):
     return wp.contiguous(), cout_pad
 
 
+def conv_split_eligible(cin, cout, cout_pad):
+    """Shapes the split-bf16 convolution (`ug_conv2d_split3`) takes."""
+    return cin % 32 == 0 and cout % 4 == 0 and cout_pad % 128 == 0 and cout >= 64
+
+
+def split_conv_weight(wp):
+    """Packed fp32 weights [taps, Cin, cout_pad] -> the three-plane bf16 tile image `ug_conv2d_split3` reads."""
+    taps, cin, cout_pad = wp.shape
+    ws = torch.empty(3 * taps * cin * cout_pad, dtype=torch.bfloat16, device=wp.device)
+    _l.check(_l.load().ug_conv_split_weights(_p(wp), _p(ws), taps, cin, cout_pad, _stream()), "ug_conv_split_weights")
+    return ws
+
+
 def conv2d_nhwc(x, wp, cout_pad, bias, cout, ksize, *, stride=1, pad=None, residual=None, upsample=False,
-                asym_pad=False):
+                asym_pad=False, w_split=None):
     """x [B,H,W,Cin] fp32 NHWC -> [B,Ho,Wo,Cout].  asym_pad: the reference Downsample's pad (0,1,0,1) +
-    stride-2 valid conv (common_modules.py:86-93)."""
+    stride-2 valid conv (common_modules.py:86-93).  With `w_split` (from `split_conv_weight`) the contraction runs as
+    six bf16 MFMA terms of the three-way split operands instead of on the fp32 MFMA."""
     B, H, W, Cin = x.shape
     He, We = (2 * H, 2 * W) if upsample else (H, W)
     if asym_pad:
@@ -530,6 +544,10 @@ def conv2d_nhwc(x, wp, cout_pad, bias, cout, ksize, *, stride=1, pad=None, resid
         pt = pl = (ksize // 2) if pad is None else pad
         Ho, Wo = (He + 2 * pt - ksize) // stride + 1, (We + 2 * pl - ksize) // stride + 1
     y = torch.empty((B, Ho, Wo, cout), dtype=torch.float32, device=x.device)
+    if w_split is not None:
+        _l.check(_l.load().ug_conv2d_split3(_p(x), _p(w_split), _p(bias), _p(residual), _p(y), B, H, W, Cin, cout, cout_pad,
+                                            ksize, stride, pt, pl, Ho, Wo, int(upsample), _stream()), "ug_conv2d_split3")
+        return y
     _l.check(_l.load().ug_conv2d_f32(_p(x), _p(wp), _p(bias), _p(residual), _p(y), B, H, W, Cin, cout, cout_pad, ksize,
                                      stride, pt, pl, Ho, Wo, int(upsample), _stream()), "ug_conv2d_f32")
     return y

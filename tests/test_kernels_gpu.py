@@ -422,6 +422,54 @@ def test_conv2d_f32(dev, cin, cout, k, stride, asym, ups, H):
     assert _maxabs(got, ref + res) < 2e-5, _maxabs(got, ref + res)
 
 
+@pytest.mark.parametrize("cin,cout,k,stride,asym,ups,H", [
+    (128, 128, 3, 1, False, False, 16), (128, 256, 1, 1, False, False, 8), (128, 128, 3, 2, True, False, 16),
+    (256, 256, 3, 1, False, True, 8), (32, 192, 3, 1, False, False, 12), (512, 512, 3, 1, False, False, 6),
+    (64, 68, 3, 1, False, False, 9)])
+def test_conv2d_split3_matches_fp64(dev, cin, cout, k, stride, asym, ups, H):
+    """Three-way bf16 split convolution: as close to the fp64 result as the exact fp32 MFMA chain is."""
+    ops = _ops()
+    gen = torch.Generator().manual_seed(cin * 17 + cout)
+    B = 2
+    x = torch.randn(B, cin, H, H, generator=gen) * 3.0
+    w = torch.randn(cout, cin, k, k, generator=gen) / math.sqrt(cin * k * k)
+    bias = torch.randn(cout, generator=gen)
+    xin = F.interpolate(x, scale_factor=2.0, mode="nearest") if ups else x
+    if asym:
+        ref = F.conv2d(F.pad(xin.double(), (0, 1, 0, 1)), w.double(), bias.double(), stride=stride)
+    else:
+        ref = F.conv2d(xin.double(), w.double(), bias.double(), stride=stride, padding=k // 2)
+    res = torch.randn(ref.shape, generator=gen)
+    ref = ref + res.double()
+    wp, cpad = ops.pack_conv_weight(w.to(dev))
+    assert ops.conv_split_eligible(cin, cout, cpad)
+    ws = ops.split_conv_weight(wp)
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    kw = dict(stride=stride, asym_pad=asym, upsample=ups, residual=res.permute(0, 2, 3, 1).contiguous().to(dev))
+    exact = ops.conv2d_nhwc(x_nhwc, wp, cpad, bias.to(dev), cout, k, **kw).permute(0, 3, 1, 2).cpu().double()
+    split = ops.conv2d_nhwc(x_nhwc, wp, cpad, bias.to(dev), cout, k, w_split=ws, **kw).permute(0, 3, 1, 2).cpu().double()
+    assert split.shape == ref.shape
+    e_exact, e_split = (exact - ref).abs().max().item(), (split - ref).abs().max().item()
+    assert e_split < 1e-4, (e_split, e_exact)
+    assert e_split <= 1.5 * e_exact + 2e-6, (e_split, e_exact)
+
+
+def test_conv_split_weights_reconstruct(dev):
+    """The three bf16 planes of the split weight image add back to the fp32 weights exactly (tile order and swizzle)."""
+    ops = _ops()
+    torch.manual_seed(3)
+    taps, cin, cpad = 9, 64, 256
+    wp = torch.randn(taps, cin, cpad, device=dev) * 0.1
+    ws = ops.split_conv_weight(wp).view(taps, cin // 32, cpad // 128, 3, 128, 4, 8).double()
+    r = torch.arange(128, device=dev)
+    stored = torch.arange(4, device=dev)[None, :] ^ ((r[:, None] >> 2) & 3)          # logical chunk -> stored position
+    idx = stored[None, None, None, None, :, :, None].expand(taps, cin // 32, cpad // 128, 3, 128, 4, 8)
+    logical = torch.gather(ws, 5, idx)                                               # [.., n, chunk, 8]
+    total = logical.sum(3).reshape(taps, cin // 32, cpad // 128, 128, 32)           # planes summed
+    back = total.permute(0, 1, 4, 2, 3).reshape(taps, cin, cpad)
+    assert torch.equal(back, wp.double())
+
+
 def test_groupnorm_swish(dev):
     ops = _ops()
     torch.manual_seed(7)

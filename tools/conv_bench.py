@@ -26,4 +26,16 @@ for cin, cout, H, k in shapes:
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     fl = 2.0 * B * H * H * cin * cout * k * k
-    print(f"conv {cin:4d}->{cout:4d} k{k} @{H:3d}^2 B={B}: {ms:8.3f} ms  {fl / ms / 1e9:7.1f} TF/s", flush=True)
+    line = f"conv {cin:4d}->{cout:4d} k{k} @{H:3d}^2 B={B}: fp32-mfma {ms:8.3f} ms {fl / ms / 1e9:7.1f} TF/s"
+    if ops.conv_split_eligible(cin, cout, cpad):
+        ws = ops.split_conv_weight(wp)
+        ops.conv2d_nhwc(x, wp, cpad, bias, cout, k, w_split=ws)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            ops.conv2d_nhwc(x, wp, cpad, bias, cout, k, w_split=ws)
+        e1.record()
+        torch.cuda.synchronize()
+        ms2 = e0.elapsed_time(e1) / reps
+        line += f" | bf16x3 {ms2:8.3f} ms {fl / ms2 / 1e9:7.1f} TF/s"
+    print(line, flush=True)
