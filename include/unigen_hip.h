@@ -249,6 +249,19 @@ int ug_conv_split_weights(const float* w_packed, uint16_t* w_split, int taps, in
 int ug_conv2d_split3(const float* x, const uint16_t* w_split, const float* bias, const float* residual, float* y,
                      int64_t B, int Hin, int Win, int Cin, int Cout, int cout_pad, int ksize, int stride,
                      int pad_top, int pad_left, int Hout, int Wout, int upsample2x, hipStream_t stream);
+/* 3x3 / stride 1 / pad 1 convolution (every conv1/conv2 of ResnetBlock, conv_in/conv_out of the middle stacks:
+ * common_modules.py:301-360, magvitv2.py:90-178) with the split operands of ug_conv2d_split3 and the 10 x 18 input
+ * patch of an 8 x 16 output block resident in LDS for all nine taps.  With gn_mu_rstd (from ug_groupnorm_stats on
+ * the same x) the load applies y = swish?(GroupNorm(x)) first -- the `conv(nonlinearity(norm(x)))` pattern of
+ * ResnetBlock.forward -- so the normalised tensor never exists in HBM; zero padding applies to the normalised tensor,
+ * as in the reference. */
+int ug_conv3x3_split3(const float* x, const uint16_t* w_split, const float* bias, const float* residual, float* y,
+                      int64_t B, int H, int W, int Cin, int Cout, int cout_pad, const float* gn_mu_rstd,
+                      const float* gn_gamma, const float* gn_beta, int gn_groups, int gn_swish, hipStream_t stream);
+/* GroupNorm statistics only: stats_ws [B][groups][2] fp64 scratch, mu_rstd [B][groups][2] fp32 = (mean, rstd),
+ * rounded as ug_groupnorm_swish rounds them (common_modules.py:19-27). */
+int ug_groupnorm_stats(const float* x, double* stats_ws, float* mu_rstd, int64_t B, int64_t HW, int C, int groups,
+                       float eps, hipStream_t stream);
 /* batched fp32 GEMM on the same kernel (AttnBlock bmm's, common_modules.py:190-214) */
 int ug_gemm_f32(const float* A, int64_t lda, int64_t stride_a, const float* B, int64_t ldb, int64_t stride_b,
                 int b_is_nk, float* C, int64_t ldc, int64_t stride_c, int64_t M, int64_t N, int64_t K,

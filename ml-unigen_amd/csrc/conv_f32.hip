@@ -323,6 +323,17 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
   }
 }
 
+// (mean, rstd) per (image, group) in fp32, rounded exactly as gn_apply_kernel rounds them: lets a consumer apply the
+// normalisation on its own load path
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restrict__ stats, float2* __restrict__ mu_rstd,
+                                                          int n_stats, double n, float eps) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_stats) return;
+  const double mean = stats[2 * i] / n;
+  double var = stats[2 * i + 1] / n - mean * mean; if (var < 0.0) var = 0.0;
+  mu_rstd[i] = make_float2((float)mean, (float)(1.0 / sqrt(var + (double)eps)));
+}
+
 // ------------------------------------------------------------------ row softmax (AttnBlock), fp32
 __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ x, int rows, int cols, int64_t ld, float scale) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -502,6 +513,24 @@ extern "C" int ug_groupnorm_swish(const float* x, const float* gamma, const floa
   hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)g), dim3(256), 0, st, x, stats_ws, gamma, beta, y, total4, (int)HW, C,
                      groups, eps, apply_swish);
   UG_CHECK_LAUNCH("ug_groupnorm_swish(apply)");
+  return UG_OK;
+}
+
+extern "C" int ug_groupnorm_stats(const float* x, double* stats_ws, float* mu_rstd, int64_t B, int64_t HW, int C,
+                                  int groups, float eps, hipStream_t st) {
+  UG_REQUIRE(B > 0 && HW > 0 && groups > 0 && groups <= 32 && C % groups == 0 && (C / groups) % 4 == 0,
+             "ug_groupnorm_stats: unsupported C=%d groups=%d", C, groups);
+  UG_REQUIRE(C / 4 <= 256 && 256 % (C / 4) == 0, "ug_groupnorm_stats: C=%d must be 4*2^k <= 1024", C);
+  UG_REQUIRE(x && stats_ws && mu_rstd && ((uintptr_t)mu_rstd & 7) == 0, "ug_groupnorm_stats: pointers");
+  UG_HIP(hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * B * groups, st));
+  const int ppb = 1024;
+  dim3 grid((unsigned)((HW + ppb - 1) / ppb), (unsigned)B);
+  hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), 0, st, x, stats_ws, (int)HW, C, groups, ppb);
+  UG_CHECK_LAUNCH("ug_groupnorm_stats(stats)");
+  const int n_stats = (int)(B * groups);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)((n_stats + 255) / 256)), dim3(256), 0, st, stats_ws,
+                     reinterpret_cast<float2*>(mu_rstd), n_stats, (double)HW * (C / groups), eps);
+  UG_CHECK_LAUNCH("ug_groupnorm_stats(finalize)");
   return UG_OK;
 }
 

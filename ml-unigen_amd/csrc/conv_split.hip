@@ -54,6 +54,43 @@ __device__ __forceinline__ void split3_pair(float a, float b, uint32_t& p1, uint
 // a ds_read_b128 fragment fetch touches land on 16 distinct chunks of a 256-byte bank row
 __device__ __forceinline__ int swz(int r, int chunk) { return r * SBK + ((chunk ^ ((r >> 2) & 3)) << 3); }
 
+// One 32-deep contraction slab of a wave's 64 x 64 result (4 x 4 MFMA blocks): six partial products per block, the
+// smallest first.  wl: this lane's row of the weight plane-0 image (blocks 16 rows apart); xj[j]: this lane's row of
+// pixel block j in plane 0; planes are XPLANE (pixels) / PLANE (weights) elements apart.
+template <int XPLANE>
+__device__ __forceinline__ void mma_slab(const bf16_t* wl, const bf16_t* const (&xj)[4], f32x4_t (&acc)[4][4]) {
+  bf16x8_t w1[4], w2[4], x1[4], x2[4], t[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w1[i] = *reinterpret_cast<const bf16x8_t*>(wl + i * 16 * SBK);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) x1[j] = *reinterpret_cast<const bf16x8_t*>(xj[j]);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) t[j] = *reinterpret_cast<const bf16x8_t*>(xj[j] + 2 * XPLANE);   // x3
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[i], t[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) t[i] = *reinterpret_cast<const bf16x8_t*>(wl + 2 * PLANE + i * 16 * SBK);   // w3
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(t[i], x1[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w2[i] = *reinterpret_cast<const bf16x8_t*>(wl + PLANE + i * 16 * SBK);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) x2[j] = *reinterpret_cast<const bf16x8_t*>(xj[j] + XPLANE);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[i], x2[j], acc[i][j], 0, 0, 0);
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[i], x2[j], acc[i][j], 0, 0, 0);
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[i], x1[j], acc[i][j], 0, 0, 0);
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[i], x1[j], acc[i][j], 0, 0, 0);
+    }
+}
+
 __global__ __launch_bounds__(256, 2) void conv_split3_kernel(SplitArgs p) {
   __shared__ __attribute__((aligned(16))) bf16_t Ws[TILE];
   __shared__ __attribute__((aligned(16))) bf16_t Xs[TILE];
@@ -149,37 +186,8 @@ __global__ __launch_bounds__(256, 2) void conv_split3_kernel(SplitArgs p) {
     if (kt + 1 < nkt) fetch();           // next slab's global loads stay in flight under the MFMAs
     const bf16_t* wl = Ws + swz(wn * 64 + l16, g);
     const bf16_t* xl = Xs + swz(wm * 64 + l16, g);
-    bf16x8_t w1[4], w2[4], x1[4], x2[4], t[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) w1[i] = *reinterpret_cast<const bf16x8_t*>(wl + i * 16 * SBK);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) x1[j] = *reinterpret_cast<const bf16x8_t*>(xl + j * 16 * SBK);
-    // smallest terms first
-#pragma unroll
-    for (int j = 0; j < 4; ++j) t[j] = *reinterpret_cast<const bf16x8_t*>(xl + 2 * PLANE + j * 16 * SBK);   // x3
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[i], t[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) t[i] = *reinterpret_cast<const bf16x8_t*>(wl + 2 * PLANE + i * 16 * SBK);   // w3
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(t[i], x1[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) w2[i] = *reinterpret_cast<const bf16x8_t*>(wl + PLANE + i * 16 * SBK);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) x2[j] = *reinterpret_cast<const bf16x8_t*>(xl + PLANE + j * 16 * SBK);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[i], x2[j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[i], x2[j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[i], x1[j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[i], x1[j], acc[i][j], 0, 0, 0);
-      }
+    const bf16_t* xj[4] = {xl, xl + 16 * SBK, xl + 32 * SBK, xl + 48 * SBK};
+    mma_slab<PLANE>(wl, xj, acc);
     __syncthreads();                     // every wave is done reading this slab
     if (kt + 1 < nkt) stash();
     __syncthreads();
@@ -204,6 +212,305 @@ __global__ __launch_bounds__(256, 2) void conv_split3_kernel(SplitArgs p) {
         v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
       }
       *reinterpret_cast<float4*>(p.y + (int64_t)m * p.Cout + n) = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ 3x3 / stride 1 / pad 1: input patch resident in LDS
+// The im2col form above re-reads (and re-splits) every input pixel once per tap.  Here a workgroup owns an 8 x 16
+// block of output pixels, keeps the 10 x 18 input patch of one 32-channel slab in LDS as split planes, and runs all
+// nine taps from it: activation traffic, split arithmetic and LDS writes drop 6.4x; only the weight tile changes per
+// tap.  Optionally the patch load applies the preceding GroupNorm(+swish) (common_modules.py:19-27,308-335: every 3x3
+// conv of a ResnetBlock reads swish(norm(x))), so the normalised tensor is never written to HBM.
+constexpr int PT_H = 8, PT_W = 16, PP_W = PT_W + 2, PP_ROWS = (PT_H + 2) * PP_W;    // 180 patch pixels
+constexpr int XPATCH = PP_ROWS * SBK;                                                // one plane of the patch
+
+struct PatchArgs {
+  const float* x; const bf16_t* w; const float* bias; const float* res; float* y;
+  int B, H, W, Cin, Cout, nblks, kslabs;
+  int tiles_x, tiles_y, ntiles;
+  const float2* mu_rstd;   // [B][G] mean / rstd of the input's GroupNorm, or null: x is used as is
+  const float* gamma; const float* beta;
+  int cpg, G, swish;
+};
+
+template <bool GN>
+__global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(PatchArgs p) {
+  __shared__ __attribute__((aligned(16))) bf16_t Ws[TILE];
+  __shared__ __attribute__((aligned(16))) bf16_t Xp[3 * XPATCH];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave & 1, wm = wave >> 1;
+  const int g = lane >> 4, l16 = lane & 15;
+  const int per_xcd = gridDim.x >> 3;
+  const int tile = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);     // contiguous band of tiles per XCD
+  if (tile >= p.ntiles) return;
+  const int nblk = blockIdx.y;
+  const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, b = tile / (p.tiles_x * p.tiles_y);
+  const int y0 = ty * PT_H, x0 = tx * PT_W;
+
+  // patch element e = tid + 256 i: patch pixel e >> 3, channel quad e & 7; the pixel's address is fixed for the kernel
+  const int q = tid & 7;
+  const float* ppix[6];
+  bool pok[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int prow = (tid >> 3) + 32 * i;
+    const int iy = y0 + prow / PP_W - 1, ix = x0 + prow % PP_W - 1;
+    pok[i] = prow < PP_ROWS && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+    ppix[i] = pok[i] ? p.x + (((int64_t)b * p.H + iy) * p.W + ix) * p.Cin + q * 4 : p.x;
+  }
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  f32x4_t rx[6];
+  u32x4_t rw[6];
+  const u32x4_t* wbase = reinterpret_cast<const u32x4_t*>(p.w) + (int64_t)nblk * (TILE / 8) + tid;
+  auto fetch_w = [&](int slab, int tap) __attribute__((always_inline)) {
+    const u32x4_t* wt = wbase + ((int64_t)tap * p.kslabs + slab) * p.nblks * (TILE / 8);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) rw[i] = wt[i * 256];
+  };
+  auto stash_w = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) reinterpret_cast<u32x4_t*>(Ws)[i * 256 + tid] = rw[i];
+  };
+  auto fetch_x = [&](int slab) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) rx[i] = *reinterpret_cast<const f32x4_t*>(pok[i] ? ppix[i] + slab * SBK : p.x);
+  };
+  auto stash_x = [&](int slab) __attribute__((always_inline)) {
+    float mu = 0.f, rstd = 1.f;
+    f32x4_t ga = {1.f, 1.f, 1.f, 1.f}, be = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (GN) {
+      const int c = slab * SBK + q * 4;
+      const float2 mr = p.mu_rstd[b * p.G + c / p.cpg];         // cpg >= 4: a quad never straddles groups
+      mu = mr.x; rstd = mr.y;
+      ga = *reinterpret_cast<const f32x4_t*>(p.gamma + c);
+      be = *reinterpret_cast<const f32x4_t*>(p.beta + c);
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int prow = (tid >> 3) + 32 * i;
+      if (prow >= PP_ROWS) continue;
+      f32x4_t v = rx[i];
+      if constexpr (GN) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float o = (v[k] - mu) * rstd * ga[k] + be[k];
+          if (p.swish) o = o / (1.f + expf(-o));
+          v[k] = o;
+        }
+      }
+      if (!pok[i]) v = f32x4_t{0.f, 0.f, 0.f, 0.f};             // the conv pads the NORMALISED tensor with zeros
+      uint32_t a1, a2, a3, b1, b2, b3;
+      split3_pair(v[0], v[1], a1, a2, a3);
+      split3_pair(v[2], v[3], b1, b2, b3);
+      const int off = swz(prow, q >> 1) + (q & 1) * 4;
+      *reinterpret_cast<uint2*>(Xp + off) = make_uint2(a1, b1);
+      *reinterpret_cast<uint2*>(Xp + XPATCH + off) = make_uint2(a2, b2);
+      *reinterpret_cast<uint2*>(Xp + 2 * XPATCH + off) = make_uint2(a3, b3);
+    }
+  };
+
+  fetch_x(0);
+  fetch_w(0, 0);
+  stash_x(0);
+  stash_w();
+  __syncthreads();
+  const bf16_t* wl = Ws + swz(wn * 64 + l16, g);
+  for (int slab = 0; slab < p.kslabs; ++slab) {
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+      const bool last_tap = tap == 8, more = !(last_tap && slab + 1 == p.kslabs);
+      if (more) fetch_w(last_tap ? slab + 1 : slab, last_tap ? 0 : tap + 1);
+      if (last_tap && more) fetch_x(slab + 1);
+      const int dy = tap / 3, dx = tap - dy * 3;
+      const bf16_t* xj[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xj[j] = Xp + swz((wm * 4 + j + dy) * PP_W + l16 + dx, g);
+      mma_slab<XPATCH>(wl, xj, acc);
+      __syncthreads();
+      if (more) stash_w();
+      if (last_tap && more) stash_x(slab + 1);
+      __syncthreads();
+    }
+  }
+
+  // epilogue: block (i, j): channels n..n+3 of output pixel (y0 + 4 wm + j, x0 + l16)
+  const int ox = x0 + l16;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int oy = y0 + wm * 4 + j;
+    if (oy >= p.H || ox >= p.W) continue;
+    const int64_t m = ((int64_t)b * p.H + oy) * p.W + ox;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int n = nblk * SBN + wn * 64 + i * 16 + g * 4;
+      if (n >= p.Cout) continue;
+      float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      if (p.bias) {
+        const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+        v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+      }
+      if (p.res) {
+        const float4 r = *reinterpret_cast<const float4*>(p.res + m * p.Cout + n);
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+      }
+      *reinterpret_cast<float4*>(p.y + m * p.Cout + n) = v;
+    }
+  }
+}
+
+// Large-layer variant: 16 x 16 output pixels x 128 channels per workgroup of EIGHT waves (the weight tile of a tap is
+// shared by twice the pixels), weight tiles in a three-slot LDS ring fetched two taps ahead by LDS-DMA -- the split
+// image in HBM is the LDS image, so a tile is 24 linear 1 KB pieces, three per wave, no VGPR staging and one barrier
+// per tap.  The three slots are separate arrays and the nine taps are unrolled so that every fragment read names a
+// different object than the DMA in flight (otherwise hipcc drains vmcnt(0) before the first ds_read of every tap).
+constexpr int QT_H = 16, QP_ROWS = (QT_H + 2) * PP_W;           // 324 patch pixels
+constexpr int XQ = QP_ROWS * SBK;
+// __syncthreads() also drains vmcnt(0); with DMA tiles deliberately left in flight the barrier is issued raw
+#define RAW_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <bool GN>
+__global__ __launch_bounds__(512) void conv3x3_patch16_kernel(PatchArgs p) {
+  __shared__ __attribute__((aligned(1024))) bf16_t W0[TILE];
+  __shared__ __attribute__((aligned(1024))) bf16_t W1[TILE];
+  __shared__ __attribute__((aligned(1024))) bf16_t W2[TILE];
+  __shared__ __attribute__((aligned(16))) bf16_t Xp[3 * XQ];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave & 1, wm = wave >> 1;
+  const int g = lane >> 4, l16 = lane & 15;
+  const int per_xcd = gridDim.x >> 3;
+  const int tile = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  if (tile >= p.ntiles) return;
+  const int nblk = blockIdx.y;
+  const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, b = tile / (p.tiles_x * p.tiles_y);
+  const int y0 = ty * QT_H, x0 = tx * PT_W;
+
+  const int q = tid & 7;
+  const float* ppix[6];
+  bool pok[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int prow = (tid >> 3) + 64 * i;
+    const int iy = y0 + prow / PP_W - 1, ix = x0 + prow % PP_W - 1;
+    pok[i] = prow < QP_ROWS && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+    ppix[i] = pok[i] ? p.x + (((int64_t)b * p.H + iy) * p.W + ix) * p.Cin + q * 4 : p.x;
+  }
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  f32x4_t rx[6];
+  const char* wsrc = reinterpret_cast<const char*>(p.w) + (int64_t)nblk * (TILE * 2) + (wave * 3 * 64 + lane) * 16;
+  auto dma_w = [&](int slab, int tap, bf16_t* slot) __attribute__((always_inline)) {
+    const char* src = wsrc + ((int64_t)tap * p.kslabs + slab) * p.nblks * (TILE * 2);
+    char* dst = reinterpret_cast<char*>(slot) + wave * 3 * 1024;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) __builtin_amdgcn_global_load_lds((gptr_t)(src + i * 1024), (lptr_t)(dst + i * 1024), 16, 0, 0);
+  };
+  auto fetch_x = [&](int slab) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) rx[i] = *reinterpret_cast<const f32x4_t*>(pok[i] ? ppix[i] + slab * SBK : p.x);
+  };
+  auto stash_x = [&](int slab) __attribute__((always_inline)) {
+    float mu = 0.f, rstd = 1.f;
+    f32x4_t ga = {1.f, 1.f, 1.f, 1.f}, be = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (GN) {
+      const int c = slab * SBK + q * 4;
+      const float2 mr = p.mu_rstd[b * p.G + c / p.cpg];
+      mu = mr.x; rstd = mr.y;
+      ga = *reinterpret_cast<const f32x4_t*>(p.gamma + c);
+      be = *reinterpret_cast<const f32x4_t*>(p.beta + c);
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int prow = (tid >> 3) + 64 * i;
+      if (prow >= QP_ROWS) continue;
+      f32x4_t v = rx[i];
+      if constexpr (GN) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float o = (v[k] - mu) * rstd * ga[k] + be[k];
+          if (p.swish) o = o / (1.f + expf(-o));
+          v[k] = o;
+        }
+      }
+      if (!pok[i]) v = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      uint32_t a1, a2, a3, b1, b2, b3;
+      split3_pair(v[0], v[1], a1, a2, a3);
+      split3_pair(v[2], v[3], b1, b2, b3);
+      const int off = swz(prow, q >> 1) + (q & 1) * 4;
+      *reinterpret_cast<uint2*>(Xp + off) = make_uint2(a1, b1);
+      *reinterpret_cast<uint2*>(Xp + XQ + off) = make_uint2(a2, b2);
+      *reinterpret_cast<uint2*>(Xp + 2 * XQ + off) = make_uint2(a3, b3);
+    }
+  };
+
+  const int nkt = p.kslabs * 9;
+  fetch_x(0);
+  dma_w(0, 0, W0);
+  dma_w(0, 1, W1);
+  stash_x(0);
+  asm volatile("s_waitcnt vmcnt(3)" ::: "memory");            // tap 0's tile; tap 1's may still be in flight
+  RAW_BARRIER();
+  const int wrow = swz(wn * 64 + l16, g);
+  for (int slab = 0; slab < p.kslabs; ++slab) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      bf16_t* cur = tap % 3 == 0 ? W0 : tap % 3 == 1 ? W1 : W2;
+      bf16_t* two_ahead = (tap + 2) % 3 == 0 ? W0 : (tap + 2) % 3 == 1 ? W1 : W2;   // last read one tap ago
+      const bool has2 = slab * 9 + tap + 2 < nkt;
+      const bool next_slab = tap == 8 && slab + 1 < p.kslabs;
+      if (has2) dma_w(slab + (tap + 2 >= 9 ? 1 : 0), (tap + 2) % 9, two_ahead);
+      if (next_slab) fetch_x(slab + 1);
+      const int dy = tap / 3, dx = tap % 3;
+      const bf16_t* xj[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xj[j] = Xp + swz((wm * 4 + j + dy) * PP_W + l16 + dx, g);
+      mma_slab<XQ>(cur + wrow, xj, acc);
+      if (next_slab) {
+        RAW_BARRIER();                 // every wave is done with this slab's patch
+        stash_x(slab + 1);
+      }
+      // the next tap's tile (issued one tap ago) must have landed; the one issued in this tap may stay in flight
+      if (has2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      RAW_BARRIER();
+    }
+  }
+
+  const int ox = x0 + l16;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int oy = y0 + wm * 4 + j;
+    if (oy >= p.H || ox >= p.W) continue;
+    const int64_t m = ((int64_t)b * p.H + oy) * p.W + ox;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int n = nblk * SBN + wn * 64 + i * 16 + g * 4;
+      if (n >= p.Cout) continue;
+      float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      if (p.bias) {
+        const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+        v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+      }
+      if (p.res) {
+        const float4 r = *reinterpret_cast<const float4*>(p.res + m * p.Cout + n);
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+      }
+      *reinterpret_cast<float4*>(p.y + m * p.Cout + n) = v;
     }
   }
 }
@@ -276,5 +583,45 @@ extern "C" int ug_conv2d_split3(const float* x, const uint16_t* w_split, const f
   dim3 grid((unsigned)(((M + SBM - 1) / SBM + 7) / 8 * 8), (unsigned)((Cout + SBN - 1) / SBN));
   hipLaunchKernelGGL(conv_split3_kernel, grid, dim3(256), 0, st, a);
   UG_CHECK_LAUNCH("ug_conv2d_split3");
+  return UG_OK;
+}
+
+extern "C" int ug_conv3x3_split3(const float* x, const uint16_t* w_split, const float* bias, const float* residual, float* y,
+                                 int64_t B, int H, int W, int Cin, int Cout, int cout_pad, const float* gn_mu_rstd,
+                                 const float* gn_gamma, const float* gn_beta, int gn_groups, int gn_swish, hipStream_t st) {
+  UG_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "ug_conv3x3_split3: bad shape");
+  UG_REQUIRE(Cin % SBK == 0 && Cout % 4 == 0 && cout_pad % SBN == 0 && cout_pad >= Cout,
+             "ug_conv3x3_split3: needs Cin %% 32 == 0, Cout %% 4 == 0, cout_pad %% 128 == 0 (Cin=%d Cout=%d cout_pad=%d)", Cin,
+             Cout, cout_pad);
+  UG_REQUIRE(x && y && w_split && ug_aligned16(x) && ug_aligned16(y) && ug_aligned16(w_split) &&
+                 (!bias || ug_aligned16(bias)) && (!residual || ug_aligned16(residual)),
+             "ug_conv3x3_split3: pointers must be 16-byte aligned");
+  PatchArgs a{};
+  a.x = x; a.w = (const bf16_t*)w_split; a.bias = bias; a.res = residual; a.y = y;
+  a.B = (int)B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.nblks = cout_pad / SBN; a.kslabs = Cin / SBK;
+  // 16-row tiles (eight waves, DMA-fed weights) when they still give every CU two workgroups' worth of work
+  const int nb_n = (Cout + SBN - 1) / SBN;
+  const int64_t big_tiles = B * ((W + PT_W - 1) / PT_W) * ((H + QT_H - 1) / QT_H);
+  const bool big = big_tiles * nb_n >= 512;
+  a.tiles_x = (W + PT_W - 1) / PT_W; a.tiles_y = big ? (H + QT_H - 1) / QT_H : (H + PT_H - 1) / PT_H;
+  const int64_t ntiles = B * a.tiles_x * a.tiles_y;
+  UG_REQUIRE(ntiles < (1LL << 30) && B * H * W < (1LL << 31), "ug_conv3x3_split3: too many output pixels");
+  a.ntiles = (int)ntiles;
+  dim3 grid((unsigned)((ntiles + 7) / 8 * 8), (unsigned)nb_n);
+  const dim3 block(big ? 512 : 256);
+  if (gn_mu_rstd) {
+    UG_REQUIRE(gn_gamma && gn_beta && gn_groups > 0 && Cin % gn_groups == 0 && (Cin / gn_groups) % 4 == 0 &&
+                   ug_aligned16(gn_gamma) && ug_aligned16(gn_beta) && ((uintptr_t)gn_mu_rstd & 7) == 0,
+               "ug_conv3x3_split3: fused GroupNorm needs gamma/beta and channels-per-group %% 4 == 0 (Cin=%d groups=%d)", Cin,
+               gn_groups);
+    a.mu_rstd = reinterpret_cast<const float2*>(gn_mu_rstd); a.gamma = gn_gamma; a.beta = gn_beta;
+    a.G = gn_groups; a.cpg = Cin / gn_groups; a.swish = gn_swish;
+    if (big) hipLaunchKernelGGL(conv3x3_patch16_kernel<true>, grid, block, 0, st, a);
+    else hipLaunchKernelGGL(conv3x3_patch_kernel<true>, grid, block, 0, st, a);
+  } else {
+    if (big) hipLaunchKernelGGL(conv3x3_patch16_kernel<false>, grid, block, 0, st, a);
+    else hipLaunchKernelGGL(conv3x3_patch_kernel<false>, grid, block, 0, st, a);
+  }
+  UG_CHECK_LAUNCH("ug_conv3x3_split3");
   return UG_OK;
 }

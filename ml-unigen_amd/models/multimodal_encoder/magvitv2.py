@@ -176,8 +176,17 @@ class MAGVITv2(ModelMixin, ConfigMixin):
         self._packed[key] = (ver, p)
         return p
 
-    def _conv(self, x, conv, residual=None, upsample=False, asym=False, pad_cin_to=None):
+    def _conv(self, x, conv, residual=None, upsample=False, asym=False, pad_cin_to=None, norm=None, swish=True):
+        """conv(x), or conv(swish?(norm(x))) when `norm` (a GroupNorm) is given.  Wide 3x3 stride-1 convs take the
+        LDS-resident-patch kernel, which applies the normalisation on its load path."""
         p = self._pk(conv, pad_cin_to)
+        if p.ws is not None and p.k == 3 and not upsample and not asym:
+            gn = None
+            if norm is not None:
+                gn = (ops.groupnorm_stats(x, groups=32, eps=norm.eps), norm.weight.detach(), norm.bias.detach(), 32, swish)
+            return ops.conv3x3_nhwc(x, p.ws, p.cpad, p.bias, p.cout, residual=residual, gn=gn)
+        if norm is not None:
+            x = self._norm(x, norm, swish)
         return ops.conv2d_nhwc(x, p.w, p.cpad, p.bias, p.cout, p.k, stride=2 if asym else 1, asym_pad=asym,
                                upsample=upsample, residual=residual, w_split=p.ws)
 
@@ -186,10 +195,9 @@ class MAGVITv2(ModelMixin, ConfigMixin):
         return ops.groupnorm_swish(x, gn.weight.detach(), gn.bias.detach(), groups=32, eps=gn.eps, swish=swish)
 
     def _res(self, x, blk):
-        h = self._conv(self._norm(x, blk.norm1), blk.conv1)
-        h = self._norm(h, blk.norm2)
+        h = self._conv(x, blk.conv1, norm=blk.norm1)
         skip = self._conv(x, blk.nin_shortcut) if hasattr(blk, "nin_shortcut") else x
-        return self._conv(h, blk.conv2, residual=skip)
+        return self._conv(h, blk.conv2, residual=skip, norm=blk.norm2)
 
     def _attn(self, x, a):
         B, H, W, C = x.shape
@@ -217,7 +225,7 @@ class MAGVITv2(ModelMixin, ConfigMixin):
             if hasattr(level, "downsample"):
                 h = self._conv(h, level.downsample.conv, asym=True)
         h = self._mid(h, e.mid)
-        h = self._conv(self._norm(h, e.norm_out), e.conv_out)
+        h = self._conv(h, e.conv_out, norm=e.norm_out)
         return self._conv(h, e.quant_conv)
 
     @torch.no_grad()
@@ -231,7 +239,7 @@ class MAGVITv2(ModelMixin, ConfigMixin):
                 h = self._res(h, blk)
             if hasattr(level, "upsample"):
                 h = self._conv(h, level.upsample.conv, upsample=True)
-        return self._conv(self._norm(h, d.norm_out), d.conv_out)
+        return self._conv(h, d.conv_out, norm=d.norm_out)
 
     # ------------------------------------------------------------------ reference API
     def forward(self, pixel_values, return_loss=False):

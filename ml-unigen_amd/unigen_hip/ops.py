@@ -576,6 +576,28 @@ def groupnorm_swish(x, gamma, beta, *, groups=32, eps=1e-6, swish=True):
     return y
 
 
+def groupnorm_stats(x, *, groups=32, eps=1e-6):
+    """(mean, rstd) of GroupNorm(groups) over NHWC fp32 x, [B, groups, 2] fp32 -- what `conv3x3_nhwc(..., gn=)` applies
+    on its load path."""
+    B, H, W, C = x.shape
+    ws = torch.empty((B, groups, 2), dtype=torch.float64, device=x.device)
+    mr = torch.empty((B, groups, 2), dtype=torch.float32, device=x.device)
+    _l.check(_l.load().ug_groupnorm_stats(_p(x), _p(ws), _p(mr), B, H * W, C, groups, eps, _stream()),
+             "ug_groupnorm_stats")
+    return mr
+
+
+def conv3x3_nhwc(x, w_split, cout_pad, bias, cout, *, residual=None, gn=None):
+    """3x3 / stride 1 / pad 1 convolution of NHWC fp32 x with split weights (`split_conv_weight`), input patch resident
+    in LDS.  gn = (mu_rstd, gamma, beta, groups, swish): apply swish?(GroupNorm(x)) on the load path."""
+    B, H, W, Cin = x.shape
+    y = torch.empty((B, H, W, cout), dtype=torch.float32, device=x.device)
+    mr, ga, be, groups, swish = gn if gn is not None else (None, None, None, 0, 0)
+    _l.check(_l.load().ug_conv3x3_split3(_p(x), _p(w_split), _p(bias), _p(residual), _p(y), B, H, W, Cin, cout, cout_pad,
+                                         _p(mr), _p(ga), _p(be), groups, int(swish), _stream()), "ug_conv3x3_split3")
+    return y
+
+
 def softmax_rows_(x2d, scale, cols=None):
     """in-place row softmax of scale*x over the first `cols` columns of a 2-D fp32 tensor (row stride = .stride(0))."""
     cols = x2d.shape[1] if cols is None else cols

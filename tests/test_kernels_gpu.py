@@ -454,6 +454,40 @@ def test_conv2d_split3_matches_fp64(dev, cin, cout, k, stride, asym, ups, H):
     assert e_split <= 1.5 * e_exact + 2e-6, (e_split, e_exact)
 
 
+@pytest.mark.parametrize("cin,cout,H,W,gn", [(128, 128, 16, 16, False), (128, 128, 16, 32, True), (256, 192, 11, 21, True),
+                                             (32, 64, 8, 16, False), (512, 512, 6, 6, True), (64, 68, 9, 40, False),
+                                             (128, 64, 250, 263, True), (64, 128, 256, 128, False)])
+def test_conv3x3_patch_matches_fp64(dev, cin, cout, H, W, gn):
+    """LDS-resident-patch 3x3 conv (optionally with GroupNorm+swish on the load path) against fp64, and against the
+    unfused path of the same library (GroupNorm kernel + im2col split conv)."""
+    ops = _ops()
+    gen = torch.Generator().manual_seed(cin * 13 + cout + W)
+    B = 3 if H * W < 4096 else 2          # the two large cases reach the 16-row / eight-wave variant (>= 512 tiles)
+    x = torch.randn(B, cin, H, W, generator=gen) * 2.0 + 0.3
+    w = torch.randn(cout, cin, 3, 3, generator=gen) / math.sqrt(cin * 9)
+    bias = torch.randn(cout, generator=gen)
+    g = torch.randn(cin, generator=gen); be = torch.randn(cin, generator=gen)
+    xin = x.double()
+    if gn:
+        xin = F.group_norm(xin, 32, g.double(), be.double(), eps=1e-6)
+        xin = xin * torch.sigmoid(xin)
+    ref = F.conv2d(xin, w.double(), bias.double(), padding=1)
+    res = torch.randn(ref.shape, generator=gen)
+    ref = ref + res.double()
+    wp, cpad = ops.pack_conv_weight(w.to(dev))
+    ws = ops.split_conv_weight(wp)
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    res_d = res.permute(0, 2, 3, 1).contiguous().to(dev)
+    fused_gn = (ops.groupnorm_stats(x_nhwc), g.to(dev), be.to(dev), 32, True) if gn else None
+    got = ops.conv3x3_nhwc(x_nhwc, ws, cpad, bias.to(dev), cout, residual=res_d, gn=fused_gn)
+    xn = ops.groupnorm_swish(x_nhwc, g.to(dev), be.to(dev), swish=True) if gn else x_nhwc
+    unfused = ops.conv2d_nhwc(xn, wp, cpad, bias.to(dev), cout, 3, residual=res_d, w_split=ws)
+    got64 = got.permute(0, 3, 1, 2).cpu().double()
+    assert got64.shape == ref.shape
+    assert (got64 - ref).abs().max().item() < 3e-5
+    assert _maxabs(got, unfused) < 3e-5
+
+
 def test_conv_split_weights_reconstruct(dev):
     """The three bf16 planes of the split weight image add back to the fp32 weights exactly (tile order and swizzle)."""
     ops = _ops()

@@ -38,4 +38,14 @@ for cin, cout, H, k in shapes:
         torch.cuda.synchronize()
         ms2 = e0.elapsed_time(e1) / reps
         line += f" | bf16x3 {ms2:8.3f} ms {fl / ms2 / 1e9:7.1f} TF/s"
+        if k == 3:
+            ops.conv3x3_nhwc(x, ws, cpad, bias, cout)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(reps):
+                ops.conv3x3_nhwc(x, ws, cpad, bias, cout)
+            e1.record()
+            torch.cuda.synchronize()
+            ms3 = e0.elapsed_time(e1) / reps
+            line += f" | patch {ms3:8.3f} ms {fl / ms3 / 1e9:7.1f} TF/s"
     print(line, flush=True)
