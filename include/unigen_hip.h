@@ -243,8 +243,9 @@ int ug_conv2d_f32(const float* x, const float* w_packed, const float* bias, cons
  * (a = a1 + a2 + a3 exactly) and the product summed from its six leading partial products in fp32 accumulators --
  * error per product <= 3 * 2^-26 |a.b|, below the fp32 rounding of the sum; 6/16 the MFMA cost of ug_conv2d_f32.
  * ug_conv_split_weights turns ug_conv2d_f32's packed weights into the split tile image once per weight version:
- * w_split holds 3 * taps * Cin * cout_pad bf16.  Needs Cin % 32 == 0, Cout % 4 == 0, cout_pad % 128 == 0; same
- * geometry arguments and the same reference call sites as ug_conv2d_f32. */
+ * w_split holds 3 * taps * roundup(Cin, 32) * cout_pad bf16 (a ragged last 32-channel slab is zero-filled).  Needs
+ * Cin % 4 == 0, Cout % 4 == 0, cout_pad % 128 == 0; same geometry arguments and the same reference call sites as
+ * ug_conv2d_f32. */
 int ug_conv_split_weights(const float* w_packed, uint16_t* w_split, int taps, int Cin, int cout_pad, hipStream_t stream);
 int ug_conv2d_split3(const float* x, const uint16_t* w_split, const float* bias, const float* residual, float* y,
                      int64_t B, int Hin, int Win, int Cin, int Cout, int cout_pad, int ksize, int stride,
@@ -262,6 +263,12 @@ int ug_conv3x3_split3(const float* x, const uint16_t* w_split, const float* bias
  * rounded as ug_groupnorm_swish rounds them (common_modules.py:19-27). */
 int ug_groupnorm_stats(const float* x, double* stats_ws, float* mu_rstd, int64_t B, int64_t HW, int C, int groups,
                        float eps, hipStream_t stream);
+/* ug_linear_f32 on the same split-bf16 contraction (SigLIP q/k/v/out_proj, fc1/fc2: siglip_encoder.py:196-199,
+ * 250-259): y = act(x W^T + bias) + residual with W^T packed as ug_conv2d_f32 weights of a 1x1 conv ([1][K][n_pad])
+ * and split by ug_conv_split_weights. */
+int ug_linear_split3(const float* x, int64_t ldx, const uint16_t* w_split, const float* bias, const float* residual,
+                     int64_t ldres, float* y, int64_t ldy, int64_t M, int64_t N, int64_t K, int n_pad, int act,
+                     hipStream_t stream);
 /* batched fp32 GEMM on the same kernel (AttnBlock bmm's, common_modules.py:190-214) */
 int ug_gemm_f32(const float* A, int64_t lda, int64_t stride_a, const float* B, int64_t ldb, int64_t stride_b,
                 int b_is_nk, float* C, int64_t ldc, int64_t stride_c, int64_t M, int64_t N, int64_t K,

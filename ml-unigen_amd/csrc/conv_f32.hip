@@ -426,6 +426,13 @@ void launch_conv_mode(const ConvArgs& a, int nb, bool vec4, hipStream_t st) {
   }
 }
 
+// pixels per statistics workgroup: ~2048 workgroups per launch (a 16-image 32x32x512 tensor used to run on 16 of them)
+int gn_pixels_per_block(int64_t B, int64_t HW) {
+  int64_t ppb = (B * HW + 2047) / 2048;
+  ppb = (ppb + 63) / 64 * 64;
+  return (int)(ppb < 64 ? 64 : ppb > 1024 ? 1024 : ppb);
+}
+
 int launch_conv(const ConvArgs& a, int nb, hipStream_t st) {
   // vector path: every 4-element A fetch is 16-byte aligned and never straddles the contraction extent
   const bool vec4 = a.gemm ? (a.lda % 4 == 0 && a.Cin % 4 == 0 && ug_aligned16(a.x) && a.sa % 4 == 0 &&
@@ -504,7 +511,7 @@ extern "C" int ug_groupnorm_swish(const float* x, const float* gamma, const floa
              "ug_groupnorm_swish: unsupported C=%d groups=%d", C, groups);
   UG_REQUIRE(C / 4 <= 256 && 256 % (C / 4) == 0, "ug_groupnorm_swish: C=%d must be 4*2^k <= 1024", C);
   UG_HIP(hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * B * groups, st));
-  const int ppb = 1024;
+  const int ppb = gn_pixels_per_block(B, HW);
   dim3 grid((unsigned)((HW + ppb - 1) / ppb), (unsigned)B);
   hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), 0, st, x, stats_ws, (int)HW, C, groups, ppb);
   UG_CHECK_LAUNCH("ug_groupnorm_swish(stats)");
@@ -523,7 +530,7 @@ extern "C" int ug_groupnorm_stats(const float* x, double* stats_ws, float* mu_rs
   UG_REQUIRE(C / 4 <= 256 && 256 % (C / 4) == 0, "ug_groupnorm_stats: C=%d must be 4*2^k <= 1024", C);
   UG_REQUIRE(x && stats_ws && mu_rstd && ((uintptr_t)mu_rstd & 7) == 0, "ug_groupnorm_stats: pointers");
   UG_HIP(hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * B * groups, st));
-  const int ppb = 1024;
+  const int ppb = gn_pixels_per_block(B, HW);
   dim3 grid((unsigned)((HW + ppb - 1) / ppb), (unsigned)B);
   hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), 0, st, x, stats_ws, (int)HW, C, groups, ppb);
   UG_CHECK_LAUNCH("ug_groupnorm_stats(stats)");

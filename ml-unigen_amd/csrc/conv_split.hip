@@ -35,6 +35,9 @@ struct SplitArgs {
   int KH, KW, stride, pad_t, pad_l, ups;
   int nblks;               // cout_pad / 128
   int M;
+  int kslabs;              // ceil(Cin / 32): a ragged last slab reads zeros (weights are packed zero-padded)
+  int64_t ldx, ldy, ldres; // row strides of x (per input pixel), y and residual (per output pixel), elements
+  int act;                 // 1: gelu_pytorch_tanh before the residual add
 };
 
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
@@ -121,8 +124,7 @@ __global__ __launch_bounds__(256, 2) void conv_split3_kernel(SplitArgs p) {
     ay[i] = r / p.Wout;
     ax[i] = r % p.Wout;
   }
-  const int kslabs = p.Cin / SBK;
-  const int nkt = p.KH * p.KW * kslabs;
+  const int nkt = p.KH * p.KW * p.kslabs;
 
   f32x4_t acc[4][4];                     // [n block][m block]
 #pragma unroll
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void conv_split3_kernel(SplitArgs p) {
 
   auto fetch = [&]() __attribute__((always_inline)) {
     cur_c0 += SBK;
-    if (cur_c0 >= p.Cin) { cur_c0 = 0; ++cur_tap; }
+    if (cur_c0 >= p.kslabs * SBK) { cur_c0 = 0; ++cur_tap; }
     if (cur_c0 == 0) {                   // new tap: im2col coordinates and bounds once per Cin/32 slabs
       const int dy = cur_tap / p.KW, dx = cur_tap % p.KW;
       const int He = p.ups ? p.Hin * 2 : p.Hin, We = p.ups ? p.Win * 2 : p.Win;
@@ -150,13 +152,14 @@ __global__ __launch_bounds__(256, 2) void conv_split3_kernel(SplitArgs p) {
         int iy = ay[i] * p.stride + dy - p.pad_t, ix = ax[i] * p.stride + dx - p.pad_l;
         aok[i] = av[i] && iy >= 0 && iy < He && ix >= 0 && ix < We;
         if (p.ups) { iy >>= 1; ix >>= 1; }
-        apix[i] = aok[i] ? p.x + (((int64_t)ab[i] * p.Hin + iy) * p.Win + ix) * p.Cin : p.x;
+        apix[i] = aok[i] ? p.x + (((int64_t)ab[i] * p.Hin + iy) * p.Win + ix) * p.ldx : p.x;
       }
     }
+    const bool cok = cur_c0 + q * 4 < p.Cin;       // Cin % 4 == 0: a quad is inside or outside as a whole
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      rx[i] = *reinterpret_cast<const float4*>(aok[i] ? apix[i] + cur_c0 + q * 4 : p.x);
-      kx[i] = aok[i];
+      kx[i] = aok[i] && cok;
+      rx[i] = *reinterpret_cast<const float4*>(kx[i] ? apix[i] + cur_c0 + q * 4 : p.x);
     }
 #pragma unroll
     for (int i = 0; i < 6; ++i) rw[i] = wt[i * 256];
@@ -202,16 +205,23 @@ __global__ __launch_bounds__(256, 2) void conv_split3_kernel(SplitArgs p) {
     for (int i = 0; i < 4; ++i) {
       const int n = nblk * SBN + wn * 64 + i * 16 + g * 4;
       if (n >= p.Cout) continue;
-      float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
       if (p.bias) {
         const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
-        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+      }
+      if (p.act == 1) {      // gelu_pytorch_tanh: 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))), as ug_linear_f32
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float u = 0.7978845608028654f * (v[k] + 0.044715f * v[k] * v[k] * v[k]);
+          v[k] = 0.5f * v[k] * (1.f + tanhf(u));
+        }
       }
       if (p.res) {
-        const float4 r = *reinterpret_cast<const float4*>(p.res + (int64_t)m * p.Cout + n);
-        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        const float4 r = *reinterpret_cast<const float4*>(p.res + (int64_t)m * p.ldres + n);
+        v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
       }
-      *reinterpret_cast<float4*>(p.y + (int64_t)m * p.Cout + n) = v;
+      *reinterpret_cast<float4*>(p.y + (int64_t)m * p.ldy + n) = make_float4(v[0], v[1], v[2], v[3]);
     }
   }
 }
@@ -519,8 +529,8 @@ __global__ __launch_bounds__(512) void conv3x3_patch16_kernel(PatchArgs p) {
 // the swizzled LDS image.  One thread per 16-byte chunk of the output.
 __global__ __launch_bounds__(256) void conv_split_weights_kernel(const float* __restrict__ wp, bf16_t* __restrict__ out,
                                                                  int taps, int Cin, int cout_pad) {
-  const int64_t chunks = (int64_t)taps * Cin * cout_pad * 3 / 8;
-  const int kslabs = Cin / SBK, nblks = cout_pad / SBN;
+  const int kslabs = (Cin + SBK - 1) / SBK, nblks = cout_pad / SBN;
+  const int64_t chunks = (int64_t)taps * kslabs * nblks * (TILE / 8);
   for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < chunks; idx += (int64_t)gridDim.x * blockDim.x) {
     const int within = (int)(idx % (TILE / 8));
     const int64_t tile = idx / (TILE / 8);
@@ -534,8 +544,8 @@ __global__ __launch_bounds__(256) void conv_split_weights_kernel(const float* __
 #pragma unroll
     for (int e = 0; e < 8; e += 2) {
       const int c = ks * SBK + chunk * 8 + e;
-      const float a = wp[((int64_t)tap * Cin + c) * cout_pad + nb * SBN + r];
-      const float b = wp[((int64_t)tap * Cin + c + 1) * cout_pad + nb * SBN + r];
+      const float a = c < Cin ? wp[((int64_t)tap * Cin + c) * cout_pad + nb * SBN + r] : 0.f;
+      const float b = c + 1 < Cin ? wp[((int64_t)tap * Cin + c + 1) * cout_pad + nb * SBN + r] : 0.f;
       uint32_t p1, p2, p3;
       split3_pair(a, b, p1, p2, p3);
       const uint32_t pk = plane == 0 ? p1 : plane == 1 ? p2 : p3;
@@ -551,10 +561,10 @@ __global__ __launch_bounds__(256) void conv_split_weights_kernel(const float* __
 // ------------------------------------------------------------------------------------ C ABI
 extern "C" int ug_conv_split_weights(const float* w_packed, uint16_t* w_split, int taps, int Cin, int cout_pad,
                                      hipStream_t st) {
-  UG_REQUIRE(w_packed && w_split && taps > 0 && Cin > 0 && Cin % SBK == 0 && cout_pad > 0 && cout_pad % SBN == 0,
-             "ug_conv_split_weights: needs Cin %% 32 == 0 and cout_pad %% 128 == 0 (Cin=%d cout_pad=%d)", Cin, cout_pad);
+  UG_REQUIRE(w_packed && w_split && taps > 0 && Cin > 0 && cout_pad > 0 && cout_pad % SBN == 0,
+             "ug_conv_split_weights: needs cout_pad %% 128 == 0 (Cin=%d cout_pad=%d)", Cin, cout_pad);
   UG_REQUIRE(ug_aligned16(w_split), "ug_conv_split_weights: output must be 16-byte aligned");
-  const int64_t chunks = (int64_t)taps * Cin * cout_pad * 3 / 8;
+  const int64_t chunks = (int64_t)taps * ((Cin + SBK - 1) / SBK) * (cout_pad / SBN) * (TILE / 8);
   int64_t g = (chunks + 255) / 256;
   if (g > 8192) g = 8192;
   hipLaunchKernelGGL(conv_split_weights_kernel, dim3((unsigned)g), dim3(256), 0, st, w_packed, (bf16_t*)w_split, taps, Cin,
@@ -567,8 +577,8 @@ extern "C" int ug_conv2d_split3(const float* x, const uint16_t* w_split, const f
                                 int64_t B, int Hin, int Win, int Cin, int Cout, int cout_pad, int ksize, int stride,
                                 int pad_top, int pad_left, int Hout, int Wout, int upsample2x, hipStream_t st) {
   UG_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && ksize >= 1 && ksize <= 16, "ug_conv2d_split3: bad shape");
-  UG_REQUIRE(Cin % SBK == 0 && Cout % 4 == 0 && cout_pad % SBN == 0 && cout_pad >= Cout,
-             "ug_conv2d_split3: needs Cin %% 32 == 0, Cout %% 4 == 0, cout_pad %% 128 == 0 (Cin=%d Cout=%d cout_pad=%d)", Cin,
+  UG_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0 && cout_pad % SBN == 0 && cout_pad >= Cout,
+             "ug_conv2d_split3: needs Cin %% 4 == 0, Cout %% 4 == 0, cout_pad %% 128 == 0 (Cin=%d Cout=%d cout_pad=%d)", Cin,
              Cout, cout_pad);
   UG_REQUIRE(x && y && w_split && ug_aligned16(x) && ug_aligned16(y) && ug_aligned16(w_split) &&
                  (!bias || ug_aligned16(bias)) && (!residual || ug_aligned16(residual)),
@@ -579,10 +589,34 @@ extern "C" int ug_conv2d_split3(const float* x, const uint16_t* w_split, const f
   a.x = x; a.w = (const bf16_t*)w_split; a.bias = bias; a.res = residual; a.y = y;
   a.B = (int)B; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Hout = Hout; a.Wout = Wout; a.Cout = Cout;
   a.KH = ksize; a.KW = ksize; a.stride = stride; a.pad_t = pad_top; a.pad_l = pad_left; a.ups = upsample2x;
-  a.nblks = cout_pad / SBN; a.M = (int)M;
+  a.nblks = cout_pad / SBN; a.M = (int)M; a.kslabs = (Cin + SBK - 1) / SBK;
+  a.ldx = Cin; a.ldy = Cout; a.ldres = Cout;
   dim3 grid((unsigned)(((M + SBM - 1) / SBM + 7) / 8 * 8), (unsigned)((Cout + SBN - 1) / SBN));
   hipLaunchKernelGGL(conv_split3_kernel, grid, dim3(256), 0, st, a);
   UG_CHECK_LAUNCH("ug_conv2d_split3");
+  return UG_OK;
+}
+
+extern "C" int ug_linear_split3(const float* x, int64_t ldx, const uint16_t* w_split, const float* bias, const float* residual,
+                                int64_t ldres, float* y, int64_t ldy, int64_t M, int64_t N, int64_t K, int n_pad, int act,
+                                hipStream_t st) {
+  UG_REQUIRE(M > 0 && N > 0 && K > 0 && (act == 0 || act == 1) && M < (1LL << 31), "ug_linear_split3: bad args");
+  UG_REQUIRE(K % 4 == 0 && N % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && (!residual || ldres % 4 == 0) && n_pad % SBN == 0 &&
+                 n_pad >= N,
+             "ug_linear_split3: needs K, N and the row strides %% 4 == 0 and n_pad %% 128 == 0 (K=%lld N=%lld n_pad=%d)",
+             (long long)K, (long long)N, n_pad);
+  UG_REQUIRE(x && y && w_split && ug_aligned16(x) && ug_aligned16(y) && ug_aligned16(w_split) &&
+                 (!bias || ug_aligned16(bias)) && (!residual || ug_aligned16(residual)),
+             "ug_linear_split3: pointers must be 16-byte aligned");
+  SplitArgs a{};
+  a.x = x; a.w = (const bf16_t*)w_split; a.bias = bias; a.res = residual; a.y = y;
+  a.B = (int)M; a.Hin = a.Win = a.Hout = a.Wout = 1; a.Cin = (int)K; a.Cout = (int)N;
+  a.KH = a.KW = 1; a.stride = 1;
+  a.nblks = n_pad / SBN; a.M = (int)M; a.kslabs = (int)((K + SBK - 1) / SBK);
+  a.ldx = ldx; a.ldy = ldy; a.ldres = ldres; a.act = act;
+  dim3 grid((unsigned)(((M + SBM - 1) / SBM + 7) / 8 * 8), (unsigned)((N + SBN - 1) / SBN));
+  hipLaunchKernelGGL(conv_split3_kernel, grid, dim3(256), 0, st, a);
+  UG_CHECK_LAUNCH("ug_linear_split3");
   return UG_OK;
 }
 

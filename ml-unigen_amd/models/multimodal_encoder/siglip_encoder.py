@@ -22,6 +22,7 @@ import torch.nn as nn
 from unigen_hip import ops
 from unigen_hip.lib import UniGenHipError
 
+_SPLIT_LINEAR = os.environ.get("UNIGEN_CONV_FP32_MFMA", "0") != "1"
 _SO400M = dict(hidden_size=1152, intermediate_size=4304, num_hidden_layers=27, num_attention_heads=16, num_channels=3,
                image_size=384, patch_size=14, layer_norm_eps=1e-6, hidden_act="gelu_pytorch_tanh")
 
@@ -161,12 +162,16 @@ class SigLipVisionTower(nn.Module):
             raise UniGenHipError("SigLipVisionTower must live in GPU memory; there is no CPU implementation")
         w4 = torch.cat([w, w.new_zeros(w.shape[0], 4 - w.shape[1], *w.shape[2:])], 1)
         wp, cpad = ops.pack_conv_weight(w4)
-        pk = {"key": key, "patch_w": wp, "patch_cpad": cpad, "patch_b": pe.bias.detach().float().contiguous(), "qkv": []}
+        pk = {"key": key, "patch_w": wp, "patch_cpad": cpad, "patch_b": pe.bias.detach().float().contiguous(), "qkv": [],
+              "split": []}
         for l in vm.encoder.layers:
             a = l.self_attn
             wq = torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight]).detach().float().contiguous()
             bq = torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias]).detach().float().contiguous()
             pk["qkv"].append((wq, bq))
+            if _SPLIT_LINEAR:       # fp32-accurate projections on the bf16 matrix cores (three-way operand split)
+                pk["split"].append(tuple(ops.split_linear_weight(w) for w in
+                                         (wq, a.out_proj.weight, l.mlp.fc1.weight, l.mlp.fc2.weight)))
         self._packed = pk
         return pk
 
@@ -192,7 +197,14 @@ class SigLipVisionTower(nn.Module):
             xn = ops.layernorm_f32(h, l.layer_norm1.weight.detach(), l.layer_norm1.bias.detach(), c.layer_norm_eps)
             wq, bq = pk["qkv"][li]
             qkv = torch.empty((B * T + 1, 3 * D), dtype=torch.float32, device=h.device)     # +1 row: tile over-read slack
-            ops.linear_f32(xn, wq, bq, out=qkv, M=B * T)
+            sp = pk["split"][li] if pk["split"] else None
+
+            def lin(x, j, W, bias, **kw):
+                if sp is not None:
+                    return ops.linear_split3(x, sp[j][0], sp[j][1], W.shape[0], bias, **kw)
+                return ops.linear_f32(x, W, bias, **kw)
+
+            lin(xn, 0, wq, bq, out=qkv, M=B * T)
             ctx = torch.empty((B * T, D), dtype=torch.float32, device=h.device)
             for b in range(B):
                 qb = qkv[b * T:(b + 1) * T]
@@ -203,10 +215,10 @@ class SigLipVisionTower(nn.Module):
                 ops.gemm_f32(s, qb[:, 2 * D:], b_is_nk=False, M=T, N=hd, K=T, batch=Hh, lda=ldS, ldb=3 * D,
                              stride_a=T * ldS, stride_b=hd, out=ctx[b * T:(b + 1) * T], ldc=D, stride_c=hd)
             o = l.self_attn.out_proj
-            h = ops.linear_f32(ctx, o.weight.detach(), o.bias.detach(), residual=h)
+            h = lin(ctx, 1, o.weight.detach(), o.bias.detach(), residual=h)
             xn2 = ops.layernorm_f32(h, l.layer_norm2.weight.detach(), l.layer_norm2.bias.detach(), c.layer_norm_eps)
-            m = ops.linear_f32(xn2, l.mlp.fc1.weight.detach(), l.mlp.fc1.bias.detach(), act=1)
-            h = ops.linear_f32(m, l.mlp.fc2.weight.detach(), l.mlp.fc2.bias.detach(), residual=h)
+            m = lin(xn2, 2, l.mlp.fc1.weight.detach(), l.mlp.fc1.bias.detach(), act=1)
+            h = lin(m, 3, l.mlp.fc2.weight.detach(), l.mlp.fc2.bias.detach(), residual=h)
         return h.view(B, T, D)
 
     def forward(self, images):

@@ -518,14 +518,14 @@ def pack_conv_weight(w):
 
 
 def conv_split_eligible(cin, cout, cout_pad):
-    """Shapes the split-bf16 convolution (`ug_conv2d_split3`) takes."""
+    """Shapes the split-bf16 convolution (`ug_conv2d_split3`) is used for (the kernel itself only needs Cin % 4 == 0)."""
     return cin % 32 == 0 and cout % 4 == 0 and cout_pad % 128 == 0 and cout >= 64
 
 
 def split_conv_weight(wp):
     """Packed fp32 weights [taps, Cin, cout_pad] -> the three-plane bf16 tile image `ug_conv2d_split3` reads."""
     taps, cin, cout_pad = wp.shape
-    ws = torch.empty(3 * taps * cin * cout_pad, dtype=torch.bfloat16, device=wp.device)
+    ws = torch.empty(3 * taps * round_up(cin, 32) * cout_pad, dtype=torch.bfloat16, device=wp.device)
     _l.check(_l.load().ug_conv_split_weights(_p(wp), _p(ws), taps, cin, cout_pad, _stream()), "ug_conv_split_weights")
     return ws
 
@@ -615,6 +615,27 @@ def linear_f32(x, W, bias=None, residual=None, act=0, out=None, M=None):
     _l.check(_l.load().ug_linear_f32(_p(x), x.stride(0), _p(W), W.stride(0), _p(bias), _p(residual),
                                      residual.stride(0) if residual is not None else 0, _p(out), out.stride(0), M, N, K, act,
                                      _stream()), "ug_linear_f32")
+    return out
+
+
+def split_linear_weight(W):
+    """nn.Linear weight [N, K] fp32 -> (split tile image of W^T as a 1x1 conv, n_pad) for `linear_split3`."""
+    N, K = W.shape
+    n_pad = round_up(N, 128)
+    wp = torch.zeros((1, K, n_pad), dtype=torch.float32, device=W.device)
+    wp[0, :, :N] = W.detach().float().t()
+    return split_conv_weight(wp), n_pad
+
+
+def linear_split3(x, w_split, n_pad, N, bias=None, residual=None, act=0, out=None, M=None):
+    """`linear_f32` with the three-way bf16 split contraction (fp32-accurate, bf16 matrix cores); x [M,K] fp32."""
+    M = x.shape[0] if M is None else M
+    K = x.shape[1]
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    _l.check(_l.load().ug_linear_split3(_p(x), x.stride(0), _p(w_split), _p(bias), _p(residual),
+                                        residual.stride(0) if residual is not None else 0, _p(out), out.stride(0), M, N, K,
+                                        n_pad, act, _stream()), "ug_linear_split3")
     return out
 
 

@@ -488,6 +488,29 @@ def test_conv3x3_patch_matches_fp64(dev, cin, cout, H, W, gn):
     assert _maxabs(got, unfused) < 3e-5
 
 
+@pytest.mark.parametrize("M,N,K,act", [(300, 1152, 1152, 0), (257, 4304, 1152, 1), (129, 1152, 4304, 0), (64, 68, 36, 1)])
+def test_linear_split3_matches_fp64(dev, M, N, K, act):
+    """Split-bf16 linear (ragged K slabs, GELU, bias, residual, strided output) against fp64 and the fp32 MFMA path."""
+    ops = _ops()
+    gen = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=gen) * 1.5
+    W = torch.randn(N, K, generator=gen) / math.sqrt(K)
+    bias = torch.randn(N, generator=gen)
+    res = torch.randn(M, N, generator=gen)
+    pre = x.double() @ W.double().t() + bias.double()
+    if act:
+        pre = F.gelu(pre, approximate="tanh")
+    ref = pre + res.double()
+    ws, n_pad = ops.split_linear_weight(W.to(dev))
+    out = torch.full((M, N + 8), 7.0, device=dev)[:, :N]                   # strided destination, sentinel columns
+    got = ops.linear_split3(x.to(dev), ws, n_pad, N, bias.to(dev), residual=res.to(dev), act=act, out=out)
+    exact = ops.linear_f32(x.to(dev), W.to(dev), bias.to(dev), residual=res.to(dev), act=act)
+    e_split = (got.cpu().double() - ref).abs().max().item()
+    e_exact = (exact.cpu().double() - ref).abs().max().item()
+    assert e_split < 1e-4 and e_split <= 1.5 * e_exact + 2e-6, (e_split, e_exact)
+    assert torch.all(out.as_strided((M, 8), (N + 8, 1), out.storage_offset() + N) == 7.0)
+
+
 def test_conv_split_weights_reconstruct(dev):
     """The three bf16 planes of the split weight image add back to the fp32 weights exactly (tile order and swizzle)."""
     ops = _ops()
