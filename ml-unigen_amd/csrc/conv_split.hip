@@ -57,6 +57,49 @@ __device__ __forceinline__ void split3_pair(float a, float b, uint32_t& p1, uint
 // a ds_read_b128 fragment fetch touches land on 16 distinct chunks of a 256-byte bank row
 __device__ __forceinline__ int swz(int r, int chunk) { return r * SBK + ((chunk ^ ((r >> 2) & 3)) << 3); }
 
+// four fp32 values of one pixel (channel quad `q` of LDS row `row`) -> the three split planes
+__device__ __forceinline__ void store_split_quad(bf16_t* planes, int plane_stride, int row, int q, f32x4_t v) {
+  uint32_t a1, a2, a3, b1, b2, b3;
+  split3_pair(v[0], v[1], a1, a2, a3);
+  split3_pair(v[2], v[3], b1, b2, b3);
+  const int off = swz(row, q >> 1) + (q & 1) * 4;
+  *reinterpret_cast<uint2*>(planes + off) = make_uint2(a1, b1);
+  *reinterpret_cast<uint2*>(planes + plane_stride + off) = make_uint2(a2, b2);
+  *reinterpret_cast<uint2*>(planes + 2 * plane_stride + off) = make_uint2(a3, b3);
+}
+
+// result block epilogue: four consecutive output channels of one pixel.  y = act(acc + bias) + residual
+__device__ __forceinline__ void store_out_quad(f32x4_t a, const float* bias, const float* res, float* y, int act) {
+  float v[4] = {a[0], a[1], a[2], a[3]};
+  if (bias) {
+    const float4 b = *reinterpret_cast<const float4*>(bias);
+    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+  }
+  if (act == 1) {            // gelu_pytorch_tanh: 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))), as ug_linear_f32
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float u = 0.7978845608028654f * (v[k] + 0.044715f * v[k] * v[k] * v[k]);
+      v[k] = 0.5f * v[k] * (1.f + tanhf(u));
+    }
+  }
+  if (res) {
+    const float4 r = *reinterpret_cast<const float4*>(res);
+    v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+  }
+  *reinterpret_cast<float4*>(y) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// GroupNorm (+ swish) of a channel quad, the arithmetic of gn_apply_kernel (conv_f32.hip)
+__device__ __forceinline__ f32x4_t gn_swish_quad(f32x4_t v, float mu, float rstd, f32x4_t ga, f32x4_t be, int swish) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float o = (v[k] - mu) * rstd * ga[k] + be[k];
+    if (swish) o = o / (1.f + expf(-o));
+    v[k] = o;
+  }
+  return v;
+}
+
 // One 32-deep contraction slab of a wave's 64 x 64 result (4 x 4 MFMA blocks): six partial products per block, the
 // smallest first.  wl: this lane's row of the weight plane-0 image (blocks 16 rows apart); xj[j]: this lane's row of
 // pixel block j in plane 0; planes are XPLANE (pixels) / PLANE (weights) elements apart.
@@ -170,15 +213,8 @@ __global__ __launch_bounds__(256, 2) void conv_split3_kernel(SplitArgs p) {
     for (int i = 0; i < 6; ++i) reinterpret_cast<u32x4_t*>(Ws)[i * 256 + tid] = rw[i];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const float4 v = kx[i] ? rx[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-      uint32_t a1, a2, a3, b1, b2, b3;
-      split3_pair(v.x, v.y, a1, a2, a3);
-      split3_pair(v.z, v.w, b1, b2, b3);
-      const int r = (tid >> 3) + i * 32;
-      const int off = swz(r, q >> 1) + (q & 1) * 4;
-      *reinterpret_cast<uint2*>(Xs + off) = make_uint2(a1, b1);
-      *reinterpret_cast<uint2*>(Xs + PLANE + off) = make_uint2(a2, b2);
-      *reinterpret_cast<uint2*>(Xs + 2 * PLANE + off) = make_uint2(a3, b3);
+      const f32x4_t v = kx[i] ? f32x4_t{rx[i].x, rx[i].y, rx[i].z, rx[i].w} : f32x4_t{0.f, 0.f, 0.f, 0.f};
+      store_split_quad(Xs, PLANE, (tid >> 3) + i * 32, q, v);
     }
   };
 
@@ -205,23 +241,8 @@ __global__ __launch_bounds__(256, 2) void conv_split3_kernel(SplitArgs p) {
     for (int i = 0; i < 4; ++i) {
       const int n = nblk * SBN + wn * 64 + i * 16 + g * 4;
       if (n >= p.Cout) continue;
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      if (p.bias) {
-        const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
-        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-      }
-      if (p.act == 1) {      // gelu_pytorch_tanh: 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))), as ug_linear_f32
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float u = 0.7978845608028654f * (v[k] + 0.044715f * v[k] * v[k] * v[k]);
-          v[k] = 0.5f * v[k] * (1.f + tanhf(u));
-        }
-      }
-      if (p.res) {
-        const float4 r = *reinterpret_cast<const float4*>(p.res + (int64_t)m * p.ldres + n);
-        v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
-      }
-      *reinterpret_cast<float4*>(p.y + (int64_t)m * p.ldy + n) = make_float4(v[0], v[1], v[2], v[3]);
+      store_out_quad(acc[i][j], p.bias ? p.bias + n : nullptr, p.res ? p.res + (int64_t)m * p.ldres + n : nullptr,
+                     p.y + (int64_t)m * p.ldy + n, p.act);
     }
   }
 }
@@ -308,22 +329,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(PatchArgs p) {
       const int prow = (tid >> 3) + 32 * i;
       if (prow >= PP_ROWS) continue;
       f32x4_t v = rx[i];
-      if constexpr (GN) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          float o = (v[k] - mu) * rstd * ga[k] + be[k];
-          if (p.swish) o = o / (1.f + expf(-o));
-          v[k] = o;
-        }
-      }
+      if constexpr (GN) v = gn_swish_quad(v, mu, rstd, ga, be, p.swish);
       if (!pok[i]) v = f32x4_t{0.f, 0.f, 0.f, 0.f};             // the conv pads the NORMALISED tensor with zeros
-      uint32_t a1, a2, a3, b1, b2, b3;
-      split3_pair(v[0], v[1], a1, a2, a3);
-      split3_pair(v[2], v[3], b1, b2, b3);
-      const int off = swz(prow, q >> 1) + (q & 1) * 4;
-      *reinterpret_cast<uint2*>(Xp + off) = make_uint2(a1, b1);
-      *reinterpret_cast<uint2*>(Xp + XPATCH + off) = make_uint2(a2, b2);
-      *reinterpret_cast<uint2*>(Xp + 2 * XPATCH + off) = make_uint2(a3, b3);
+      store_split_quad(Xp, XPATCH, prow, q, v);
     }
   };
 
@@ -362,16 +370,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(PatchArgs p) {
     for (int i = 0; i < 4; ++i) {
       const int n = nblk * SBN + wn * 64 + i * 16 + g * 4;
       if (n >= p.Cout) continue;
-      float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-      if (p.bias) {
-        const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
-        v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
-      }
-      if (p.res) {
-        const float4 r = *reinterpret_cast<const float4*>(p.res + m * p.Cout + n);
-        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-      }
-      *reinterpret_cast<float4*>(p.y + m * p.Cout + n) = v;
+      store_out_quad(acc[i][j], p.bias ? p.bias + n : nullptr, p.res ? p.res + m * p.Cout + n : nullptr,
+                     p.y + m * p.Cout + n, 0);
     }
   }
 }
@@ -449,22 +449,9 @@ __global__ __launch_bounds__(512) void conv3x3_patch16_kernel(PatchArgs p) {
       const int prow = (tid >> 3) + 64 * i;
       if (prow >= QP_ROWS) continue;
       f32x4_t v = rx[i];
-      if constexpr (GN) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          float o = (v[k] - mu) * rstd * ga[k] + be[k];
-          if (p.swish) o = o / (1.f + expf(-o));
-          v[k] = o;
-        }
-      }
-      if (!pok[i]) v = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      uint32_t a1, a2, a3, b1, b2, b3;
-      split3_pair(v[0], v[1], a1, a2, a3);
-      split3_pair(v[2], v[3], b1, b2, b3);
-      const int off = swz(prow, q >> 1) + (q & 1) * 4;
-      *reinterpret_cast<uint2*>(Xp + off) = make_uint2(a1, b1);
-      *reinterpret_cast<uint2*>(Xp + XQ + off) = make_uint2(a2, b2);
-      *reinterpret_cast<uint2*>(Xp + 2 * XQ + off) = make_uint2(a3, b3);
+      if constexpr (GN) v = gn_swish_quad(v, mu, rstd, ga, be, p.swish);
+      if (!pok[i]) v = f32x4_t{0.f, 0.f, 0.f, 0.f};             // the conv pads the NORMALISED tensor with zeros
+      store_split_quad(Xp, XQ, prow, q, v);
     }
   };
 
@@ -511,16 +498,8 @@ __global__ __launch_bounds__(512) void conv3x3_patch16_kernel(PatchArgs p) {
     for (int i = 0; i < 4; ++i) {
       const int n = nblk * SBN + wn * 64 + i * 16 + g * 4;
       if (n >= p.Cout) continue;
-      float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-      if (p.bias) {
-        const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
-        v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
-      }
-      if (p.res) {
-        const float4 r = *reinterpret_cast<const float4*>(p.res + m * p.Cout + n);
-        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-      }
-      *reinterpret_cast<float4*>(p.y + m * p.Cout + n) = v;
+      store_out_quad(acc[i][j], p.bias ? p.bias + n : nullptr, p.res ? p.res + m * p.Cout + n : nullptr,
+                     p.y + m * p.Cout + n, 0);
     }
   }
 }
