@@ -103,6 +103,10 @@ def load():
         raise UniGenHipError(
             f"{LIB_PATH} is missing: the HIP extension is the only implementation of this path "
             f"(no CPU fallback). Build it with `make -C {CSRC_DIR}` or `python -c 'import __graft_entry__ as g; g.build()'`.")
+    # torch ships its own libamdhip64.so.7; whichever copy of that soname is mapped first serves the whole process.
+    # Loading ours first maps /opt/rocm's runtime, and a later `import torch` then runs on a HIP/HSA mix that finds no
+    # device -- so torch's runtime always goes first (the host side of this library is PyTorch anyway).
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     lib.ug_last_error.restype = ctypes.c_char_p
     lib.ug_last_error.argtypes = []
