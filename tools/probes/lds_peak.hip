@@ -1,0 +1,42 @@
+// LDS read bandwidth probe for gfx950: every wave streams conflict-free ds_read_b128 fragments (the bf16 GEMM's
+// fragment pattern: 16 rows x 64 B, XOR-swizzled) out of a 64 KB LDS tile, optionally with MFMAs consuming them.
+#include <hip/hip_runtime.h>
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+template <int MFMA_PER_READ>
+__global__ __launch_bounds__(512) void lds_read_kernel(float* __restrict__ out, int iters) {
+  __shared__ __attribute__((aligned(16))) char tile[65536];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < 65536 / 4; i += blockDim.x) reinterpret_cast<int*>(tile)[i] = i * 2654435761u;
+  __syncthreads();
+  const int row = lane & 15, g = lane >> 4;
+  f32x4_t acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+  bf16x8_t keep = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int r = ((wave * 16 + u) * 16 + row + it) & 1023;                 // 1024 rows x 64 B
+      const bf16x8_t f = *reinterpret_cast<const bf16x8_t*>(tile + r * 64 + ((g ^ ((r >> 2) & 3)) << 4));
+      if constexpr (MFMA_PER_READ == 0) {
+        keep ^= f;
+      } else {
+#pragma unroll
+        for (int m = 0; m < MFMA_PER_READ; ++m) acc[(u + m) & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f, f, acc[(u + m) & 3], 0, 0, 0);
+      }
+    }
+  }
+  float s = acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3];
+  for (int k = 0; k < 8; ++k) s += (float)keep[k];
+  if (s == 1.2345f) out[blockIdx.x * blockDim.x + tid] = s;
+}
+
+extern "C" void lds_read_launch(float* out, int blocks, int threads, int iters, int mfma_per_read, hipStream_t st) {
+  switch (mfma_per_read) {
+    case 0: hipLaunchKernelGGL(lds_read_kernel<0>, dim3(blocks), dim3(threads), 0, st, out, iters); break;
+    case 1: hipLaunchKernelGGL(lds_read_kernel<1>, dim3(blocks), dim3(threads), 0, st, out, iters); break;
+    case 2: hipLaunchKernelGGL(lds_read_kernel<2>, dim3(blocks), dim3(threads), 0, st, out, iters); break;
+    case 3: hipLaunchKernelGGL(lds_read_kernel<3>, dim3(blocks), dim3(threads), 0, st, out, iters); break;
+    default: hipLaunchKernelGGL(lds_read_kernel<4>, dim3(blocks), dim3(threads), 0, st, out, iters); break;
+  }
+}
