@@ -145,6 +145,9 @@ class MAGVITv2(ModelMixin, ConfigMixin):
         self.quantize = LFQuantizer()
         self._packed = {}
         self._err = None
+        # True: every conv on the exact fp32 MFMA chain (ug_conv2d_f32) and stand-alone GroupNorm passes;
+        # False (default): wide convs on the split-bf16 contraction.  Flip it on an instance to compare the two.
+        self.exact_fp32_convs = not _SPLIT_CONV
 
     # ------------------------------------------------------------------ plumbing
     def _apply(self, fn, *a, **k):
@@ -156,7 +159,7 @@ class MAGVITv2(ModelMixin, ConfigMixin):
         return super().load_state_dict(*a, **k)
 
     def _pk(self, conv, pad_cin_to=None):
-        key = id(conv)
+        key = (id(conv), self.exact_fp32_convs)
         ver = conv.weight._version
         hit = self._packed.get(key)
         if hit is not None and hit[0] == ver:
@@ -172,7 +175,7 @@ class MAGVITv2(ModelMixin, ConfigMixin):
         p.cout, p.cin, p.k = w.shape[0], w.shape[1], w.shape[2]
         # wide convs run on the bf16 matrix cores with three-way split operands (fp32-accurate, 16/6 the MFMA rate);
         # UNIGEN_CONV_FP32_MFMA=1 keeps every conv on the exact fp32 MFMA chain
-        p.ws = ops.split_conv_weight(p.w) if (_SPLIT_CONV and ops.conv_split_eligible(p.cin, p.cout, p.cpad)) else None
+        p.ws = ops.split_conv_weight(p.w) if (not self.exact_fp32_convs and ops.conv_split_eligible(p.cin, p.cout, p.cpad)) else None
         self._packed[key] = (ver, p)
         return p
 

@@ -162,6 +162,29 @@ def test_magvit_tokens_match_reference_golden(dev):
     assert (rec.mean(dim=(2, 3)) - g["rec_mean"]).abs().max().item() < 1e-5
 
 
+def test_magvit_split_convs_match_exact_fp32_path(dev):
+    """The default tokenizer (split-bf16 convolutions, GroupNorm on the conv load path) against the same module with
+    every conv on the exact fp32 MFMA chain: latents agree to fp32 summation noise, tokens outside that band are equal,
+    reconstructions agree."""
+    from models import MAGVITv2
+    from oracle import weights
+    vq = MAGVITv2().to(dev).eval()
+    sd = weights.synth_magvit_state([(n, tuple(p.shape)) for n, p in vq.named_parameters()], seed=77)
+    vq.load_state_dict(sd, strict=False)
+    x = weights.synth_images(3, 256, seed=9).to(dev)
+    assert not vq.exact_fp32_convs
+    z_split, idx_split = vq.get_latents(x).cpu(), vq.get_code(x).cpu()
+    rec_split = vq.decode_code(idx_split.to(dev)).cpu()
+    vq.exact_fp32_convs = True
+    z_exact, idx_exact = vq.get_latents(x).cpu(), vq.get_code(x).cpu()
+    rec_exact = vq.decode_code(idx_split.to(dev)).cpu()
+    dz = (z_split - z_exact).abs().max().item()
+    assert dz < 5e-5, dz
+    safe = (z_exact.abs() > 4 * dz + 1e-6).permute(0, 2, 3, 1).reshape(3, 256, 13).all(-1)
+    assert torch.equal(idx_split[safe], idx_exact[safe]) and safe.float().mean().item() > 0.95
+    assert (rec_split - rec_exact).abs().max().item() < 2e-4
+
+
 def test_ar_generation_kv_cache_matches_oracle(dev):
     """t2i_generate_ar (static KV cache, captured graph) vs the oracle's DynamicCache-style greedy decode:
     tokens must agree step by step until the oracle's own top-2 margin drops below bf16 noise."""
