@@ -276,6 +276,8 @@ int ug_gemm_f32(const float* A, int64_t lda, int64_t stride_a, const float* B, i
 /* replaces: Normalize = GroupNorm(32, eps 1e-6) (+ swish), common_modules.py:19-27 */
 int ug_groupnorm_swish(const float* x, const float* gamma, const float* beta, float* y, double* stats_ws,
                        int64_t B, int64_t HW, int C, int groups, float eps, int apply_swish, hipStream_t stream);
+/* in-place softmax(scale * x) over the first `cols` columns of each row; columns [cols, min(ld, roundup(cols, 4))) are
+ * set to zero so the probabilities can be contracted over a 16-byte-aligned width. */
 int ug_softmax_rows_f32(float* x, int64_t rows, int64_t cols, int64_t ld, float scale, hipStream_t stream);
 /* ---- SigLIP ViT (fp32, frozen; reference models/multimodal_encoder/siglip_encoder.py:152-309) ---- */
 /* y = act(x W^T + bias) + residual, W [N][K] as nn.Linear stores it; act 1 = gelu_pytorch_tanh.

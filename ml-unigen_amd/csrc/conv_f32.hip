@@ -348,6 +348,10 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ x
   s = wave_sum(s);
   const float inv = 1.f / s;
   for (int c = lane; c < cols; c += 64) r[c] *= inv;
+  // columns up to the next multiple of four (when the row has them) read as zero, so a consumer may contract over the
+  // padded width with 16-byte loads
+  const int padded = min((int)ld, (cols + 3) & ~3);
+  if (cols + lane < padded) r[cols + lane] = 0.f;
 }
 
 // ------------------------------------------------------------------ LayerNorm (SigLIP, eps 1e-6), fp32, one wave per row

@@ -193,10 +193,14 @@ class SigLipVisionTower(nn.Module):
                             residual=pos_b).view(B * T, D)
         ldS = ops.round_up(T, 4)
         scale = float(hd) ** -0.5
+        # q|k|v of every token, reused by all layers.  Four slack rows that stay zero: the P.V contraction runs over
+        # T rounded up to four keys (16-byte loads); the padded probabilities are zero and the rows they meet are finite
+        qkv = torch.empty((B * T + 4, 3 * D), dtype=torch.float32, device=h.device)
+        qkv[B * T:].zero_()
+        Tp = ops.round_up(T, 4)
         for li, l in enumerate(vm.encoder.layers):
             xn = ops.layernorm_f32(h, l.layer_norm1.weight.detach(), l.layer_norm1.bias.detach(), c.layer_norm_eps)
             wq, bq = pk["qkv"][li]
-            qkv = torch.empty((B * T + 1, 3 * D), dtype=torch.float32, device=h.device)     # +1 row: tile over-read slack
             sp = pk["split"][li] if pk["split"] else None
 
             def lin(x, j, W, bias, **kw):
@@ -212,7 +216,7 @@ class SigLipVisionTower(nn.Module):
                 ops.gemm_f32(qb[:, 0:D], qb[:, D:2 * D], b_is_nk=True, M=T, N=T, K=hd, batch=Hh, lda=3 * D, ldb=3 * D,
                              stride_a=hd, stride_b=hd, out=s, ldc=ldS, stride_c=T * ldS)
                 ops.softmax_rows_(s.view(Hh * T, ldS), scale, cols=T)
-                ops.gemm_f32(s, qb[:, 2 * D:], b_is_nk=False, M=T, N=hd, K=T, batch=Hh, lda=ldS, ldb=3 * D,
+                ops.gemm_f32(s, qb[:, 2 * D:], b_is_nk=False, M=T, N=hd, K=Tp, batch=Hh, lda=ldS, ldb=3 * D,
                              stride_a=T * ldS, stride_b=hd, out=ctx[b * T:(b + 1) * T], ldc=D, stride_c=hd)
             o = l.self_attn.out_proj
             h = lin(ctx, 1, o.weight.detach(), o.bias.detach(), residual=h)
