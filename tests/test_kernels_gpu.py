@@ -1,6 +1,7 @@
 """Kernel-level parity: every HIP entry point against the CPU oracle (oracle/ops_ref.py) on seeded
 inputs.  All tests call through the C ABI (ctypes) -- there is no other implementation."""
 import math
+import random
 
 import pytest
 import torch
@@ -509,6 +510,48 @@ def test_linear_split3_matches_fp64(dev, M, N, K, act):
     e_exact = (exact.cpu().double() - ref).abs().max().item()
     assert e_split < 1e-4 and e_split <= 1.5 * e_exact + 2e-6, (e_split, e_exact)
     assert torch.all(out.as_strided((M, 8), (N + 8, 1), out.storage_offset() + N) == 7.0)
+
+
+def test_conv_split_randomised_shapes(dev):
+    """Seeded sweep over channel counts, ragged image sizes, kernel sizes / strides / upsampling, bias / residual / fused
+    GroupNorm: every split-bf16 kernel (im2col, 8-row patch, 16-row patch) against the exact fp32 MFMA convolution."""
+    ops = _ops()
+    rng = random.Random(2024)
+    gen = torch.Generator().manual_seed(2024)
+    for case in range(24):
+        cin = rng.choice([32, 64, 96, 128, 160, 256])
+        cout = rng.choice([64, 68, 128, 192, 256, 320])
+        k = rng.choice([1, 3, 3, 3])
+        big = case % 6 == 0                                   # a few cases large enough for the 16-row variant
+        H, W = (rng.randint(120, 136), rng.randint(250, 270)) if big else (rng.randint(3, 40), rng.randint(3, 40))
+        B = 2 if big else rng.randint(1, 3)
+        if big:
+            cin, cout = rng.choice([32, 64]), rng.choice([64, 128])
+        mode = rng.choice(["plain", "plain", "stride2", "ups"]) if k == 3 else "plain"
+        use_gn = k == 3 and mode == "plain" and cin % 128 == 0 and rng.random() < 0.7
+        use_res, use_bias = rng.random() < 0.5, rng.random() < 0.8
+        x = (torch.randn(B, H, W, cin, generator=gen) * 1.5 + 0.2).to(dev)
+        w = (torch.randn(cout, cin, k, k, generator=gen) / math.sqrt(cin * k * k)).to(dev)
+        bias = torch.randn(cout, generator=gen).to(dev) if use_bias else None
+        wp, cpad = ops.pack_conv_weight(w)
+        ws = ops.split_conv_weight(wp)
+        kw = dict(stride=2 if mode == "stride2" else 1, asym_pad=mode == "stride2", upsample=mode == "ups")
+        xin = x
+        gn = None
+        if use_gn:
+            ga, be = torch.randn(cin, generator=gen).to(dev), torch.randn(cin, generator=gen).to(dev)
+            xin = ops.groupnorm_swish(x, ga, be, swish=True)
+            gn = (ops.groupnorm_stats(x), ga, be, 32, True)
+        ref = ops.conv2d_nhwc(xin, wp, cpad, bias, cout, k, **kw)
+        res = torch.randn(ref.shape, generator=gen).to(dev) if use_res else None
+        if res is not None:
+            ref = ref + res
+        got = ops.conv2d_nhwc(xin, wp, cpad, bias, cout, k, residual=res, w_split=ws, **kw)
+        tol = 2e-5 * max(1.0, ref.abs().max().item())
+        assert got.shape == ref.shape and _maxabs(got, ref) < tol, (case, cin, cout, k, H, W, mode, _maxabs(got, ref))
+        if k == 3 and mode == "plain":
+            got3 = ops.conv3x3_nhwc(x, ws, cpad, bias, cout, residual=res, gn=gn)
+            assert _maxabs(got3, ref) < tol, (case, cin, cout, H, W, use_gn, _maxabs(got3, ref))
 
 
 def test_conv_split_weights_reconstruct(dev):
