@@ -56,16 +56,15 @@ typedef unsigned short bf16_t;                                 // raw bf16 bits
 
 // ---------------------------------------------------------------- bf16 <-> f32
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-// round-to-nearest-even, NaN preserved (same rounding torch uses for .to(bfloat16))
-__device__ __forceinline__ bf16_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
+// round-to-nearest-even, NaN stays NaN (same rounding torch uses for .to(bfloat16)): gfx950's packed hardware
+// conversion, one VALU instruction per two values (the integer sequence it replaces cost ~6 per value and was a
+// visible share of the attention kernels' VALU time)
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  uint32_t r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, f) & 0xffffu); }
 
 // ---------------------------------------------------------------- wave reductions (64 lanes)
 __device__ __forceinline__ float wave_sum(float v) {
