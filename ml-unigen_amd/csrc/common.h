@@ -60,9 +60,10 @@ __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint3
 // conversion, one VALU instruction per two values (the integer sequence it replaces cost ~6 per value and was a
 // visible share of the attention kernels' VALU time)
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-  uint32_t r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  typedef __bf16 hwbf16x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, hwbf16x2_t));    // v_cvt_pk_bf16_f32
 }
 __device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, f) & 0xffffu); }
 

@@ -40,11 +40,7 @@ struct SplitArgs {
   int act;                 // 1: gelu_pytorch_tanh before the residual add
 };
 
-__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
-  uint32_t r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
-}
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) { return pack_bf2(lo, hi); }   // v_cvt_pk_bf16_f32
 // two fp32 values -> three packed bf16 pairs
 __device__ __forceinline__ void split3_pair(float a, float b, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
   p1 = cvt_pk_bf16(a, b);
