@@ -384,6 +384,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
     stage_tr(Kt, kTs, p.Lp, t * 64, tid);
     __syncthreads();
     const uint64_t word = wrow[t];
+    const uint32_t mlo = (uint32_t)(word >> (g * 4)), mhi = (uint32_t)(word >> (32 + g * 4));   // bit 16 (j & 1) + r
     f32x4_t ds[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -395,7 +396,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const bool on = (word >> (j * 16 + g * 4 + r)) & 1ull;
+        const bool on = ((j < 2 ? mlo : mhi) >> ((j & 1) * 16 + r)) & 1u;
         const float pr = on ? __expf(s[r] * p.scale - lse) : 0.f;
         ds[j][r] = pr * (dp[r] - dl) * p.scale;
       }
@@ -431,7 +432,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
   bf16_t* Ds = QD + 64 * RM_LD;
   __shared__ __attribute__((aligned(16))) bf16_t Qt[128 * TR_LD];
   __shared__ __attribute__((aligned(16))) bf16_t Dt[128 * TR_LD];    // dO^T
-  __shared__ float lse_s[64], dl_s[64];
+  __shared__ __attribute__((aligned(16))) float lse_s[64], dl_s[64];
   __shared__ uint64_t word_s[64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
   const int t = blockIdx.x, b = blockIdx.z;
@@ -483,13 +484,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
           s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rm(Qs, j, ks, lane), kf[ks], s, 0, 0, 0);
           dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rm(Ds, j, ks, lane), vf[ks], dp, 0, 0, 0);
         }
+        const f32x4_t ls = *reinterpret_cast<const f32x4_t*>(lse_s + j * 16 + g * 4);
+        const f32x4_t dl4 = *reinterpret_cast<const f32x4_t*>(dl_s + j * 16 + g * 4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int ql = j * 16 + g * 4 + r;
           const bool on = (word_s[ql] >> kbit) & 1ull;
-          const float e = on ? __expf(s[r] * p.scale - lse_s[ql]) : 0.f;
+          const float e = on ? __expf(s[r] * p.scale - ls[r]) : 0.f;
           pr[j][r] = e;
-          ds[j][r] = e * (dp[r] - dl_s[ql]) * p.scale;
+          ds[j][r] = e * (dp[r] - dl4[r]) * p.scale;
         }
       }
       const bf16x8_t pf0 = pack_p(pr[0], pr[1]), pf1 = pack_p(pr[2], pr[3]);
