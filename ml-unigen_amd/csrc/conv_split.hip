@@ -101,31 +101,31 @@ __device__ __forceinline__ f32x4_t gn_swish_quad(f32x4_t v, float mu, float rstd
 // One 32-deep contraction slab of a wave's 64 x 64 result (4 x 4 MFMA blocks): six partial products per block, the
 // smallest first.  wl: this lane's row of the weight plane-0 image (blocks 16 rows apart); xj[j]: this lane's row of
 // pixel block j in plane 0; planes are XPLANE (pixels) / PLANE (weights) elements apart.
-template <int XPLANE>
-__device__ __forceinline__ void mma_slab(const bf16_t* wl, const bf16_t* const (&xj)[4], f32x4_t (&acc)[4][4]) {
-  bf16x8_t w1[4], w2[4], x1[4], x2[4], t[4];
+template <int XPLANE, int NI = 4>
+__device__ __forceinline__ void mma_slab(const bf16_t* wl, const bf16_t* const (&xj)[4], f32x4_t (&acc)[NI][4]) {
+  bf16x8_t w1[NI], w2[NI], x1[4], x2[4], tx[4], tw[NI];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) w1[i] = *reinterpret_cast<const bf16x8_t*>(wl + i * 16 * SBK);
+  for (int i = 0; i < NI; ++i) w1[i] = *reinterpret_cast<const bf16x8_t*>(wl + i * 16 * SBK);
 #pragma unroll
   for (int j = 0; j < 4; ++j) x1[j] = *reinterpret_cast<const bf16x8_t*>(xj[j]);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) t[j] = *reinterpret_cast<const bf16x8_t*>(xj[j] + 2 * XPLANE);   // x3
+  for (int j = 0; j < 4; ++j) tx[j] = *reinterpret_cast<const bf16x8_t*>(xj[j] + 2 * XPLANE);   // x3
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[i], t[j], acc[i][j], 0, 0, 0);
+    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[i], tx[j], acc[i][j], 0, 0, 0);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) t[i] = *reinterpret_cast<const bf16x8_t*>(wl + 2 * PLANE + i * 16 * SBK);   // w3
+  for (int i = 0; i < NI; ++i) tw[i] = *reinterpret_cast<const bf16x8_t*>(wl + 2 * PLANE + i * 16 * SBK);   // w3
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(t[i], x1[j], acc[i][j], 0, 0, 0);
+    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tw[i], x1[j], acc[i][j], 0, 0, 0);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) w2[i] = *reinterpret_cast<const bf16x8_t*>(wl + PLANE + i * 16 * SBK);
+  for (int i = 0; i < NI; ++i) w2[i] = *reinterpret_cast<const bf16x8_t*>(wl + PLANE + i * 16 * SBK);
 #pragma unroll
   for (int j = 0; j < 4; ++j) x2[j] = *reinterpret_cast<const bf16x8_t*>(xj[j] + XPLANE);
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[i], x2[j], acc[i][j], 0, 0, 0);
@@ -263,7 +263,9 @@ struct PatchArgs {
   int cpg, G, swish;
 };
 
-template <bool GN>
+// NI: 16-channel output blocks per wave.  4 = 128 output channels per workgroup; 2 = 64 (half of a weight tile's rows),
+// for the small late layers whose 128-channel tiling leaves half the CUs without a workgroup.
+template <bool GN, int NI>
 __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(PatchArgs p) {
   __shared__ __attribute__((aligned(16))) bf16_t Ws[TILE];
   __shared__ __attribute__((aligned(16))) bf16_t Xp[3 * XPATCH];
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(PatchArgs p) {
   const int per_xcd = gridDim.x >> 3;
   const int tile = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);     // contiguous band of tiles per XCD
   if (tile >= p.ntiles) return;
-  const int nblk = blockIdx.y;
+  const int nblk = NI == 4 ? blockIdx.y : blockIdx.y >> 1, nhalf = NI == 4 ? 0 : blockIdx.y & 1;
   const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, b = tile / (p.tiles_x * p.tiles_y);
   const int y0 = ty * PT_H, x0 = tx * PT_W;
 
@@ -290,23 +292,27 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(PatchArgs p) {
     ppix[i] = pok[i] ? p.x + (((int64_t)b * p.H + iy) * p.W + ix) * p.Cin + q * 4 : p.x;
   }
 
-  f32x4_t acc[4][4];
+  f32x4_t acc[NI][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   f32x4_t rx[6];
-  u32x4_t rw[6];
-  const u32x4_t* wbase = reinterpret_cast<const u32x4_t*>(p.w) + (int64_t)nblk * (TILE / 8) + tid;
+  // weight tile: NI == 4 all 128 rows of each plane (6 x 16 B per thread); NI == 2 this workgroup's 64 rows of each plane
+  // (3 x 16 B per thread, one plane per piece), parked at rows 0..63 of the plane's LDS image
+  constexpr int WPIECES = NI == 4 ? 6 : 3;
+  constexpr int WSTEP = NI == 4 ? 256 : PLANE / 8;              // 16-byte units between a thread's pieces
+  u32x4_t rw[WPIECES];
+  const u32x4_t* wbase = reinterpret_cast<const u32x4_t*>(p.w) + (int64_t)nblk * (TILE / 8) + nhalf * 256 + tid;
   auto fetch_w = [&](int slab, int tap) __attribute__((always_inline)) {
     const u32x4_t* wt = wbase + ((int64_t)tap * p.kslabs + slab) * p.nblks * (TILE / 8);
 #pragma unroll
-    for (int i = 0; i < 6; ++i) rw[i] = wt[i * 256];
+    for (int i = 0; i < WPIECES; ++i) rw[i] = wt[i * WSTEP];
   };
   auto stash_w = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) reinterpret_cast<u32x4_t*>(Ws)[i * 256 + tid] = rw[i];
+    for (int i = 0; i < WPIECES; ++i) reinterpret_cast<u32x4_t*>(Ws)[i * WSTEP + tid] = rw[i];
   };
   auto fetch_x = [&](int slab) __attribute__((always_inline)) {
 #pragma unroll
@@ -338,7 +344,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(PatchArgs p) {
   stash_x(0);
   stash_w();
   __syncthreads();
-  const bf16_t* wl = Ws + swz(wn * 64 + l16, g);
+  const bf16_t* wl = Ws + swz(wn * (NI * 16) + l16, g);
   for (int slab = 0; slab < p.kslabs; ++slab) {
 #pragma unroll 1
     for (int tap = 0; tap < 9; ++tap) {
@@ -349,7 +355,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(PatchArgs p) {
       const bf16_t* xj[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) xj[j] = Xp + swz((wm * 4 + j + dy) * PP_W + l16 + dx, g);
-      mma_slab<XPATCH>(wl, xj, acc);
+      mma_slab<XPATCH, NI>(wl, xj, acc);
       __syncthreads();
       if (more) stash_w();
       if (last_tap && more) stash_x(slab + 1);
@@ -365,8 +371,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(PatchArgs p) {
     if (oy >= p.H || ox >= p.W) continue;
     const int64_t m = ((int64_t)b * p.H + oy) * p.W + ox;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int n = nblk * SBN + wn * 64 + i * 16 + g * 4;
+    for (int i = 0; i < NI; ++i) {
+      const int n = nblk * SBN + nhalf * 64 + wn * (NI * 16) + i * 16 + g * 4;
       if (n >= p.Cout) continue;
       store_out_quad(acc[i][j], p.bias ? p.bias + n : nullptr, p.res ? p.res + m * p.Cout + n : nullptr,
                      p.y + m * p.Cout + n, 0);
@@ -618,7 +624,9 @@ extern "C" int ug_conv3x3_split3(const float* x, const uint16_t* w_split, const 
   const int64_t ntiles = B * a.tiles_x * a.tiles_y;
   UG_REQUIRE(ntiles < (1LL << 30) && B * H * W < (1LL << 31), "ug_conv3x3_split3: too many output pixels");
   a.ntiles = (int)ntiles;
-  dim3 grid((unsigned)((ntiles + 7) / 8 * 8), (unsigned)nb_n);
+  // 64-channel workgroups when the 128-channel tiling of the 8-row variant would leave CUs without work
+  const bool half = !big && ntiles * nb_n < 256;
+  dim3 grid((unsigned)((ntiles + 7) / 8 * 8), (unsigned)(half ? (Cout + 63) / 64 : nb_n));
   const dim3 block(big ? 512 : 256);
   if (gn_mu_rstd) {
     UG_REQUIRE(gn_gamma && gn_beta && gn_groups > 0 && Cin % gn_groups == 0 && (Cin / gn_groups) % 4 == 0 &&
@@ -628,10 +636,12 @@ extern "C" int ug_conv3x3_split3(const float* x, const uint16_t* w_split, const 
     a.mu_rstd = reinterpret_cast<const float2*>(gn_mu_rstd); a.gamma = gn_gamma; a.beta = gn_beta;
     a.G = gn_groups; a.cpg = Cin / gn_groups; a.swish = gn_swish;
     if (big) hipLaunchKernelGGL(conv3x3_patch16_kernel<true>, grid, block, 0, st, a);
-    else hipLaunchKernelGGL(conv3x3_patch_kernel<true>, grid, block, 0, st, a);
+    else if (half) hipLaunchKernelGGL((conv3x3_patch_kernel<true, 2>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((conv3x3_patch_kernel<true, 4>), grid, block, 0, st, a);
   } else {
     if (big) hipLaunchKernelGGL(conv3x3_patch16_kernel<false>, grid, block, 0, st, a);
-    else hipLaunchKernelGGL(conv3x3_patch_kernel<false>, grid, block, 0, st, a);
+    else if (half) hipLaunchKernelGGL((conv3x3_patch_kernel<false, 2>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((conv3x3_patch_kernel<false, 4>), grid, block, 0, st, a);
   }
   UG_CHECK_LAUNCH("ug_conv3x3_split3");
   return UG_OK;
