@@ -625,7 +625,7 @@ extern "C" int ug_conv3x3_split3(const float* x, const uint16_t* w_split, const 
   UG_REQUIRE(ntiles < (1LL << 30) && B * H * W < (1LL << 31), "ug_conv3x3_split3: too many output pixels");
   a.ntiles = (int)ntiles;
   // 64-channel workgroups when the 128-channel tiling of the 8-row variant would leave CUs without work
-  const bool half = !big && ntiles * nb_n < 256;
+  const bool half = !big && ntiles * nb_n < 512;
   dim3 grid((unsigned)((ntiles + 7) / 8 * 8), (unsigned)(half ? (Cout + 63) / 64 : nb_n));
   const dim3 block(big ? 512 : 256);
   if (gn_mu_rstd) {
