@@ -135,6 +135,9 @@ __device__ __forceinline__ void mma_slab(const bf16_t* wl, const bf16_t* const (
     }
 }
 
+// NI: 16-channel output blocks per wave (4: 128 output channels per workgroup; 2: 64, for outputs whose 128-wide tiling
+// leaves CUs idle -- SigLIP's 1152-wide projections at four images, the tokenizer's 1x1 convs at 16 x 16)
+template <int NI>
 __global__ __launch_bounds__(256, 2) void conv_split3_kernel(SplitArgs p) {
   __shared__ __attribute__((aligned(16))) bf16_t Ws[TILE];
   __shared__ __attribute__((aligned(16))) bf16_t Xs[TILE];
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void conv_split3_kernel(SplitArgs p) {
   const int mt = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
   const int m0 = mt * SBM;
   if (m0 >= p.M) return;
-  const int nblk = blockIdx.y;
+  const int nblk = NI == 4 ? blockIdx.y : blockIdx.y >> 1, nhalf = NI == 4 ? 0 : blockIdx.y & 1;
 
   // activation fetch: thread owns channel quad q of pixel rows (tid >> 3) + 32 i
   const int q = tid & 7;
@@ -167,19 +170,21 @@ __global__ __launch_bounds__(256, 2) void conv_split3_kernel(SplitArgs p) {
   }
   const int nkt = p.KH * p.KW * p.kslabs;
 
-  f32x4_t acc[4][4];                     // [n block][m block]
+  f32x4_t acc[NI][4];                    // [n block][m block]
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   float4 rx[4];
   bool kx[4];
-  u32x4_t rw[6];
+  constexpr int WPIECES = NI == 4 ? 6 : 3;                  // NI == 2: this workgroup's 64 rows of each weight plane
+  constexpr int WSTEP = NI == 4 ? 256 : PLANE / 8;
+  u32x4_t rw[WPIECES];
   int cur_tap = 0, cur_c0 = -SBK;
   const float* apix[4] = {p.x, p.x, p.x, p.x};
   bool aok[4] = {false, false, false, false};
-  const u32x4_t* wt = reinterpret_cast<const u32x4_t*>(p.w) + (int64_t)nblk * (TILE / 8) + tid;
+  const u32x4_t* wt = reinterpret_cast<const u32x4_t*>(p.w) + (int64_t)nblk * (TILE / 8) + nhalf * 256 + tid;
   const int64_t wt_step = (int64_t)p.nblks * (TILE / 8);
 
   auto fetch = [&]() __attribute__((always_inline)) {
@@ -203,12 +208,12 @@ __global__ __launch_bounds__(256, 2) void conv_split3_kernel(SplitArgs p) {
       rx[i] = *reinterpret_cast<const float4*>(kx[i] ? apix[i] + cur_c0 + q * 4 : p.x);
     }
 #pragma unroll
-    for (int i = 0; i < 6; ++i) rw[i] = wt[i * 256];
+    for (int i = 0; i < WPIECES; ++i) rw[i] = wt[i * WSTEP];
     wt += wt_step;
   };
   auto stash = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) reinterpret_cast<u32x4_t*>(Ws)[i * 256 + tid] = rw[i];
+    for (int i = 0; i < WPIECES; ++i) reinterpret_cast<u32x4_t*>(Ws)[i * WSTEP + tid] = rw[i];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const f32x4_t v = kx[i] ? f32x4_t{rx[i].x, rx[i].y, rx[i].z, rx[i].w} : f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -221,10 +226,10 @@ __global__ __launch_bounds__(256, 2) void conv_split3_kernel(SplitArgs p) {
   __syncthreads();
   for (int kt = 0; kt < nkt; ++kt) {
     if (kt + 1 < nkt) fetch();           // next slab's global loads stay in flight under the MFMAs
-    const bf16_t* wl = Ws + swz(wn * 64 + l16, g);
+    const bf16_t* wl = Ws + swz(wn * (NI * 16) + l16, g);
     const bf16_t* xl = Xs + swz(wm * 64 + l16, g);
     const bf16_t* xj[4] = {xl, xl + 16 * SBK, xl + 32 * SBK, xl + 48 * SBK};
-    mma_slab<PLANE>(wl, xj, acc);
+    mma_slab<PLANE, NI>(wl, xj, acc);
     __syncthreads();                     // every wave is done reading this slab
     if (kt + 1 < nkt) stash();
     __syncthreads();
@@ -236,8 +241,8 @@ __global__ __launch_bounds__(256, 2) void conv_split3_kernel(SplitArgs p) {
     const int m = m0 + wm * 64 + j * 16 + l16;
     if (m >= p.M) continue;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int n = nblk * SBN + wn * 64 + i * 16 + g * 4;
+    for (int i = 0; i < NI; ++i) {
+      const int n = nblk * SBN + nhalf * 64 + wn * (NI * 16) + i * 16 + g * 4;
       if (n >= p.Cout) continue;
       store_out_quad(acc[i][j], p.bias ? p.bias + n : nullptr, p.res ? p.res + (int64_t)m * p.ldres + n : nullptr,
                      p.y + (int64_t)m * p.ldy + n, p.act);
@@ -539,6 +544,14 @@ __global__ __launch_bounds__(256) void conv_split_weights_kernel(const float* __
   }
 }
 
+// 64-channel workgroups when the 128-channel tiling would not give every CU two workgroups
+void launch_split3(const SplitArgs& a, int64_t M, int64_t N, hipStream_t st) {
+  const unsigned mt = (unsigned)(((M + SBM - 1) / SBM + 7) / 8 * 8);
+  const int64_t wgs = ((M + SBM - 1) / SBM) * ((N + SBN - 1) / SBN);
+  if (wgs < 512) hipLaunchKernelGGL(conv_split3_kernel<2>, dim3(mt, (unsigned)((N + 63) / 64)), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(conv_split3_kernel<4>, dim3(mt, (unsigned)((N + SBN - 1) / SBN)), dim3(256), 0, st, a);
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------ C ABI
@@ -574,8 +587,7 @@ extern "C" int ug_conv2d_split3(const float* x, const uint16_t* w_split, const f
   a.KH = ksize; a.KW = ksize; a.stride = stride; a.pad_t = pad_top; a.pad_l = pad_left; a.ups = upsample2x;
   a.nblks = cout_pad / SBN; a.M = (int)M; a.kslabs = (Cin + SBK - 1) / SBK;
   a.ldx = Cin; a.ldy = Cout; a.ldres = Cout;
-  dim3 grid((unsigned)(((M + SBM - 1) / SBM + 7) / 8 * 8), (unsigned)((Cout + SBN - 1) / SBN));
-  hipLaunchKernelGGL(conv_split3_kernel, grid, dim3(256), 0, st, a);
+  launch_split3(a, M, Cout, st);
   UG_CHECK_LAUNCH("ug_conv2d_split3");
   return UG_OK;
 }
@@ -597,8 +609,7 @@ extern "C" int ug_linear_split3(const float* x, int64_t ldx, const uint16_t* w_s
   a.KH = a.KW = 1; a.stride = 1;
   a.nblks = n_pad / SBN; a.M = (int)M; a.kslabs = (int)((K + SBK - 1) / SBK);
   a.ldx = ldx; a.ldy = ldy; a.ldres = ldres; a.act = act;
-  dim3 grid((unsigned)(((M + SBM - 1) / SBM + 7) / 8 * 8), (unsigned)((N + SBN - 1) / SBN));
-  hipLaunchKernelGGL(conv_split3_kernel, grid, dim3(256), 0, st, a);
+  launch_split3(a, M, N, st);
   UG_CHECK_LAUNCH("ug_linear_split3");
   return UG_OK;
 }
