@@ -273,6 +273,12 @@ int ug_linear_split3(const float* x, int64_t ldx, const uint16_t* w_split, const
 int ug_gemm_f32(const float* A, int64_t lda, int64_t stride_a, const float* B, int64_t ldb, int64_t stride_b,
                 int b_is_nk, float* C, int64_t ldc, int64_t stride_c, int64_t M, int64_t N, int64_t K,
                 int64_t batch, float alpha, hipStream_t stream);
+/* ug_gemm_f32 over a two-level batch z = outer * batch_in + inner (operand z starts inner * s*_in + outer * s*_out
+ * elements into its tensor): all heads of all images of SigLipAttention in one launch (siglip_encoder.py:196-230). */
+int ug_gemm_f32_nested(const float* A, int64_t lda, int64_t sa_in, int64_t sa_out, const float* B, int64_t ldb,
+                       int64_t sb_in, int64_t sb_out, int b_is_nk, float* C, int64_t ldc, int64_t sc_in, int64_t sc_out,
+                       int64_t M, int64_t N, int64_t K, int64_t batch_in, int64_t batch_out, float alpha,
+                       hipStream_t stream);
 /* replaces: Normalize = GroupNorm(32, eps 1e-6) (+ swish), common_modules.py:19-27 */
 int ug_groupnorm_swish(const float* x, const float* gamma, const float* beta, float* y, double* stats_ws,
                        int64_t B, int64_t HW, int C, int groups, float eps, int apply_swish, hipStream_t stream);

@@ -29,6 +29,8 @@ struct ConvArgs {
   // plain (batched) GEMM mode: x = A[M,K] row stride lda, w = B ([K][N] ldb, or [N][K] if b_nk)
   int gemm, lda, b_nk;
   int64_t sa, sb, sc;                      // batch strides (elements)
+  int inner;                               // two-level batches: z = outer * inner + i; 0 = one level
+  int64_t sa2, sb2, sc2;                   // strides of the outer level
   float alpha;
   int act;                                 // 0 none, 1 GELU(tanh) applied before the residual add
 };
@@ -79,11 +81,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int m0 = blockIdx.x * CBM, n0 = blockIdx.y * BN;
-  const int bz = blockIdx.z;
-  const float* xb = p.x + bz * p.sa;
-  const float* wb = p.w + bz * p.sb;
-  float* yb = p.y + bz * p.sc;
-  const float* rb = p.res ? p.res + bz * p.sc : nullptr;
+  const int bz = p.inner ? (int)blockIdx.z % p.inner : (int)blockIdx.z, bo = p.inner ? (int)blockIdx.z / p.inner : 0;
+  const float* xb = p.x + bz * p.sa + bo * p.sa2;
+  const float* wb = p.w + bz * p.sb + bo * p.sb2;
+  float* yb = p.y + bz * p.sc + bo * p.sc2;
+  const float* rb = p.res ? p.res + bz * p.sc + bo * p.sc2 : nullptr;
 
   // this thread's two A pixels (rows tid>>2 and 64 + tid>>2), channel quad tid&3
   const int kc = tid & 3;
@@ -439,8 +441,8 @@ int gn_pixels_per_block(int64_t B, int64_t HW) {
 
 int launch_conv(const ConvArgs& a, int nb, hipStream_t st) {
   // vector path: every 4-element A fetch is 16-byte aligned and never straddles the contraction extent
-  const bool vec4 = a.gemm ? (a.lda % 4 == 0 && a.Cin % 4 == 0 && ug_aligned16(a.x) && a.sa % 4 == 0 &&
-                              (!a.b_nk || (a.ldw % 4 == 0 && ug_aligned16(a.w) && a.sb % 4 == 0)))
+  const bool vec4 = a.gemm ? (a.lda % 4 == 0 && a.Cin % 4 == 0 && ug_aligned16(a.x) && a.sa % 4 == 0 && a.sa2 % 4 == 0 &&
+                              (!a.b_nk || (a.ldw % 4 == 0 && ug_aligned16(a.w) && a.sb % 4 == 0 && a.sb2 % 4 == 0)))
                            : (a.Cin % 4 == 0 && ug_aligned16(a.x));
   if (!a.gemm) launch_conv_mode<0>(a, nb, vec4, st);
   else if (!a.b_nk) launch_conv_mode<1>(a, nb, vec4, st);
@@ -483,6 +485,24 @@ extern "C" int ug_gemm_f32(const float* A, int64_t lda, int64_t stride_a, const 
   a.sa = stride_a; a.sb = stride_b; a.sc = stride_c; a.alpha = alpha; a.KH = a.KW = 1;
   launch_conv(a, (int)batch, st);
   UG_CHECK_LAUNCH("ug_gemm_f32");
+  return UG_OK;
+}
+
+extern "C" int ug_gemm_f32_nested(const float* A, int64_t lda, int64_t sa_in, int64_t sa_out, const float* Bm, int64_t ldb,
+                                  int64_t sb_in, int64_t sb_out, int b_is_nk, float* C, int64_t ldc, int64_t sc_in,
+                                  int64_t sc_out, int64_t M, int64_t N, int64_t K, int64_t batch_in, int64_t batch_out,
+                                  float alpha, hipStream_t st) {
+  UG_REQUIRE(M > 0 && N > 0 && K > 0 && batch_in > 0 && batch_out > 0 && batch_in * batch_out < 65536, "ug_gemm_f32_nested: bad sizes");
+  UG_REQUIRE(b_is_nk || (ldb % 4 == 0 && ug_aligned16(Bm) && sb_in % 4 == 0 && sb_out % 4 == 0 &&
+                         ldb >= ((N > 32) ? (N + 127) / 128 * 128 : 32)),
+             "ug_gemm_f32_nested: [K][N] operand needs ldb padded to the N tile and 16B alignment");
+  ConvArgs a{};
+  a.x = A; a.w = Bm; a.y = C; a.Cin = (int)K; a.Cout = (int)N; a.M = (int)M;
+  a.gemm = 1; a.lda = (int)lda; a.ldw = (int)ldb; a.ldy = (int)ldc; a.b_nk = b_is_nk;
+  a.sa = sa_in; a.sb = sb_in; a.sc = sc_in; a.inner = (int)batch_in; a.sa2 = sa_out; a.sb2 = sb_out; a.sc2 = sc_out;
+  a.alpha = alpha; a.KH = a.KW = 1;
+  launch_conv(a, (int)(batch_in * batch_out), st);
+  UG_CHECK_LAUNCH("ug_gemm_f32_nested");
   return UG_OK;
 }
 

@@ -210,14 +210,13 @@ class SigLipVisionTower(nn.Module):
 
             lin(xn, 0, wq, bq, out=qkv, M=B * T)
             ctx = torch.empty((B * T, D), dtype=torch.float32, device=h.device)
-            for b in range(B):
-                qb = qkv[b * T:(b + 1) * T]
-                s = torch.empty((Hh, T, ldS), dtype=torch.float32, device=h.device)
-                ops.gemm_f32(qb[:, 0:D], qb[:, D:2 * D], b_is_nk=True, M=T, N=T, K=hd, batch=Hh, lda=3 * D, ldb=3 * D,
-                             stride_a=hd, stride_b=hd, out=s, ldc=ldS, stride_c=T * ldS)
-                ops.softmax_rows_(s.view(Hh * T, ldS), scale, cols=T)
-                ops.gemm_f32(s, qb[:, 2 * D:], b_is_nk=False, M=T, N=hd, K=Tp, batch=Hh, lda=ldS, ldb=3 * D,
-                             stride_a=T * ldS, stride_b=hd, out=ctx[b * T:(b + 1) * T], ldc=D, stride_c=hd)
+            # all heads of all images per launch: batch = (head, image); scores [B, Hh, T, ldS]
+            s = torch.empty((B, Hh, T, ldS), dtype=torch.float32, device=h.device)
+            ops.gemm_f32_nested(qkv[:, 0:D], qkv[:, D:2 * D], s, b_is_nk=True, M=T, N=T, K=hd, batch_in=Hh, batch_out=B,
+                                lda=3 * D, ldb=3 * D, ldc=ldS, sa=(hd, T * 3 * D), sb=(hd, T * 3 * D), sc=(T * ldS, Hh * T * ldS))
+            ops.softmax_rows_(s.view(B * Hh * T, ldS), scale, cols=T)
+            ops.gemm_f32_nested(s, qkv[:, 2 * D:], ctx, b_is_nk=False, M=T, N=hd, K=Tp, batch_in=Hh, batch_out=B, lda=ldS,
+                                ldb=3 * D, ldc=D, sa=(T * ldS, Hh * T * ldS), sb=(hd, T * 3 * D), sc=(hd, T * D))
             o = l.self_attn.out_proj
             h = lin(ctx, 1, o.weight.detach(), o.bias.detach(), residual=h)
             xn2 = ops.layernorm_f32(h, l.layer_norm2.weight.detach(), l.layer_norm2.bias.detach(), c.layer_norm_eps)

@@ -566,6 +566,13 @@ def gemm_f32(a, b, *, b_is_nk, M, N, K, batch=1, lda=None, ldb=None, stride_a=0,
     return out
 
 
+def gemm_f32_nested(a, b, out, *, b_is_nk, M, N, K, batch_in, batch_out, lda, ldb, ldc, sa, sb, sc, alpha=1.0):
+    """`gemm_f32` over a two-level batch (inner, outer); sa / sb / sc = (inner stride, outer stride) in elements."""
+    _l.check(_l.load().ug_gemm_f32_nested(_p(a), lda, sa[0], sa[1], _p(b), ldb, sb[0], sb[1], int(b_is_nk), _p(out), ldc,
+                                          sc[0], sc[1], M, N, K, batch_in, batch_out, alpha, _stream()), "ug_gemm_f32_nested")
+    return out
+
+
 def groupnorm_swish(x, gamma, beta, *, groups=32, eps=1e-6, swish=True):
     """x NHWC [B,H,W,C] fp32."""
     B, H, W, C = x.shape
