@@ -600,6 +600,36 @@ def test_gemm_f32_and_softmax(dev):
     assert _maxabs(h, ref @ v) < 1e-5
 
 
+def test_gemm_f32_nested_batches_and_padded_softmax(dev):
+    """Two-level batch (heads inside images) of the fp32 GEMM on a fused q|k|v buffer with a ragged token count: scores,
+    softmax with zero-filled pad columns, P.V over the padded key count -- the SigLIP attention data path."""
+    ops = _ops()
+    torch.manual_seed(18)
+    B, Hh, T, hd = 3, 4, 37, 24                       # T % 4 != 0: the padded-key path
+    D = Hh * hd
+    ldS, Tp = ops.round_up(T, 4), ops.round_up(T, 4)
+    qkv = torch.randn(B * T + 4, 3 * D)
+    qkv[B * T:] = 0
+    qd = qkv.to(dev)
+    s = torch.full((B, Hh, T, ldS), float("nan"), device=dev)
+    ops.gemm_f32_nested(qd[:, 0:D], qd[:, D:2 * D], s, b_is_nk=True, M=T, N=T, K=hd, batch_in=Hh, batch_out=B, lda=3 * D,
+                        ldb=3 * D, ldc=ldS, sa=(hd, T * 3 * D), sb=(hd, T * 3 * D), sc=(T * ldS, Hh * T * ldS))
+    q = qkv[:B * T, 0:D].view(B, T, Hh, hd).transpose(1, 2)
+    k = qkv[:B * T, D:2 * D].view(B, T, Hh, hd).transpose(1, 2)
+    v = qkv[:B * T, 2 * D:].view(B, T, Hh, hd).transpose(1, 2)
+    ref_s = q @ k.transpose(-1, -2)
+    assert _maxabs(s[..., :T], ref_s) < 1e-4
+    scale = hd ** -0.5
+    ops.softmax_rows_(s.view(B * Hh * T, ldS), scale, cols=T)
+    ref_p = torch.softmax(ref_s * scale, -1)
+    assert _maxabs(s[..., :T], ref_p) < 1e-6 and s[..., T:].abs().max().item() == 0.0
+    ctx = torch.empty(B * T, D, device=dev)
+    ops.gemm_f32_nested(s, qd[:, 2 * D:], ctx, b_is_nk=False, M=T, N=hd, K=Tp, batch_in=Hh, batch_out=B, lda=ldS, ldb=3 * D,
+                        ldc=D, sa=(T * ldS, Hh * T * ldS), sb=(hd, T * 3 * D), sc=(hd, T * D))
+    ref_ctx = (ref_p @ v).transpose(1, 2).reshape(B * T, D)
+    assert _maxabs(ctx, ref_ctx) < 1e-5
+
+
 def test_lfq_and_layout(dev):
     ops = _ops()
     from oracle.ops_ref import lfq_indices_ref, lfq_entries_ref
