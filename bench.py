@@ -196,7 +196,7 @@ def main():
 
     cpu = None
     L = 2 + args.text_len + NVQ + 2
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:      # reported at N = 1 only (bench contract)
         cpu = cpu_baseline(L)
 
     from models import MAGVITv2, UniGen
