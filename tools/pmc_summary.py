@@ -9,8 +9,8 @@ for r in csv.DictReader(open(path)):
     name = r["Kernel_Name"]
     if flt and not any(f in name for f in flt):
         continue
-    key = name[:name.index("(")] if "(" in name else name
-    key = key.replace("void ", "").replace("(anonymous namespace)::", "")[:60]
+    key = name.replace("void ", "").replace("(anonymous namespace)::", "")
+    key = (key[:key.index("(")] if "(" in key else key)[:60]
     agg[key][r["Counter_Name"]] += float(r["Counter_Value"])
     n[(key, r["Counter_Name"])] += 1
 for k, v in agg.items():
