@@ -15,7 +15,7 @@ out = torch.empty(1 << 20, device=dev)
 mhz = 2400.0     # MI355X peak engine clock; sustained clocks under load are lower
 print(f"bytes/clock quoted at {mhz:.0f} MHz")
 for threads in (256, 512):
-    for mpr in (0, 1, 2, 3, 4):
+    for mpr in (0, 1, 2, 3, 4, 100, 102, 103):
         iters = 4000
         args = (ctypes.c_void_p(out.data_ptr()), 256, threads, iters, mpr, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         lib.lds_read_launch(*args)
@@ -28,6 +28,6 @@ for threads in (256, 512):
         ms = e0.elapsed_time(e1)
         waves = threads // 64
         byts = 256 * waves * iters * 16 * 1024.0
-        flops = 256 * waves * iters * 16 * mpr * 2.0 * 16 * 16 * 32
-        print(f"waves/CU={waves} mfma/read={mpr}: LDS {byts / ms / 1e9:7.1f} TB/s = {byts / 256 / (ms * 1e-3) / (mhz * 1e6):6.1f} B/clk/CU"
+        flops = 256 * waves * iters * 16 * (mpr % 100) * 2.0 * 16 * 16 * 32
+        print(f"waves/CU={waves} {'tr16_b64 x2' if mpr >= 100 else 'b128'} mfma/read={mpr % 100}: LDS {byts / ms / 1e9:7.1f} TB/s = {byts / 256 / (ms * 1e-3) / (mhz * 1e6):6.1f} B/clk/CU"
               f"   MFMA {flops / ms / 1e9:7.1f} TF/s ({ms:.2f} ms)", flush=True)
