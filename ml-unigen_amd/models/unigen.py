@@ -475,6 +475,54 @@ class UniGen(ModelMixin, ConfigMixin):
                 st.advance()
         return result
 
+    @torch.no_grad()
+    def mmu_generate_batch(self, idx=None, input_embeddings=None, attention_mask=None, max_new_tokens=100, temperature=0.0,
+                           top_k=None, eot_token=None):
+        """`mmu_generate` for up to 32 prompts at once -- the rating loop of CoT-V (reference
+        evaluation/inference_unigen_cot.py:308-415 calls mmu_generate once per (image, question) pair; every decode
+        step streams the whole backbone whatever the row count, so R pairs cost about one).  Rows are LEFT-padded to a
+        common length L: idx [R, L] (or input_embeddings [R, L, H]) and the rows' dense additive masks [R, 1, L, L] with
+        the pad columns blocked (the reference's mask builders do that for left-padded rows).  Each row follows the
+        procedure of `mmu_generate`: prefill under its mask, then one decode step per token attending to the keys its
+        last prompt row could see plus everything generated since.  Returns R lists of tokens, each cut after its
+        `eot_token`."""
+        from unigen_hip.qwen2 import DecodeState
+        eng = self.llm.engine
+        embed = self.llm.model.embed_tokens
+        prompt = (embed(idx) if input_embeddings is None else input_embeddings).float()
+        dev = prompt.device
+        R, L = prompt.shape[0], prompt.shape[1]
+        if R > 32:
+            raise ValueError("mmu_generate_batch: at most 32 rows per call")
+        if attention_mask is None or tuple(attention_mask.shape) != (R, 1, L, L):
+            raise ValueError("mmu_generate_batch: attention_mask must be the rows' dense [R, 1, L, L] additive masks")
+        mb = eng.mask_bits(attention_mask, R, L)
+        eng.check_errors()
+        key_valid = attention_mask[:, 0, -1, :] == 0
+        st = DecodeState(eng.dims, R, L + max_new_tokens, dev, key_valid=key_valid)
+        hn = eng.prefill(st, prompt, mask_bits=mb)
+        V = self.config.vocab_size
+        x = torch.empty((R, eng.dims.hidden_size), dtype=torch.float32, device=dev)
+        tokens = torch.zeros((R, max_new_tokens), dtype=torch.long, device=dev)
+        done = torch.zeros(R, dtype=torch.bool, device=dev)
+        lengths = torch.full((R,), max_new_tokens, dtype=torch.long, device=dev)
+        for i in range(max_new_tokens):
+            last = eng.head_slice(hn, 0, V).float()
+            idx_next = self._pick_next(last, temperature, top_k)
+            tokens[:, i] = idx_next[:, 0]
+            if eot_token is not None:
+                hit = (idx_next[:, 0] == eot_token) & ~done
+                lengths = torch.where(hit, torch.full_like(lengths, i + 1), lengths)
+                done |= hit
+                if bool(done.all()):
+                    break
+            if i + 1 < max_new_tokens:
+                x.copy_(embed(idx_next)[:, 0])
+                hn = eng.decode_step(st, x)
+                st.advance()
+        tokens, lengths = tokens.cpu(), lengths.cpu()
+        return [list(tokens[r, :int(lengths[r])]) for r in range(R)]
+
     def _mmu_generate_recompute(self, idx, input_embeddings, attention_mask, max_new_tokens, temperature, top_k, eot_token):
         device = idx.device if idx is not None else input_embeddings.device
         result = []

@@ -349,6 +349,38 @@ def test_mmu_generate_kv_cache_matches_recompute(dev):
     assert [int(t) for t in stop] == fast[:fast.index(fast[2]) + 1]
 
 
+def test_mmu_generate_batch_matches_per_row_calls(dev):
+    """mmu_generate_batch (left-padded rows decoded together, the CoT-V rating loop batched) returns, row by row, what
+    mmu_generate returns for that padded row alone (greedy), and cuts each row at its own end-of-turn token."""
+    g = golden("g2_tiny_unigen.pt")
+    model, _ = _tiny_unigen(g, dev)
+    model.eval()
+    pad = g["ids"]["pad"]
+    L, lens = 30, [30, 22, 26]
+    rows, masks = [], []
+    gen = torch.Generator().manual_seed(4)
+    for n in lens:
+        ids = torch.full((L,), pad, dtype=torch.long)
+        ids[L - n:] = torch.randint(0, 290, (n,), generator=gen)
+        allow = torch.tril(torch.ones(L, L, dtype=torch.bool))
+        allow[:, :L - n] = False                                  # left padding: pad columns blocked for every query
+        allow[torch.arange(L - n), torch.arange(L - n)] = True    # (a pad row still attends to itself: no empty rows)
+        rows.append(ids); masks.append(allow)
+    idx = torch.stack(rows).to(dev)
+    mask = additive(torch.stack(masks)).to(torch.float32).to(dev)
+    batch = model.mmu_generate_batch(idx=idx, attention_mask=mask, max_new_tokens=10, temperature=0.0)
+    assert len(batch) == 3 and all(len(b) == 10 for b in batch)
+    for r in range(3):
+        single = model.mmu_generate(idx=idx[r:r + 1], attention_mask=mask[r:r + 1], max_new_tokens=10, temperature=0.0)
+        assert [int(t) for t in batch[r]][:8] == [int(t) for t in single][:8], (r, batch[r], single)
+    eot = int(batch[1][3])
+    cut = model.mmu_generate_batch(idx=idx, attention_mask=mask, max_new_tokens=10, temperature=0.0, eot_token=eot)
+    for r in range(3):
+        full = [int(t) for t in batch[r]]
+        want = full[:full.index(eot) + 1] if eot in full else full
+        assert [int(t) for t in cut[r]] == want[:len(cut[r])] and (eot not in want or len(cut[r]) == len(want))
+
+
 def test_checkpoint_round_trip_and_hf_llm_loading(dev, tmp_path):
     """save_pretrained -> from_pretrained keeps every tensor (reference key names, tied head written once per name) and
     the logits; a HF-layout Qwen2 directory (config.json + *.safetensors) loads through llm_model_path with the
