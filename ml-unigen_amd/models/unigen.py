@@ -176,6 +176,64 @@ class UniGen(ModelMixin, ConfigMixin):
     def prepare_inputs_for_t2i(self, input_ids, num_vq_tokens):
         return self.llm.model.embed_tokens(input_ids)
 
+    def prepare_inputs_for_mmu(self, image_feats, spatial_shapes, input_ids, label_ids, prompt_template, input_ids_system=None):
+        """Understanding-sample assembly for variable-size image features (reference models/unigen.py:133-228; callers
+        training/train_w_clip_vit.py:754,801).  Row i is
+            [system] <|im_start|><|mmu|><|soi|> | mm_projector(image_feats[i, :h_i*w_i]) | <|eoi|> input_ids[i, 1:] | pad...
+        cut to `prompt_template.max_seq_len`; labels are ignore_id up to and including <|eoi|>, then label_ids[i, 1:],
+        pads ignored; the key-validity mask ends at the row's last `eos_token_id` label.  Returns (embeddings [B, L, H],
+        attention_mask bool [B, max_seq_len], labels [B, L], input_ids_part1 [B, L1]).  One index computation for the
+        whole batch instead of the reference's per-row concatenations; the projector and the embedding lookup run on the
+        HIP kernels and stay differentiable."""
+        pt = prompt_template
+        dev = input_ids.device
+        B, Lt = input_ids.shape
+        N = image_feats.shape[1]
+        pad_id, ignore, max_len = pt.text_tokenizer.pad_token_id, pt.ignore_id, pt.max_seq_len
+        sp = pt.sptids_dict
+        head = ['<|mmu|>', '<|im_start|>', '<|soi|>'] if pt.task_token_first else ['<|im_start|>', '<|mmu|>', '<|soi|>']
+        part1 = torch.tensor([int(sp[t]) for t in head], dtype=torch.long, device=dev)[None].expand(B, 3)
+        if input_ids_system is not None:
+            part1 = torch.cat([input_ids_system.to(dev).long(), part1], dim=1)
+        part1 = part1.contiguous()
+        L1 = part1.shape[1]
+        n_img = (spatial_shapes[:, 0] * spatial_shapes[:, 1]).to(dev).long()                      # [B]
+        # row lengths before the cut: embeddings carry N trailing pads when training, (max_i n_img - n_img[i]) otherwise;
+        # the label rows always carry N trailing ignore entries (reference :176-203)
+        emb_len = L1 + n_img + Lt + (N if self.training else int(n_img.max()) - n_img)
+        lab_len = L1 + n_img + Lt + N
+
+        def common_length(lens, what):
+            lo, hi = int(lens.min()), int(lens.max())
+            if lo < max_len and lo != hi:
+                raise UniGenHipError(f"prepare_inputs_for_mmu: {what} rows shorter than max_seq_len differ in length")
+            return min(lo, max_len)
+        T, T_lab = common_length(emb_len, "embedding"), common_length(lab_len, "label")
+        const = lambda v: torch.full((), int(v), dtype=torch.long, device=dev)
+
+        p = torch.arange(T, device=dev)[None]                                                     # [1, T]
+        q = p - L1 - n_img[:, None]                                                               # offset into the text part
+        is_img = (p >= L1) & (q < 0)
+        text = torch.cat([const(sp['<|eoi|>']).expand(B, 1), input_ids[:, 1:].long()], dim=1)     # <|eoi|> replaces column 0
+        ids = torch.where((q >= 0) & (q < Lt), text.gather(1, q.clamp(0, Lt - 1)), const(pad_id))
+        head_ids = torch.nn.functional.pad(part1, (0, max(0, T - L1)), value=pad_id)[:, :T]
+        ids = torch.where(p < L1, head_ids, ids)
+        image_embeds = self.mm_projector(image_feats)                                             # [B, N, H]
+        emb = self.llm.model.embed_tokens(ids)                                                    # image slots: pad rows, replaced below
+        slot = (p - L1).clamp(0, N - 1).expand(B, T)
+        img_rows = image_embeds.gather(1, slot[..., None].expand(B, T, image_embeds.shape[-1])).to(emb.dtype)
+        full_embeddings = torch.where(is_img[..., None], img_rows, emb)
+
+        if label_ids is None:
+            label_ids = input_ids.clone()
+        ql = torch.arange(T_lab, device=dev)[None] - L1 - n_img[:, None]
+        labels = torch.where((ql >= 1) & (ql < Lt), label_ids.to(dev).long().gather(1, ql.clamp(0, Lt - 1)), const(ignore))
+        labels = torch.where(labels == pad_id, const(ignore), labels)
+        is_eos = labels == pt.eos_token_id
+        last_eos = torch.where(is_eos.any(1), T_lab - 1 - is_eos.flip(-1).long().argmax(1), const(T_lab - 1))
+        attention_mask = torch.arange(max_len, device=dev)[None] <= last_eos[:, None]
+        return full_embeddings, attention_mask, labels, part1
+
     # ------------------------------------------------------------------ forward
     def _loss_rows(self, B, L, bt, blm, bmmu, n, mode, device):
         """Row indices (into [B*L]) of the logits each loss reads and of the labels it compares to
@@ -296,6 +354,7 @@ class UniGen(ModelMixin, ConfigMixin):
             and torch.is_tensor(attention_mask) and attention_mask.dim() == 4 \
             and not bool((attention_mask[:, 0, :seg_start, seg_start:] == 0).any())
         sess = None
+        trace = kwargs.get("trace", None)
         for step in range(timesteps):
             img = torch.cat([image_embeddings, image_embeddings]) if cfg else image_embeddings
             if incremental:
@@ -324,6 +383,8 @@ class UniGen(ModelMixin, ConfigMixin):
             u = torch.rand((2, bsz, n), device=u_dev, generator=generator).to(lg.device)
             sampled_ids, cur_ids, next_ids = ops.maskgit_step(lg.contiguous(), bsz, n, cfg, guidance_scale, u[0], u[1], cur_ids,
                                                               mask_token_id, text_vocab_size, mask_len, temperature)
+            if trace is not None:                        # parity tests follow the trajectory round by round
+                trace.append((sampled_ids.clone(), next_ids.clone()))
             image_embeddings = embed(next_ids)
         return sampled_ids
 
@@ -423,6 +484,74 @@ class UniGen(ModelMixin, ConfigMixin):
                 out_tokens[:, i] = tok[:, 0]
         eng.last_decode_graph = graph is not None
         return out_tokens
+
+    # ------------------------------------------------------------------ plain causal generation
+    @torch.no_grad()
+    def generate(self, input_ids=None, input_embeddings=None, attention_mask=None, max_new_tokens=20, do_sample=False,
+                 temperature=1.0, top_k=None, top_p=None, eos_token_id=None, pad_token_id=None, use_cache=True,
+                 generator=None, **kwargs):
+        """Causal text generation with the conventions of transformers' `generate`, which the reference delegates to
+        (models/unigen.py:584-588; caller evaluation/inference_unigen_cot.py:360): prompts as ids [B, L] or as
+        `input_embeddings` [B, L, H] with an optional 2-D [B, L] key-validity mask (left padding); greedy when
+        `do_sample` is false, otherwise temperature -> top-k -> top-p -> multinomial; a row that produced
+        `eos_token_id` is filled with `pad_token_id` from then on and decoding stops when every row has finished.
+        Returns prompt + continuation [B, L + new] for ids, the continuation alone [B, new] for embeddings (HF rule).
+        One prefill into the static KV cache, then one decode step per token (`use_cache` is accepted and ignored: the
+        recompute form would return the same tokens)."""
+        from unigen_hip.qwen2 import DecodeState
+        from .sampling import top_k_top_p_filtering
+        unsupported = [k for k in ("num_beams", "num_return_sequences", "repetition_penalty", "penalty_alpha") if kwargs.get(k) not in (None, 1, 1.0)]
+        if unsupported:
+            raise UniGenHipError(f"generate: {unsupported} are not implemented (greedy / sampling only)")
+        if "max_length" in kwargs and kwargs["max_length"] is not None and input_ids is not None:
+            max_new_tokens = int(kwargs["max_length"]) - input_ids.shape[1]
+        eng = self.llm.engine
+        embed = self.llm.model.embed_tokens
+        dev = eng.device
+        prompt = (embed(input_ids.to(dev)) if input_embeddings is None else input_embeddings.to(dev)).float()
+        R, L, _ = prompt.shape
+        key_valid = None
+        if attention_mask is not None:
+            if attention_mask.dim() != 2:
+                raise UniGenHipError("generate expects a 2-D [rows, L] attention mask (1 = real token)")
+            key_valid = attention_mask.to(dev) != 0
+        eos = [] if eos_token_id is None else ([int(e) for e in eos_token_id] if isinstance(eos_token_id, (list, tuple)) else [int(eos_token_id)])
+        if eos and pad_token_id is None:
+            pad_token_id = eos[0]
+        st = DecodeState(eng.dims, R, L + max_new_tokens, dev, key_valid=key_valid)
+        hn = eng.prefill(st, prompt, key_valid)
+        eng.check_errors()
+        V = self.config.vocab_size
+        x = torch.empty((R, eng.dims.hidden_size), dtype=torch.float32, device=dev)
+        out = torch.full((R, max_new_tokens), int(pad_token_id or 0), dtype=torch.long, device=dev)
+        done = torch.zeros(R, dtype=torch.bool, device=dev)
+        n_out = 0
+        for i in range(max_new_tokens):
+            last = eng.head_slice(hn, 0, V).float()
+            if do_sample:
+                if temperature is not None and temperature != 1.0:
+                    last = last / temperature
+                last = top_k_top_p_filtering(last, top_k=int(top_k or 0), top_p=float(1.0 if top_p is None else top_p))
+                u_dev = dev if generator is None else generator.device
+                nxt = torch.multinomial(torch.softmax(last, dim=-1).to(u_dev), num_samples=1, generator=generator).to(dev)
+            else:
+                nxt = last.argmax(-1, keepdim=True)
+            if eos:
+                nxt = torch.where(done[:, None], torch.full_like(nxt, int(pad_token_id)), nxt)
+            out[:, i] = nxt[:, 0]
+            n_out = i + 1
+            if eos:
+                done |= torch.isin(nxt[:, 0], torch.tensor(eos, device=dev))
+                if bool(done.all()):
+                    break
+            if i + 1 < max_new_tokens:
+                x.copy_(embed(nxt)[:, 0])
+                hn = eng.decode_step(st, x)
+                st.advance()
+        out = out[:, :n_out]
+        if input_embeddings is None:
+            return torch.cat([input_ids.to(dev), out], dim=1)
+        return out
 
     # ------------------------------------------------------------------ text decoding for understanding
     @torch.no_grad()

@@ -257,6 +257,37 @@ def ar_generate_ref(lm, cond_embeds, uncond_embeds, n_tokens, guidance_scale, te
     return torch.cat(toks, 1), torch.stack(margins, 1)
 
 
+def mmu_generate_ref(lm, idx=None, input_embeddings=None, attention_mask=None, max_new_tokens=100, eot_token=None,
+                     autocast=True):
+    """Greedy (temperature == 0) UniGen.mmu_generate (models/unigen.py:523-581), statement by statement: every new token
+    re-runs the WHOLE sequence (no KV cache); the additive [1,1,L,L] mask grows by one column of
+    finfo(logits.dtype).min and one row that copies the previous last row and ends in 0 (:543-558); the next token is
+    argmax(logits[:, -1]) (:570); it is appended as an id (w_und_encoder False) or as its embedding (:573-577); the loop
+    stops after the `eot_token` (:579).  Returns (tokens list[int], top-2 margin of the last-position logits per step)."""
+    toks, margins = [], []
+    with torch.no_grad():
+        for _ in range(max_new_tokens):
+            with autocast_ctx(autocast):
+                logits = lm(idx if input_embeddings is None else None, input_embeddings, attention_mask)
+            L = attention_mask.shape[-1]
+            m = attention_mask.squeeze()
+            a = torch.hstack([m, torch.zeros((L, 1)) + torch.finfo(logits.dtype).min])
+            b = torch.vstack([a, torch.hstack([m[-1, :], torch.tensor([0])]).unsqueeze(0)])
+            attention_mask = b.unsqueeze(0).unsqueeze(0)
+            last = logits[:, -1]
+            nxt = torch.argmax(last, dim=-1).reshape(-1, 1)
+            top2 = last.float().topk(2, -1).values
+            toks.append(int(nxt[0][0]))
+            margins.append(float(top2[0, 0] - top2[0, 1]))
+            if input_embeddings is not None:
+                input_embeddings = torch.cat([input_embeddings, lm.model.embed_tokens(nxt)], dim=1)
+            else:
+                idx = torch.cat((idx, nxt), dim=1)
+            if eot_token is not None and int(nxt[0][0]) == eot_token:
+                break
+    return toks, margins
+
+
 # ------------------------------------------------------------------ MaskGIT parallel decoding
 class TorchSampler:
     """The reference's randomness: torch.multinomial + uniform_()-based Gumbel noise on one generator
@@ -335,7 +366,7 @@ def maskgit_generate_ref(lm, input_ids, uncond_input_ids, attention_mask, guidan
             thr = torch.gather(torch.sort(conf, -1).values, 1, mask_len.long())
             masking = conf < thr
             if trace is not None:
-                trace.append(dict(mixed=lg, sampled=sampled.clone(), masking=masking.clone(), conf=conf))
+                trace.append(dict(mixed=lg, sampled=sampled.clone(), masking=masking.clone(), conf=conf, thr=thr))
             image_emb = embed(torch.where(masking, mask_token_id, sampled + text_vocab))
             cur_ids = torch.where(masking, mask_token_id, sampled)
     return sampled

@@ -22,13 +22,13 @@ def llm_config_dir(cfg):
     return d
 
 
-def oracle_lm(cfg, seed):
+def oracle_lm(cfg, seed, std=0.02):
     """CPU oracle model + the synthetic state dict it was loaded with."""
     from oracle import qwen2_ref, weights
     c = qwen2_ref.Qwen2Cfg(**cfg)
     lm = qwen2_ref.RefCausalLM(c)
     names = [(n, tuple(p.shape)) for n, p in lm.named_parameters()]
-    sd = weights.synth_llm_state(names, seed=seed)
+    sd = weights.synth_llm_state(names, seed=seed, std=std)
     lm.load_state_dict(sd, strict=False)
     return lm, sd
 

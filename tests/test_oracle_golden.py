@@ -107,3 +107,23 @@ def test_wide_layer_oracle_bit_exact_vs_reference():
     l1.backward()
     for n, p in lm.named_parameters():
         assert abs(p.grad.norm().item() - g["grad_norms"][n]) <= 1e-6 * max(1.0, g["grad_norms"][n]), n
+
+
+def test_generation_oracles_match_reference_trajectories():
+    """G9: ar_generate_ref / mmu_generate_ref return the tokens the real reference's t2i_generate_ar (temperature 1e-6 =
+    argmax through its own multinomial) and mmu_generate (temperature 0) returned, in fp32 and under bf16 autocast."""
+    from oracle import host_ref, qwen2_ref
+    g = golden("g9_generate.pt")
+    lm, _ = oracle_lm(g["cfg"], g["weight_seed"], std=g["weight_std"])
+    ar, tv = g["ar"], g["ids"]["text_vocab"]
+    P, n = ar["P"], ar["n"]
+    with torch.no_grad():
+        ce, ue = lm.model.embed_tokens(ar["cond"][:, :P]), lm.model.embed_tokens(ar["uncond"][:, :P])
+    for mode, ac in (("fp32", False), ("bf16", True)):
+        tok, margin = qwen2_ref.ar_generate_ref(lm, ce, ue, n, ar["scale"], tv, key_valid=ar["attention_mask"][:, :P], autocast=ac)
+        assert torch.equal(tok.long(), ar[mode]["tokens"]) and len(set(tok[0].tolist())) > 4      # not a degenerate echo
+        assert torch.allclose(margin, ar[mode]["margin"])
+        mm = g["mmu"]
+        mask = host_ref.to_additive(mm["mask_allow"]).to(torch.float32)
+        toks, _ = qwen2_ref.mmu_generate_ref(lm, idx=mm["idx"], attention_mask=mask, max_new_tokens=mm["max_new_tokens"], autocast=ac)
+        assert toks == mm[mode]["tokens"].tolist() and len(set(toks)) > 6

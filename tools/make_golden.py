@@ -417,3 +417,201 @@ if __name__ == "__main__" and "dpo" in sys.argv[1:]:
     golden_dpo()
 if __name__ == "__main__" and "wide" in sys.argv[1:]:
     golden_wide()
+
+
+# ------------------------------------------------------------------ G9: greedy generation trajectories (AR image tokens, mmu text)
+def golden_generate():
+    """The real reference's `t2i_generate_ar` (models/unigen.py:457-521) and `mmu_generate` (:523-581) on the tiny model
+    of G2, made deterministic without touching them: AR runs with temperature 1e-6, which turns its
+    softmax(logits / temperature) into a one-hot and `torch.multinomial` into argmax; mmu runs with temperature 0 (its own
+    argmax branch).  The oracle's ar_generate_ref / mmu_generate_ref must return the same tokens, fp32 and bf16-autocast."""
+    from models import UniGen
+    g2 = torch.load(os.path.join(OUT, "g2_tiny_unigen.pt"), weights_only=False)
+    cfgd, ids = g2["cfg"], g2["ids"]
+    V, TV = cfgd["vocab_size"], ids["text_vocab"]
+    cfg = qwen2_ref.Qwen2Cfg(**cfgd)
+    d = ref_shims.write_llm_config_dir(cfg.to_hf_dict())
+    torch.manual_seed(0)
+    model = UniGen(w_und_encoder=False, vocab_size=V, llm_vocab_size=TV, llm_model_path=d, codebook_size=20, num_vq_tokens=16,
+                   load_from_pretrained=True).eval()
+    names = [(n, tuple(p.shape)) for n, p in model.llm.named_parameters()]
+    # matrices 7.5x wider than the HF init of G2: with std 0.02 the tied head just echoes the last input token and every
+    # trajectory is one repeated id; at 0.15 the layers dominate and the tokens depend on masks, positions and the cache
+    STD = float(os.environ.get("G9_STD", "0.15"))
+    sd = weights.synth_llm_state(names, seed=g2["weight_seed"], std=STD)
+    model.llm.load_state_dict(sd, strict=False)
+    lm = qwen2_ref.RefCausalLM(cfg)
+    lm.load_state_dict(sd, strict=False)
+    out = {"cfg": cfgd, "weight_seed": g2["weight_seed"], "weight_std": STD, "ids": ids}
+
+    # ---- AR image tokens with CFG: left-padded cond / uncond prompts, 2-D attention mask (what inference_t2i.py passes)
+    n, B, P = 16, 2, 30
+    gen = torch.Generator().manual_seed(5)
+    cond = torch.randint(0, 290, (B, P + n + 1), generator=gen)
+    uncond = torch.randint(0, 290, (B, P + n + 1), generator=gen)
+    cond[0, :6] = ids["pad"]
+    uncond[:, :20] = ids["pad"]
+    am = torch.cat([cond != ids["pad"], uncond != ids["pad"]]).long()
+    am[:, P:] = 1
+    out["ar"] = {"cond": cond, "uncond": uncond, "attention_mask": am, "n": n, "P": P, "scale": 3.0}
+    for mode, ac in (("fp32", False), ("bf16", True)):
+        ctx = torch.autocast("cpu", dtype=torch.bfloat16) if ac else torch.autocast("cpu", enabled=False)
+        with torch.no_grad(), ctx:
+            ce, ue = model.llm.model.embed_tokens(cond), model.llm.model.embed_tokens(uncond)
+            ref_tok = model.t2i_generate_ar(input_ids=cond, uncond_input_ids=uncond, input_embeddings=ce, uncond_input_embeddings=ue,
+                                            attention_mask=am, guidance_scale=3.0, temperature=1e-6, text_vocab_size=TV,
+                                            image_token_num_per_image=n)
+        with torch.no_grad():
+            mine, margin = qwen2_ref.ar_generate_ref(lm, lm.model.embed_tokens(cond[:, :P]), lm.model.embed_tokens(uncond[:, :P]), n, 3.0,
+                                                     TV, key_valid=am[:, :P], autocast=ac)
+        same = torch.equal(ref_tok.long(), mine.long())
+        print(f"G9 AR[{mode}] reference tokens {ref_tok.tolist()}  oracle equal: {same}  min margin {margin.min():.3f}")
+        assert same, "oracle ar_generate_ref != reference t2i_generate_ar"
+        out["ar"][mode] = {"tokens": ref_tok.long(), "margin": margin}
+
+    # ---- mmu text continuation: the mmu row of G2 (image tokens then text) under its create_attention_mask_for_mmu mask
+    Pm, new = 30, 12
+    idx = g2["input_ids"][-1:, :Pm]
+    allow = g2["mask_allow"][-1:, :Pm, :Pm]
+    mask = host_ref.to_additive(allow).to(torch.float32)
+    out["mmu"] = {"idx": idx, "mask_allow": allow, "max_new_tokens": new}
+    for mode, ac in (("fp32", False), ("bf16", True)):
+        ctx = torch.autocast("cpu", dtype=torch.bfloat16) if ac else torch.autocast("cpu", enabled=False)
+        with ctx:
+            ref_tok = [int(t) for t in model.mmu_generate(idx=idx, attention_mask=mask, max_new_tokens=new, temperature=0.0)]
+        mine, margin = qwen2_ref.mmu_generate_ref(lm, idx=idx, attention_mask=mask, max_new_tokens=new, autocast=ac)
+        print(f"G9 mmu[{mode}] reference tokens {ref_tok}  oracle equal: {ref_tok == mine}  min margin {min(margin):.3f}")
+        assert ref_tok == mine, "oracle mmu_generate_ref != reference mmu_generate"
+        out["mmu"][mode] = {"tokens": torch.tensor(ref_tok), "margin": torch.tensor(margin)}
+        # early stop on eot_token: same rule in both
+        eot = ref_tok[3]
+        with ctx:
+            ref_stop = [int(t) for t in model.mmu_generate(idx=idx, attention_mask=mask, max_new_tokens=new, temperature=0.0, eot_token=eot)]
+        stop, _ = qwen2_ref.mmu_generate_ref(lm, idx=idx, attention_mask=mask, max_new_tokens=new, eot_token=eot, autocast=ac)
+        assert ref_stop == stop and stop == ref_tok[:ref_tok.index(eot) + 1]
+    torch.save(out, os.path.join(OUT, "g9_generate.pt"))
+    print("G9 generation trajectories: captured (oracle == reference)")
+
+
+if __name__ == "__main__" and "generate" in sys.argv[1:]:
+    golden_generate()
+
+
+# ------------------------------------------------------------------ G10: checkpoints written by the reference's own save_pretrained
+CKPT_TINY = dict(hidden_size=128, intermediate_size=64, num_hidden_layers=1, num_attention_heads=1, num_key_value_heads=1,
+                 rope_theta=1e6, rms_norm_eps=1e-6)
+
+
+def golden_checkpoint():
+    """The real reference `ModelMixin.save_pretrained` (models/modeling_utils.py:257-399; the call of
+    utils/checkpoint.py:53-59 uses safe_serialization=False) writes a very small UniGen twice: one `pytorch_model.bin`
+    and a sharded set (`max_shard_size` small) with its index file.  The directories are committed as DATA under
+    tests/golden/ and loaded through the build's from_pretrained in tests/test_checkpoint_gpu.py.  safetensors output
+    of a tied-embedding UniGen is refused by safetensors itself in the reference, so only the .bin formats exist."""
+    import shutil
+    from models import UniGen
+    V, TV = 333, 312
+    cfg = qwen2_ref.Qwen2Cfg(vocab_size=V, **CKPT_TINY)
+    d = ref_shims.write_llm_config_dir(cfg.to_hf_dict())
+    torch.manual_seed(0)
+    model = UniGen(w_und_encoder=False, vocab_size=V, llm_vocab_size=TV, llm_model_path=d, codebook_size=20, num_vq_tokens=16,
+                   load_from_pretrained=True).eval()
+    names = [(n, tuple(p.shape)) for n, p in model.llm.named_parameters()]
+    sd = weights.synth_llm_state(names, seed=55)
+    model.llm.load_state_dict(sd, strict=False)
+    model.register_to_config(llm_model_path="qwen2.5-ckpt-tiny")        # a name, not this container's temp dir
+    ids = torch.randint(0, 290, (2, 24), generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        logits = model(input_ids=ids, attention_mask=None)
+    for name, kw in (("ckpt_ref_single", {}), ("ckpt_ref_sharded", {"max_shard_size": "200KB"})):
+        out = os.path.join(OUT, name)
+        shutil.rmtree(out, ignore_errors=True)
+        model.save_pretrained(out, safe_serialization=False, **kw)
+        print(f"G10 {name}: {sorted(os.listdir(out))}")
+    torch.save({"cfg": dict(CKPT_TINY, vocab_size=V), "weight_seed": 55, "input_ids": ids, "logits_last": logits[:, -3:].clone(),
+                "keys": sorted(model.state_dict().keys())}, os.path.join(OUT, "g10_checkpoint.pt"))
+    print("G10 reference-written checkpoints: captured")
+
+
+if __name__ == "__main__" and "checkpoint" in sys.argv[1:]:
+    golden_checkpoint()
+
+
+# ------------------------------------------------------------------ G11: prepare_inputs_for_mmu and generate (models/unigen.py:133-228, 584-588)
+def golden_mmu_inputs():
+    """The real reference UniGen with an mm_projector: `prepare_inputs_for_mmu` in training and eval mode on ragged image
+    features (with and without a system prompt), and `generate` (transformers' GenerationMixin underneath) greedy on
+    left-padded ids and on embeddings."""
+    from models import UniGen
+    from training.prompting_utils import UniversalPromptingQwen2
+    g2 = torch.load(os.path.join(OUT, "g2_tiny_unigen.pt"), weights_only=False)
+    cfgd, ids = g2["cfg"], g2["ids"]
+    V, TV, MMD = cfgd["vocab_size"], ids["text_vocab"], 32
+    tok = FakeTok()
+    up = UniversalPromptingQwen2(tok, max_seq_len=32, cond_dropout_prob=0.0, ignore_id=-100)
+    cfg = qwen2_ref.Qwen2Cfg(**cfgd)
+    d = ref_shims.write_llm_config_dir(cfg.to_hf_dict())
+    torch.manual_seed(0)
+    model = UniGen(w_und_encoder=True, vocab_size=V, llm_vocab_size=TV, llm_model_path=d, codebook_size=20, num_vq_tokens=16,
+                   load_from_pretrained=True, mm_input_dim=MMD, und_proj_depth=2)
+    names = [(n, tuple(p.shape)) for n, p in model.named_parameters() if not n.startswith("llm.lm_head")]
+    STD = 0.15
+    sd = weights.synth_llm_state(names, seed=61, std=STD)
+    res = model.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys, res
+    out = {"cfg": cfgd, "weight_seed": 61, "weight_std": STD, "mm_input_dim": MMD, "ids": ids,
+           "template": dict(max_seq_len=32, ignore_id=-100, eos_token_id=tok.eos_token_id, pad_token_id=tok.pad_token_id,
+                            task_token_first=False, sptids={k: int(v) for k, v in up.sptids_dict.items()})}
+    g = torch.Generator().manual_seed(13)
+    B, N, Lt = 3, 12, 14
+    feats = torch.randn(B, N, MMD, generator=g)
+    shapes = torch.tensor([[3, 4], [2, 3], [2, 5]])
+    txt = torch.randint(0, 290, (B, Lt), generator=g)
+    txt[0, 9] = tok.eos_token_id; txt[0, 10:] = tok.pad_token_id          # row 0: answer ends early, right-padded
+    txt[1, -1] = tok.eos_token_id
+    labels = txt.clone(); labels[:, :4] = -100
+    sysids = torch.randint(0, 290, (B, 5), generator=g)
+    out["mmu_in"] = dict(image_feats=feats, spatial_shapes=shapes, input_ids=txt, label_ids=labels, input_ids_system=sysids)
+    for mode in ("train", "eval"):
+        model.train(mode == "train")
+        for tag, sys_ in (("nosys", None), ("sys", sysids)):
+            with torch.no_grad():
+                e, am, lab, p1 = model.prepare_inputs_for_mmu(feats, shapes, txt, labels, up, sys_)
+            out[f"mmu_{mode}_{tag}"] = dict(embeddings=e, attention_mask=am, labels=lab, part1=p1)
+            print(f"G11 prepare_inputs_for_mmu[{mode},{tag}]: emb {tuple(e.shape)} mask {tuple(am.shape)} labels {tuple(lab.shape)}")
+    # ---- generate(): greedy, left-padded ids with a 2-D mask; then the same prompts as embeddings
+    model.eval()
+    P, new = 18, 10
+    prompt = torch.randint(0, 290, (2, P), generator=g)
+    prompt[1, :5] = tok.pad_token_id
+    am = (prompt != tok.pad_token_id).long()
+    with torch.no_grad():
+        full = model.generate(input_ids=prompt, attention_mask=am, max_new_tokens=new, do_sample=False, use_cache=True,
+                              pad_token_id=tok.eos_token_id)
+        cont = model.generate(input_embeddings=model.llm.model.embed_tokens(prompt), attention_mask=am, max_new_tokens=new,
+                              do_sample=False, use_cache=True, pad_token_id=tok.eos_token_id)
+        eos = int(full[0, P + 3])
+        stop = model.generate(input_ids=prompt, attention_mask=am, max_new_tokens=new, do_sample=False, use_cache=True,
+                              pad_token_id=tok.pad_token_id, eos_token_id=eos)
+    assert torch.equal(full[:, :P], prompt) and torch.equal(full[:, P:], cont)
+    # margins from the oracle (causal + key-validity mask, positions = arange like UniGen.forward; HF generate numbers the
+    # positions from the first real token, which RoPE's relative form makes equivalent up to rounding)
+    lm = qwen2_ref.RefCausalLM(cfg)
+    lm.load_state_dict({k[4:]: v for k, v in sd.items() if k.startswith("llm.")}, strict=False)
+    toks, margins = [], []
+    for r in range(2):
+        allow = torch.tril(torch.ones(P, P, dtype=torch.bool)) & am[r].bool()[None, :]
+        allow |= torch.eye(P, dtype=torch.bool)
+        t, m = qwen2_ref.mmu_generate_ref(lm, idx=prompt[r:r + 1], attention_mask=host_ref.to_additive(allow[None]).float(),
+                                          max_new_tokens=new, autocast=False)
+        toks.append(t); margins.append(m)
+    print(f"G11 generate: reference {full[:, P:].tolist()}\n             oracle    {toks}  stop@{eos}: {stop.tolist()}")
+    assert toks == full[:, P:].tolist(), "oracle causal greedy decode != reference generate"
+    out["generate"] = dict(prompt=prompt, attention_mask=am, max_new_tokens=new, full=full, cont=cont, eos=eos, stop=stop,
+                           margin=torch.tensor(margins))
+    torch.save(out, os.path.join(OUT, "g11_mmu_inputs.pt"))
+    print("G11 prepare_inputs_for_mmu / generate: captured")
+
+
+if __name__ == "__main__" and "mmu_inputs" in sys.argv[1:]:
+    golden_mmu_inputs()

@@ -49,6 +49,16 @@ def install():
         def config(self):
             return self._internal_dict
 
+        def save_config(self, save_directory, **kw):
+            """what diffusers' ConfigMixin.save_config / to_json_string write: the registered kwargs plus _class_name and
+            _diffusers_version, sorted keys, indent 2"""
+            os.makedirs(save_directory, exist_ok=True)
+            cfg = dict(self._internal_dict)
+            cfg["_class_name"] = type(self).__name__
+            cfg["_diffusers_version"] = "0.0.0-shim"
+            with open(os.path.join(save_directory, self.config_name), "w", encoding="utf-8") as f:
+                f.write(json.dumps(cfg, indent=2, sort_keys=True) + "\n")
+
     def register_to_config(init):
         @functools.wraps(init)
         def inner(self, *a, **kw):
@@ -65,7 +75,8 @@ def install():
     d.__path__ = []
     _mod("diffusers.configuration_utils", ConfigMixin=ConfigMixin, register_to_config=register_to_config)
     lg = types.SimpleNamespace(get_logger=lambda name=None: logging.getLogger(name or "diffusers"))
-    _mod("diffusers.utils", FLAX_WEIGHTS_NAME="flax.msgpack", SAFE_WEIGHTS_INDEX_NAME="a.json", WEIGHTS_INDEX_NAME="b.json",
+    _mod("diffusers.utils", FLAX_WEIGHTS_NAME="flax.msgpack", SAFE_WEIGHTS_INDEX_NAME="diffusion_pytorch_model.safetensors.index.json",
+         WEIGHTS_INDEX_NAME="diffusion_pytorch_model.bin.index.json",      # diffusers.utils.constants values
          _add_variant=lambda n, v=None: n, _get_checkpoint_shard_files=None, _get_model_file=None,
          deprecate=lambda *a, **k: None, is_accelerate_available=lambda: False,
          is_torch_version=lambda *a: True, logging=lg).__path__ = []
