@@ -189,6 +189,14 @@ int ug_t2i_assemble(const int64_t* text_ids, const int64_t* text_offsets, const 
 int ug_attn_mask_from_ids(const int64_t* ids, int64_t B, int64_t L, int64_t pad_id, int64_t soi_id, int64_t eoi_id, int mode,
                           int* meta_ws, uint8_t* flags_ws, uint64_t* bits, uint8_t* tileany, hipStream_t stream);
 
+/* replaces: mask_or_random_replace_tokens (data/masking.py:13-94, the branch every shipped config takes: noise_type
+ * 'mask', no contiguous region, predict_all_tokens off).  scores [B, n] fp32 are the caller's `torch.rand(B, n)`;
+ * num_masked [B] fp32 = (n * mask_prob).round().clamp(min=1).  Position j is masked iff argsort(scores)[j] < num_masked
+ * (ties broken by index).  input_ids = mask_id on masked positions else the token; labels = token on masked positions
+ * else ignore_id.  Bit-equal to the reference for distinct scores. */
+int ug_maskgit_train_mask(const int64_t* tokens, const float* scores, const float* num_masked, int64_t B, int64_t n,
+                          int64_t mask_id, int64_t ignore_id, int64_t* input_ids, int64_t* labels, hipStream_t stream);
+
 /* ---- MaskGIT parallel decoding step ------------------------------------------------------------ */
 /* replaces, per round of UniGen.t2i_generate (models/unigen.py:404-451): the CFG mix of the code-book logits, softmax,
  * torch.multinomial, the gather of the drawn token's probability and models/sampling.py:41-46 mask_by_random_topk.
@@ -231,6 +239,14 @@ int ug_ce_bwd(void* logits_inout, int64_t ld, int64_t R, int64_t V, const int64_
 int ug_adamw_flat(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr,
                   float beta1, float beta2, float eps, float weight_decay, int64_t step, float grad_scale,
                   hipStream_t stream);
+
+/* ---- data-parallel gradient exchange staging ------------------------------------------------ */
+/* replaces: the bucket copies + fp32 all-reduce of torch DistributedDataParallel's reducer behind
+ * accelerator.backward (training/train.py:492,775).  A bucket of the flat fp32 gradient buffer is packed as
+ * bf16(g * scale) (scale = 1 / world size: the mean is formed by the SUM all-reduce), exchanged by RCCL on the side
+ * stream, and unpacked back in place.  Buffers 16-byte aligned; tails of any length. */
+int ug_grad_pack_bf16(const float* in, void* out_bf16, int64_t n, float scale, hipStream_t stream);
+int ug_grad_unpack_bf16(const void* in_bf16, float* out, int64_t n, hipStream_t stream);
 
 /* ---- MAGVITv2 tokenizer (fp32, NHWC) ------------------------------------------------------- */
 /* replaces: torch.nn.Conv2d in VQGANEncoder/Decoder, ResnetBlock, Downsample (asymmetric pad via

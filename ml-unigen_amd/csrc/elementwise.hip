@@ -345,6 +345,36 @@ __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restr
   if (ti < n) out[ti] = f2bf(in[ti]);
 }
 
+// =========================================================================== gradient exchange staging
+// out = bf16(in * scale): the flat fp32 gradient bucket, pre-divided by the world size, packed for the bf16 all-reduce.
+__global__ __launch_bounds__(256) void grad_pack_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, int64_t n, float scale) {
+  const int64_t n8 = n >> 3;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 a = reinterpret_cast<const float4*>(in)[2 * i], b = reinterpret_cast<const float4*>(in)[2 * i + 1];
+    uint4 o;
+    o.x = pack_bf2(a.x * scale, a.y * scale); o.y = pack_bf2(a.z * scale, a.w * scale);
+    o.z = pack_bf2(b.x * scale, b.y * scale); o.w = pack_bf2(b.z * scale, b.w * scale);
+    reinterpret_cast<uint4*>(out)[i] = o;
+  }
+  const int64_t ti = (n8 << 3) + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (ti < n) out[ti] = f2bf(in[ti] * scale);
+}
+// out = float(in): the reduced bf16 bucket back into the flat fp32 gradient buffer.
+__global__ __launch_bounds__(256) void grad_unpack_kernel(const bf16_t* __restrict__ in, float* __restrict__ out, int64_t n) {
+  const int64_t n8 = n >> 3;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint4 v = reinterpret_cast<const uint4*>(in)[i];
+    float4 a, b;
+    a.x = __uint_as_float(v.x << 16); a.y = __uint_as_float(v.x & 0xffff0000u);
+    a.z = __uint_as_float(v.y << 16); a.w = __uint_as_float(v.y & 0xffff0000u);
+    b.x = __uint_as_float(v.z << 16); b.y = __uint_as_float(v.z & 0xffff0000u);
+    b.z = __uint_as_float(v.w << 16); b.w = __uint_as_float(v.w & 0xffff0000u);
+    reinterpret_cast<float4*>(out)[2 * i] = a; reinterpret_cast<float4*>(out)[2 * i + 1] = b;
+  }
+  const int64_t ti = (n8 << 3) + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (ti < n) out[ti] = bf2f(in[ti]);
+}
+
 // =========================================================================== row gather / scatter
 // out[i, :] = in[idx[i], :]  (bf16 rows, 16-byte chunks).  Used to pick the label positions that feed
 // the lm_head GEMM and to route their gradient back.
@@ -495,6 +525,22 @@ extern "C" int ug_cast_f32_bf16(const float* in, void* out, int64_t n, hipStream
   dim3 grid(grid_for(n / 4 + 1)), block(256);
   hipLaunchKernelGGL(cast_f32_bf16_kernel, grid, block, 0, st, in, (bf16_t*)out, n);
   UG_CHECK_LAUNCH("ug_cast_f32_bf16");
+  return UG_OK;
+}
+
+extern "C" int ug_grad_pack_bf16(const float* in, void* out, int64_t n, float scale, hipStream_t st) {
+  UG_REQUIRE(n > 0 && ug_aligned16(in) && ug_aligned16(out), "ug_grad_pack_bf16: n > 0 and 16-byte aligned buffers required");
+  dim3 grid(grid_for(n / 8 + 1)), block(256);
+  hipLaunchKernelGGL(grad_pack_kernel, grid, block, 0, st, in, (bf16_t*)out, n, scale);
+  UG_CHECK_LAUNCH("ug_grad_pack_bf16");
+  return UG_OK;
+}
+
+extern "C" int ug_grad_unpack_bf16(const void* in, float* out, int64_t n, hipStream_t st) {
+  UG_REQUIRE(n > 0 && ug_aligned16(in) && ug_aligned16(out), "ug_grad_unpack_bf16: n > 0 and 16-byte aligned buffers required");
+  dim3 grid(grid_for(n / 8 + 1)), block(256);
+  hipLaunchKernelGGL(grad_unpack_kernel, grid, block, 0, st, (const bf16_t*)in, out, n);
+  UG_CHECK_LAUNCH("ug_grad_unpack_bf16");
   return UG_OK;
 }
 

@@ -40,6 +40,36 @@ __global__ __launch_bounds__(256) void t2i_assemble_kernel(const int64_t* __rest
   }
 }
 
+// MaskGIT training-time masking (data/masking.py:13-94, default branch).  The reference draws scores ~ U(0,1) [B, n],
+// takes `perm = scores.argsort(-1)` and masks position j iff perm[j] < k_b (k_b = round(n * mask_prob_b) clamped to >= 1):
+// position j is masked iff the element with the j-th smallest score has an index below k_b.  With rank(i) = number of
+// scores ordered before element i (ties broken by index, i.e. a stable sort), that is mask[rank(i)] = 1 for every
+// i < k_b -- no sort needed.  One workgroup per row, the row's scores in LDS.
+__global__ __launch_bounds__(256) void maskgit_train_mask_kernel(const int64_t* __restrict__ tokens, const float* __restrict__ scores,
+                                                                 const float* __restrict__ num_masked, int n, int64_t mask_id,
+                                                                 int64_t ignore_id, int64_t* __restrict__ input_ids,
+                                                                 int64_t* __restrict__ labels) {
+  extern __shared__ float lds[];
+  float* s = lds;                                       // n scores
+  unsigned char* m = reinterpret_cast<unsigned char*>(lds + n);   // n mask bytes
+  const int b = blockIdx.x;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) { s[i] = scores[(int64_t)b * n + i]; m[i] = 0; }
+  __syncthreads();
+  const int k = (int)num_masked[b];
+  for (int i = threadIdx.x; i < k && i < n; i += blockDim.x) {
+    const float si = s[i];
+    int r = 0;
+    for (int j = 0; j < n; ++j) r += (s[j] < si) || (s[j] == si && j < i);
+    m[r] = 1;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int64_t t = tokens[(int64_t)b * n + i];
+    input_ids[(int64_t)b * n + i] = m[i] ? mask_id : t;
+    labels[(int64_t)b * n + i] = m[i] ? t : ignore_id;
+  }
+}
+
 }  // namespace
 
 extern "C" int ug_t2i_assemble(const int64_t* text_ids, const int64_t* text_offsets, const int64_t* conv_start, int64_t n_start,
@@ -53,5 +83,16 @@ extern "C" int ug_t2i_assemble(const int64_t* text_ids, const int64_t* text_offs
                      conv_end, (int)n_end, image_in, image_labels, (int)n_image, (int)max_seq_len, pad_id, soi_id, eoi_id, ignore_id,
                      input_ids, labels, attn01);
   UG_CHECK_LAUNCH("ug_t2i_assemble");
+  return UG_OK;
+}
+
+extern "C" int ug_maskgit_train_mask(const int64_t* tokens, const float* scores, const float* num_masked, int64_t B, int64_t n,
+                                     int64_t mask_id, int64_t ignore_id, int64_t* input_ids, int64_t* labels, hipStream_t st) {
+  UG_REQUIRE(tokens && scores && num_masked && input_ids && labels && B > 0 && n > 0 && n <= 8192,
+             "ug_maskgit_train_mask: bad args (B=%ld n=%ld, n <= 8192)", (long)B, (long)n);
+  const size_t lds = (size_t)n * sizeof(float) + (size_t)n;
+  hipLaunchKernelGGL(maskgit_train_mask_kernel, dim3((unsigned)B), dim3(256), lds, st, tokens, scores, num_masked, (int)n, mask_id,
+                     ignore_id, input_ids, labels);
+  UG_CHECK_LAUNCH("ug_maskgit_train_mask");
   return UG_OK;
 }

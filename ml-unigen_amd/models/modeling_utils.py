@@ -100,7 +100,13 @@ class ModelMixin(torch.nn.Module):
         with open(os.path.join(save_directory, self.config_name), "w", encoding="utf-8") as f:
             f.write(json.dumps(cfg, indent=2, sort_keys=True, default=str) + "\n")
         sd = state_dict if state_dict is not None else self.state_dict()
-        sd = {k: v.detach().to("cpu").contiguous() for k, v in sd.items()}
+        host, cpu_sd = {}, {}
+        for k, v in sd.items():              # one host copy per distinct tensor: tied names (lm_head / embed_tokens) stay aliased
+            key = (v.data_ptr(), tuple(v.shape), tuple(v.stride()))
+            if key not in host:
+                host[key] = v.detach().to("cpu").contiguous()
+            cpu_sd[k] = host[key]
+        sd = cpu_sd
         ext = "safetensors" if safe_serialization else "bin"
         stem = WEIGHTS_STEM if variant is None else f"{WEIGHTS_STEM}.{variant}"
         shards = _split_into_shards(sd, _parse_size(max_shard_size))

@@ -225,6 +225,12 @@ class SigLipVisionTower(nn.Module):
         return h.view(B, T, D)
 
     def forward(self, images):
+        # The tower has no backward here: every shipped config freezes it (configs/*: model.vision_tower.freeze true).
+        # Training it (mm_tunable_parts containing 'mm_vision_tower', train_w_clip_vit.py:311-312) must not silently
+        # train nothing.
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.vision_tower.parameters()):
+            raise UniGenHipError("SigLipVisionTower: training the vision tower is not implemented (forward only); freeze it "
+                                 "(`vision_tower.requires_grad_(False)`, config model.vision_tower.freeze) or run under no_grad")
         if type(images) is list:
             return [self._encode(im.to(device=self.device, dtype=self.dtype).unsqueeze(0)).to(im.dtype) for im in images]
         return self._encode(images.to(device=self.device, dtype=self.dtype)).to(images.dtype)

@@ -54,6 +54,15 @@ def _load_llm_config(llm_model_path, ckpt_base_path=""):
     raise UniGenHipError(f"cannot find an LLM config for '{llm_model_path}' (no config.json, unknown name)")
 
 
+def _drop_anchor_from_state_dict(module, state_dict, prefix, local_metadata):
+    state_dict.pop(prefix + "_ddp_anchor", None)          # not part of the reference checkpoint format
+    return state_dict
+
+
+def _forgive_missing_anchor(module, incompatible_keys):
+    incompatible_keys.missing_keys[:] = [k for k in incompatible_keys.missing_keys if not k.endswith("_ddp_anchor")]
+
+
 class UniGen(ModelMixin, ConfigMixin):
     _supports_gradient_checkpointing = True
 
@@ -108,10 +117,59 @@ class UniGen(ModelMixin, ConfigMixin):
         self.img_output_size = codebook_size
         self.register_to_config(mask_token_id=vocab_size - 1)
         self._loss_idx_cache = {}
+        # Data parallelism (reference: accelerator.prepare wraps the model in DistributedDataParallel, train.py:492).
+        # The backbone's parameters are views of one flat buffer whose gradients the kernels write directly and
+        # unigen_hip.ddp.FlatGradSync averages, so DDP's reducer must leave them alone (see
+        # `_ddp_params_and_buffers_to_ignore`); `_ddp_anchor` is the one ordinary parameter DDP always finds (it refuses
+        # a module with none) and the input that puts the engine's autograd Functions on every graph.  It receives a
+        # zero gradient per backward and never changes.
+        eng = self.llm.engine
+        self._ddp_anchor = torch.nn.Parameter(torch.zeros(1, device=eng.device))
+        eng._anchor = self._ddp_anchor
+        eng.extra_grad_params = self._ordinary_grad_params
+        self.__dict__["_ddp_wrapped"] = False
+        self._register_state_dict_hook(_drop_anchor_from_state_dict)
+        self.register_load_state_dict_post_hook(_forgive_missing_anchor)
         if w_und_encoder:
             if vision_tower_name is not None:
                 self.init_vision_tower(vision_tower_name)
             self.add_mm_projector(max(2, und_proj_depth), mm_input_dim)
+
+    # ------------------------------------------------------------------ data parallel plumbing
+    def _flat_view_ids(self):
+        return {id(p) for p in self.llm.engine.named_param_views().values()}
+
+    @property
+    def _ddp_params_and_buffers_to_ignore(self):
+        """Read by torch's DistributedDataParallel constructor (nn/parallel/distributed.py: parameters_to_ignore): every
+        name under which a flat-view parameter is reachable, including the tied `llm.lm_head.weight`.  Reading it also
+        records that a DDP wrapper exists, i.e. that the ordinary parameters (mm_projector, ...) are averaged by DDP's
+        own reducer and FlatGradSync only has to move the flat buffer."""
+        self.__dict__["_ddp_wrapped"] = True
+        flat = self._flat_view_ids()
+        return [f"{mn}.{pn}" if mn else pn for mn, m in self.named_modules() for pn, p in m.named_parameters(recurse=False)
+                if id(p) in flat]
+
+    def _ordinary_grad_params(self):
+        if self.__dict__.get("_ddp_wrapped"):
+            return []
+        flat = self._flat_view_ids()
+        return [p for p in self.parameters() if id(p) not in flat and p is not self._ddp_anchor and p.requires_grad]
+
+    def no_sync(self):
+        """Context manager for gradient-accumulation micro-steps outside accelerate (inside it, `accelerator.accumulate`
+        is honoured automatically): backward passes run here add to the local gradients and exchange nothing."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            eng = self.llm.engine
+            prev, eng.require_grad_sync = eng.require_grad_sync, False
+            try:
+                yield
+            finally:
+                eng.require_grad_sync = prev
+        return ctx()
 
     # ------------------------------------------------------------------ construction helpers
     def _load_hf_llm_weights(self, llm_model_path, ckpt_base_path):

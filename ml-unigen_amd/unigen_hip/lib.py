@@ -52,12 +52,15 @@ SIGNATURES = {
     "ug_decode_finish_swiglu": [P, I64, P, I64, I64, P],
     "ug_t2i_assemble": [P, P, P, I64, P, I64, P, P, I64, I64, I64, I64, I64, I64, I64, P, P, P, P],
     "ug_attn_mask_from_ids": [P, I64, I64, I64, I64, I64, I32, P, P, P, P, P],
+    "ug_maskgit_train_mask": [P, P, P, I64, I64, I64, I64, P, P, P],
     "ug_ar_sample": [P, I64, I64, I64, F32, F32, I32, P, P, I64, I64, P, I64, I64, I64, P, P, P, P],
     "ug_maskgit_step": [P, I64, I64, I64, I64, I32, F32, P, P, P, I64, I64, I64, F32, P, P, P, P, P, P],
     "ug_skinny_finish": [P, P, P, P, I64, I64, I32, P],
     "ug_ce_fwd": [P, I64, I64, I64, P, I64, P, P, P, P, P],
     "ug_ce_bwd": [P, I64, I64, I64, P, I64, P, P, P, P, P],
     "ug_adamw_flat": [P, P, P, P, P, I64, F32, F32, F32, F32, F32, I64, F32, P],
+    "ug_grad_pack_bf16": [P, P, I64, F32, P],
+    "ug_grad_unpack_bf16": [P, P, I64, P],
     "ug_conv2d_f32": [P, P, P, P, P, I64, I32, I32, I32, I32, I32, I32, I32, I32, I32, I32, I32, I32, P],
     "ug_conv_split_weights": [P, P, I32, I32, I32, P],
     "ug_conv2d_split3": [P, P, P, P, P, I64, I32, I32, I32, I32, I32, I32, I32, I32, I32, I32, I32, I32, P],

@@ -19,7 +19,7 @@ from .lib import UniGenHipError
 from .qwen2 import Qwen2Dims, Qwen2Engine, _hf_name_map
 
 
-def _anchor_of(engine):
+def anchor_of(engine):
     return engine._anchor
 
 
@@ -48,6 +48,8 @@ class _StackFn(torch.autograd.Function):
         B, L, H = h0.shape
         need = any(ctx.needs_input_grad)
         saved = [] if need else None
+        if need:
+            engine._dp_sync()               # world > 1: install the gradient exchange / align the replicas before step 1
         h_last, hn, rstd = engine.stack_fwd(h0.reshape(B * L, H).float().contiguous(), mb, L, saved)
         if need:
             ctx.engine, ctx.saved, ctx.h_last, ctx.rstd, ctx.mb, ctx.shape = engine, saved, h_last, rstd, mb, (B, L, H)
@@ -61,7 +63,10 @@ class _StackFn(torch.autograd.Function):
         dhn = dhn.reshape(B * L, H).to(torch.bfloat16).contiguous()
         dh0 = eng.stack_bwd(ctx.saved, ctx.h_last, ctx.rstd, dhn, ctx.mb, L)
         ctx.saved = None
-        return None, dh0.view(B, L, H), None, None
+        # the anchor gets a (zero) gradient once per backward: when it is the `_ddp_anchor` Parameter of a model wrapped
+        # in DistributedDataParallel this is what tells DDP's reducer that the iteration is complete
+        danchor = torch.zeros_like(anchor_of(eng)) if ctx.needs_input_grad[0] else None
+        return danchor, dh0.view(B, L, H), None, None
 
 
 class _HeadLossFn(torch.autograd.Function):
@@ -351,13 +356,19 @@ class HipQwen2ForCausalLM(nn.Module):
 
 
 class TrainEngine(Qwen2Engine):
-    """Qwen2Engine + the glue the module layer needs (parameter views, grad bookkeeping, masks)."""
+    """Qwen2Engine + the glue the module layer needs (parameter views, grad bookkeeping, masks, data-parallel hook-up)."""
 
     def __init__(self, dims, device):
         super().__init__(dims, device)
         self._anchor = torch.zeros(1, device=device, requires_grad=True)
         self._params = None
         self._mask_cache = (None, None)
+        # data parallelism (unigen_hip/ddp.py): installed lazily when torch.distributed runs with world > 1
+        self.grad_sync = None
+        self.auto_data_parallel = True
+        self.require_grad_sync = True        # False inside UniGen.no_sync(): gradient-accumulation micro-steps
+        self.extra_grad_params = None        # callable -> ordinary Parameters to average when no DDP wrapper does it
+        self._in_backward = False
 
     def named_param_views(self):
         if self._params is None:
@@ -372,16 +383,59 @@ class TrainEngine(Qwen2Engine):
                 self._params[name] = p
         return self._params
 
+    # ------------------------------------------------------------------ data parallel
+    def _dp_sync(self):
+        """The FlatGradSync of this engine; created on first use once torch.distributed is initialised with world > 1.
+        Creation also broadcasts rank 0's master weights: DistributedDataParallel does that for the parameters it
+        manages, and the flat views are deliberately hidden from it (`UniGen._ddp_params_and_buffers_to_ignore`)."""
+        if self.grad_sync is None and self.auto_data_parallel:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                from .ddp import FlatGradSync
+                self.grad_sync = FlatGradSync(self, extra_params=lambda: self.extra_grad_params() if self.extra_grad_params else [])
+                dist.broadcast(self.fp.master, 0)
+                self.fp._seen_version = -1
+        return self.grad_sync
+
+    def _sync_this_pass(self):
+        """False on a gradient-accumulation micro-step: inside `UniGen.no_sync()`, or when accelerate's shared
+        GradientState (set by `accelerator.accumulate` / `no_sync`, training/train.py's own mechanism) says so."""
+        if not self.require_grad_sync:
+            return False
+        import sys
+        st = sys.modules.get("accelerate.state")
+        gs = getattr(st, "GradientState", None) if st is not None else None
+        if gs is not None and getattr(gs, "_shared_state", None):
+            return bool(gs().sync_gradients)
+        return True
+
+    def _end_of_backward(self):
+        self._in_backward = False
+        if self.grad_sync is not None:
+            self.grad_sync.finish()
+
     def begin_grad_pass(self):
         """Called at the start of every backward segment.  If the caller dropped the gradients
         (`optimizer.zero_grad(set_to_none=True)`, reference training/train.py:793) the flat buffer is
-        cleared once and every Parameter gets its persistent grad view back."""
+        cleared once and every Parameter gets its persistent grad view back.  The first segment of a backward pass also
+        arms the data-parallel exchange and queues its completion on the autograd engine's end-of-backward callbacks."""
         views = self.__dict__.get("_grad_views", {})
-        probe = views.get("model.norm.weight")
-        if probe is not None and probe[0].grad is None:
-            self.fp.clear_grads()
+        if any(p.grad is None for p, _ in views.values() if p.requires_grad):
+            if all(p.grad is None for p, _ in views.values() if p.requires_grad):
+                self.fp.clear_grads()
+            else:                                # only some were dropped: those restart from zero
+                for p, g in views.values():
+                    if p.grad is None and p.requires_grad:
+                        g.zero_()
             for p, g in views.values():
-                p.grad = g
+                if p.grad is None and p.requires_grad:
+                    p.grad = g
+        if not self._in_backward:
+            sync = self._dp_sync()
+            if sync is not None:
+                self._in_backward = True
+                sync.begin(enabled=self._sync_this_pass())
+                torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
 
     def mask_bits(self, attention_mask, B, L):
         if attention_mask is None:

@@ -96,6 +96,17 @@ def cast_bf16(x, out=None):
     return out
 
 
+def grad_pack_bf16(g, out, scale):
+    """out (bf16) = g (fp32) * scale: staging for the data-parallel bf16 all-reduce (unigen_hip/ddp.py)."""
+    _need_cuda(g, out)
+    _l.check(_l.load().ug_grad_pack_bf16(_p(g), _p(out), g.numel(), float(scale), _stream()), "ug_grad_pack_bf16")
+
+
+def grad_unpack_bf16(src, g):
+    _need_cuda(src, g)
+    _l.check(_l.load().ug_grad_unpack_bf16(_p(src), _p(g), g.numel(), _stream()), "ug_grad_unpack_bf16")
+
+
 # ------------------------------------------------------------------------------------ row ops
 def rmsnorm_fwd(x, w, eps, out_f32=False, want_rstd=True, out=None):
     _need_cuda(x, w)
@@ -445,6 +456,18 @@ def maskgit_step(logits, N, n, cfg, guidance_scale, u_sample, u_conf, cur_ids, m
                                        int(id_offset), int(mask_len_sched), float(temperature), _p(sampled), _p(sel), _p(next_cur),
                                        _p(next_ids), _p(masking), _stream()), "ug_maskgit_step")
     return (sampled, next_cur, next_ids, masking.bool()) if want_masking else (sampled, next_cur, next_ids)
+
+
+def maskgit_train_mask(tokens, scores, num_masked, mask_id, ignore_id=-100):
+    """tokens int64 [B, n], scores fp32 [B, n], num_masked fp32 [B] -> (input_ids, labels) int64 [B, n]; see
+    include/unigen_hip.h: ug_maskgit_train_mask."""
+    _need_cuda(tokens, scores, num_masked)
+    B, n = tokens.shape
+    tokens = tokens.to(torch.int64).contiguous()
+    ids, labels = torch.empty_like(tokens), torch.empty_like(tokens)
+    _l.check(_l.load().ug_maskgit_train_mask(_p(tokens), _p(scores.float().contiguous()), _p(num_masked.float().contiguous()), B, n,
+                                             int(mask_id), int(ignore_id), _p(ids), _p(labels), _stream()), "ug_maskgit_train_mask")
+    return ids, labels
 
 
 def ar_sample_(acc, bsz, V, guidance_scale, temperature, greedy, uniforms, pos_dev, pos0, nsteps, embed_master, id_offset, tok,

@@ -14,10 +14,19 @@ class _Run:
 
 
 class FusedAdamW(torch.optim.Optimizer):
+    """State layout = torch.optim.AdamW's: `self.state[p]` holds `step`, `exp_avg`, `exp_avg_sq` per parameter, so
+    `state_dict()` / `load_state_dict()` (what the reference checkpoints through `accelerator.save_state` and
+    utils/checkpoint.py:67-69) interoperate with torch.optim.AdamW.  The moment tensors are views of one buffer per
+    flat run, which is what the kernel walks."""
+
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._runs = None
         self._step = 0
+
+    def add_param_group(self, param_group):
+        super().add_param_group(param_group)
+        self._runs = None                          # rebuilt (moments carried over from self.state) at the next step
 
     def _build_runs(self):
         runs = []
@@ -42,7 +51,25 @@ class FusedAdamW(torch.optim.Optimizer):
             dev = r.params[0].device
             r.m = torch.zeros(r.numel, dtype=torch.float32, device=dev)
             r.v = torch.zeros(r.numel, dtype=torch.float32, device=dev)
+            for p in r.params:
+                o = (p.data_ptr() - r.p_ptr) // 4
+                m, v = r.m[o:o + p.numel()].view_as(p), r.v[o:o + p.numel()].view_as(p)
+                old = self.state.get(p)
+                if old:                            # loaded checkpoint / earlier run layout: carry the moments over
+                    m.copy_(old["exp_avg"])
+                    v.copy_(old["exp_avg_sq"])
+                    self._step = max(self._step, int(float(old.get("step", 0))))
+                self.state[p] = {"step": torch.tensor(float(self._step)), "exp_avg": m, "exp_avg_sq": v}
         self._runs = runs
+
+    def load_state_dict(self, state_dict):
+        """torch.optim.AdamW layout in (from this class or from torch.optim.AdamW); the loaded moments are copied into the
+        flat run buffers and the single bias-correction step count resumes from the stored one."""
+        super().load_state_dict(state_dict)
+        self._step = 0
+        self._runs = None
+        with torch.no_grad():
+            self._build_runs()
 
     @torch.no_grad()
     def step(self, closure=None, grad_scale=1.0):
@@ -80,4 +107,6 @@ class FusedAdamW(torch.optim.Optimizer):
         for owner, ok in synced.values():
             if ok:
                 owner._seen_version = owner.master._version
+        for st in self.state.values():
+            st["step"].fill_(float(self._step))
         return loss
