@@ -188,11 +188,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    # UNIGEN_DIST_BACKEND=gloo + UNIGEN_BENCH_ONE_DEVICE=1: rehearse the N > 1 path with every rank on cuda:0 (RCCL refuses
+    # two ranks on one device); the default is RCCL ("nccl") with one GPU per rank
+    backend = os.environ.get("UNIGEN_DIST_BACKEND", "nccl")
+    if os.environ.get("UNIGEN_BENCH_ONE_DEVICE") == "1":
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     cpu = None
     L = 2 + args.text_len + NVQ + 2
@@ -201,7 +209,6 @@ def main():
 
     from models import MAGVITv2, UniGen
     from unigen_hip import ops
-    from unigen_hip.ddp import FlatGradSync
     from unigen_hip.optim import FusedAdamW
 
     torch.manual_seed(SEED)
@@ -215,7 +222,8 @@ def main():
     nodecay = [p for n, p in model.named_parameters() if "bias" in n]
     opt = FusedAdamW([{"params": decay, "weight_decay": 0.01}, {"params": nodecay, "weight_decay": 0.0}],
                      lr=1e-4, betas=(0.9, 0.999), eps=1e-8)
-    sync = FlatGradSync(model.llm.engine)
+    # N > 1: nothing to set up here -- the engine installs the flat-gradient exchange (unigen_hip/ddp.py) by itself on the
+    # first backward of a process whose torch.distributed world is larger than one, and leaves the MEAN in the gradients
 
     B = args.batch
     g = torch.Generator(device=dev).manual_seed(SEED + rank)
@@ -231,8 +239,7 @@ def main():
         _, l_t2i, _, _ = model(input_ids=ids, attention_mask=mask, labels=labels, batch_size_t2i=B,
                                max_seq_length=args.text_len + 1, num_vq_tokens=NVQ)
         l_t2i.backward()
-        sync.finish()
-        opt.step(grad_scale=sync.grad_scale)
+        opt.step()
         opt.zero_grad(set_to_none=True)
         losses.append(l_t2i.detach())
 

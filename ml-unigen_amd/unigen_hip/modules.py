@@ -393,7 +393,10 @@ class TrainEngine(Qwen2Engine):
             if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
                 from .ddp import FlatGradSync
                 self.grad_sync = FlatGradSync(self, extra_params=lambda: self.extra_grad_params() if self.extra_grad_params else [])
-                dist.broadcast(self.fp.master, 0)
+                with torch.no_grad():
+                    dist.broadcast(self.fp.master, 0)
+                    for p in (self.extra_grad_params() if self.extra_grad_params else []):
+                        dist.broadcast(p.data, 0)
                 self.fp._seen_version = -1
         return self.grad_sync
 

@@ -1,6 +1,7 @@
 """N > 1 path on CPU: two gloo processes drive unigen_hip.ddp.FlatGradSync over a flat gradient buffer
 with the backbone's real layout (tiny dims) and the hook order backward produces; after finish() every
-rank must hold the SUM of the per-rank gradients, and grad_scale must turn it into DDP's mean."""
+rank must hold the MEAN of the per-rank gradients (what DDP leaves in .grad), also for ordinary parameters handed
+in as `extra_params`; a pass begun with enabled=False (no_sync) must exchange nothing."""
 import os
 import socket
 import sys
@@ -41,8 +42,12 @@ def _worker(rank, world, port, layers_per_bucket, q):
     mine = grad.clone()
     eng = types.SimpleNamespace(fp=types.SimpleNamespace(grad=grad, off=off), dims=types.SimpleNamespace(num_hidden_layers=n_layers),
                                 grad_ready_hook=None)
-    sync = FlatGradSync(eng, layers_per_bucket=layers_per_bucket)
+    extra = torch.nn.Parameter(torch.zeros(7))
+    extra.grad = torch.full((7,), float(rank + 1))
+    sync = FlatGradSync(eng, layers_per_bucket=layers_per_bucket, extra_params=lambda: [extra])
+    assert sync.reduce == "fp32"
     # backward order: final norm, layers N-1..0, embedding
+    sync.begin()
     eng.grad_ready_hook("norm")
     for i in reversed(range(n_layers)):
         eng.grad_ready_hook(i)
@@ -50,15 +55,27 @@ def _worker(rank, world, port, layers_per_bucket, q):
     sync.finish()
     gathered = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(gathered, mine)
-    want = torch.stack(gathered).sum(0)
-    ok = torch.allclose(grad, want, atol=1e-6) and abs(sync.grad_scale - 1.0 / world) < 1e-12
+    want = torch.stack(gathered).mean(0)
+    ok = torch.allclose(grad, want, atol=1e-6) and sync.grad_scale == 1.0
+    ok = ok and torch.allclose(extra.grad, torch.full((7,), (1 + world) / 2.0)) and sync.bytes_on_wire == (numel + 7) * 4
     # second step, inputs_embeds path: the embedding hook never fires, finish() must flush the head itself
     grad.copy_(mine)
+    sync.begin()
     eng.grad_ready_hook("norm")
     for i in reversed(range(n_layers)):
         eng.grad_ready_hook(i)
     sync.finish()
     ok = ok and torch.allclose(grad, want, atol=1e-6)
+    # third pass, gradient-accumulation micro-step: nothing moves, local gradients stay
+    grad.copy_(mine)
+    sent = sync.bytes_on_wire
+    sync.begin(enabled=False)
+    eng.grad_ready_hook("norm")
+    for i in reversed(range(n_layers)):
+        eng.grad_ready_hook(i)
+    eng.grad_ready_hook("embed")
+    sync.finish()
+    ok = ok and torch.equal(grad, mine) and sync.bytes_on_wire == sent
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 
