@@ -128,7 +128,8 @@ class ModelMixin(torch.nn.Module):
             else:
                 (save_function or torch.save)(part, os.path.join(save_directory, fn))
         if len(shards) > 1:
-            index = {"metadata": {"total_size": sum(v.numel() * v.element_size() for v in sd.values())},
+            uniq = {(v.data_ptr(), tuple(v.shape)): v.numel() * v.element_size() for v in sd.values()}    # tied names count once
+            index = {"metadata": {"total_size": sum(uniq.values())},
                      "weight_map": {k: fn for fn, keys in zip(names, shards) for k in keys}}
             idx_name = SAFE_WEIGHTS_INDEX_NAME if safe_serialization else WEIGHTS_INDEX_NAME
             with open(os.path.join(save_directory, idx_name), "w", encoding="utf-8") as f:

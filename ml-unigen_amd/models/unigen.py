@@ -146,6 +146,7 @@ class UniGen(ModelMixin, ConfigMixin):
         records that a DDP wrapper exists, i.e. that the ordinary parameters (mm_projector, ...) are averaged by DDP's
         own reducer and FlatGradSync only has to move the flat buffer."""
         self.__dict__["_ddp_wrapped"] = True
+        self.llm.engine._dp_sync()          # the wrapper is being built: align the flat weights to rank 0 now, like DDP does for its own
         flat = self._flat_view_ids()
         return [f"{mn}.{pn}" if mn else pn for mn, m in self.named_modules() for pn, p in m.named_parameters(recurse=False)
                 if id(p) in flat]

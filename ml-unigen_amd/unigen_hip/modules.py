@@ -223,6 +223,8 @@ class HipEmbedding(nn.Module):
 
     def forward(self, ids):
         eng = self.__dict__["_engine"]
+        if torch.is_grad_enabled():
+            eng._dp_sync()                  # world > 1: replicas aligned to rank 0 before the first training lookup
         return _EmbedFn.apply(eng._anchor, ids.to(eng.device), eng)
 
 
