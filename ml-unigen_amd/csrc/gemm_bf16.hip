@@ -61,6 +61,7 @@ struct GemmArgs {
   int full_tiles, tail_split;
   float* tail_ws;
   int tail_private;        // 1: every k-slice stores its own [256][256] partial (no atomics); the finisher sums them
+  int wide_epilogue;       // 256x256 kernel: LDS-transposed 16-byte stores (0 only for A/B runs, ug_gemm_set_tile_policy(100))
 };
 
 __device__ __forceinline__ int swz_rowk(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
@@ -195,6 +196,83 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, f32x4_t (&acc)[4][
         }
       }
     }
+  }
+}
+
+// Epilogue of the 256x256 kernel for interior column panels: each wave turns its 128x64 accumulator block through a private
+// LDS strip (the operand ring is idle by then) 32 rows at a time, so that every global store is 16 bytes per lane and a
+// wave writes whole 128-byte (bf16) / 256-byte (fp32) row segments -- 16 dwordx4 stores per wave instead of 32 dwordx2
+// to 32-byte pieces of 16 different rows each (the no-store ablation put the scattered form at ~20 % of a K = 1536 GEMM).
+//   strip pitch: bf16 144 B (36 dwords: the 16 rows of a ds_write_b64 group fall on 8 bank quads, 2-way at worst; rows stay
+//   16-byte aligned for the ds_read_b128 that follows), fp32 272 B (68 dwords: ds_write_b128's 8-lane groups conflict-free).
+constexpr int EP_ROWS = 32;
+constexpr int EP_PITCH_BF16 = 144, EP_PITCH_F32 = 272;
+constexpr int EP_STRIP = EP_ROWS * EP_PITCH_F32;            // 8704 B per wave (the bf16 strip needs 4608)
+
+template <int EPI>
+__device__ __forceinline__ void store_tile_lds(const GemmArgs& p, f32x4_t (&acc)[8][4], char* strip, int mbase, int nbase, int lane) {
+  float alpha = 1.f;
+  if constexpr (EPI == EPI_F32) { if (p.alpha_dev) alpha = *p.alpha_dev; }
+  float bias4[4][4];
+  if constexpr (EPI == EPI_BF16) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint2 b = make_uint2(0u, 0u);                          // 4 bf16 of this lane's columns (8-byte aligned: the flat
+      if (p.bias) b = *reinterpret_cast<const uint2*>(p.bias + nbase + j * 16 + (lane >> 4) * 4);    // buffers are 64-element aligned)
+      bias4[j][0] = __uint_as_float(b.x << 16); bias4[j][1] = __uint_as_float(b.x & 0xffff0000u);
+      bias4[j][2] = __uint_as_float(b.y << 16); bias4[j][3] = __uint_as_float(b.y & 0xffff0000u);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {                              // 32-row chunk = accumulator row blocks 2c, 2c+1
+    // ---- registers -> strip (MFMA layout: lane holds rows lane&15, 4 consecutive columns per block)
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii) {
+      const int row = ii * 16 + (lane & 15);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = j * 16 + (lane >> 4) * 4;
+        const f32x4_t v = acc[2 * c + ii][j];
+        if constexpr (EPI == EPI_BF16) {
+          uint2 o;
+          o.x = pack_bf2(v[0] + bias4[j][0], v[1] + bias4[j][1]);
+          o.y = pack_bf2(v[2] + bias4[j][2], v[3] + bias4[j][3]);
+          *reinterpret_cast<uint2*>(strip + row * EP_PITCH_BF16 + col * 2) = o;
+        } else {
+          *reinterpret_cast<float4*>(strip + row * EP_PITCH_F32 + col * 4) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the strip is wave-private: no barrier, only this wave's writes
+    // ---- strip -> global, 16 bytes per lane, whole row segments
+    if constexpr (EPI == EPI_BF16) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = q * 8 + (lane >> 3), ch = lane & 7;
+        const int m = mbase + c * EP_ROWS + row;
+        const uint4 v = *reinterpret_cast<const uint4*>(strip + row * EP_PITCH_BF16 + ch * 16);
+        if (m < p.M) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc + nbase + ch * 8) = v;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int row = q * 4 + (lane >> 4), ch = lane & 15;
+        const int m = mbase + c * EP_ROWS + row;
+        float4 v = *reinterpret_cast<const float4*>(strip + row * EP_PITCH_F32 + ch * 16);
+        if (m < p.M) {
+          float* cptr = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + nbase + ch * 4;
+          if constexpr (EPI == EPI_F32) {
+            v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha;
+            if (p.beta) { const float4 old = *reinterpret_cast<const float4*>(cptr); v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w; }
+          } else {
+            const float4 old = *reinterpret_cast<const float4*>(p.resid + (int64_t)m * p.ldr + nbase + ch * 4);
+            v.x = old.x + bf2f(f2bf(v.x)); v.y = old.y + bf2f(f2bf(v.y)); v.z = old.z + bf2f(f2bf(v.z)); v.w = old.w + bf2f(f2bf(v.w));
+          }
+          *reinterpret_cast<float4*>(cptr) = v;
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // strip reads retired before the next chunk overwrites it
   }
 }
 
@@ -457,6 +535,15 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p8(GemmArgs p) {
     }
     return;
   }
+  // interior column panel with 16-byte-addressable rows: wide stores through the (now idle) ring; ragged panels keep the
+  // guarded element-wise form
+  const bool wide = (n0 + PBN <= p.N) && p.wide_epilogue &&
+                    (EPI == EPI_BF16 ? (p.ldc % 8 == 0 && (!p.bias || (reinterpret_cast<uintptr_t>(p.bias) & 7) == 0))
+                                     : (p.ldc % 4 == 0 && (EPI != EPI_RESID || p.ldr % 4 == 0)));
+  if (wide) {                                    // (the balancing barrier above already put every wave past its last ring read)
+    store_tile_lds<EPI>(p, acc, lds + wave * EP_STRIP, m0 + grp * 128, n0 + wn * 64, lane);
+    return;
+  }
   store_tile<EPI>(p, reinterpret_cast<f32x4_t (&)[4][4]>(acc[0]), m0 + grp * 128, n0 + wn * 64, lane, false);
   store_tile<EPI>(p, reinterpret_cast<f32x4_t (&)[4][4]>(acc[4]), m0 + grp * 128 + 64, n0 + wn * 64, lane, false);
 }
@@ -524,6 +611,7 @@ bool ensure_tail_ws(int ntiles) {
   return true;
 }
 
+int g_wide_epilogue = 1;   // ug_gemm_set_tile_policy(100) / (101): element-wise / LDS-transposed wide epilogue of the 256x256 kernel
 int g_tile_policy = -1;   // -1 auto, 0 two LDS stages, 2 one LDS stage, 3 staggered 256x256 (ug_gemm_set_tile_policy; A/B runs)
 
 template <int EPI, bool AK, bool BKM>
@@ -607,7 +695,11 @@ int launch(GemmArgs a, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int ug_gemm_set_tile_policy(int v) { g_tile_policy = v; return UG_OK; }
+extern "C" int ug_gemm_set_tile_policy(int v) {
+  if (v == 100 || v == 101) { g_wide_epilogue = v - 100; return UG_OK; }
+  g_tile_policy = v;
+  return UG_OK;
+}
 
 extern "C" int ug_gemm_bf16(const void* A, int64_t lda, int a_kmajor, const void* B, int64_t ldb, int b_kmajor,
                             void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int epilogue, const void* bias,
@@ -632,6 +724,7 @@ extern "C" int ug_gemm_bf16(const void* A, int64_t lda, int a_kmajor, const void
   a.bias = (const bf16_t*)bias; a.resid = resid; a.alpha_dev = alpha_dev;
   a.M = (int)M; a.N = (int)N; a.K = (int)K;
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = ldr; a.beta = beta;
+  a.wide_epilogue = g_wide_epilogue;
   a.tiles_m = (int)((M + BM - 1) / BM); a.tiles_n = (int)((N + BN - 1) / BN);
   const int mode = (a_kmajor ? 2 : 0) | (b_kmajor ? 1 : 0);
   if (epilogue == EPI_RESID) UG_REQUIRE(resid != nullptr && ldr % 4 == 0, "ug_gemm_bf16: EPI_RESID needs a 16B-aligned residual");

@@ -240,7 +240,7 @@ class UniGen(ModelMixin, ConfigMixin):
         training/train_w_clip_vit.py:754,801).  Row i is
             [system] <|im_start|><|mmu|><|soi|> | mm_projector(image_feats[i, :h_i*w_i]) | <|eoi|> input_ids[i, 1:] | pad...
         cut to `prompt_template.max_seq_len`; labels are ignore_id up to and including <|eoi|>, then label_ids[i, 1:],
-        pads ignored; the key-validity mask ends at the row's last `eos_token_id` label.  Returns (embeddings [B, L, H],
+        pads ignored; the key-validity mask is cut after the last `eos_token_id` label of the first row that has one (sic).  Returns (embeddings [B, L, H],
         attention_mask bool [B, max_seq_len], labels [B, L], input_ids_part1 [B, L1]).  One index computation for the
         whole batch instead of the reference's per-row concatenations; the projector and the embedding lookup run on the
         HIP kernels and stay differentiable."""
@@ -288,9 +288,15 @@ class UniGen(ModelMixin, ConfigMixin):
         ql = torch.arange(T_lab, device=dev)[None] - L1 - n_img[:, None]
         labels = torch.where((ql >= 1) & (ql < Lt), label_ids.to(dev).long().gather(1, ql.clamp(0, Lt - 1)), const(ignore))
         labels = torch.where(labels == pad_id, const(ignore), labels)
+        # key-validity mask (:211-226).  The reference walks the (row, column) list of eos labels with a cursor that never
+        # moves past the first row it matched, so ONLY the first row that contains an eos label is cut (after its last
+        # eos); every other row -- with or without eos labels -- stays fully valid.  Reproduced as is.
         is_eos = labels == pt.eos_token_id
-        last_eos = torch.where(is_eos.any(1), T_lab - 1 - is_eos.flip(-1).long().argmax(1), const(T_lab - 1))
-        attention_mask = torch.arange(max_len, device=dev)[None] <= last_eos[:, None]
+        has = is_eos.any(1)
+        first_row = torch.where(has.any(), has.long().argmax(), const(-1))
+        last_eos = T_lab - 1 - is_eos.flip(-1).long().argmax(1)
+        cut = torch.where(torch.arange(B, device=dev) == first_row, last_eos, const(T_lab - 1))
+        attention_mask = torch.arange(max_len, device=dev)[None] <= cut[:, None]
         return full_embeddings, attention_mask, labels, part1
 
     # ------------------------------------------------------------------ forward

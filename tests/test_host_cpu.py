@@ -98,3 +98,29 @@ def test_ops_refuse_cpu_tensors():
     from unigen_hip import ops, lib
     with pytest.raises(lib.UniGenHipError):
         ops.gemm_nt(torch.zeros(64, 64, dtype=torch.bfloat16), torch.zeros(64, 64, dtype=torch.bfloat16))
+
+
+def test_prepare_inputs_for_mmu_host_logic_matches_reference():
+    """The index assembly of UniGen.prepare_inputs_for_mmu (labels, key-validity mask incl. the reference's eos-cursor quirk,
+    part-1 ids, sequence lengths in train / eval mode) against what the REAL reference returned (golden G11); the two device
+    ops it calls (embedding lookup, mm_projector) are stubbed, the GPU suite checks them."""
+    import types
+    import torch
+    from helpers import golden
+    from models.unigen import UniGen
+    g = golden("g11_mmu_inputs.pt")
+    t = g["template"]
+    tmpl = types.SimpleNamespace(text_tokenizer=types.SimpleNamespace(pad_token_id=t["pad_token_id"]), max_seq_len=t["max_seq_len"],
+                                 sptids_dict={k: torch.tensor([v]) for k, v in t["sptids"].items()}, ignore_id=t["ignore_id"],
+                                 eos_token_id=t["eos_token_id"], task_token_first=t["task_token_first"])
+    x = g["mmu_in"]
+    for mode in ("train", "eval"):
+        for tag in ("nosys", "sys"):
+            fake = types.SimpleNamespace(training=(mode == "train"), mm_projector=lambda f: torch.zeros(f.shape[0], f.shape[1], 4),
+                                         llm=types.SimpleNamespace(model=types.SimpleNamespace(
+                                             embed_tokens=lambda ids: ids[..., None].float().expand(*ids.shape, 4))))
+            e, am, lab, p1 = UniGen.prepare_inputs_for_mmu(fake, x["image_feats"], x["spatial_shapes"], x["input_ids"], x["label_ids"],
+                                                           tmpl, x["input_ids_system"] if tag == "sys" else None)
+            w = g[f"mmu_{mode}_{tag}"]
+            assert torch.equal(am, w["attention_mask"]) and torch.equal(lab, w["labels"]) and torch.equal(p1, w["part1"]), (mode, tag)
+            assert e.shape[:2] == w["embeddings"].shape[:2]
