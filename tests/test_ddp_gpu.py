@@ -76,7 +76,7 @@ def test_two_ranks_on_one_gpu_match_single_process(dev, tmp_path, reduce):
             # 3 steps + 1 exchanged accumulation step (+ the ordinary parameters, a few KB); the no_sync step moved nothing
             assert r0["no_sync_bytes"] == 0 and r0["accum_bytes"] > 0
             extras = 4 * 4 * (32 * 256 + 256 + 256 * 256 + 256)          # mm_projector gradients, fp32, 4 exchanges
-                assert r0["sync"]["bytes"] == 4 * per_step + extras
+            assert r0["sync"]["bytes"] == 4 * per_step + extras
             assert not torch.equal(r0["accum_local_first"], r1["accum_local_first"])           # local so far ...
             assert torch.equal(r0["accum_grad"], r1["accum_grad"])                             # ... averaged sum afterwards
         else:

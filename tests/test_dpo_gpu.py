@@ -52,13 +52,13 @@ def test_dpo_loss_and_grads_match_oracle(dev):
     all_logits = all_logits.to(torch.float32)
     assert tuple(all_logits.shape[:-1]) == tuple(labels.shape)
     lp = batch_logps(all_logits, labels.to(dev), n)
-    assert _rel(lp, lp_ref) < 2e-3
+    _check("lp", lp, lp_ref, 2e-3)
     loss = dpo(lp)
     assert abs(loss.item() - loss_ref.item()) < 2e-3 * max(1.0, abs(loss_ref.item()))
     loss.backward()
     ref_g = dict(lm.named_parameters())
     for nme, p in model.llm.named_parameters():
-        assert _rel(p.grad, ref_g[nme].grad) < 6e-2, (nme, _rel(p.grad, ref_g[nme].grad))
+        _check("p.grad", p.grad, ref_g[nme].grad, 6e-2)
 
 
 def test_fused_batch_logps_matches_reference_function(dev):
@@ -91,12 +91,12 @@ def test_fused_batch_logps_matches_reference_function(dev):
             lp = host_ref.batch_logps_ref(lz.to(torch.float32), labels.to(dev), n)
         (lp * up).sum().backward()
         grads.append((lp.detach().float().cpu(), {k: p.grad.clone() for k, p in model.llm.named_parameters()}))
-    assert _rel(grads[1][0], grads[0][0]) < 1e-4
+    _check("grads[1][0]", grads[1][0], grads[0][0], 1e-4)
     for k in grads[0][1]:
-        assert _rel(grads[1][1][k], grads[0][1][k]) < 2e-2, (k, _rel(grads[1][1][k], grads[0][1][k]))
+        _check("grads[1][1][k]", grads[1][1][k], grads[0][1][k], 2e-2)
     lz = model(input_ids=seq.to(dev), attention_mask=mask, batch_size_t2i=B)
     for mode in ("mask", "ar"):
         for avg in (False, True):
             a = get_batch_logps(lz, labels.to(dev), average_log_prob=avg, num_vq_tokens=n, t2i_gen_mode=mode)
             b = host_ref.batch_logps_ref(lz.to(torch.float32), labels.to(dev), n, average_log_prob=avg, t2i_gen_mode=mode)
-            assert _rel(a, b) < 1e-4, (mode, avg)
+            _check("a", a, b, 1e-4)
