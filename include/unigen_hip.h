@@ -26,11 +26,20 @@
 extern "C" {
 #endif
 
-#define UG_ABI_VERSION 1
+#define UG_ABI_VERSION 2
 
 /* ---- library ---------------------------------------------------------------------------- */
 const char* ug_last_error(void);
 int ug_abi_version(void);
+
+/* ---- handle ----------------------------------------------------------------------------------
+ * The library's only allocation: an opaque per-stream workspace (192 MiB of device scratch for k-sliced GEMM partials).
+ * ug_create may allocate and must be called outside stream capture; no op entry point allocates, frees, clears or
+ * synchronises, so every op is legal inside a hipGraph capture.  One handle per concurrently used stream (SURVEY 8b:
+ * "allocates only an opaque workspace/handle created by ug_create() / released by ug_destroy()"). */
+typedef struct ug_handle ug_handle;
+int ug_create(ug_handle** out);
+int ug_destroy(ug_handle* h);
 
 /* ---- dense contraction ------------------------------------------------------------------- */
 /* C[M,N] = opA . opB^T, bf16 operands, fp32 accumulate.  Each operand is given either row-major
@@ -45,10 +54,18 @@ int ug_abi_version(void);
 #define UG_EPI_BF16 0
 #define UG_EPI_F32 1
 #define UG_EPI_RESID 2
-int ug_gemm_bf16(const void* A, int64_t lda, int a_kmajor, const void* B, int64_t ldb, int b_kmajor,
+int ug_gemm_bf16(const ug_handle* h, const void* A, int64_t lda, int a_kmajor, const void* B, int64_t ldb, int b_kmajor,
                  void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int epilogue, const void* bias,
-                 const float* resid, int64_t ldr, int beta, const float* alpha_dev, hipStream_t stream);
-int ug_gemm_set_tile_policy(int policy); /* -1 auto (default), 0 = 128x128 two LDS stages, 2 = 128x128 one LDS stage, 3 = staggered 256x256: A/B benchmarking */
+                 const float* resid, int64_t ldr, int beta, const float* alpha_dev, int policy, hipStream_t stream);
+/* h: the calling stream's handle (ug_create) or null.  The handle owns the fp32 scratch of the k-sliced launch forms
+ * (partial last round of 256x256 tiles, small weight gradients, lm-head dgrad); without one those forms are not chosen.
+ * One handle must not be used by two streams at once; any number of handles may run concurrently.
+ * policy: -1 = automatic kernel selection (the product path); >= 0 pins a kernel for A/B benchmarks and tests:
+ * 0 = 128x128 two LDS stages, 2 = 128x128 one LDS stage, 3 = staggered 256x256, 6 = 256x256 with the k-sliced tail forced,
+ * 8 = k-sliced small outputs; UG_GEMM_POLICY_AUTO_BITS = automatic selection when only modifier bits are wanted;
+ * | UG_GEMM_NARROW_EPILOGUE = element-wise instead of LDS-transposed 16-byte stores in the 256x256 kernel. */
+#define UG_GEMM_NARROW_EPILOGUE 0x100
+#define UG_GEMM_POLICY_AUTO_BITS 0xff
 
 /* in [R,C] (fp32 if in_f32 else bf16) -> out bf16 [R,C] (optional) and outT bf16 [C,ldT] with
  * columns R..ldT-1 zero-filled (layout utility; the training path no longer needs it). */

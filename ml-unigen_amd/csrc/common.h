@@ -42,6 +42,12 @@ void ug_set_error(const char* fmt, ...);
     }                                                                             \
   } while (0)
 
+// ---------------------------------------------------------------- handle (include/unigen_hip.h: ug_create / ug_destroy)
+#define UG_HANDLE_WS_SLOTS 768                      // x 256 KiB of fp32 partials
+struct ug_handle {
+  float* tail_ws;                                   // [UG_HANDLE_WS_SLOTS][256][256] fp32, owned
+};
+
 static inline bool ug_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // ---------------------------------------------------------------- vector types

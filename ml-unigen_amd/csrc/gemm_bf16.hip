@@ -596,26 +596,16 @@ __global__ __launch_bounds__(256) void tail_finish_kernel(GemmArgs p, int ntail)
   }
 }
 
-// scratch of the k-sliced tiles: 768 slots of 256 KiB for private partials; allocated on first use
-constexpr int WS_ATOMIC_SLOTS = 0, WS_PRIVATE_SLOTS = 768;     // 192 MiB: room for 3 rounds of k-slices
-float* g_tail_ws = nullptr;
-bool ensure_tail_ws(int ntiles) {
-  if (ntiles > WS_PRIVATE_SLOTS) return false;
-  if (!g_tail_ws) {
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    const size_t slots = WS_ATOMIC_SLOTS + WS_PRIVATE_SLOTS;
-    if (hipMalloc(&g_tail_ws, slots * PBM * PBN * sizeof(float)) != hipSuccess) { g_tail_ws = nullptr; (void)hipGetLastError(); return false; }
-    if (hipMemset(g_tail_ws, 0, slots * PBM * PBN * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); return false; }
-    (void)cs;
-  }
-  return true;
-}
-
-int g_wide_epilogue = 1;   // ug_gemm_set_tile_policy(100) / (101): element-wise / LDS-transposed wide epilogue of the 256x256 kernel
-int g_tile_policy = -1;   // -1 auto, 0 two LDS stages, 2 one LDS stage, 3 staggered 256x256 (ug_gemm_set_tile_policy; A/B runs)
+// Scratch of the k-sliced tiles: WS_PRIVATE_SLOTS slots of 256 KiB for private partials (192 MiB: room for 3 rounds of
+// k-slices).  It belongs to a ug_handle (ug_create / ug_destroy, runtime.hip): nothing on the op path allocates, clears or
+// synchronises, and two streams that each use their own handle never share partials.  A launch without a handle simply
+// does not use the k-sliced forms.
+constexpr int WS_PRIVATE_SLOTS = UG_HANDLE_WS_SLOTS;
 
 template <int EPI, bool AK, bool BKM>
-int launch(GemmArgs a, hipStream_t st) {
+int launch(GemmArgs a, const ug_handle* h, int policy, hipStream_t st) {
+  float* const ws = (h && h->tail_ws) ? h->tail_ws : nullptr;          // k-sliced forms need a handle's scratch
+  const int g_tile_policy = policy;                                    // per call: -1 auto, see ug_gemm_bf16 in the header
   const int tiles = a.tiles_m * a.tiles_n;
   int splits = 1;
   if (EPI == EPI_F32 && a.beta == 1 && tiles < 384) {            // wgrad of a small weight: fill the chip along K
@@ -637,7 +627,7 @@ int launch(GemmArgs a, hipStream_t st) {
     // measured with private partials (tools/gemm_bench.py): slices of >= 40 k-tiles and >= 3 slices win (down fwd
     // 856 -> 1073, gate_up dgrad 748 -> ~1000 TF/s); the K = 1536 shapes (<= 24 k-tiles per slice) lose to 128x128
     while (sp > 1 && nk32 / sp < 40) --sp;
-    if ((sp >= 3 || g_tile_policy == 6) && sp >= 2 && r * sp <= WS_PRIVATE_SLOTS && ensure_tail_ws(r)) { tail_r = r; tail_s = sp; }
+    if ((sp >= 3 || g_tile_policy == 6) && sp >= 2 && r * sp <= WS_PRIVATE_SLOTS && ws) { tail_r = r; tail_s = sp; }
   }
   // Small accumulating fp32 outputs (weight gradients of the attention projections: 48 / 36 tiles): cut EVERY tile
   // along K so one round fills the chip, each slice storing a private partial that a finishing pass sums into C.
@@ -659,10 +649,10 @@ int launch(GemmArgs a, hipStream_t st) {
         if (eff > best + 0.01f) { best = eff; sp = c; }
       }
     }
-    if (sp >= 2 && tiles_p8 * sp <= WS_PRIVATE_SLOTS && (g_tile_policy < 0 || g_tile_policy == 8) && ensure_tail_ws(1)) {
+    if (sp >= 2 && tiles_p8 * sp <= WS_PRIVATE_SLOTS && (g_tile_policy < 0 || g_tile_policy == 8) && ws) {
       a.tiles_m = (a.M + PBM - 1) / PBM; a.tiles_n = (a.N + PBN - 1) / PBN;
       a.full_tiles = 0; a.tail_split = sp; a.tail_private = 1;
-      a.tail_ws = g_tail_ws + (size_t)WS_ATOMIC_SLOTS * PBM * PBN;
+      a.tail_ws = ws;
       hipLaunchKernelGGL((gemm_kernel_p8<EPI, AK, BKM>), dim3(tiles_p8 * sp), dim3(512), 0, st, a);
       UG_CHECK_LAUNCH("ug_gemm_bf16(p8 k-sliced)");
       hipLaunchKernelGGL((tail_finish_kernel<EPI>), dim3(tiles_p8 * 16), dim3(256), 0, st, a, tiles_p8);
@@ -674,7 +664,7 @@ int launch(GemmArgs a, hipStream_t st) {
     a.tiles_m = (a.M + PBM - 1) / PBM; a.tiles_n = (a.N + PBN - 1) / PBN;
     a.full_tiles = tiles_p8 - tail_r; a.tail_split = tail_s;
     a.tail_private = 1;                          // private partials beat atomics here too (gate_up dgrad 886 -> see DESIGN)
-    a.tail_ws = g_tail_ws ? g_tail_ws + (size_t)WS_ATOMIC_SLOTS * PBM * PBN : nullptr;
+    a.tail_ws = ws;
     hipLaunchKernelGGL((gemm_kernel_p8<EPI, AK, BKM>), dim3(a.full_tiles + tail_r * tail_s), dim3(512), 0, st, a);
     UG_CHECK_LAUNCH("ug_gemm_bf16(p8)");
     if (tail_s > 1) {
@@ -695,15 +685,9 @@ int launch(GemmArgs a, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int ug_gemm_set_tile_policy(int v) {
-  if (v == 100 || v == 101) { g_wide_epilogue = v - 100; return UG_OK; }
-  g_tile_policy = v;
-  return UG_OK;
-}
-
-extern "C" int ug_gemm_bf16(const void* A, int64_t lda, int a_kmajor, const void* B, int64_t ldb, int b_kmajor,
+extern "C" int ug_gemm_bf16(const ug_handle* h, const void* A, int64_t lda, int a_kmajor, const void* B, int64_t ldb, int b_kmajor,
                             void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int epilogue, const void* bias,
-                            const float* resid, int64_t ldr, int beta, const float* alpha_dev, hipStream_t stream) {
+                            const float* resid, int64_t ldr, int beta, const float* alpha_dev, int policy, hipStream_t stream) {
   UG_REQUIRE(M > 0 && N > 0 && K > 0, "ug_gemm_bf16: empty problem M=%ld N=%ld K=%ld", (long)M, (long)N, (long)K);
   UG_REQUIRE(lda % 8 == 0 && ldb % 8 == 0, "ug_gemm_bf16: lda/ldb must be multiples of 8 elements (16-byte rows)");
   UG_REQUIRE(ug_aligned16(A) && ug_aligned16(B) && ug_aligned16(C), "ug_gemm_bf16: A/B/C must be 16-byte aligned");
@@ -724,18 +708,20 @@ extern "C" int ug_gemm_bf16(const void* A, int64_t lda, int a_kmajor, const void
   a.bias = (const bf16_t*)bias; a.resid = resid; a.alpha_dev = alpha_dev;
   a.M = (int)M; a.N = (int)N; a.K = (int)K;
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = ldr; a.beta = beta;
-  a.wide_epilogue = g_wide_epilogue;
+  a.wide_epilogue = (policy >= 0 && (policy & UG_GEMM_NARROW_EPILOGUE)) ? 0 : 1;
+  if (policy >= 0) policy &= ~UG_GEMM_NARROW_EPILOGUE;
+  if (policy == UG_GEMM_POLICY_AUTO_BITS) policy = -1;
   a.tiles_m = (int)((M + BM - 1) / BM); a.tiles_n = (int)((N + BN - 1) / BN);
   const int mode = (a_kmajor ? 2 : 0) | (b_kmajor ? 1 : 0);
   if (epilogue == EPI_RESID) UG_REQUIRE(resid != nullptr && ldr % 4 == 0, "ug_gemm_bf16: EPI_RESID needs a 16B-aligned residual");
   switch (mode * 4 + epilogue) {
-    case 0 * 4 + EPI_BF16: return launch<EPI_BF16, false, false>(a, stream);
-    case 0 * 4 + EPI_F32: return launch<EPI_F32, false, false>(a, stream);
-    case 0 * 4 + EPI_RESID: return launch<EPI_RESID, false, false>(a, stream);
-    case 1 * 4 + EPI_BF16: return launch<EPI_BF16, false, true>(a, stream);
-    case 1 * 4 + EPI_F32: return launch<EPI_F32, false, true>(a, stream);
-    case 3 * 4 + EPI_F32: return launch<EPI_F32, true, true>(a, stream);
-    case 3 * 4 + EPI_BF16: return launch<EPI_BF16, true, true>(a, stream);
+    case 0 * 4 + EPI_BF16: return launch<EPI_BF16, false, false>(a, h, policy, stream);
+    case 0 * 4 + EPI_F32: return launch<EPI_F32, false, false>(a, h, policy, stream);
+    case 0 * 4 + EPI_RESID: return launch<EPI_RESID, false, false>(a, h, policy, stream);
+    case 1 * 4 + EPI_BF16: return launch<EPI_BF16, false, true>(a, h, policy, stream);
+    case 1 * 4 + EPI_F32: return launch<EPI_F32, false, true>(a, h, policy, stream);
+    case 3 * 4 + EPI_F32: return launch<EPI_F32, true, true>(a, h, policy, stream);
+    case 3 * 4 + EPI_BF16: return launch<EPI_BF16, true, true>(a, h, policy, stream);
     default:
       ug_set_error("ug_gemm_bf16: layout/epilogue combination (a_kmajor=%d b_kmajor=%d epilogue=%d) is not instantiated",
                    a_kmajor, b_kmajor, epilogue);

@@ -3,6 +3,7 @@
 #include "common.h"
 #include "unigen_hip.h"
 #include <string.h>
+#include <new>
 
 static thread_local char g_err[512] = "";
 
@@ -15,6 +16,30 @@ void ug_set_error(const char* fmt, ...) {
 
 extern "C" const char* ug_last_error(void) { return g_err; }
 extern "C" int ug_abi_version(void) { return UG_ABI_VERSION; }
+
+extern "C" int ug_create(ug_handle** out) {
+  UG_REQUIRE(out != nullptr, "ug_create: null output pointer");
+  ug_handle* h = new (std::nothrow) ug_handle;
+  UG_REQUIRE(h != nullptr, "ug_create: out of host memory");
+  h->tail_ws = nullptr;
+  const size_t bytes = (size_t)UG_HANDLE_WS_SLOTS * 256 * 256 * sizeof(float);
+  // private partials are fully written before they are read: the scratch needs no clearing
+  if (hipMalloc(&h->tail_ws, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    delete h;
+    ug_set_error("ug_create: hipMalloc of the %zu-byte GEMM scratch failed", bytes);
+    return UG_ERR_STATE;
+  }
+  *out = h;
+  return UG_OK;
+}
+
+extern "C" int ug_destroy(ug_handle* h) {
+  if (!h) return UG_OK;
+  if (h->tail_ws) (void)hipFree(h->tail_ws);
+  delete h;
+  return UG_OK;
+}
 
 namespace {
 typedef __attribute__((ext_vector_type(4))) short s16x4;

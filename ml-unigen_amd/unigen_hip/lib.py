@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
 LIB_PATH = os.path.join(CSRC_DIR, "libunigen_hip.so")
 
+ABI_VERSION = 2
 P = ctypes.c_void_p
 I64 = ctypes.c_int64
 I32 = ctypes.c_int
@@ -20,8 +21,9 @@ F32 = ctypes.c_float
 # exported symbol list against the header)
 SIGNATURES = {
     "ug_abi_version": [],
-    "ug_gemm_bf16": [P, I64, I32, P, I64, I32, P, I64, I64, I64, I64, I32, P, P, I64, I32, P, P],
-    "ug_gemm_set_tile_policy": [I32],
+    "ug_create": [P],
+    "ug_destroy": [P],
+    "ug_gemm_bf16": [P, P, I64, I32, P, I64, I32, P, I64, I64, I64, I64, I32, P, P, I64, I32, P, I32, P],
     "ug_transpose_cast": [P, I32, I64, P, I64, P, I64, I64, I64, P],
     "ug_cast_f32_bf16": [P, P, I64, P],
     "ug_rmsnorm_fwd": [P, P, P, P, I64, I64, F32, I32, P],
@@ -118,8 +120,8 @@ def load():
         fn = getattr(lib, name)   # AttributeError here = header/library mismatch: fail loudly
         fn.argtypes = argtypes
         fn.restype = ctypes.c_int
-    if lib.ug_abi_version() != 1:
-        raise UniGenHipError(f"ABI version mismatch: library reports {lib.ug_abi_version()}, binding expects 1")
+    if lib.ug_abi_version() != ABI_VERSION:
+        raise UniGenHipError(f"ABI version mismatch: library reports {lib.ug_abi_version()}, binding expects {ABI_VERSION}")
     _lib = lib
     return lib
 

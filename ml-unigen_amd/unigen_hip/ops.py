@@ -1,5 +1,6 @@
 """Tensor-level wrappers over the C ABI: torch supplies device memory and the stream, the kernels do
 the work.  Every wrapper launches on torch's current HIP stream and never synchronises."""
+import ctypes
 import math
 import torch
 
@@ -19,6 +20,36 @@ def _stream():
 
 def _p(t):
     return 0 if t is None else t.data_ptr()
+
+
+# ------------------------------------------------------------------------------------ handles
+# One ug_handle (the library's only allocation: scratch for k-sliced GEMM partials) per (device, stream) that launches a
+# GEMM, created on first use outside stream capture.  Under capture no handle is created -- the GEMM then simply does not
+# pick its k-sliced forms -- so nothing on the op path ever allocates or synchronises.
+_HANDLES = {}
+GEMM_POLICY = -1          # -1 auto; tests / tools pin a kernel with set_gemm_tile_policy (passed per call, no library state)
+UG_GEMM_NARROW_EPILOGUE, UG_GEMM_POLICY_AUTO_BITS = 0x100, 0xff
+
+
+def _handle():
+    s = torch.cuda.current_stream()
+    key = (s.device_index, s.cuda_stream)
+    h = _HANDLES.get(key)
+    if h is None:
+        if torch.cuda.is_current_stream_capturing():
+            return 0
+        out = ctypes.c_void_p()
+        _l.check(_l.load().ug_create(ctypes.byref(out)), "ug_create")
+        h = _HANDLES[key] = out.value
+    return h
+
+
+def release_handles():
+    """ug_destroy every handle (tests; the caller must have synchronised the streams that used them)."""
+    lib = _l.load()
+    for h in _HANDLES.values():
+        lib.ug_destroy(h)
+    _HANDLES.clear()
 
 
 def _need_cuda(*ts):
@@ -51,9 +82,9 @@ def gemm(a, b, out=None, *, M=None, N=None, K=None, a_kmajor=False, b_kmajor=Fal
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    rc = lib.ug_gemm_bf16(_p(a), a.stride(0), int(a_kmajor), _p(b), b.stride(0), int(b_kmajor), _p(out), out.stride(0),
+    rc = lib.ug_gemm_bf16(_handle(), _p(a), a.stride(0), int(a_kmajor), _p(b), b.stride(0), int(b_kmajor), _p(out), out.stride(0),
                           M, N, K, epilogue, _p(bias), _p(resid), resid.stride(0) if resid is not None else 0, beta,
-                          _p(alpha_dev), _stream())
+                          _p(alpha_dev), GEMM_POLICY, _stream())
     _l.check(rc, "ug_gemm_bf16")
     if prof is not None:
         e1.record()
@@ -62,8 +93,17 @@ def gemm(a, b, out=None, *, M=None, N=None, K=None, a_kmajor=False, b_kmajor=Fal
 
 
 def set_gemm_tile_policy(policy):
-    """-1 auto, 0 = 128x128 tiles, 1 = 256x128 tiles (A/B benchmarking and tests)."""
-    _l.check(_l.load().ug_gemm_set_tile_policy(int(policy)), "ug_gemm_set_tile_policy")
+    """Kernel selection passed with every following GEMM call (include/unigen_hip.h: ug_gemm_bf16 `policy`): -1 auto, 0 / 2 =
+    128x128 tiles with two / one LDS stages, 3 = staggered 256x256, 6 / 8 = k-sliced forms forced; 100 / 101 switch the 256x256
+    kernel's LDS-transposed wide epilogue off / on while leaving the selection automatic (A/B benchmarking and tests)."""
+    global GEMM_POLICY
+    policy = int(policy)
+    if policy == 100:
+        GEMM_POLICY = UG_GEMM_POLICY_AUTO_BITS | UG_GEMM_NARROW_EPILOGUE
+    elif policy == 101:
+        GEMM_POLICY = -1
+    else:
+        GEMM_POLICY = policy
 
 
 def gemm_nt(a, b, out=None, **kw):

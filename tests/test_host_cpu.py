@@ -32,13 +32,13 @@ def test_abi_library_exports_every_declared_symbol():
     bound = set(lib.SIGNATURES) | {"ug_last_error"}
     assert set(syms) == bound, (set(syms) ^ bound)
     lib.load()
-    assert lib.load().ug_abi_version() == 1
+    assert lib.load().ug_abi_version() == lib.ABI_VERSION == 2
 
 
 def test_abi_argument_errors_are_reported_not_thrown():
     from unigen_hip import lib
     L = lib.load()
-    rc = L.ug_gemm_bf16(0, 80, 0, 0, 80, 0, 0, 8, 16, 16, 68, 0, 0, 0, 0, 0, 0, 0)   # K % 8 != 0, both row-major: rejected before any launch
+    rc = L.ug_gemm_bf16(0, 0, 80, 0, 0, 80, 0, 0, 8, 16, 16, 68, 0, 0, 0, 0, 0, 0, -1, 0)   # K % 8 != 0, both row-major: rejected before any launch
     assert rc == -1 and b"multiple of 8" in L.ug_last_error()
 
 

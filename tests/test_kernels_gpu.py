@@ -979,3 +979,43 @@ def test_gemm_bf16_randomised_shapes_against_device_fp32(dev):
             want = ref + 0.5 if beta else ref
             assert _rel(c32[:, :N], want) < 1e-5 * math.sqrt(K) + 1e-6, (M, N, K, mode, beta)
             c32.fill_(0.5)
+
+
+def test_gemm_k_sliced_on_two_streams_and_under_capture(dev):
+    """Library contract (include/unigen_hip.h: ug_create): the k-sliced GEMM forms keep their partials in the calling
+    stream's handle, so two streams running such GEMMs at once never share scratch; and no op entry point allocates or
+    synchronises -- a GEMM of the k-sliced class issued on a fresh stream under hipGraph capture (no handle may be created
+    there) runs in its plain form and replays correctly."""
+    ops = _ops()
+    ops.set_gemm_tile_policy(-1)
+    M, N, K = 2048, 1536, 5000                      # attention-projection weight gradient class: every tile cut along K
+    g = torch.Generator(device=dev).manual_seed(11)
+    data = []
+    for i in range(2):
+        a = (torch.randn(K, M, device=dev, generator=g) * 0.5).to(torch.bfloat16)
+        b = (torch.randn(K, N, device=dev, generator=g) * 0.5).to(torch.bfloat16)
+        data.append((a, b, a.float().t() @ b.float(), torch.zeros(M, N, device=dev)))
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    reps = 12
+    for _ in range(reps):
+        for s, (a, b, _, out) in zip(streams, data):
+            with torch.cuda.stream(s):
+                ops.gemm(a, b, out=out, a_kmajor=True, b_kmajor=True, epilogue=ops.UG_EPI_F32, beta=1)
+    torch.cuda.synchronize()
+    for a, b, ref, out in data:
+        assert _rel(out, reps * ref) < 1e-5 * math.sqrt(K) + 1e-6
+    handles = {ops._HANDLES[(s.device_index, s.cuda_stream)] for s in streams}
+    assert len(handles) == 2 and 0 not in handles
+    # under capture: a stream that has no handle yet gets none, the launch takes the un-sliced path, nothing allocates
+    a, b, ref, _ = data[0]
+    out = torch.zeros(M, N, device=dev)
+    n_before = len(ops._HANDLES)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        ops.gemm(a, b, out=out, a_kmajor=True, b_kmajor=True, epilogue=ops.UG_EPI_F32, beta=1)
+    assert len(ops._HANDLES) == n_before
+    out.zero_()
+    graph.replay(); graph.replay()
+    torch.cuda.synchronize()
+    assert _rel(out, 2 * ref) < 1e-5 * math.sqrt(K) + 1e-6
