@@ -113,24 +113,26 @@ def cpu_baseline(seq_len, sample_layers=4):
         t0 = time.perf_counter()
         h = lm.backbone(ids, None, None)
         t1 = time.perf_counter()
-        logits = lm.lm_head(h[:, -(NVQ + 1):-1])
+        h_head = h.detach().requires_grad_(True)             # cut: head and stack backward are timed separately
+        logits = lm.lm_head(h_head[:, -(NVQ + 1):-1])
         loss = torch.nn.functional.cross_entropy(logits.view(-1, VOCAB), labels[:, -(NVQ + 1):-1].reshape(-1))
         t2 = time.perf_counter()
-        loss.backward()
+        loss.backward()                                      # head: dlogits, tied-embedding wgrad, d(hidden)
         t3 = time.perf_counter()
+        h.backward(h_head.grad)                              # stack: sample_layers decoder layers + embedding lookup
+        t4 = time.perf_counter()
         opt.step()
         opt.zero_grad(set_to_none=True)
-        t4 = time.perf_counter()
-        return t1 - t0, t2 - t1, t3 - t2, t4 - t3
+        t5 = time.perf_counter()
+        return t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4
     one()                                           # warm-up (allocator, Adam state)
-    f, hd, b, o = one()
-    # split backward/optimizer between the layer stack and the head by parameter count
+    f, hd, b_head, b_stack, o = one()
     n_layer = sum(p.numel() for p in lm.model.layers.parameters())
     n_head = lm.model.embed_tokens.weight.numel()
     scale = 28.0 / sample_layers
-    layer_t = (f + b * 0.85) * scale                # backward is ~85% stack at this shape; stated, not hidden
-    head_t = hd + b * 0.15
-    opt_t = o * (n_layer * scale + n_head) / (n_layer + n_head)
+    layer_t = (f + b_stack) * scale                 # every term measured; only the layer count is scaled
+    head_t = hd + b_head
+    opt_t = o * (n_layer * scale + n_head) / (n_layer + n_head)     # AdamW is linear in the parameter count
     del lm, opt
     sd = weights.synth_magvit_state(magvit_ref.magvit_param_shapes(), seed=31)
     x = weights.synth_images(1, 256, seed=32)
@@ -141,8 +143,8 @@ def cpu_baseline(seq_len, sample_layers=4):
     total = layer_t + head_t + opt_t + vq_t
     return {"value": round(1.0 / total, 5), "unit": "samples/s", "cores": cores, "kind": "port",
             "sample": f"1 t2i sample L={seq_len} fp32 eager: {sample_layers}/28 decoder layers fwd+bwd (x{scale:.0f}), "
-                      f"tied head+CE on 256 rows, AdamW, MAGVITv2.get_code(1 image); "
-                      f"extrapolated step {total:.1f}s = layers {layer_t:.1f} + head {head_t:.1f} + adamw {opt_t:.1f} + vq {vq_t:.1f}"}
+                      f"tied head+CE on 256 rows fwd+bwd (timed separately from the stack), AdamW (x param-count ratio), "
+                      f"MAGVITv2.get_code(1 image); step {total:.1f}s = layers {layer_t:.1f} + head {head_t:.1f} + adamw {opt_t:.1f} + vq {vq_t:.1f}"}
 
 
 def ar_decode_bench(model, dev, n_img=8, prefix=138, reps=2):
@@ -171,6 +173,87 @@ def ar_decode_bench(model, dev, n_img=8, prefix=138, reps=2):
                                                                       "frac": round(floor_ms / (best / NVQ * 1e3), 4)}}
 
 
+def extra_cases(model, vq, opt, dev, args, steps=3):
+    """Secondary cases reported next to the headline (not `value`):
+      * `t2i_L771_real_mask_ratio`: the headline step with the masking the reference applies (data/masking.py through the
+        device kernel: t ~ U(0,1), cosine schedule, round(256 p) masked positions per sample) instead of mask_prob = 1 --
+        fewer label rows reach the head + CE;
+      * `pt1_mixed_L387`: the stage-1 pretraining batch of configs/unigen_1_5b/unigen_pt1.yaml:87-93 -- 16 t2i + 8 mmu rows at
+        L = 387 (128 text + 256 image + 3), VQ tokens on both sides, t2i + mmu losses, 24 images through MAGVITv2."""
+    import types
+    from data.masking import mask_or_random_replace_tokens
+    from models.sampling import cosine_schedule
+    cfg = types.SimpleNamespace(training=types.SimpleNamespace(min_masking_rate=0.0, get=lambda k, d=None: d),
+                                model=types.SimpleNamespace(codebook_size=CODEBOOK))
+    g = torch.Generator(device=dev).manual_seed(SEED + 7)
+    out = {}
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3
+
+    # ---- headline shape, real mask ratios
+    B = args.batch
+    images = torch.rand(B, 3, 256, 256, device=dev, generator=g) * 2 - 1
+    text = torch.randint(0, 151643, (B, args.text_len), device=dev, generator=g)
+    n_lab = []
+
+    def step_real():
+        codes = vq.get_code(images) + TEXT_VOCAB
+        ids_img, lab_img, _, _ = mask_or_random_replace_tokens(codes, MASK_ID, cfg, cosine_schedule)
+        ids, labels = t2i_layout(text, ids_img, lab_img)
+        mask = device_mask_predict_next(ids, PAD, SOI, EOI)
+        _, l, _, _ = model(input_ids=ids, attention_mask=mask, labels=labels, batch_size_t2i=B, max_seq_length=args.text_len + 1,
+                           num_vq_tokens=NVQ)
+        l.backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        n_lab.append((lab_img != -100).sum())
+    ms = timed(step_real)
+    out["t2i_L771_real_mask_ratio"] = {"ms_per_step": round(ms, 2), "samples_per_s": round(B / ms * 1e3, 2),
+                                       "mean_label_rows": round(float(torch.stack(n_lab).float().mean()), 1), "of": B * NVQ}
+
+    # ---- pt1 mixed batch
+    Bt, Bm, T = 16, 8, 128
+    L = T + NVQ + 3
+    images = torch.rand(Bt + Bm, 3, 256, 256, device=dev, generator=g) * 2 - 1
+    text_t = torch.randint(0, 151643, (Bt, T - 1), device=dev, generator=g)
+    text_m = torch.randint(0, 151643, (Bm, L - NVQ - 4), device=dev, generator=g)
+    MMU = 151670
+    r = torch.arange(L, device=dev)
+
+    def step_pt1():
+        codes = vq.get_code(images) + TEXT_VOCAB
+        ids_img, lab_img, _, _ = mask_or_random_replace_tokens(codes[:Bt], MASK_ID, cfg, cosine_schedule)
+        ids_t, lab_t = t2i_layout(text_t, ids_img, lab_img)
+        col = lambda v: torch.full((Bm, 1), v, device=dev)
+        ids_m = torch.cat([col(IM_START), col(MMU), col(SOI), codes[Bt:], col(EOI), text_m], 1)       # mmu_prompt layout
+        lab_m = ids_m.clone()
+        lab_m[:, :NVQ + 4] = -100
+        m_t = device_mask_predict_next(ids_t, PAD, SOI, EOI)
+        allow = (r[None, :] <= r[:, None]) | (r[None, :] <= NVQ + 3)                                    # create_attention_mask_for_mmu
+        neg = torch.full((), float(torch.iinfo(torch.int64).min), device=dev)
+        m_m = torch.where(allow, torch.zeros((), device=dev), neg)[None, None].expand(Bm, 1, L, L)
+        _, l_t, _, l_m = model(input_ids=torch.cat([ids_t, ids_m]), attention_mask=torch.cat([m_t, m_m]), labels=torch.cat([lab_t, lab_m]),
+                               batch_size_t2i=Bt, batch_size_mmu=Bm, max_seq_length=T, num_vq_tokens=NVQ)
+        (l_t + l_m).backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+    ms = timed(step_pt1)
+    # algorithmic FLOPs (SURVEY 8d): t2i row at L = 387 3.475 TFLOP (+0.355 tokenizer); an mmu row carries the head on its
+    # 386 shifted positions instead of 256 label rows: 3 x (1.0141 + 0.0186 + 386/256 x 0.1257) + 0.355
+    fl = Bt * (3.475e12 + 0.3551e12) + Bm * (3 * (1.0141e12 + 0.0186e12 + 386 / 256 * 0.1257e12) + 0.3551e12)
+    out["pt1_mixed_L387"] = {"ms_per_step": round(ms, 2), "samples_per_s": round((Bt + Bm) / ms * 1e3, 2), "rows": f"{Bt} t2i + {Bm} mmu",
+                             "seq_len": L, "step_frac_of_bf16_peak": round(fl / (ms * 1e-3) / PEAK_BF16, 4)}
+    model.llm.engine.check_errors()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -180,6 +263,7 @@ def main():
     ap.add_argument("--text-len", type=int, default=511, help="text tokens after the 2 template tokens (513 total)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary cases (pt1 mixed batch, real MaskGIT mask ratios)")
     ap.add_argument("--no-ar", action="store_true", help="skip the AR image-token generation measurement (second half of the metric)")
     args = ap.parse_args()
 
@@ -276,18 +360,25 @@ def main():
         tot_fl = sum(f for _, _, f in rec)
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
         # HBM-side bytes per GEMM launch: PMC counters cannot be read from inside the benchmark process, so the value is
-        # the one rocprofv3 recorded for this build's GEMM mix (profiles/r01e_gemm_traffic.json: FETCH_SIZE x2 as the
-        # gfx950 guide prescribes + WRITE_SIZE, separate passes); null if that record is missing
+        # taken from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/gemm_step_mix.py (the same GEMM mix) --
+        # but ONLY when that record was made from this very gemm_bf16.hip (sha256 stored with it); a stale record is null
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01e_gemm_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "gemm_traffic_current.json")
         if os.path.exists(tpath):
+            import hashlib
             with open(tpath) as fh:
-                traffic = json.load(fh).get("traffic_bytes_per_launch")
+                rec_t = json.load(fh)
+            with open(os.path.join(ROOT, "ml-unigen_amd", "csrc", "gemm_bf16.hip"), "rb") as fh:
+                if rec_t.get("gemm_src_sha256") == hashlib.sha256(fh.read()).hexdigest():
+                    traffic = rec_t.get("traffic_bytes_per_launch")
         roof = {"bound": "mfma", "kernel": "gemm_nt_kernel (bf16 MFMA GEMM)", "achieved": round(ach, 1), "peak": 2500.0,
                 "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4), "traffic": traffic,
                 "launches_per_step": len(rec), "avg_launch_ms": round(tot_ms / len(rec), 4),
                 "flops_per_launch": round(tot_fl / len(rec) / 1e9, 2), "gemm_ms_per_step": round(tot_ms, 2),
                 "step_frac_of_bf16_peak": round(value / world * FLOP_SAMPLE / PEAK_BF16, 4)}
+    extra = None
+    if rank == 0 and world == 1 and not args.no_extra:
+        extra = extra_cases(model, vq, opt, dev, args)
     ar = None
     if rank == 0 and world == 1 and not args.no_ar:
         ar = ar_decode_bench(model, dev)
@@ -300,7 +391,7 @@ def main():
                                       "fwd+bwd+grad all-reduce+AdamW, random-init weights",
                           "global_batch": B * world, "seq_len": L, "parallelism": f"dp{world}"},
                "loss_first_last": [round(losses[0].item(), 4), round(losses[-1].item(), 4)],
-               "roofline": roof, "cpu_baseline": cpu, "ar_decode": ar}
+               "roofline": roof, "cpu_baseline": cpu, "ar_decode": ar, "extra_cases": extra}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

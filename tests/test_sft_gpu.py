@@ -6,7 +6,7 @@ import torch
 import torch.nn as nn
 
 from helpers import additive, golden, oracle_lm
-from test_model_gpu import _tiny_unigen, _rel
+from test_model_gpu import _check, _tiny_unigen, _rel
 
 pytestmark = pytest.mark.gpu
 
