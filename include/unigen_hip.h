@@ -272,36 +272,41 @@ int ug_grad_unpack_bf16(const void* in_bf16, float* out, int64_t n, hipStream_t 
 int ug_conv2d_f32(const float* x, const float* w_packed, const float* bias, const float* residual, float* y,
                   int64_t B, int Hin, int Win, int Cin, int Cout, int cout_pad, int ksize, int stride,
                   int pad_top, int pad_left, int Hout, int Wout, int upsample2x, hipStream_t stream);
-/* The same convolution at fp32 accuracy on the bf16 matrix cores: every fp32 operand is split into three bf16 terms
- * (a = a1 + a2 + a3 exactly) and the product summed from its six leading partial products in fp32 accumulators --
- * error per product <= 3 * 2^-26 |a.b|, below the fp32 rounding of the sum; 6/16 the MFMA cost of ug_conv2d_f32.
- * ug_conv_split_weights turns ug_conv2d_f32's packed weights into the split tile image once per weight version:
- * w_split holds 3 * taps * roundup(Cin, 32) * cout_pad bf16 (a ragged last 32-channel slab is zero-filled).  Needs
- * Cin % 4 == 0, Cout % 4 == 0, cout_pad % 128 == 0; same geometry arguments and the same reference call sites as
- * ug_conv2d_f32. */
+/* The same convolution at fp32 accuracy on the f16 matrix cores.  Each operand tensor is scaled by the power of two that
+ * puts its largest magnitude into [2^14, 2^15), every scaled value split into two fp16 terms (a = a1 + a2, 23 of fp32's 24
+ * significand bits) and a.b summed from the three partial products a1b1 + a1b2 + a2b1 in fp32 accumulators; the epilogue
+ * undoes the scales.  Error vs fp64 equals a plain fp32 accumulation's (3.5e-7 relative at K = 1152; the reference's own GPU
+ * path runs these convs with TF32 operands, 7.7e-4); 3/16 the MFMA cost of ug_conv2d_f32.
+ * ug_conv_split_weights turns ug_conv2d_f32's packed weights into the split tile image once per weight version: w_split
+ * holds 2 * taps * roundup(Cin, 32) * cout_pad 16-bit elements (a ragged last 32-channel slab is zero-filled) + 8 more
+ * whose first four bytes record max|w| (computed here).  x_amax: device fp32, ANY upper bound of max|x| of the activation
+ * tensor (ug_amax_f32 computes the exact one; a constant bound is as good -- only its binade is used); null = unscaled
+ * (|x| < 65504 assumed, values saturate otherwise).  Needs Cin % 4 == 0, Cout % 4 == 0, cout_pad % 128 == 0; same geometry
+ * arguments and the same reference call sites as ug_conv2d_f32. */
 int ug_conv_split_weights(const float* w_packed, uint16_t* w_split, int taps, int Cin, int cout_pad, hipStream_t stream);
-int ug_conv2d_split3(const float* x, const uint16_t* w_split, const float* bias, const float* residual, float* y,
-                     int64_t B, int Hin, int Win, int Cin, int Cout, int cout_pad, int ksize, int stride,
-                     int pad_top, int pad_left, int Hout, int Wout, int upsample2x, hipStream_t stream);
+int ug_amax_f32(const float* x, int64_t rows, int64_t cols, int64_t ld, float* out_amax, hipStream_t stream);
+int ug_conv2d_split(const float* x, const float* x_amax, const uint16_t* w_split, const float* bias, const float* residual,
+                    float* y, int64_t B, int Hin, int Win, int Cin, int Cout, int cout_pad, int ksize, int stride,
+                    int pad_top, int pad_left, int Hout, int Wout, int upsample2x, hipStream_t stream);
 /* 3x3 / stride 1 / pad 1 convolution (every conv1/conv2 of ResnetBlock, conv_in/conv_out of the middle stacks:
- * common_modules.py:301-360, magvitv2.py:90-178) with the split operands of ug_conv2d_split3 and the 10 x 18 input
+ * common_modules.py:301-360, magvitv2.py:90-178) with the split operands of ug_conv2d_split and the 10 x 18 input
  * patch of an 8 x 16 output block resident in LDS for all nine taps.  With gn_mu_rstd (from ug_groupnorm_stats on
  * the same x) the load applies y = swish?(GroupNorm(x)) first -- the `conv(nonlinearity(norm(x)))` pattern of
  * ResnetBlock.forward -- so the normalised tensor never exists in HBM; zero padding applies to the normalised tensor,
- * as in the reference. */
-int ug_conv3x3_split3(const float* x, const uint16_t* w_split, const float* bias, const float* residual, float* y,
-                      int64_t B, int H, int W, int Cin, int Cout, int cout_pad, const float* gn_mu_rstd,
-                      const float* gn_gamma, const float* gn_beta, int gn_groups, int gn_swish, hipStream_t stream);
+ * as in the reference.  x_amax then bounds the NORMALISED tensor. */
+int ug_conv3x3_split(const float* x, const float* x_amax, const uint16_t* w_split, const float* bias, const float* residual,
+                     float* y, int64_t B, int H, int W, int Cin, int Cout, int cout_pad, const float* gn_mu_rstd,
+                     const float* gn_gamma, const float* gn_beta, int gn_groups, int gn_swish, hipStream_t stream);
 /* GroupNorm statistics only: stats_ws [B][groups][2] fp64 scratch, mu_rstd [B][groups][2] fp32 = (mean, rstd),
  * rounded as ug_groupnorm_swish rounds them (common_modules.py:19-27). */
 int ug_groupnorm_stats(const float* x, double* stats_ws, float* mu_rstd, int64_t B, int64_t HW, int C, int groups,
                        float eps, hipStream_t stream);
-/* ug_linear_f32 on the same split-bf16 contraction (SigLIP q/k/v/out_proj, fc1/fc2: siglip_encoder.py:196-199,
+/* ug_linear_f32 on the same split-f16 contraction (SigLIP q/k/v/out_proj, fc1/fc2: siglip_encoder.py:196-199,
  * 250-259): y = act(x W^T + bias) + residual with W^T packed as ug_conv2d_f32 weights of a 1x1 conv ([1][K][n_pad])
  * and split by ug_conv_split_weights. */
-int ug_linear_split3(const float* x, int64_t ldx, const uint16_t* w_split, const float* bias, const float* residual,
-                     int64_t ldres, float* y, int64_t ldy, int64_t M, int64_t N, int64_t K, int n_pad, int act,
-                     hipStream_t stream);
+int ug_linear_split(const float* x, int64_t ldx, const float* x_amax, const uint16_t* w_split, const float* bias,
+                    const float* residual, int64_t ldres, float* y, int64_t ldy, int64_t M, int64_t N, int64_t K, int n_pad,
+                    int act, hipStream_t stream);
 /* batched fp32 GEMM on the same kernel (AttnBlock bmm's, common_modules.py:190-214) */
 int ug_gemm_f32(const float* A, int64_t lda, int64_t stride_a, const float* B, int64_t ldb, int64_t stride_b,
                 int b_is_nk, float* C, int64_t ldc, int64_t stride_c, int64_t M, int64_t N, int64_t K,

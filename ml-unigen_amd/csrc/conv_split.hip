@@ -1,18 +1,22 @@
-// MAGVITv2 tokenizer convolutions at fp32 accuracy on the bf16 matrix cores (reference: common_modules.py:19-360,
-// magvitv2.py:57-200 -- every nn.Conv2d of VQGANEncoder / VQGANDecoder runs in fp32 there).
+// MAGVITv2 tokenizer convolutions (and SigLIP projections) at fp32 accuracy on the 16-bit matrix cores (reference:
+// common_modules.py:19-360, magvitv2.py:57-200 -- every nn.Conv2d of VQGANEncoder / VQGANDecoder runs in fp32 there).
 //
-// gfx950's bf16 MFMA runs 16x the rate of its fp32 MFMA, so an fp32 product is rebuilt from bf16 pieces:
-// every fp32 value is split into three bf16 terms a = a1 + a2 + a3 (each the round-to-nearest bf16 of the
-// remainder; 3 x 8 significand bits carry all 24), and a.b is summed from the six partial products whose weight
-// is >= 2^-16 of the full product:  a1b1 + a1b2 + a2b1 + a1b3 + a2b2 + a3b1.  Each bf16 x bf16 product is exact
-// in the fp32 accumulator; the three dropped terms are <= 3 * 2^-26 |a.b|, below the fp32 rounding of the sum
-// itself.  Six bf16 MFMAs cost 6/16 of one fp32 MFMA, so the bound moves from 157 TF/s to ~410 TF/s equivalent.
+// gfx950's f16 MFMA runs 16x the rate of its fp32 MFMA, so an fp32 product is rebuilt from fp16 pieces.  Each operand
+// tensor is first scaled by a power of two that puts its largest magnitude into [2^14, 2^15) (exact; the exponent comes
+// from an upper bound of max|x| supplied by the caller / computed at weight-pack time), then every value is split into
+// two fp16 terms a = a1 + a2 (a1 = RNE(a), a2 = RNE(a - a1): 11 + 11 significand bits plus the sign of a2 carry 23 of
+// fp32's 24 bits; a2 of a value far below the tensor's maximum goes subnormal, an absolute error of 2^-39 of that
+// maximum), and a.b is summed from the three partial products a1b1 + a1b2 + a2b1, each exact in the fp32 accumulator;
+// the dropped a2b2 is <= 2^-22 |a.b|.  Measured against fp64 the result is as close as a plain fp32 accumulation
+// (relative error 3.5e-7 at K = 1152, the same as an fp32 matmul; the reference's own GPU path uses TF32 operands,
+// 7.7e-4).  Three f16 MFMAs cost 3/16 of one fp32 MFMA: the bound moves from 157 TF/s to ~830 TF/s fp32-equivalent.
+// (Round 1 used three bf16 terms and six products: exact operand split, twice the MFMA work, error 1.7e-7.)
 //
 // Implicit GEMM  y[m, n] = sum_{tap, c} x[pix(m, tap), c] * w[tap][c][n]  with the WEIGHTS as the MFMA A operand
 // (rows = cout) and the PIXELS as the B operand, so that each lane of a 16x16 result block holds four consecutive
-// output channels of one pixel (one float4 store, NHWC).  Weights are split once at pack time
+// output channels of one pixel (one float4 store, NHWC).  Weights are scaled and split once at pack time
 // (ug_conv_split_weights) into the exact LDS image of each (tap, 32-channel slab, 128-cout block) tile; activations
-// are split on the way from registers to LDS.
+// are scaled and split on the way from registers to LDS; the epilogue multiplies the accumulator by 2^-(ex + ew).
 #include "common.h"
 #include "unigen_hip.h"
 
@@ -21,13 +25,28 @@ namespace {
 constexpr int SBM = 128;                 // output pixels per workgroup
 constexpr int SBN = 128;                 // output channels per workgroup
 constexpr int SBK = 32;                  // contraction slab = one 16x16x32 MFMA step
-constexpr int PLANE = SBN * SBK;         // bf16 elements of one plane of one tile (128 rows x 32 k)
-constexpr int TILE = 3 * PLANE;          // three planes
+constexpr int PLANE = SBN * SBK;         // 16-bit elements of one plane of one tile (128 rows x 32 k)
+constexpr int NPL = 2;                   // planes: x1 = RNE_f16(x), x2 = RNE_f16(x - x1)
+constexpr int TILE = NPL * PLANE;
+typedef _Float16 h16x8_t __attribute__((ext_vector_type(8)));     // f16 MFMA operand
+typedef _Float16 h16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+constexpr float F16_MAX = 65504.f;
+
+// power-of-two scale exponent from an upper bound of max|x| (device float, or null = unscaled): the bound's binade
+// [2^k, 2^(k+1)) maps to [2^14, 2^15).  Zero / denormal / non-finite bounds clamp; so does anything outside 2^+-60.
+__device__ __forceinline__ int scale_exp(const float* amax) {
+  if (!amax) return 0;
+  const int k = (int)((__float_as_uint(*amax) >> 23) & 0xffu) - 127;
+  return max(-60, min(60, 14 - k));
+}
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 
 struct SplitArgs {
   const float* x;          // [B, Hin, Win, Cin] fp32 NHWC
-  const bf16_t* w;         // split tiles, see ug_conv_split_weights
+  const bf16_t* w;         // split tiles (raw fp16 bits), see ug_conv_split_weights
+  const float* w_amax;     // max|w| recorded behind the tiles at pack time
+  const float* x_amax;     // upper bound of max|x| (device) or null
   const float* bias;       // [Cout] or null
   const float* res;        // [M, Cout] or null
   float* y;                // [M, Cout]
@@ -40,33 +59,33 @@ struct SplitArgs {
   int act;                 // 1: gelu_pytorch_tanh before the residual add
 };
 
-__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) { return pack_bf2(lo, hi); }   // v_cvt_pk_bf16_f32
-// two fp32 values -> three packed bf16 pairs
-__device__ __forceinline__ void split3_pair(float a, float b, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
-  p1 = cvt_pk_bf16(a, b);
-  const float ra = a - __uint_as_float(p1 << 16), rb = b - __uint_as_float(p1 & 0xffff0000u);
-  p2 = cvt_pk_bf16(ra, rb);
-  const float sa = ra - __uint_as_float(p2 << 16), sb = rb - __uint_as_float(p2 & 0xffff0000u);
-  p3 = cvt_pk_bf16(sa, sb);
+// two fp32 values (already scaled) -> two packed fp16 pairs; saturating, so a caller's too-small bound cannot make infinities
+__device__ __forceinline__ void split2_pair(float a, float b, uint32_t& p1, uint32_t& p2) {
+  a = __builtin_fminf(__builtin_fmaxf(a, -F16_MAX), F16_MAX);
+  b = __builtin_fminf(__builtin_fmaxf(b, -F16_MAX), F16_MAX);
+  const h16x2_t h1 = __builtin_convertvector(f32x2_t{a, b}, h16x2_t);              // round to nearest even
+  const f32x2_t back = __builtin_convertvector(h1, f32x2_t);
+  const h16x2_t h2 = __builtin_convertvector(f32x2_t{a - back[0], b - back[1]}, h16x2_t);
+  p1 = __builtin_bit_cast(uint32_t, h1);
+  p2 = __builtin_bit_cast(uint32_t, h2);
 }
 // LDS image of one plane: row r (64 B), 16-byte chunk c (8 k) stored at chunk c ^ ((r >> 2) & 3): the 16 rows x 1 chunk
 // a ds_read_b128 fragment fetch touches land on 16 distinct chunks of a 256-byte bank row
 __device__ __forceinline__ int swz(int r, int chunk) { return r * SBK + ((chunk ^ ((r >> 2) & 3)) << 3); }
 
-// four fp32 values of one pixel (channel quad `q` of LDS row `row`) -> the three split planes
-__device__ __forceinline__ void store_split_quad(bf16_t* planes, int plane_stride, int row, int q, f32x4_t v) {
-  uint32_t a1, a2, a3, b1, b2, b3;
-  split3_pair(v[0], v[1], a1, a2, a3);
-  split3_pair(v[2], v[3], b1, b2, b3);
+// four fp32 values of one pixel (channel quad `q` of LDS row `row`), scaled by 2^ex -> the two split planes
+__device__ __forceinline__ void store_split_quad(bf16_t* planes, int plane_stride, int row, int q, f32x4_t v, int ex) {
+  uint32_t a1, a2, b1, b2;
+  split2_pair(__builtin_ldexpf(v[0], ex), __builtin_ldexpf(v[1], ex), a1, a2);
+  split2_pair(__builtin_ldexpf(v[2], ex), __builtin_ldexpf(v[3], ex), b1, b2);
   const int off = swz(row, q >> 1) + (q & 1) * 4;
   *reinterpret_cast<uint2*>(planes + off) = make_uint2(a1, b1);
   *reinterpret_cast<uint2*>(planes + plane_stride + off) = make_uint2(a2, b2);
-  *reinterpret_cast<uint2*>(planes + 2 * plane_stride + off) = make_uint2(a3, b3);
 }
 
-// result block epilogue: four consecutive output channels of one pixel.  y = act(acc + bias) + residual
-__device__ __forceinline__ void store_out_quad(f32x4_t a, const float* bias, const float* res, float* y, int act) {
-  float v[4] = {a[0], a[1], a[2], a[3]};
+// result block epilogue: four consecutive output channels of one pixel.  y = act(acc * 2^-(ex+ew) + bias) + residual
+__device__ __forceinline__ void store_out_quad(f32x4_t a, float unscale, const float* bias, const float* res, float* y, int act) {
+  float v[4] = {a[0] * unscale, a[1] * unscale, a[2] * unscale, a[3] * unscale};
   if (bias) {
     const float4 b = *reinterpret_cast<const float4*>(bias);
     v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
@@ -98,53 +117,45 @@ __device__ __forceinline__ f32x4_t gn_swish_quad(f32x4_t v, float mu, float rstd
   return v;
 }
 
-// One 32-deep contraction slab of a wave's 64 x 64 result (4 x 4 MFMA blocks): six partial products per block, the
-// smallest first.  wl: this lane's row of the weight plane-0 image (blocks 16 rows apart); xj[j]: this lane's row of
+// One 32-deep contraction slab of a wave's 64 x 64 result (4 x 4 MFMA blocks): three partial products per block, the
+// small ones first.  wl: this lane's row of the weight plane-0 image (blocks 16 rows apart); xj[j]: this lane's row of
 // pixel block j in plane 0; planes are XPLANE (pixels) / PLANE (weights) elements apart.
 template <int XPLANE, int NI = 4>
 __device__ __forceinline__ void mma_slab(const bf16_t* wl, const bf16_t* const (&xj)[4], f32x4_t (&acc)[NI][4]) {
-  bf16x8_t w1[NI], w2[NI], x1[4], x2[4], tx[4], tw[NI];
+  h16x8_t w1[NI], w2[NI], x1[4], x2[4];
 #pragma unroll
-  for (int i = 0; i < NI; ++i) w1[i] = *reinterpret_cast<const bf16x8_t*>(wl + i * 16 * SBK);
+  for (int i = 0; i < NI; ++i) w1[i] = *reinterpret_cast<const h16x8_t*>(wl + i * 16 * SBK);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) x1[j] = *reinterpret_cast<const bf16x8_t*>(xj[j]);
-#pragma unroll
-  for (int j = 0; j < 4; ++j) tx[j] = *reinterpret_cast<const bf16x8_t*>(xj[j] + 2 * XPLANE);   // x3
+  for (int j = 0; j < 4; ++j) x2[j] = *reinterpret_cast<const h16x8_t*>(xj[j] + XPLANE);
 #pragma unroll
   for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[i], tx[j], acc[i][j], 0, 0, 0);
+    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[i], x2[j], acc[i][j], 0, 0, 0);
 #pragma unroll
-  for (int i = 0; i < NI; ++i) tw[i] = *reinterpret_cast<const bf16x8_t*>(wl + 2 * PLANE + i * 16 * SBK);   // w3
+  for (int i = 0; i < NI; ++i) w2[i] = *reinterpret_cast<const h16x8_t*>(wl + PLANE + i * 16 * SBK);
 #pragma unroll
-  for (int i = 0; i < NI; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tw[i], x1[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-  for (int i = 0; i < NI; ++i) w2[i] = *reinterpret_cast<const bf16x8_t*>(wl + PLANE + i * 16 * SBK);
-#pragma unroll
-  for (int j = 0; j < 4; ++j) x2[j] = *reinterpret_cast<const bf16x8_t*>(xj[j] + XPLANE);
+  for (int j = 0; j < 4; ++j) x1[j] = *reinterpret_cast<const h16x8_t*>(xj[j]);
 #pragma unroll
   for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[i], x2[j], acc[i][j], 0, 0, 0);
-      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[i], x2[j], acc[i][j], 0, 0, 0);
-      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[i], x1[j], acc[i][j], 0, 0, 0);
-      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1[i], x1[j], acc[i][j], 0, 0, 0);
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2[i], x1[j], acc[i][j], 0, 0, 0);
+      acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[i], x1[j], acc[i][j], 0, 0, 0);
     }
 }
 
 // NI: 16-channel output blocks per wave (4: 128 output channels per workgroup; 2: 64, for outputs whose 128-wide tiling
 // leaves CUs idle -- SigLIP's 1152-wide projections at four images, the tokenizer's 1x1 convs at 16 x 16)
 template <int NI>
-__global__ __launch_bounds__(256, 2) void conv_split3_kernel(SplitArgs p) {
+__global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitArgs p) {
   __shared__ __attribute__((aligned(16))) bf16_t Ws[TILE];
   __shared__ __attribute__((aligned(16))) bf16_t Xs[TILE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave & 1, wm = wave >> 1;
   const int g = lane >> 4, l16 = lane & 15;
+  const int ex = scale_exp(p.x_amax);
+  const float unscale = __builtin_ldexpf(1.f, -(ex + scale_exp(p.w_amax)));
   // consecutive workgroup ids land on different XCDs (8 L2s): give each XCD a contiguous band of pixel tiles so the
   // rows two vertically adjacent tiles share are fetched into one L2, not three
   const int per_xcd = gridDim.x >> 3;
@@ -178,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void conv_split3_kernel(SplitArgs p) {
 
   float4 rx[4];
   bool kx[4];
-  constexpr int WPIECES = NI == 4 ? 6 : 3;                  // NI == 2: this workgroup's 64 rows of each weight plane
+  constexpr int WPIECES = NI == 4 ? 4 : 2;                  // NI == 2: this workgroup's 64 rows of each weight plane
   constexpr int WSTEP = NI == 4 ? 256 : PLANE / 8;
   u32x4_t rw[WPIECES];
   int cur_tap = 0, cur_c0 = -SBK;
@@ -217,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void conv_split3_kernel(SplitArgs p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const f32x4_t v = kx[i] ? f32x4_t{rx[i].x, rx[i].y, rx[i].z, rx[i].w} : f32x4_t{0.f, 0.f, 0.f, 0.f};
-      store_split_quad(Xs, PLANE, (tid >> 3) + i * 32, q, v);
+      store_split_quad(Xs, PLANE, (tid >> 3) + i * 32, q, v, ex);
     }
   };
 
@@ -244,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void conv_split3_kernel(SplitArgs p) {
     for (int i = 0; i < NI; ++i) {
       const int n = nblk * SBN + nhalf * 64 + wn * (NI * 16) + i * 16 + g * 4;
       if (n >= p.Cout) continue;
-      store_out_quad(acc[i][j], p.bias ? p.bias + n : nullptr, p.res ? p.res + (int64_t)m * p.ldres + n : nullptr,
+      store_out_quad(acc[i][j], unscale, p.bias ? p.bias + n : nullptr, p.res ? p.res + (int64_t)m * p.ldres + n : nullptr,
                      p.y + (int64_t)m * p.ldy + n, p.act);
     }
   }
@@ -261,6 +272,7 @@ constexpr int XPATCH = PP_ROWS * SBK;                                           
 
 struct PatchArgs {
   const float* x; const bf16_t* w; const float* bias; const float* res; float* y;
+  const float* w_amax; const float* x_amax;   // scale bounds, see SplitArgs
   int B, H, W, Cin, Cout, nblks, kslabs;
   int tiles_x, tiles_y, ntiles;
   const float2* mu_rstd;   // [B][G] mean / rstd of the input's GroupNorm, or null: x is used as is
@@ -273,11 +285,13 @@ struct PatchArgs {
 template <bool GN, int NI>
 __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(PatchArgs p) {
   __shared__ __attribute__((aligned(16))) bf16_t Ws[TILE];
-  __shared__ __attribute__((aligned(16))) bf16_t Xp[3 * XPATCH];
+  __shared__ __attribute__((aligned(16))) bf16_t Xp[NPL * XPATCH];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave & 1, wm = wave >> 1;
   const int g = lane >> 4, l16 = lane & 15;
+  const int ex = scale_exp(p.x_amax);
+  const float unscale = __builtin_ldexpf(1.f, -(ex + scale_exp(p.w_amax)));
   const int per_xcd = gridDim.x >> 3;
   const int tile = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);     // contiguous band of tiles per XCD
   if (tile >= p.ntiles) return;
@@ -304,9 +318,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(PatchArgs p) {
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   f32x4_t rx[6];
-  // weight tile: NI == 4 all 128 rows of each plane (6 x 16 B per thread); NI == 2 this workgroup's 64 rows of each plane
-  // (3 x 16 B per thread, one plane per piece), parked at rows 0..63 of the plane's LDS image
-  constexpr int WPIECES = NI == 4 ? 6 : 3;
+  // weight tile: NI == 4 all 128 rows of each plane (4 x 16 B per thread); NI == 2 this workgroup's 64 rows of each plane
+  // (2 x 16 B per thread, one plane per piece), parked at rows 0..63 of the plane's LDS image
+  constexpr int WPIECES = NI == 4 ? 4 : 2;
   constexpr int WSTEP = NI == 4 ? 256 : PLANE / 8;              // 16-byte units between a thread's pieces
   u32x4_t rw[WPIECES];
   const u32x4_t* wbase = reinterpret_cast<const u32x4_t*>(p.w) + (int64_t)nblk * (TILE / 8) + nhalf * 256 + tid;
@@ -340,7 +354,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(PatchArgs p) {
       f32x4_t v = rx[i];
       if constexpr (GN) v = gn_swish_quad(v, mu, rstd, ga, be, p.swish);
       if (!pok[i]) v = f32x4_t{0.f, 0.f, 0.f, 0.f};             // the conv pads the NORMALISED tensor with zeros
-      store_split_quad(Xp, XPATCH, prow, q, v);
+      store_split_quad(Xp, XPATCH, prow, q, v, ex);
     }
   };
 
@@ -379,7 +393,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(PatchArgs p) {
     for (int i = 0; i < NI; ++i) {
       const int n = nblk * SBN + nhalf * 64 + wn * (NI * 16) + i * 16 + g * 4;
       if (n >= p.Cout) continue;
-      store_out_quad(acc[i][j], p.bias ? p.bias + n : nullptr, p.res ? p.res + m * p.Cout + n : nullptr,
+      store_out_quad(acc[i][j], unscale, p.bias ? p.bias + n : nullptr, p.res ? p.res + m * p.Cout + n : nullptr,
                      p.y + m * p.Cout + n, 0);
     }
   }
@@ -387,7 +401,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(PatchArgs p) {
 
 // Large-layer variant: 16 x 16 output pixels x 128 channels per workgroup of EIGHT waves (the weight tile of a tap is
 // shared by twice the pixels), weight tiles in a three-slot LDS ring fetched two taps ahead by LDS-DMA -- the split
-// image in HBM is the LDS image, so a tile is 24 linear 1 KB pieces, three per wave, no VGPR staging and one barrier
+// image in HBM is the LDS image, so a tile is 16 linear 1 KB pieces, two per wave, no VGPR staging and one barrier
 // per tap.  The three slots are separate arrays and the nine taps are unrolled so that every fragment read names a
 // different object than the DMA in flight (otherwise hipcc drains vmcnt(0) before the first ds_read of every tap).
 constexpr int QT_H = 16, QP_ROWS = (QT_H + 2) * PP_W;           // 324 patch pixels
@@ -402,11 +416,13 @@ __global__ __launch_bounds__(512) void conv3x3_patch16_kernel(PatchArgs p) {
   __shared__ __attribute__((aligned(1024))) bf16_t W0[TILE];
   __shared__ __attribute__((aligned(1024))) bf16_t W1[TILE];
   __shared__ __attribute__((aligned(1024))) bf16_t W2[TILE];
-  __shared__ __attribute__((aligned(16))) bf16_t Xp[3 * XQ];
+  __shared__ __attribute__((aligned(16))) bf16_t Xp[NPL * XQ];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave & 1, wm = wave >> 1;
   const int g = lane >> 4, l16 = lane & 15;
+  const int ex = scale_exp(p.x_amax);
+  const float unscale = __builtin_ldexpf(1.f, -(ex + scale_exp(p.w_amax)));
   const int per_xcd = gridDim.x >> 3;
   const int tile = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
   if (tile >= p.ntiles) return;
@@ -432,12 +448,12 @@ __global__ __launch_bounds__(512) void conv3x3_patch16_kernel(PatchArgs p) {
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   f32x4_t rx[6];
-  const char* wsrc = reinterpret_cast<const char*>(p.w) + (int64_t)nblk * (TILE * 2) + (wave * 3 * 64 + lane) * 16;
+  const char* wsrc = reinterpret_cast<const char*>(p.w) + (int64_t)nblk * (TILE * 2) + (wave * 2 * 64 + lane) * 16;
   auto dma_w = [&](int slab, int tap, bf16_t* slot) __attribute__((always_inline)) {
     const char* src = wsrc + ((int64_t)tap * p.kslabs + slab) * p.nblks * (TILE * 2);
-    char* dst = reinterpret_cast<char*>(slot) + wave * 3 * 1024;
+    char* dst = reinterpret_cast<char*>(slot) + wave * 2 * 1024;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) __builtin_amdgcn_global_load_lds((gptr_t)(src + i * 1024), (lptr_t)(dst + i * 1024), 16, 0, 0);
+    for (int i = 0; i < 2; ++i) __builtin_amdgcn_global_load_lds((gptr_t)(src + i * 1024), (lptr_t)(dst + i * 1024), 16, 0, 0);
   };
   auto fetch_x = [&](int slab) __attribute__((always_inline)) {
 #pragma unroll
@@ -460,7 +476,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch16_kernel(PatchArgs p) {
       f32x4_t v = rx[i];
       if constexpr (GN) v = gn_swish_quad(v, mu, rstd, ga, be, p.swish);
       if (!pok[i]) v = f32x4_t{0.f, 0.f, 0.f, 0.f};             // the conv pads the NORMALISED tensor with zeros
-      store_split_quad(Xp, XQ, prow, q, v);
+      store_split_quad(Xp, XQ, prow, q, v, ex);
     }
   };
 
@@ -469,7 +485,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch16_kernel(PatchArgs p) {
   dma_w(0, 0, W0);
   dma_w(0, 1, W1);
   stash_x(0);
-  asm volatile("s_waitcnt vmcnt(3)" ::: "memory");            // tap 0's tile; tap 1's may still be in flight
+  asm volatile("s_waitcnt vmcnt(2)" ::: "memory");            // tap 0's tile; tap 1's (two pieces per wave) may still be in flight
   RAW_BARRIER();
   const int wrow = swz(wn * 64 + l16, g);
   for (int slab = 0; slab < p.kslabs; ++slab) {
@@ -491,7 +507,7 @@ __global__ __launch_bounds__(512) void conv3x3_patch16_kernel(PatchArgs p) {
         stash_x(slab + 1);
       }
       // the next tap's tile (issued one tap ago) must have landed; the one issued in this tap may stay in flight
-      if (has2) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      if (has2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       RAW_BARRIER();
     }
@@ -507,18 +523,20 @@ __global__ __launch_bounds__(512) void conv3x3_patch16_kernel(PatchArgs p) {
     for (int i = 0; i < 4; ++i) {
       const int n = nblk * SBN + wn * 64 + i * 16 + g * 4;
       if (n >= p.Cout) continue;
-      store_out_quad(acc[i][j], p.bias ? p.bias + n : nullptr, p.res ? p.res + m * p.Cout + n : nullptr,
+      store_out_quad(acc[i][j], unscale, p.bias ? p.bias + n : nullptr, p.res ? p.res + m * p.Cout + n : nullptr,
                      p.y + m * p.Cout + n, 0);
     }
   }
 }
 
-// packed fp32 weights [taps][Cin][cout_pad] -> per (tap, slab, cout block) tile: 3 planes x [128 cout][32 cin] bf16 in
-// the swizzled LDS image.  One thread per 16-byte chunk of the output.
+// packed fp32 weights [taps][Cin][cout_pad] -> per (tap, slab, cout block) tile: 2 planes x [128 cout][32 cin] fp16 of
+// the weights scaled by 2^ew (ew from *amax, the tensor's max|w| computed just before), in the swizzled LDS image.
+// One thread per 16-byte chunk of the output.
 __global__ __launch_bounds__(256) void conv_split_weights_kernel(const float* __restrict__ wp, bf16_t* __restrict__ out,
-                                                                 int taps, int Cin, int cout_pad) {
+                                                                 const float* __restrict__ amax, int taps, int Cin, int cout_pad) {
   const int kslabs = (Cin + SBK - 1) / SBK, nblks = cout_pad / SBN;
   const int64_t chunks = (int64_t)taps * kslabs * nblks * (TILE / 8);
+  const int ew = scale_exp(amax);
   for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < chunks; idx += (int64_t)gridDim.x * blockDim.x) {
     const int within = (int)(idx % (TILE / 8));
     const int64_t tile = idx / (TILE / 8);
@@ -534,9 +552,9 @@ __global__ __launch_bounds__(256) void conv_split_weights_kernel(const float* __
       const int c = ks * SBK + chunk * 8 + e;
       const float a = c < Cin ? wp[((int64_t)tap * Cin + c) * cout_pad + nb * SBN + r] : 0.f;
       const float b = c + 1 < Cin ? wp[((int64_t)tap * Cin + c + 1) * cout_pad + nb * SBN + r] : 0.f;
-      uint32_t p1, p2, p3;
-      split3_pair(a, b, p1, p2, p3);
-      const uint32_t pk = plane == 0 ? p1 : plane == 1 ? p2 : p3;
+      uint32_t p1, p2;
+      split2_pair(__builtin_ldexpf(a, ew), __builtin_ldexpf(b, ew), p1, p2);
+      const uint32_t pk = plane == 0 ? p1 : p2;
       o[e] = (bf16_t)(pk & 0xffffu);
       o[e + 1] = (bf16_t)(pk >> 16);
     }
@@ -544,88 +562,136 @@ __global__ __launch_bounds__(256) void conv_split_weights_kernel(const float* __
   }
 }
 
+// max|x| over rows x cols fp32 (row stride ld), as an order-preserving unsigned max of the float bits into *out
+// (cleared by a memset node ahead of the launch)
+__global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, int64_t rows, int64_t cols, int64_t ld,
+                                                   float* __restrict__ out) {
+  __shared__ float red[4];
+  float m = 0.f;
+  const int64_t c4 = cols >> 2, total4 = rows * c4;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / c4, c = (i % c4) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(x + r * ld + c);
+    m = fmaxf(fmaxf(fmaxf(m, fabsf(v.x)), fmaxf(fabsf(v.y), fabsf(v.z))), fabsf(v.w));
+  }
+  if (cols & 3) {
+    const int64_t tail = cols & 3, totalt = rows * tail;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < totalt; i += (int64_t)gridDim.x * blockDim.x)
+      m = fmaxf(m, fabsf(x[(i / tail) * ld + (cols & ~3LL) + i % tail]));
+  }
+  m = block_max<4>(m, red);
+  if (threadIdx.x == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(m));
+}
+
+int launch_amax(const float* x, int64_t rows, int64_t cols, int64_t ld, float* out, hipStream_t st) {
+  UG_HIP(hipMemsetAsync(out, 0, sizeof(float), st));
+  int64_t g = (rows * cols / 4 + 255) / 256;
+  if (g > 2048) g = 2048;
+  if (g < 1) g = 1;
+  hipLaunchKernelGGL(amax_kernel, dim3((unsigned)g), dim3(256), 0, st, x, rows, cols, ld, out);
+  UG_CHECK_LAUNCH("ug_amax_f32");
+  return UG_OK;
+}
+
 // 64-channel workgroups when the 128-channel tiling would not give every CU two workgroups
-void launch_split3(const SplitArgs& a, int64_t M, int64_t N, hipStream_t st) {
+void launch_split(const SplitArgs& a, int64_t M, int64_t N, hipStream_t st) {
   const unsigned mt = (unsigned)(((M + SBM - 1) / SBM + 7) / 8 * 8);
   const int64_t wgs = ((M + SBM - 1) / SBM) * ((N + SBN - 1) / SBN);
-  if (wgs < 512) hipLaunchKernelGGL(conv_split3_kernel<2>, dim3(mt, (unsigned)((N + 63) / 64)), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(conv_split3_kernel<4>, dim3(mt, (unsigned)((N + SBN - 1) / SBN)), dim3(256), 0, st, a);
+  if (wgs < 512) hipLaunchKernelGGL(conv_split_kernel<2>, dim3(mt, (unsigned)((N + 63) / 64)), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(conv_split_kernel<4>, dim3(mt, (unsigned)((N + SBN - 1) / SBN)), dim3(256), 0, st, a);
 }
 
 }  // namespace
 
 // ------------------------------------------------------------------------------------ C ABI
+// 16-bit elements of a split weight buffer: the tiles, then 8 elements whose first 4 bytes hold max|w| (fp32)
+static inline int64_t split_tile_elems(int taps, int Cin, int cout_pad) {
+  return (int64_t)taps * ((Cin + SBK - 1) / SBK) * (cout_pad / SBN) * TILE;
+}
+
+extern "C" int ug_amax_f32(const float* x, int64_t rows, int64_t cols, int64_t ld, float* out_amax, hipStream_t st) {
+  UG_REQUIRE(x && out_amax && rows > 0 && cols > 0 && ld >= cols, "ug_amax_f32: bad args");
+  UG_REQUIRE((cols < 4) || (ug_aligned16(x) && ld % 4 == 0), "ug_amax_f32: x must be 16-byte aligned with ld %% 4 == 0");
+  return launch_amax(x, rows, cols, ld, out_amax, st);
+}
+
 extern "C" int ug_conv_split_weights(const float* w_packed, uint16_t* w_split, int taps, int Cin, int cout_pad,
                                      hipStream_t st) {
   UG_REQUIRE(w_packed && w_split && taps > 0 && Cin > 0 && cout_pad > 0 && cout_pad % SBN == 0,
              "ug_conv_split_weights: needs cout_pad %% 128 == 0 (Cin=%d cout_pad=%d)", Cin, cout_pad);
-  UG_REQUIRE(ug_aligned16(w_split), "ug_conv_split_weights: output must be 16-byte aligned");
-  const int64_t chunks = (int64_t)taps * ((Cin + SBK - 1) / SBK) * (cout_pad / SBN) * (TILE / 8);
+  UG_REQUIRE(ug_aligned16(w_split) && ug_aligned16(w_packed), "ug_conv_split_weights: buffers must be 16-byte aligned");
+  const int64_t elems = split_tile_elems(taps, Cin, cout_pad);
+  float* amax = reinterpret_cast<float*>(w_split + elems);
+  if (int rc = launch_amax(w_packed, 1, (int64_t)taps * Cin * cout_pad, (int64_t)taps * Cin * cout_pad, amax, st)) return rc;
+  const int64_t chunks = elems / 8;
   int64_t g = (chunks + 255) / 256;
   if (g > 8192) g = 8192;
-  hipLaunchKernelGGL(conv_split_weights_kernel, dim3((unsigned)g), dim3(256), 0, st, w_packed, (bf16_t*)w_split, taps, Cin,
+  hipLaunchKernelGGL(conv_split_weights_kernel, dim3((unsigned)g), dim3(256), 0, st, w_packed, (bf16_t*)w_split, amax, taps, Cin,
                      cout_pad);
   UG_CHECK_LAUNCH("ug_conv_split_weights");
   return UG_OK;
 }
 
-extern "C" int ug_conv2d_split3(const float* x, const uint16_t* w_split, const float* bias, const float* residual, float* y,
-                                int64_t B, int Hin, int Win, int Cin, int Cout, int cout_pad, int ksize, int stride,
-                                int pad_top, int pad_left, int Hout, int Wout, int upsample2x, hipStream_t st) {
-  UG_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && ksize >= 1 && ksize <= 16, "ug_conv2d_split3: bad shape");
+extern "C" int ug_conv2d_split(const float* x, const float* x_amax, const uint16_t* w_split, const float* bias, const float* residual,
+                               float* y, int64_t B, int Hin, int Win, int Cin, int Cout, int cout_pad, int ksize, int stride,
+                               int pad_top, int pad_left, int Hout, int Wout, int upsample2x, hipStream_t st) {
+  UG_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && ksize >= 1 && ksize <= 16, "ug_conv2d_split: bad shape");
   UG_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0 && cout_pad % SBN == 0 && cout_pad >= Cout,
-             "ug_conv2d_split3: needs Cin %% 4 == 0, Cout %% 4 == 0, cout_pad %% 128 == 0 (Cin=%d Cout=%d cout_pad=%d)", Cin,
+             "ug_conv2d_split: needs Cin %% 4 == 0, Cout %% 4 == 0, cout_pad %% 128 == 0 (Cin=%d Cout=%d cout_pad=%d)", Cin,
              Cout, cout_pad);
   UG_REQUIRE(x && y && w_split && ug_aligned16(x) && ug_aligned16(y) && ug_aligned16(w_split) &&
                  (!bias || ug_aligned16(bias)) && (!residual || ug_aligned16(residual)),
-             "ug_conv2d_split3: pointers must be 16-byte aligned");
+             "ug_conv2d_split: pointers must be 16-byte aligned");
   const int64_t M = B * Hout * Wout;
-  UG_REQUIRE(M < (1LL << 31), "ug_conv2d_split3: too many output pixels");
+  UG_REQUIRE(M < (1LL << 31), "ug_conv2d_split: too many output pixels");
   SplitArgs a{};
   a.x = x; a.w = (const bf16_t*)w_split; a.bias = bias; a.res = residual; a.y = y;
+  a.x_amax = x_amax; a.w_amax = reinterpret_cast<const float*>(w_split + split_tile_elems(ksize * ksize, Cin, cout_pad));
   a.B = (int)B; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Hout = Hout; a.Wout = Wout; a.Cout = Cout;
   a.KH = ksize; a.KW = ksize; a.stride = stride; a.pad_t = pad_top; a.pad_l = pad_left; a.ups = upsample2x;
   a.nblks = cout_pad / SBN; a.M = (int)M; a.kslabs = (Cin + SBK - 1) / SBK;
   a.ldx = Cin; a.ldy = Cout; a.ldres = Cout;
-  launch_split3(a, M, Cout, st);
-  UG_CHECK_LAUNCH("ug_conv2d_split3");
+  launch_split(a, M, Cout, st);
+  UG_CHECK_LAUNCH("ug_conv2d_split");
   return UG_OK;
 }
 
-extern "C" int ug_linear_split3(const float* x, int64_t ldx, const uint16_t* w_split, const float* bias, const float* residual,
-                                int64_t ldres, float* y, int64_t ldy, int64_t M, int64_t N, int64_t K, int n_pad, int act,
-                                hipStream_t st) {
-  UG_REQUIRE(M > 0 && N > 0 && K > 0 && (act == 0 || act == 1) && M < (1LL << 31), "ug_linear_split3: bad args");
+extern "C" int ug_linear_split(const float* x, int64_t ldx, const float* x_amax, const uint16_t* w_split, const float* bias,
+                               const float* residual, int64_t ldres, float* y, int64_t ldy, int64_t M, int64_t N, int64_t K,
+                               int n_pad, int act, hipStream_t st) {
+  UG_REQUIRE(M > 0 && N > 0 && K > 0 && (act == 0 || act == 1) && M < (1LL << 31), "ug_linear_split: bad args");
   UG_REQUIRE(K % 4 == 0 && N % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && (!residual || ldres % 4 == 0) && n_pad % SBN == 0 &&
                  n_pad >= N,
-             "ug_linear_split3: needs K, N and the row strides %% 4 == 0 and n_pad %% 128 == 0 (K=%lld N=%lld n_pad=%d)",
+             "ug_linear_split: needs K, N and the row strides %% 4 == 0 and n_pad %% 128 == 0 (K=%lld N=%lld n_pad=%d)",
              (long long)K, (long long)N, n_pad);
   UG_REQUIRE(x && y && w_split && ug_aligned16(x) && ug_aligned16(y) && ug_aligned16(w_split) &&
                  (!bias || ug_aligned16(bias)) && (!residual || ug_aligned16(residual)),
-             "ug_linear_split3: pointers must be 16-byte aligned");
+             "ug_linear_split: pointers must be 16-byte aligned");
   SplitArgs a{};
   a.x = x; a.w = (const bf16_t*)w_split; a.bias = bias; a.res = residual; a.y = y;
+  a.x_amax = x_amax; a.w_amax = reinterpret_cast<const float*>(w_split + split_tile_elems(1, (int)K, n_pad));
   a.B = (int)M; a.Hin = a.Win = a.Hout = a.Wout = 1; a.Cin = (int)K; a.Cout = (int)N;
   a.KH = a.KW = 1; a.stride = 1;
   a.nblks = n_pad / SBN; a.M = (int)M; a.kslabs = (int)((K + SBK - 1) / SBK);
   a.ldx = ldx; a.ldy = ldy; a.ldres = ldres; a.act = act;
-  launch_split3(a, M, N, st);
-  UG_CHECK_LAUNCH("ug_linear_split3");
+  launch_split(a, M, N, st);
+  UG_CHECK_LAUNCH("ug_linear_split");
   return UG_OK;
 }
 
-extern "C" int ug_conv3x3_split3(const float* x, const uint16_t* w_split, const float* bias, const float* residual, float* y,
-                                 int64_t B, int H, int W, int Cin, int Cout, int cout_pad, const float* gn_mu_rstd,
-                                 const float* gn_gamma, const float* gn_beta, int gn_groups, int gn_swish, hipStream_t st) {
-  UG_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "ug_conv3x3_split3: bad shape");
+extern "C" int ug_conv3x3_split(const float* x, const float* x_amax, const uint16_t* w_split, const float* bias, const float* residual,
+                                float* y, int64_t B, int H, int W, int Cin, int Cout, int cout_pad, const float* gn_mu_rstd,
+                                const float* gn_gamma, const float* gn_beta, int gn_groups, int gn_swish, hipStream_t st) {
+  UG_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "ug_conv3x3_split: bad shape");
   UG_REQUIRE(Cin % SBK == 0 && Cout % 4 == 0 && cout_pad % SBN == 0 && cout_pad >= Cout,
-             "ug_conv3x3_split3: needs Cin %% 32 == 0, Cout %% 4 == 0, cout_pad %% 128 == 0 (Cin=%d Cout=%d cout_pad=%d)", Cin,
+             "ug_conv3x3_split: needs Cin %% 32 == 0, Cout %% 4 == 0, cout_pad %% 128 == 0 (Cin=%d Cout=%d cout_pad=%d)", Cin,
              Cout, cout_pad);
   UG_REQUIRE(x && y && w_split && ug_aligned16(x) && ug_aligned16(y) && ug_aligned16(w_split) &&
                  (!bias || ug_aligned16(bias)) && (!residual || ug_aligned16(residual)),
-             "ug_conv3x3_split3: pointers must be 16-byte aligned");
+             "ug_conv3x3_split: pointers must be 16-byte aligned");
   PatchArgs a{};
   a.x = x; a.w = (const bf16_t*)w_split; a.bias = bias; a.res = residual; a.y = y;
+  a.x_amax = x_amax; a.w_amax = reinterpret_cast<const float*>(w_split + split_tile_elems(9, Cin, cout_pad));
   a.B = (int)B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.nblks = cout_pad / SBN; a.kslabs = Cin / SBK;
   // 16-row tiles (eight waves, DMA-fed weights) when they still give every CU two workgroups' worth of work
   const int nb_n = (Cout + SBN - 1) / SBN;
@@ -633,7 +699,7 @@ extern "C" int ug_conv3x3_split3(const float* x, const uint16_t* w_split, const 
   const bool big = big_tiles * nb_n >= 512;
   a.tiles_x = (W + PT_W - 1) / PT_W; a.tiles_y = big ? (H + QT_H - 1) / QT_H : (H + PT_H - 1) / PT_H;
   const int64_t ntiles = B * a.tiles_x * a.tiles_y;
-  UG_REQUIRE(ntiles < (1LL << 30) && B * H * W < (1LL << 31), "ug_conv3x3_split3: too many output pixels");
+  UG_REQUIRE(ntiles < (1LL << 30) && B * H * W < (1LL << 31), "ug_conv3x3_split: too many output pixels");
   a.ntiles = (int)ntiles;
   // 64-channel workgroups when the 128-channel tiling of the 8-row variant would leave CUs without work
   const bool half = !big && ntiles * nb_n < 512;
@@ -642,7 +708,7 @@ extern "C" int ug_conv3x3_split3(const float* x, const uint16_t* w_split, const 
   if (gn_mu_rstd) {
     UG_REQUIRE(gn_gamma && gn_beta && gn_groups > 0 && Cin % gn_groups == 0 && (Cin / gn_groups) % 4 == 0 &&
                    ug_aligned16(gn_gamma) && ug_aligned16(gn_beta) && ((uintptr_t)gn_mu_rstd & 7) == 0,
-               "ug_conv3x3_split3: fused GroupNorm needs gamma/beta and channels-per-group %% 4 == 0 (Cin=%d groups=%d)", Cin,
+               "ug_conv3x3_split: fused GroupNorm needs gamma/beta and channels-per-group %% 4 == 0 (Cin=%d groups=%d)", Cin,
                gn_groups);
     a.mu_rstd = reinterpret_cast<const float2*>(gn_mu_rstd); a.gamma = gn_gamma; a.beta = gn_beta;
     a.G = gn_groups; a.cpg = Cin / gn_groups; a.swish = gn_swish;
@@ -654,6 +720,6 @@ extern "C" int ug_conv3x3_split3(const float* x, const uint16_t* w_split, const 
     else if (half) hipLaunchKernelGGL((conv3x3_patch_kernel<false, 2>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((conv3x3_patch_kernel<false, 4>), grid, block, 0, st, a);
   }
-  UG_CHECK_LAUNCH("ug_conv3x3_split3");
+  UG_CHECK_LAUNCH("ug_conv3x3_split");
   return UG_OK;
 }

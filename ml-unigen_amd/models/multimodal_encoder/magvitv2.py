@@ -146,7 +146,7 @@ class MAGVITv2(ModelMixin, ConfigMixin):
         self._packed = {}
         self._err = None
         # True: every conv on the exact fp32 MFMA chain (ug_conv2d_f32) and stand-alone GroupNorm passes;
-        # False (default): wide convs on the split-bf16 contraction.  Flip it on an instance to compare the two.
+        # False (default): wide convs on the split-f16 contraction.  Flip it on an instance to compare the two.
         self.exact_fp32_convs = not _SPLIT_CONV
 
     # ------------------------------------------------------------------ plumbing
@@ -173,7 +173,7 @@ class MAGVITv2(ModelMixin, ConfigMixin):
         p.w, p.cpad = ops.pack_conv_weight(w)
         p.bias = conv.bias.detach().float().contiguous()
         p.cout, p.cin, p.k = w.shape[0], w.shape[1], w.shape[2]
-        # wide convs run on the bf16 matrix cores with three-way split operands (fp32-accurate, 16/6 the MFMA rate);
+        # wide convs run on the f16 matrix cores with scaled two-way split operands (fp32-accurate, 16/3 the MFMA rate);
         # UNIGEN_CONV_FP32_MFMA=1 keeps every conv on the exact fp32 MFMA chain
         p.ws = ops.split_conv_weight(p.w) if (not self.exact_fp32_convs and ops.conv_split_eligible(p.cin, p.cout, p.cpad)) else None
         self._packed[key] = (ver, p)

@@ -169,7 +169,7 @@ class SigLipVisionTower(nn.Module):
             wq = torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight]).detach().float().contiguous()
             bq = torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias]).detach().float().contiguous()
             pk["qkv"].append((wq, bq))
-            if _SPLIT_LINEAR:       # fp32-accurate projections on the bf16 matrix cores (three-way operand split)
+            if _SPLIT_LINEAR:       # fp32-accurate projections on the f16 matrix cores (scaled two-way operand split, three products)
                 pk["split"].append(tuple(ops.split_linear_weight(w) for w in
                                          (wq, a.out_proj.weight, l.mlp.fc1.weight, l.mlp.fc2.weight)))
         self._packed = pk
@@ -205,7 +205,7 @@ class SigLipVisionTower(nn.Module):
 
             def lin(x, j, W, bias, **kw):
                 if sp is not None:
-                    return ops.linear_split3(x, sp[j][0], sp[j][1], W.shape[0], bias, **kw)
+                    return ops.linear_split(x, sp[j][0], sp[j][1], W.shape[0], bias, **kw)
                 return ops.linear_f32(x, W, bias, **kw)
 
             lin(xn, 0, wq, bq, out=qkv, M=B * T)

@@ -581,23 +581,50 @@ def pack_conv_weight(w):
 
 
 def conv_split_eligible(cin, cout, cout_pad):
-    """Shapes the split-bf16 convolution (`ug_conv2d_split3`) is used for (the kernel itself only needs Cin % 4 == 0)."""
+    """Shapes the split-f16 convolution (`ug_conv2d_split`) is used for (the kernel itself only needs Cin % 4 == 0)."""
     return cin % 32 == 0 and cout % 4 == 0 and cout_pad % 128 == 0 and cout >= 64
 
 
 def split_conv_weight(wp):
-    """Packed fp32 weights [taps, Cin, cout_pad] -> the three-plane bf16 tile image `ug_conv2d_split3` reads."""
+    """Packed fp32 weights [taps, Cin, cout_pad] -> the two-plane scaled fp16 tile image `ug_conv2d_split` reads (+ the
+    tensor's max|w| in the 8 trailing elements)."""
     taps, cin, cout_pad = wp.shape
-    ws = torch.empty(3 * taps * round_up(cin, 32) * cout_pad, dtype=torch.bfloat16, device=wp.device)
+    ws = torch.empty(2 * taps * round_up(cin, 32) * cout_pad + 8, dtype=torch.float16, device=wp.device)
     _l.check(_l.load().ug_conv_split_weights(_p(wp), _p(ws), taps, cin, cout_pad, _stream()), "ug_conv_split_weights")
     return ws
 
 
+_AMAX_CONST = {}
+
+
+def amax_const(value, device):
+    """A cached device scalar holding a fixed upper bound of max|x| (only its binade matters to the split convolutions)."""
+    key = (float(value), str(device))
+    if key not in _AMAX_CONST:
+        _AMAX_CONST[key] = torch.full((1,), float(value), dtype=torch.float32, device=device)
+    return _AMAX_CONST[key]
+
+
+def amax(x2d):
+    """max|x| of a 2-D (or any contiguous) fp32 tensor as a device scalar: the scale bound of `conv2d_nhwc(w_split=)` /
+    `linear_split` for inputs whose range is not known by construction."""
+    _need_cuda(x2d)
+    out = torch.empty((1,), dtype=torch.float32, device=x2d.device)
+    if x2d.dim() == 2 and x2d.stride(1) == 1:
+        rows, cols, ld = x2d.shape[0], x2d.shape[1], x2d.stride(0)
+    else:
+        x2d = x2d.contiguous()
+        rows, cols, ld = 1, x2d.numel(), x2d.numel()
+    _l.check(_l.load().ug_amax_f32(_p(x2d), rows, cols, ld, _p(out), _stream()), "ug_amax_f32")
+    return out
+
+
 def conv2d_nhwc(x, wp, cout_pad, bias, cout, ksize, *, stride=1, pad=None, residual=None, upsample=False,
-                asym_pad=False, w_split=None):
+                asym_pad=False, w_split=None, x_amax=None):
     """x [B,H,W,Cin] fp32 NHWC -> [B,Ho,Wo,Cout].  asym_pad: the reference Downsample's pad (0,1,0,1) +
     stride-2 valid conv (common_modules.py:86-93).  With `w_split` (from `split_conv_weight`) the contraction runs as
-    six bf16 MFMA terms of the three-way split operands instead of on the fp32 MFMA."""
+    three f16 MFMA terms of the scaled two-way split operands instead of on the fp32 MFMA; `x_amax` (device scalar, an
+    upper bound of max|x|) sets the activation scale, measured here when not given."""
     B, H, W, Cin = x.shape
     He, We = (2 * H, 2 * W) if upsample else (H, W)
     if asym_pad:
@@ -608,8 +635,10 @@ def conv2d_nhwc(x, wp, cout_pad, bias, cout, ksize, *, stride=1, pad=None, resid
         Ho, Wo = (He + 2 * pt - ksize) // stride + 1, (We + 2 * pl - ksize) // stride + 1
     y = torch.empty((B, Ho, Wo, cout), dtype=torch.float32, device=x.device)
     if w_split is not None:
-        _l.check(_l.load().ug_conv2d_split3(_p(x), _p(w_split), _p(bias), _p(residual), _p(y), B, H, W, Cin, cout, cout_pad,
-                                            ksize, stride, pt, pl, Ho, Wo, int(upsample), _stream()), "ug_conv2d_split3")
+        if x_amax is None:
+            x_amax = amax(x.view(-1, Cin))
+        _l.check(_l.load().ug_conv2d_split(_p(x), _p(x_amax), _p(w_split), _p(bias), _p(residual), _p(y), B, H, W, Cin, cout,
+                                           cout_pad, ksize, stride, pt, pl, Ho, Wo, int(upsample), _stream()), "ug_conv2d_split")
         return y
     _l.check(_l.load().ug_conv2d_f32(_p(x), _p(wp), _p(bias), _p(residual), _p(y), B, H, W, Cin, cout, cout_pad, ksize,
                                      stride, pt, pl, Ho, Wo, int(upsample), _stream()), "ug_conv2d_f32")
@@ -657,14 +686,21 @@ def groupnorm_stats(x, *, groups=32, eps=1e-6):
     return mr
 
 
-def conv3x3_nhwc(x, w_split, cout_pad, bias, cout, *, residual=None, gn=None):
+GN_OUT_BOUND = 256.0      # |gamma * xhat + beta| stays below 2 x this for any |xhat| <= 500 with |gamma| <= 1, |beta| <= 12
+
+
+def conv3x3_nhwc(x, w_split, cout_pad, bias, cout, *, residual=None, gn=None, x_amax=None):
     """3x3 / stride 1 / pad 1 convolution of NHWC fp32 x with split weights (`split_conv_weight`), input patch resident
-    in LDS.  gn = (mu_rstd, gamma, beta, groups, swish): apply swish?(GroupNorm(x)) on the load path."""
+    in LDS.  gn = (mu_rstd, gamma, beta, groups, swish): apply swish?(GroupNorm(x)) on the load path; the scale bound of
+    the normalised tensor is then a constant (a unit-variance group cannot exceed sqrt(group size) <= 512; values past the
+    bound's binade saturate at 1023 instead of overflowing).  Without gn the bound is measured unless `x_amax` is given."""
     B, H, W, Cin = x.shape
     y = torch.empty((B, H, W, cout), dtype=torch.float32, device=x.device)
     mr, ga, be, groups, swish = gn if gn is not None else (None, None, None, 0, 0)
-    _l.check(_l.load().ug_conv3x3_split3(_p(x), _p(w_split), _p(bias), _p(residual), _p(y), B, H, W, Cin, cout, cout_pad,
-                                         _p(mr), _p(ga), _p(be), groups, int(swish), _stream()), "ug_conv3x3_split3")
+    if x_amax is None:
+        x_amax = amax_const(GN_OUT_BOUND, x.device) if gn is not None else amax(x.view(-1, Cin))
+    _l.check(_l.load().ug_conv3x3_split(_p(x), _p(x_amax), _p(w_split), _p(bias), _p(residual), _p(y), B, H, W, Cin, cout,
+                                        cout_pad, _p(mr), _p(ga), _p(be), groups, int(swish), _stream()), "ug_conv3x3_split")
     return y
 
 
@@ -689,7 +725,7 @@ def linear_f32(x, W, bias=None, residual=None, act=0, out=None, M=None):
 
 
 def split_linear_weight(W):
-    """nn.Linear weight [N, K] fp32 -> (split tile image of W^T as a 1x1 conv, n_pad) for `linear_split3`."""
+    """nn.Linear weight [N, K] fp32 -> (split tile image of W^T as a 1x1 conv, n_pad) for `linear_split`."""
     N, K = W.shape
     n_pad = round_up(N, 128)
     wp = torch.zeros((1, K, n_pad), dtype=torch.float32, device=W.device)
@@ -697,15 +733,18 @@ def split_linear_weight(W):
     return split_conv_weight(wp), n_pad
 
 
-def linear_split3(x, w_split, n_pad, N, bias=None, residual=None, act=0, out=None, M=None):
-    """`linear_f32` with the three-way bf16 split contraction (fp32-accurate, bf16 matrix cores); x [M,K] fp32."""
+def linear_split(x, w_split, n_pad, N, bias=None, residual=None, act=0, out=None, M=None, x_amax=None):
+    """`linear_f32` with the scaled two-way f16 split contraction (fp32-accurate, f16 matrix cores); x [M,K] fp32.
+    x_amax: device scalar bounding max|x| (measured here when not given)."""
     M = x.shape[0] if M is None else M
     K = x.shape[1]
     if out is None:
         out = torch.empty((M, N), dtype=torch.float32, device=x.device)
-    _l.check(_l.load().ug_linear_split3(_p(x), x.stride(0), _p(w_split), _p(bias), _p(residual),
-                                        residual.stride(0) if residual is not None else 0, _p(out), out.stride(0), M, N, K,
-                                        n_pad, act, _stream()), "ug_linear_split3")
+    if x_amax is None:
+        x_amax = amax(x[:M])
+    _l.check(_l.load().ug_linear_split(_p(x), x.stride(0), _p(x_amax), _p(w_split), _p(bias), _p(residual),
+                                       residual.stride(0) if residual is not None else 0, _p(out), out.stride(0), M, N, K,
+                                       n_pad, act, _stream()), "ug_linear_split")
     return out
 
 

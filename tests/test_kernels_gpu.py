@@ -427,8 +427,9 @@ def test_conv2d_f32(dev, cin, cout, k, stride, asym, ups, H):
     (128, 128, 3, 1, False, False, 16), (128, 256, 1, 1, False, False, 8), (128, 128, 3, 2, True, False, 16),
     (256, 256, 3, 1, False, True, 8), (32, 192, 3, 1, False, False, 12), (512, 512, 3, 1, False, False, 6),
     (64, 68, 3, 1, False, False, 9)])
-def test_conv2d_split3_matches_fp64(dev, cin, cout, k, stride, asym, ups, H):
-    """Three-way bf16 split convolution: as close to the fp64 result as the exact fp32 MFMA chain is."""
+def test_conv2d_split_matches_fp64(dev, cin, cout, k, stride, asym, ups, H):
+    """Scaled two-way f16 split convolution (three partial products): fp32-accurate -- within 3x of the exact fp32 MFMA
+    chain's own distance to the fp64 result (measured ~1-2x; the reference's GPU path runs these convs in TF32, ~1000x)."""
     ops = _ops()
     gen = torch.Generator().manual_seed(cin * 17 + cout)
     B = 2
@@ -451,8 +452,9 @@ def test_conv2d_split3_matches_fp64(dev, cin, cout, k, stride, asym, ups, H):
     split = ops.conv2d_nhwc(x_nhwc, wp, cpad, bias.to(dev), cout, k, w_split=ws, **kw).permute(0, 3, 1, 2).cpu().double()
     assert split.shape == ref.shape
     e_exact, e_split = (exact - ref).abs().max().item(), (split - ref).abs().max().item()
+    print(f"    split conv cin={cin} cout={cout} k={k}: max err vs fp64 {e_split:.2e} (exact fp32 chain {e_exact:.2e}, ratio {e_split / max(e_exact, 1e-12):.2f})")
     assert e_split < 1e-4, (e_split, e_exact)
-    assert e_split <= 1.5 * e_exact + 2e-6, (e_split, e_exact)
+    assert e_split <= 3.0 * e_exact + 4e-6, (e_split, e_exact)
 
 
 @pytest.mark.parametrize("cin,cout,H,W,gn", [(128, 128, 16, 16, False), (128, 128, 16, 32, True), (256, 192, 11, 21, True),
@@ -490,8 +492,8 @@ def test_conv3x3_patch_matches_fp64(dev, cin, cout, H, W, gn):
 
 
 @pytest.mark.parametrize("M,N,K,act", [(300, 1152, 1152, 0), (257, 4304, 1152, 1), (129, 1152, 4304, 0), (64, 68, 36, 1)])
-def test_linear_split3_matches_fp64(dev, M, N, K, act):
-    """Split-bf16 linear (ragged K slabs, GELU, bias, residual, strided output) against fp64 and the fp32 MFMA path."""
+def test_linear_split_matches_fp64(dev, M, N, K, act):
+    """Split-f16 linear (ragged K slabs, GELU, bias, residual, strided output) against fp64 and the fp32 MFMA path."""
     ops = _ops()
     gen = torch.Generator().manual_seed(M + N + K)
     x = torch.randn(M, K, generator=gen) * 1.5
@@ -504,11 +506,12 @@ def test_linear_split3_matches_fp64(dev, M, N, K, act):
     ref = pre + res.double()
     ws, n_pad = ops.split_linear_weight(W.to(dev))
     out = torch.full((M, N + 8), 7.0, device=dev)[:, :N]                   # strided destination, sentinel columns
-    got = ops.linear_split3(x.to(dev), ws, n_pad, N, bias.to(dev), residual=res.to(dev), act=act, out=out)
+    got = ops.linear_split(x.to(dev), ws, n_pad, N, bias.to(dev), residual=res.to(dev), act=act, out=out)
     exact = ops.linear_f32(x.to(dev), W.to(dev), bias.to(dev), residual=res.to(dev), act=act)
     e_split = (got.cpu().double() - ref).abs().max().item()
     e_exact = (exact.cpu().double() - ref).abs().max().item()
-    assert e_split < 1e-4 and e_split <= 1.5 * e_exact + 2e-6, (e_split, e_exact)
+    print(f"    split linear M={M} N={N} K={K}: max err vs fp64 {e_split:.2e} (exact fp32 chain {e_exact:.2e})")
+    assert e_split < 1e-4 and e_split <= 3.0 * e_exact + 4e-6, (e_split, e_exact)
     assert torch.all(out.as_strided((M, 8), (N + 8, 1), out.storage_offset() + N) == 7.0)
 
 
@@ -1019,3 +1022,44 @@ def test_gemm_k_sliced_on_two_streams_and_under_capture(dev):
     graph.replay(); graph.replay()
     torch.cuda.synchronize()
     assert _rel(out, 2 * ref) < 1e-5 * math.sqrt(K) + 1e-6
+
+
+@pytest.mark.parametrize("scale_x,scale_w", [(1e4, 1.0), (1e-6, 1.0), (1.0, 1e5), (3e-5, 2e-4), (5e7, 1e-9)])
+def test_split_linear_is_scale_invariant(dev, scale_x, scale_w):
+    """The power-of-two operand scaling keeps the f16 split fp32-accurate whatever the tensors' magnitudes (fp16 alone covers
+    6e-8 .. 65504): relative error vs fp64 stays at the fp32 level from 1e-9 to 5e7, including one 1000x outlier that sets
+    the bound while every other value sits three decades below it."""
+    ops = _ops()
+    gen = torch.Generator().manual_seed(17)
+    M, N, K = 192, 256, 1152
+    x = torch.randn(M, K, generator=gen) * scale_x
+    x[5, 7] = 1000.0 * scale_x
+    W = torch.randn(N, K, generator=gen) / math.sqrt(K) * scale_w
+    ref = x.double() @ W.double().t()
+    ws, n_pad = ops.split_linear_weight(W.to(dev))
+    got = ops.linear_split(x.to(dev), ws, n_pad, N).cpu().double()
+    exact = ops.linear_f32(x.to(dev), W.to(dev)).cpu().double()
+    rel = ((got - ref).norm() / ref.norm()).item()
+    rel_exact = ((exact - ref).norm() / ref.norm()).item()
+    print(f"    scales x={scale_x:g} w={scale_w:g}: split rel err {rel:.2e}, fp32 chain {rel_exact:.2e}")
+    assert rel < 1e-6 and rel <= 3.0 * rel_exact + 1e-7, (rel, rel_exact)
+
+
+def test_amax_and_saturating_bound(dev):
+    """ug_amax_f32 (exact max|x| incl. ragged columns and strided rows), and the behaviour under a WRONG (too small) bound:
+    values past the bound's binade saturate at the fp16 maximum instead of turning into infinities / NaNs."""
+    ops = _ops()
+    gen = torch.Generator().manual_seed(3)
+    for rows, cols, pad in ((1, 5, 0), (37, 1152, 0), (129, 70, 6), (4, 3, 1), (1000, 4304, 0)):
+        x = torch.randn(rows, cols + pad, generator=gen)
+        x[rows // 2, cols // 2] = -77.5
+        xd = x.to(dev)[:, :cols]
+        assert float(ops.amax(xd)) == float(x[:, :cols].abs().max())
+    assert float(ops.amax(torch.zeros(8, 8, device=dev))) == 0.0
+    M, N, K = 64, 128, 64
+    x = torch.ones(M, K) * 3.0
+    x[0, 0] = 1.0e6                                                   # 2^14 / 4 * 1e6 >> 65504 under the bound below
+    W = torch.eye(N, K)
+    ws, n_pad = ops.split_linear_weight(W.to(dev))
+    y = ops.linear_split(x.to(dev), ws, n_pad, N, x_amax=ops.amax_const(4.0, dev)).cpu()
+    assert torch.isfinite(y).all() and abs(float(y[1, 1]) - 3.0) < 1e-5 and float(y[0, 0]) < 1.0e6
