@@ -565,19 +565,22 @@ __global__ __launch_bounds__(256) void conv_split_weights_kernel(const float* __
 // max|x| over rows x cols fp32 (row stride ld), as an order-preserving unsigned max of the float bits into *out
 // (cleared by a memset node ahead of the launch)
 __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, int64_t rows, int64_t cols, int64_t ld,
-                                                   float* __restrict__ out) {
+                                                   float* __restrict__ out, int vec) {
   __shared__ float red[4];
   float m = 0.f;
-  const int64_t c4 = cols >> 2, total4 = rows * c4;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = i / c4, c = (i % c4) * 4;
-    const float4 v = *reinterpret_cast<const float4*>(x + r * ld + c);
-    m = fmaxf(fmaxf(fmaxf(m, fabsf(v.x)), fmaxf(fabsf(v.y), fabsf(v.z))), fabsf(v.w));
+  const int64_t cv = vec ? (cols & ~3LL) : 0;           // columns covered by 16-byte loads (aligned rows only)
+  if (cv) {
+    const int64_t c4 = cv >> 2, total4 = rows * c4;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+      const int64_t r = i / c4, c = (i % c4) * 4;
+      const float4 v = *reinterpret_cast<const float4*>(x + r * ld + c);
+      m = fmaxf(fmaxf(fmaxf(m, fabsf(v.x)), fmaxf(fabsf(v.y), fabsf(v.z))), fabsf(v.w));
+    }
   }
-  if (cols & 3) {
-    const int64_t tail = cols & 3, totalt = rows * tail;
+  if (cv < cols) {
+    const int64_t tail = cols - cv, totalt = rows * tail;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < totalt; i += (int64_t)gridDim.x * blockDim.x)
-      m = fmaxf(m, fabsf(x[(i / tail) * ld + (cols & ~3LL) + i % tail]));
+      m = fmaxf(m, fabsf(x[(i / tail) * ld + cv + i % tail]));
   }
   m = block_max<4>(m, red);
   if (threadIdx.x == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(m));
@@ -588,7 +591,8 @@ int launch_amax(const float* x, int64_t rows, int64_t cols, int64_t ld, float* o
   int64_t g = (rows * cols / 4 + 255) / 256;
   if (g > 2048) g = 2048;
   if (g < 1) g = 1;
-  hipLaunchKernelGGL(amax_kernel, dim3((unsigned)g), dim3(256), 0, st, x, rows, cols, ld, out);
+  const int vec = ug_aligned16(x) && ld % 4 == 0;
+  hipLaunchKernelGGL(amax_kernel, dim3((unsigned)g), dim3(256), 0, st, x, rows, cols, ld, out, vec);
   UG_CHECK_LAUNCH("ug_amax_f32");
   return UG_OK;
 }
@@ -611,7 +615,6 @@ static inline int64_t split_tile_elems(int taps, int Cin, int cout_pad) {
 
 extern "C" int ug_amax_f32(const float* x, int64_t rows, int64_t cols, int64_t ld, float* out_amax, hipStream_t st) {
   UG_REQUIRE(x && out_amax && rows > 0 && cols > 0 && ld >= cols, "ug_amax_f32: bad args");
-  UG_REQUIRE((cols < 4) || (ug_aligned16(x) && ld % 4 == 0), "ug_amax_f32: x must be 16-byte aligned with ld %% 4 == 0");
   return launch_amax(x, rows, cols, ld, out_amax, st);
 }
 

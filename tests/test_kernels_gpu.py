@@ -558,19 +558,27 @@ def test_conv_split_randomised_shapes(dev):
 
 
 def test_conv_split_weights_reconstruct(dev):
-    """The three bf16 planes of the split weight image add back to the fp32 weights exactly (tile order and swizzle)."""
+    """The two fp16 planes of the split weight image, divided by the recorded power-of-two scale, add back to the fp32
+    weights to 2^-22 relative (tile order, swizzle, scale exponent, trailing max|w| record)."""
     ops = _ops()
     torch.manual_seed(3)
     taps, cin, cpad = 9, 64, 256
     wp = torch.randn(taps, cin, cpad, device=dev) * 0.1
-    ws = ops.split_conv_weight(wp).view(taps, cin // 32, cpad // 128, 3, 128, 4, 8).double()
+    buf = ops.split_conv_weight(wp)
+    n = 2 * taps * cin * cpad
+    amax = buf[n:n + 2].view(torch.float32)
+    assert float(amax) == float(wp.abs().max())
+    ew = 14 - math.floor(math.log2(float(amax)))
+    ws = buf[:n].view(taps, cin // 32, cpad // 128, 2, 128, 4, 8).double()
     r = torch.arange(128, device=dev)
     stored = torch.arange(4, device=dev)[None, :] ^ ((r[:, None] >> 2) & 3)          # logical chunk -> stored position
-    idx = stored[None, None, None, None, :, :, None].expand(taps, cin // 32, cpad // 128, 3, 128, 4, 8)
+    idx = stored[None, None, None, None, :, :, None].expand(taps, cin // 32, cpad // 128, 2, 128, 4, 8)
     logical = torch.gather(ws, 5, idx)                                               # [.., n, chunk, 8]
+    assert float(logical[:, :, :, 0].abs().max()) < 2.0 ** 15 and float(logical[:, :, :, 0].abs().max()) >= 2.0 ** 14
     total = logical.sum(3).reshape(taps, cin // 32, cpad // 128, 128, 32)           # planes summed
-    back = total.permute(0, 1, 4, 2, 3).reshape(taps, cin, cpad)
-    assert torch.equal(back, wp.double())
+    back = total.permute(0, 1, 4, 2, 3).reshape(taps, cin, cpad) * 2.0 ** -ew
+    err = (back - wp.double()).abs()
+    assert bool((err <= wp.double().abs() * 2.0 ** -22 + float(amax) * 2.0 ** -38).all()), float(err.max())
 
 
 def test_groupnorm_swish(dev):
