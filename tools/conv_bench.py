@@ -37,7 +37,7 @@ for cin, cout, H, k in shapes:
         e1.record()
         torch.cuda.synchronize()
         ms2 = e0.elapsed_time(e1) / reps
-        line += f" | bf16x3 {ms2:8.3f} ms {fl / ms2 / 1e9:7.1f} TF/s"
+        line += f" | f16x2  {ms2:8.3f} ms {fl / ms2 / 1e9:7.1f} TF/s"
         if k == 3:
             ops.conv3x3_nhwc(x, ws, cpad, bias, cout)
             torch.cuda.synchronize()
