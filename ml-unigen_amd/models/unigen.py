@@ -13,8 +13,9 @@ Behavioural notes (all mirror the reference unless stated):
   * precision: the reference's bf16-autocast training mode (fp32 master weights / residual stream,
     bf16 matmuls, fp32 statistics) is what the kernels implement, with or without an enclosing
     torch.autocast.
-  * gen_proj_depth > 0 (alternate image embedding + img_head, unigen.py:74-92) is not used by any
-    shipped config and is rejected loudly.
+  * gen_proj_depth > 0 (alternate image embedding gen_embed -> gen_projector and the 8192-way img_head,
+    unigen.py:74-92; off in every shipped config) is implemented for forward / training and MaskGIT
+    generation; t2i_generate_ar with it raises.
 """
 import json
 import os
@@ -24,7 +25,8 @@ import torch
 
 from unigen_hip import ops
 from unigen_hip.lib import UniGenHipError
-from unigen_hip.modules import HipQwen2ForCausalLM, LazyLogits, _HeadLossFn
+from unigen_hip.modules import (HipProjector, HipQwen2ForCausalLM, LazyLogits, _CrossEntropyFn, _HeadLossFn, _LinearFn,
+                                _TableEmbedFn)
 from unigen_hip.qwen2 import Qwen2Dims
 
 from .modeling_utils import ConfigMixin, ModelMixin, register_to_config
@@ -89,9 +91,6 @@ class UniGen(ModelMixin, ConfigMixin):
             **kwargs,
     ):
         super().__init__()
-        if gen_proj_depth > 0:
-            raise UniGenHipError("gen_proj_depth > 0 (gen_embed / gen_projector / img_head) is outside the shipped "
-                                 "configurations and not implemented")
         if scaling_factor != 1:
             raise UniGenHipError("rope scaling is not used by any shipped config and is not implemented")
         device = kwargs.get("device", None) or torch.device("cuda", torch.cuda.current_device())
@@ -115,7 +114,25 @@ class UniGen(ModelMixin, ConfigMixin):
             self._load_hf_llm_weights(llm_model_path, ckpt_base_path)
         self.output_size = self.vocab_size
         self.img_output_size = codebook_size
-        self.register_to_config(mask_token_id=vocab_size - 1)
+        if gen_proj_depth > 0:
+            # separate image-token embedding + MLP into the backbone and an 8192-way head out of it (reference :74-90)
+            hidden = llm_cfg["hidden_size"]
+            if use_gen_dim:
+                self.gen_embed = torch.nn.Embedding(codebook_size + 1, gen_input_dim)
+                layers, width = [torch.nn.Linear(gen_input_dim, hidden)], hidden
+            else:
+                self.gen_embed = torch.nn.Embedding(codebook_size + 1, hidden)
+                layers, width = [torch.nn.Linear(hidden, hidden * 2)], hidden * 2
+            for _ in range(1, gen_proj_depth):
+                layers += [torch.nn.GELU(), torch.nn.Linear(width, hidden)]
+                width = hidden
+            self.gen_projector = HipProjector(*layers)
+            self.img_head = torch.nn.Linear(hidden, codebook_size, bias=False)
+            for m in (self.gen_embed, self.gen_projector, self.img_head):
+                m.to(device)
+            self.register_to_config(mask_token_id=codebook_size)
+        else:
+            self.register_to_config(mask_token_id=vocab_size - 1)
         self._loss_idx_cache = {}
         # Data parallelism (reference: accelerator.prepare wraps the model in DistributedDataParallel, train.py:492).
         # The backbone's parameters are views of one flat buffer whose gradients the kernels write directly and
@@ -229,11 +246,27 @@ class UniGen(ModelMixin, ConfigMixin):
         from unigen_hip.modules import HipProjector
         self.mm_projector = HipProjector(*layers).to(self.llm.engine.device)
 
+    def _use_gen(self):
+        return self.config.get('gen_proj_depth', 0) > 0
+
     def get_gen_embed(self, img_tokens):
-        raise UniGenHipError("gen_projector path (gen_proj_depth > 0) is not implemented")
+        """gen_projector(gen_embed(img_tokens)) (reference :130-131); img_tokens are raw codes 0..codebook_size (the
+        last id is this path's mask token)."""
+        if not self._use_gen():
+            raise UniGenHipError("get_gen_embed needs a model built with gen_proj_depth > 0")
+        eng = self.llm.engine
+        e = _TableEmbedFn.apply(self.gen_embed.weight, img_tokens.to(eng.device), eng.err_flag)
+        return self.gen_projector(e)
 
     def prepare_inputs_for_t2i(self, input_ids, num_vq_tokens):
-        return self.llm.model.embed_tokens(input_ids)
+        emb = self.llm.model.embed_tokens(input_ids)
+        if self._use_gen():                       # image slots carry the projected gen embeddings instead (reference :230-238)
+            img = self.get_gen_embed(input_ids[:, -(num_vq_tokens + 1):-1].contiguous()).to(emb.dtype)
+            emb = torch.cat([emb[:, :-(num_vq_tokens + 1)], img, emb[:, -1:]], dim=1)
+        return emb
+
+    def _img_head(self, hn):
+        return _LinearFn.apply(hn, self.img_head.weight, None)
 
     def prepare_inputs_for_mmu(self, image_feats, spatial_shapes, input_ids, label_ids, prompt_template, input_ids_system=None):
         """Understanding-sample assembly for variable-size image features (reference models/unigen.py:133-228; callers
@@ -300,10 +333,11 @@ class UniGen(ModelMixin, ConfigMixin):
         return full_embeddings, attention_mask, labels, part1
 
     # ------------------------------------------------------------------ forward
-    def _loss_rows(self, B, L, bt, blm, bmmu, n, mode, device):
+    def _loss_rows(self, B, L, bt, blm, bmmu, n, mode, device, lm_start=None):
         """Row indices (into [B*L]) of the logits each loss reads and of the labels it compares to
         (the slices of models/unigen.py:310-338)."""
-        key = (B, L, bt, blm, bmmu, n, mode)
+        lm0 = bt if lm_start is None else lm_start
+        key = (B, L, bt, blm, bmmu, n, mode, lm0)
         if key not in self._loss_idx_cache:
             def grid(b0, b1, p0, p1):
                 b = torch.arange(b0, b1, device=device)[:, None] * L
@@ -314,7 +348,7 @@ class UniGen(ModelMixin, ConfigMixin):
             else:
                 segs.append((grid(0, bt, L - (n + 2), L - 1), 1))
             if blm > 0:
-                segs.append((grid(bt, bt + blm, 0, L - 1), 1))
+                segs.append((grid(lm0, lm0 + blm, 0, L - 1), 1))
             if bmmu > 0:
                 segs.append((grid(B - bmmu, B, 0, L - 1), 1))
             bounds, r = [], 0
@@ -342,11 +376,23 @@ class UniGen(ModelMixin, ConfigMixin):
             **kwargs,
     ):
         eng = self.llm.engine
+        gen = self._use_gen() and batch_size_t2i > 0
+        if gen and input_embeddings is None:
+            # the gen_projector path embeds the image slots through gen_embed + gen_projector; their ids are the raw
+            # codes there (mask id = codebook_size), so the token-table lookup runs with those slots neutralised
+            n = num_vq_tokens
+            safe = input_ids.clone()
+            safe[:, -(n + 1):-1] = 0
+            emb = self.llm.model.embed_tokens(safe)
+            img = self.get_gen_embed(input_ids[:, -(n + 1):-1].contiguous()).to(emb.dtype)
+            input_embeddings = torch.cat([emb[:, :-(n + 1)], img, emb[:, -1:]], dim=1)
         if input_embeddings is None:
             out = self.llm.model(input_ids=input_ids, attention_mask=attention_mask)
         else:
             out = self.llm.model(inputs_embeds=input_embeddings, attention_mask=attention_mask)
         hn = out.last_hidden_state                                  # bf16 [B, L, H] (final norm applied)
+        if gen:
+            return self._forward_gen_head(hn, labels, batch_size_t2i, batch_size_lm, batch_size_mmu, num_vq_tokens, t2i_mode)
         if labels is None:
             return LazyLogits(eng, hn)          # stays on the autograd graph: DPO differentiates through its slices
         logits = LazyLogits(eng, hn.detach())
@@ -371,6 +417,37 @@ class UniGen(ModelMixin, ConfigMixin):
         if batch_size_mmu > 0:
             loss_mmu = by_seg[s]
         return logits, loss_t2i, loss_lm, loss_mmu
+
+    def _forward_gen_head(self, hn, labels, bt, blm, bmmu, n, t2i_mode):
+        """gen_proj_depth > 0 branch of forward (reference :255-341): the t2i rows go through img_head (codebook-wide
+        logits, labels are raw codes), lm / mmu rows through the tied lm_head exactly as in the default branch; the first
+        return value is img_logits."""
+        eng = self.llm.engine
+        B, L, _ = hn.shape
+        img_logits = self._img_head(hn[:bt])                          # bf16 [bt, L, codebook]
+        if labels is None:
+            return img_logits
+        labels = labels.to(hn.device)
+        C = self.img_output_size
+        if t2i_mode == 'mask':
+            lg, lb = img_logits[:, -(n + 1):-1], labels[:bt, -(n + 1):-1]
+        else:
+            lg, lb = img_logits[:, -(n + 2):-1], labels[:bt, -(n + 1):]
+        loss_t2i = _CrossEntropyFn.apply(lg.reshape(-1, C), lb.reshape(-1).contiguous())
+        loss_lm, loss_mmu = 0., 0.
+        if blm > 0 or bmmu > 0:
+            idx, lab_idx, bounds = self._loss_rows(B, L, 0, blm, bmmu, n, t2i_mode, hn.device, lm_start=bt)
+            lab = labels.reshape(-1)[lab_idx].contiguous()
+            live = [(s, b) for s, b in enumerate(bounds) if b[1] > b[0]]
+            losses = _HeadLossFn.apply(eng._anchor, hn, eng, idx, lab, tuple(b for _, b in live))
+            by_seg = {s: losses[j] for j, (s, _) in enumerate(live)}
+            s = 1
+            if blm > 0:
+                loss_lm = by_seg[s]
+                s += 1
+            if bmmu > 0:
+                loss_mmu = by_seg[s]
+        return img_logits, loss_t2i, loss_lm, loss_mmu
 
     # ------------------------------------------------------------------ MaskGIT generation
     @torch.no_grad()
@@ -397,9 +474,11 @@ class UniGen(ModelMixin, ConfigMixin):
         mask_token_id = self.config.mask_token_id
         embed = self.llm.model.embed_tokens
         cur_ids = input_ids[:, -(n + 1):-1].clone()
+        gen = self._use_gen()                        # gen_projector path: raw codes in, gen embeddings, img_head out (:372-373)
         if input_embeddings is None:
             input_embeddings = embed(input_ids)
-        image_embeddings = input_embeddings[:, -(n + 1):-1]
+        image_embeddings = (self.get_gen_embed(cur_ids).to(input_embeddings.dtype) if gen
+                            else input_embeddings[:, -(n + 1):-1])
         bsz = image_embeddings.shape[0]
         prefix = input_embeddings[:, :-(n + 1)]
         suffix = input_embeddings[:, -1:]
@@ -433,7 +512,11 @@ class UniGen(ModelMixin, ConfigMixin):
                     seg = torch.cat([prefix[:, -1:], img, suffix], 1).float()
                     hn = eng.maskgit_step(sess, seg.reshape(R * (n + 2), -1).contiguous())
                 rows = hn.view(R, n + 2, -1)[:, 1:n + 1].reshape(R * n, -1).contiguous()
-                lg = eng.head_slice(rows, text_vocab_size, self.vocab_size - 1).reshape(R, n, -1)
+                lg = (self._img_head(rows) if gen else eng.head_slice(rows, text_vocab_size, self.vocab_size - 1)).reshape(R, n, -1)
+            elif gen:
+                seq = torch.cat([prefix, img, suffix], 1)
+                hn = self.llm.model(inputs_embeds=seq, attention_mask=attention_mask).last_hidden_state
+                lg = self._img_head(hn[:, -(n + 1):-1].contiguous())
             else:
                 seq = torch.cat([prefix, img, suffix], 1)
                 out = self(input_ids=input_ids, input_embeddings=seq, attention_mask=attention_mask)
@@ -447,10 +530,10 @@ class UniGen(ModelMixin, ConfigMixin):
             u_dev = lg.device if generator is None else generator.device
             u = torch.rand((2, bsz, n), device=u_dev, generator=generator).to(lg.device)
             sampled_ids, cur_ids, next_ids = ops.maskgit_step(lg.contiguous(), bsz, n, cfg, guidance_scale, u[0], u[1], cur_ids,
-                                                              mask_token_id, text_vocab_size, mask_len, temperature)
+                                                              mask_token_id, 0 if gen else text_vocab_size, mask_len, temperature)
             if trace is not None:                        # parity tests follow the trajectory round by round
                 trace.append((sampled_ids.clone(), next_ids.clone()))
-            image_embeddings = embed(next_ids)
+            image_embeddings = self.get_gen_embed(next_ids).to(input_embeddings.dtype) if gen else embed(next_ids)
         return sampled_ids
 
     # ------------------------------------------------------------------ autoregressive generation
@@ -473,6 +556,9 @@ class UniGen(ModelMixin, ConfigMixin):
         only works when both embedding tensors are supplied; ids are accepted here too
         and embedded, which is what its callers intend."""
         from unigen_hip.qwen2 import DecodeState
+        if self._use_gen():
+            raise UniGenHipError("t2i_generate_ar with gen_proj_depth > 0 (img_head / gen_projector per step, reference :487-498,"
+                                 "513-515) is not implemented; the training forward and t2i_generate are")
         n = image_token_num_per_image
         embed = self.llm.model.embed_tokens
         eng = self.llm.engine

@@ -461,6 +461,47 @@ class TrainEngine(Qwen2Engine):
         return self._mask_cache[1]
 
 
+# ------------------------------------------------------------------------------------ generic table lookup / CE (gen_projector path)
+class _TableEmbedFn(torch.autograd.Function):
+    """rows of an ordinary fp32 embedding table (UniGen.gen_embed, reference models/unigen.py:76,82) on the embedding
+    kernels; the gradient is scatter-added into a dense table gradient like torch's nn.Embedding."""
+
+    @staticmethod
+    def forward(ctx, weight, ids, err_flag):
+        flat = ids.reshape(-1).contiguous()
+        out = ops.embed_fwd(flat, weight.detach().float().contiguous(), err_flag)
+        ctx.ids, ctx.shape = flat, tuple(weight.shape)
+        return out.view(*ids.shape, weight.shape[1])
+
+    @staticmethod
+    def backward(ctx, dout):
+        dW = torch.zeros(ctx.shape, dtype=torch.float32, device=dout.device)
+        ops.embed_bwd(ctx.ids, dout.reshape(-1, ctx.shape[1]).float().contiguous(), dW)
+        return dW, None, None
+
+
+class _CrossEntropyFn(torch.autograd.Function):
+    """F.cross_entropy(logits [R, V] bf16, labels [R], ignore_index=-100), mean over the kept rows, on the CE kernels
+    (img_head logits of the gen_projector path, reference models/unigen.py:301-311)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        R, V = logits.shape
+        lg = torch.empty((R, ops.round_up(V, 8)), dtype=torch.bfloat16, device=logits.device)      # 16-byte rows for the kernel
+        lg[:, :V] = logits
+        lc, lse, _, _ = ops.ce_fwd(lg, V, labels)
+        ctx.save_for_backward(lg, labels, lse, lc)
+        ctx.in_dtype, ctx.V = logits.dtype, V
+        return lc[0].clone()
+
+    @staticmethod
+    def backward(ctx, dloss):
+        lg, labels, lse, lc = ctx.saved_tensors
+        g = lg.clone()
+        ops.ce_bwd_(g, ctx.V, labels, lse, lc, dloss.float().reshape(1).contiguous())
+        return g[:, :ctx.V].to(ctx.in_dtype), None
+
+
 # ------------------------------------------------------------------------------------ mm_projector
 class _LinearFn(torch.autograd.Function):
     """y = x W^T + b with bf16 operands / fp32 accumulate (what nn.Linear does under the reference's bf16

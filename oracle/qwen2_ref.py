@@ -216,6 +216,58 @@ def unigen_forward_ref(lm, input_ids, attention_mask, labels=None, input_embeddi
     return logits, loss_t2i, loss_lm, loss_mmu
 
 
+class GenHeadRef(nn.Module):
+    """The gen_projector path's extra modules (models/unigen.py:74-90): gen_embed (codebook + 1 rows), gen_projector
+    (Linear -> GELU -> Linear ...), img_head (hidden -> codebook, no bias).  State-dict keys as in the reference."""
+
+    def __init__(self, hidden, codebook, depth=2, use_gen_dim=False, gen_input_dim=16):
+        super().__init__()
+        if use_gen_dim:
+            self.gen_embed = nn.Embedding(codebook + 1, gen_input_dim)
+            mods, width = [nn.Linear(gen_input_dim, hidden)], hidden
+        else:
+            self.gen_embed = nn.Embedding(codebook + 1, hidden)
+            mods, width = [nn.Linear(hidden, hidden * 2)], hidden * 2
+        for _ in range(1, depth):
+            mods += [nn.GELU(), nn.Linear(width, hidden)]
+            width = hidden
+        self.gen_projector = nn.Sequential(*mods)
+        self.img_head = nn.Linear(hidden, codebook, bias=False)
+
+
+def unigen_forward_gen_ref(lm, gen, input_ids, attention_mask, labels=None, batch_size_t2i=0, batch_size_lm=0,
+                           batch_size_mmu=0, num_vq_tokens=256, t2i_mode="mask", autocast=True):
+    """UniGen.forward, gen_proj_depth > 0 branch (models/unigen.py:255-270, 301-341): image slots embedded by
+    gen_projector(gen_embed(raw codes)), img_head on the t2i rows, tied lm_head on the remaining rows."""
+    n, bt = num_vq_tokens, batch_size_t2i
+    V, C = lm.cfg.vocab_size, gen.img_head.out_features
+    with autocast_ctx(autocast):
+        emb = lm.model.embed_tokens(input_ids)
+        img = gen.gen_projector(gen.gen_embed(input_ids[:, -(n + 1):-1].contiguous()))
+        emb = torch.cat([emb[:, :-(n + 1)], img.to(emb.dtype), emb[:, -1:]], 1)        # = the in-place slot assignment
+        hidden = lm.backbone(None, emb, attention_mask)
+        img_logits = gen.img_head(hidden[:bt])
+        if labels is None:
+            return img_logits.float() if autocast else img_logits
+        logits = lm.lm_head(hidden[bt:])
+        if t2i_mode == "mask":
+            loss_t2i = F.cross_entropy(img_logits[:, -(n + 1):-1].contiguous().view(-1, C),
+                                       labels[:bt, -(n + 1):-1].contiguous().view(-1), ignore_index=-100)
+        else:
+            loss_t2i = F.cross_entropy(img_logits[:, -(n + 2):-1].contiguous().view(-1, C),
+                                       labels[:bt, -(n + 1):].contiguous().view(-1), ignore_index=-100)
+        loss_lm = 0.0
+        if batch_size_lm > 0:
+            loss_lm = F.cross_entropy(logits[:batch_size_lm, :-1].contiguous().view(-1, V),
+                                      labels[bt:bt + batch_size_lm, 1:].contiguous().view(-1), ignore_index=-100)
+        loss_mmu = 0.0
+        if batch_size_mmu > 0:
+            loss_mmu = F.cross_entropy(logits[-batch_size_mmu:, :-1].contiguous().view(-1, V),
+                                       labels[-batch_size_mmu:, 1:].contiguous().view(-1), ignore_index=-100)
+    f = (lambda t: t.float() if torch.is_tensor(t) else t) if autocast else (lambda t: t)
+    return f(img_logits), f(loss_t2i), f(loss_lm), f(loss_mmu)
+
+
 def ar_generate_ref(lm, cond_embeds, uncond_embeds, n_tokens, guidance_scale, text_vocab, key_valid=None, autocast=True):
     """Greedy (argmax) version of UniGen.t2i_generate_ar (models/unigen.py:457-521): prefix = embeddings with the
     last n+1 positions already cut off; KV cache grown by concatenation like DynamicCache; CFG

@@ -127,3 +127,22 @@ def test_generation_oracles_match_reference_trajectories():
         mask = host_ref.to_additive(mm["mask_allow"]).to(torch.float32)
         toks, _ = qwen2_ref.mmu_generate_ref(lm, idx=mm["idx"], attention_mask=mask, max_new_tokens=mm["max_new_tokens"], autocast=ac)
         assert toks == mm[mode]["tokens"].tolist() and len(set(toks)) > 6
+
+
+def test_gen_projector_oracle_matches_reference():
+    """G12: unigen_forward_gen_ref vs the real reference built with gen_proj_depth = 2."""
+    from oracle import host_ref, qwen2_ref, weights
+    g = golden("g12_gen_head.pt")
+    cfg = qwen2_ref.Qwen2Cfg(**g["cfg"])
+    mask = host_ref.to_additive(g["mask_allow"]).float()
+    kw = {k: v for k, v in g["kw"].items() if k != "max_seq_length"}
+    for use_dim in (False, True):
+        lm = qwen2_ref.RefCausalLM(cfg)
+        gen = qwen2_ref.GenHeadRef(g["cfg"]["hidden_size"], g["codebook"], depth=2, use_gen_dim=use_dim, gen_input_dim=16)
+        names = [("llm." + k, tuple(p.shape)) for k, p in lm.named_parameters()] + [(k, tuple(p.shape)) for k, p in gen.named_parameters()]
+        sd = weights.synth_llm_state(names, seed=g["weight_seed"], std=0.05)
+        lm.load_state_dict({k[4:]: v for k, v in sd.items() if k.startswith("llm.")}, strict=False)
+        gen.load_state_dict({k: v for k, v in sd.items() if not k.startswith("llm.")})
+        lo, r1, _, _ = qwen2_ref.unigen_forward_gen_ref(lm, gen, g["input_ids"], mask, g["labels"], autocast=True, **kw)
+        want = g[f"dim{int(use_dim)}"]
+        assert torch.equal(lo.to(torch.bfloat16), want["img_logits"]) and r1.item() == want["loss"].item()

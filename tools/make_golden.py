@@ -615,3 +615,66 @@ def golden_mmu_inputs():
 
 if __name__ == "__main__" and "mmu_inputs" in sys.argv[1:]:
     golden_mmu_inputs()
+
+
+# ------------------------------------------------------------------ G12: gen_projector path (models/unigen.py:74-92,255-270)
+def golden_gen_head():
+    """The real reference UniGen built with gen_proj_depth = 2 (both use_gen_dim settings): mixed t2i + lm + mmu batch,
+    forward + backward under bf16 autocast; the oracle (unigen_forward_gen_ref) must be bit-identical."""
+    from models import UniGen
+    g2 = torch.load(os.path.join(OUT, "g2_tiny_unigen.pt"), weights_only=False)
+    cfgd, ids = g2["cfg"], g2["ids"]
+    V, TV, CB, n = cfgd["vocab_size"], ids["text_vocab"], 20, 16
+    cfg = qwen2_ref.Qwen2Cfg(**cfgd)
+    d = ref_shims.write_llm_config_dir(cfg.to_hf_dict())
+    out = {"cfg": cfgd, "weight_seed": 77, "ids": ids, "codebook": CB, "n": n}
+    # the G2 batch with the image slots rewritten as RAW codes (mask id = codebook_size) and raw-code labels
+    inp, lab = g2["input_ids"].clone(), g2["labels"].clone()
+    bt = g2["kw"]["batch_size_t2i"]
+    slot = inp[:bt, -(n + 1):-1]
+    inp[:bt, -(n + 1):-1] = torch.where(slot == ids["mask"], CB, slot - TV)
+    ls = lab[:bt, -(n + 1):-1]
+    lab[:bt, -(n + 1):-1] = torch.where(ls == -100, -100, ls - TV)
+    # t2i rows only: the reference applies gen_embed to the last n+1 slots of EVERY row of the batch (:258-259), so a row
+    # whose slots hold text ids (lm / mmu rows) indexes past its codebook_size + 1 table -- the path only runs on pure t2i batches
+    inp, lab, allow = inp[:bt], lab[:bt], g2["mask_allow"][:bt]
+    mask = host_ref.to_additive(allow).float()
+    kw = dict(g2["kw"], batch_size_lm=0, batch_size_mmu=0)
+    out.update(input_ids=inp, labels=lab, mask_allow=allow, kw=kw)
+    for use_dim in (False, True):
+        torch.manual_seed(0)
+        model = UniGen(w_und_encoder=False, vocab_size=V, llm_vocab_size=TV, llm_model_path=d, codebook_size=CB, num_vq_tokens=n,
+                       load_from_pretrained=True, gen_proj_depth=2, use_gen_dim=use_dim, gen_input_dim=16).train()
+        assert model.config.mask_token_id == CB
+        names = [(k, tuple(p.shape)) for k, p in model.named_parameters()]
+        sd = weights.synth_llm_state(names, seed=77, std=0.05)
+        res = model.load_state_dict(sd, strict=False)
+        assert not res.unexpected_keys
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            img_logits, l1, l2, l3 = model(input_ids=inp, attention_mask=mask, labels=lab, **kw)
+        l1.float().backward()
+        grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+        lm = qwen2_ref.RefCausalLM(cfg)
+        lm.load_state_dict({k[4:]: v for k, v in sd.items() if k.startswith("llm.")}, strict=False)
+        gen = qwen2_ref.GenHeadRef(cfgd["hidden_size"], CB, depth=2, use_gen_dim=use_dim, gen_input_dim=16)
+        gen.load_state_dict({k: v for k, v in sd.items() if not k.startswith("llm.")})
+        okw = {k: v for k, v in kw.items() if k != "max_seq_length"}
+        o_logits, r1, r2, r3 = qwen2_ref.unigen_forward_gen_ref(lm, gen, inp, mask, lab, autocast=True, **okw)
+        r1.backward()
+        gd = max(maxdiff(grads[k], p.grad) for k, p in list(gen.named_parameters()) + [("llm." + k, p) for k, p in lm.named_parameters()]
+                 if k in grads)
+        print(f"G12[use_gen_dim={use_dim}] oracle vs reference: img_logits {maxdiff(o_logits, img_logits):.3e} losses "
+              f"{abs(r1.item() - l1.item()):.1e} grads {gd:.3e}")
+        assert maxdiff(o_logits, img_logits) == 0 and gd == 0, "oracle gen branch is not bit-identical to the reference"
+        out[f"dim{int(use_dim)}"] = {"img_logits": img_logits.detach().to(torch.bfloat16),
+                                     "loss": l1.detach().float(),
+                                     "grads_gen_head": {k: (v if v.numel() <= 8192 else v[:4].clone()) for k, v in grads.items()
+                                                        if not k.startswith("llm.")},
+                                     "grad_norms_gen": {k: v.norm().item() for k, v in grads.items() if not k.startswith("llm.")},
+                                     "grad_norms_llm": {k: v.norm().item() for k, v in grads.items() if k.startswith("llm.")}}
+    torch.save(out, os.path.join(OUT, "g12_gen_head.pt"))
+    print("G12 gen_projector path: captured")
+
+
+if __name__ == "__main__" and "gen_head" in sys.argv[1:]:
+    golden_gen_head()
