@@ -117,20 +117,21 @@ int ug_attn_mask_compress(const void* mask, int mask_dtype, int64_t stride_b, in
                           hipStream_t stream);
 int ug_attn_mask_causal(const uint8_t* key_valid /* [B,L] or null */, uint64_t* bits, uint8_t* tileany,
                         int64_t B, int64_t L, hipStream_t stream);
-/* in rows (b*L+t), C columns at stride ld  ->  out[b][c][t], t zero-padded to Lp (multiple of 64) */
+/* in rows (b*L+t), C columns at stride ld  ->  out[b][c][t], t zero-padded to Lp (multiple of 64).  (No attention kernel
+ * needs it any more -- they transpose in LDS with ds_read_b64_tr_b16; kept as a utility.) */
 int ug_attn_transpose(const void* in, int64_t ld, void* out, int64_t B, int64_t L, int64_t Lp, int64_t C,
                       hipStream_t stream);
 /* replaces: torch SDPA in Qwen2Attention.forward (modeling_qwen2.py:196-234), GQA H:HKV, head_dim 128.
- * q/k/v: row (b*L+t), head h at column h*128, row stride ldq.  vT: [B][HKV*128][Lp].
+ * q/k/v: row (b*L+t), head h at column h*128, row stride ldq.
  * o: [tokens, ldo] bf16, lse: [B][H][L] fp32. */
-int ug_attn_fwd(const void* q, const void* k, const void* v, int64_t ldq, const void* vT, void* o,
+int ug_attn_fwd(const void* q, const void* k, const void* v, int64_t ldq, void* o,
                 int64_t ldo, float* lse, const uint64_t* bits, const uint8_t* tileany, int64_t B, int64_t L,
                 int64_t Lp, int H, int HKV, int head_dim, float scale, hipStream_t stream);
 /* dq/dk/dv written with row stride ldg (heads laid out like q/k/v); delta: [B][H][L] workspace.
  * dkv_ws: optional fp32 [B*L][2*HKV*128] workspace, ZERO on entry and left zero: dK/dV are then accumulated per query
  * head (6x the workgroups, balanced under causal masks) with fp32 atomics; null -> per-kv-head kernel, no atomics. */
-int ug_attn_bwd(const void* q, const void* k, const void* v, int64_t ldq, const void* qT, const void* kT,
-                const void* o, const void* dout, int64_t ldo, const void* doT, const float* lse,
+int ug_attn_bwd(const void* q, const void* k, const void* v, int64_t ldq,
+                const void* o, const void* dout, int64_t ldo, const float* lse,
                 float* delta, void* dq, void* dk, void* dv, int64_t ldg, const uint64_t* bits,
                 const uint8_t* tileany, int64_t B, int64_t L, int64_t Lp, int H, int HKV, int head_dim,
                 float scale, float* dkv_ws, hipStream_t stream);

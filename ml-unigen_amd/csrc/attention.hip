@@ -10,18 +10,21 @@
 // axis, mfma_f32_16x16x32_bf16.  Scores are produced TRANSPOSED (rows = the streamed axis) so that
 // each lane owns one query (resp. key) column: row statistics are lane-local plus two shuffles, and
 // the probabilities feed the second MFMA as a B operand straight from registers.  The second
-// contraction needs the streamed operand k-major; those come from pre-transposed global copies
-// (ug_attn_transpose) -- 16-byte loads all the way, no in-kernel transposes.
+// contraction needs the streamed operand k-major: its fragments are read from the SAME row-major LDS
+// tile with the hardware transposing read (ds_read_b64_tr_b16), so every operand is staged once, row-major,
+// with 16-byte loads, and no transposed copy exists in HBM or LDS.
 #include "common.h"
 #include "unigen_hip.h"
 
 namespace {
 
 constexpr int HD = 128;      // head_dim
-constexpr int RM_LD = 136;   // LDS row stride (elements) of a row-major [64][128] tile
-constexpr int TR_LD = 72;    // LDS row stride (elements) of a transposed [128][64] tile
-constexpr int RM_BYTES = 64 * RM_LD * 2;    // 17408
-constexpr int TR_BYTES = 128 * TR_LD * 2;   // 18432
+// LDS row stride (elements) of a row-major [64][128] tile: 288 B = 8 banks past a multiple of the 64-bank row, so the
+// 16 rows x 16 B of a ds_read_b128 fragment fetch and the 8 rows x 32 B a ds_read_b64_tr_b16 half-wave touches both
+// fall on distinct banks
+constexpr int RM_LD = 144;
+constexpr int RM_BYTES = 64 * RM_LD * 2;    // 18432
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 
 // ------------------------------------------------------------------ mask compression
 template <typename T> __device__ __forceinline__ bool mask_attend(T v, int* err);
@@ -213,31 +216,22 @@ __device__ __forceinline__ void stage_rm(bf16_t* dst, const bf16_t* src_seq, int
     *reinterpret_cast<bf16x8_t*>(dst + r * RM_LD + ch * 8) = v;
   }
 }
-// transposed tile: 128 rows (d) x 64 cols from a [128][Lp] global slab starting at column col_first
-__device__ __forceinline__ void stage_tr(bf16_t* dst, const bf16_t* srcT, int Lp, int col_first, int tid) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = tid + i * 256;
-    const int r = c >> 3, ch = c & 7;
-    const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(srcT + (int64_t)r * Lp + col_first + ch * 8);
-    *reinterpret_cast<bf16x8_t*>(dst + r * TR_LD + ch * 8) = v;
-  }
-}
 // MFMA A-fragment (16 rows x 32 k) from a row-major tile: rows rb*16.., k-step ks
 __device__ __forceinline__ bf16x8_t frag_rm(const bf16_t* t, int rb, int ks, int lane) {
   return *reinterpret_cast<const bf16x8_t*>(t + (rb * 16 + (lane & 15)) * RM_LD + ks * 32 + (lane >> 4) * 8);
 }
-// MFMA A-fragment (16 rows x 32 k) from a transposed tile, k index mapped as
-// slot s of lane-group g  <->  column  jp*32 + (s>>2)*16 + g*4 + (s&3)   (matches the C-layout of
-// two adjacent 16-wide score blocks, so probabilities feed the B operand without a shuffle)
-__device__ __forceinline__ bf16x8_t frag_tr(const bf16_t* t, int rb, int jp, int lane) {
-  const bf16_t* p = t + (rb * 16 + (lane & 15)) * TR_LD + jp * 32 + (lane >> 4) * 4;
-  const bf16x4_t lo = *reinterpret_cast<const bf16x4_t*>(p);
-  const bf16x4_t hi = *reinterpret_cast<const bf16x4_t*>(p + 16);
-  bf16x8_t r;
-  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-  return r;
+// MFMA A-fragment (16 rows x 32 k) of the TRANSPOSE of a row-major tile t[64 streamed rows][128 d]: fragment rows are
+// d = rb*16 .. rb*16+15, the contraction runs over the tile's rows with the k index mapped as
+// slot s of lane-group g  <->  tile row  jp*32 + (s>>2)*16 + g*4 + (s&3)   (matches the C-layout of two adjacent 16-wide
+// score blocks, so probabilities feed the B operand without a shuffle).  ds_read_b64_tr_b16: within a 16-lane group the
+// lanes 4j..4j+3 address the four 8-byte pieces of tile row j (16 d values), and lane i receives column i of that 4 x 16
+// block -- the four streamed rows of d = rb*16 + i.
+__device__ __forceinline__ bf16x8_t frag_trr(const bf16_t* t, int rb, int jp, int lane) {
+  const int i16 = lane & 15, g = lane >> 4;
+  const bf16_t* p0 = t + (jp * 32 + g * 4 + (i16 >> 2)) * RM_LD + rb * 16 + (i16 & 3) * 4;
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p0);
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p0 + 16 * RM_LD));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 __device__ __forceinline__ bf16x8_t pack_p(const f32x4_t& a, const f32x4_t& b) {
   bf16x8_t r;
@@ -265,8 +259,6 @@ __device__ __forceinline__ float group_sum(float v) { v += __shfl_xor(v, 16, 64)
 
 struct AttnArgs {
   const bf16_t* q; const bf16_t* k; const bf16_t* v;   // row (b*L+t), head h at +h*128 ; row stride ldq
-  const bf16_t* kT; const bf16_t* vT;                  // [B][HKV*128][Lp]
-  const bf16_t* qT; const bf16_t* doT;                 // [B][H*128][Lp]
   bf16_t* o; const bf16_t* dout;                       // [tokens, ldo]
   bf16_t* dq; bf16_t* dk; bf16_t* dv;                  // row stride ldg
   float* dkv_ws;                                       // [tokens][2*HKV*128] fp32, split-head dK/dV accumulation (or null)
@@ -281,7 +273,7 @@ struct AttnArgs {
 // grid (nQtiles, H, B)
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * RM_LD];
-  __shared__ __attribute__((aligned(16))) bf16_t Vt[128 * TR_LD];
+  __shared__ __attribute__((aligned(16))) bf16_t Vs[64 * RM_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
   const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int hk = h / (p.H / p.HKV);
@@ -289,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   const int qrow_c = min(qrow, p.L - 1);
   const bf16_t* qseq = p.q + (int64_t)b * p.L * p.ldq + h * HD;
   const bf16_t* kseq = p.k + (int64_t)b * p.L * p.ldq + hk * HD;
-  const bf16_t* vTs = p.vT + ((int64_t)b * p.HKV + hk) * HD * p.Lp;
+  const bf16_t* vseq = p.v + (int64_t)b * p.L * p.ldq + hk * HD;
 
   bf16x8_t qf[4];
 #pragma unroll
@@ -307,7 +299,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     if (!tany[t]) continue;                                     // uniform per block
     __syncthreads();
     stage_rm(Ks, kseq, p.ldq, t * 64, p.L, tid);
-    stage_tr(Vt, vTs, p.Lp, t * 64, tid);
+    stage_rm(Vs, vseq, p.ldq, t * 64, p.L, tid);     // rows past L repeat the last key: their probabilities are exact zeros
     __syncthreads();
 
     f32x4_t st[4];
@@ -346,8 +338,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
     const bf16x8_t pf0 = pack_p(st[0], st[1]), pf1 = pack_p(st[2], st[3]);
 #pragma unroll
     for (int d = 0; d < 8; ++d) {
-      ot[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(Vt, d, 0, lane), pf0, ot[d], 0, 0, 0);
-      ot[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(Vt, d, 1, lane), pf1, ot[d], 0, 0, 0);
+      ot[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_trr(Vs, d, 0, lane), pf0, ot[d], 0, 0, 0);
+      ot[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_trr(Vs, d, 1, lane), pf1, ot[d], 0, 0, 0);
     }
   }
   if (qrow < p.L) {
@@ -367,7 +359,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
   __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * RM_LD];
   __shared__ __attribute__((aligned(16))) bf16_t Vs[64 * RM_LD];
-  __shared__ __attribute__((aligned(16))) bf16_t Kt[128 * TR_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
   const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int hk = h / (p.H / p.HKV);
@@ -377,7 +368,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
   const bf16_t* kseq = p.k + (int64_t)b * p.L * p.ldq + hk * HD;
   const bf16_t* vseq = p.v + (int64_t)b * p.L * p.ldq + hk * HD;
   const bf16_t* doseq = p.dout + (int64_t)b * p.L * p.ldo + h * HD;
-  const bf16_t* kTs = p.kT + ((int64_t)b * p.HKV + hk) * HD * p.Lp;
 
   bf16x8_t qf[4], dof[4];
 #pragma unroll
@@ -412,7 +402,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
     __syncthreads();
     stage_rm(Ks, kseq, p.ldq, t * 64, p.L, tid);
     stage_rm(Vs, vseq, p.ldq, t * 64, p.L, tid);
-    stage_tr(Kt, kTs, p.Lp, t * 64, tid);
     __syncthreads();
     const uint64_t word = wrow[t];
     const uint32_t mlo = (uint32_t)(word >> (g * 4)), mhi = (uint32_t)(word >> (32 + g * 4));   // bit 16 (j & 1) + r
@@ -435,8 +424,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
     const bf16x8_t sf0 = pack_p_sw(ds[0], ds[1]), sf1 = pack_p_sw(ds[2], ds[3]);
 #pragma unroll
     for (int d = 0; d < 8; ++d) {
-      dqt[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(Kt, d, 0, lane), sf0, dqt[d], 0, 0, 0);
-      dqt[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(Kt, d, 1, lane), sf1, dqt[d], 0, 0, 0);
+      dqt[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_trr(Ks, d, 0, lane), sf0, dqt[d], 0, 0, 0);
+      dqt[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_trr(Ks, d, 1, lane), sf1, dqt[d], 0, 0, 0);
     }
   }
   if (qrow < p.L) {
@@ -461,8 +450,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
   __shared__ __attribute__((aligned(16))) bf16_t QD[2 * 64 * RM_LD];  // Q rows | dO rows (one array: reused as the
   bf16_t* Qs = QD;                                                    // SPLIT epilogue's fp32 transpose scratch)
   bf16_t* Ds = QD + 64 * RM_LD;
-  __shared__ __attribute__((aligned(16))) bf16_t Qt[128 * TR_LD];
-  __shared__ __attribute__((aligned(16))) bf16_t Dt[128 * TR_LD];    // dO^T
   __shared__ __attribute__((aligned(16))) float lse_s[64], dl_s[64];
   __shared__ uint64_t word_s[64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
@@ -488,15 +475,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
     const int h = hk * grp + hh;
     const bf16_t* qseq = p.q + (int64_t)b * p.L * p.ldq + h * HD;
     const bf16_t* doseq = p.dout + (int64_t)b * p.L * p.ldo + h * HD;
-    const bf16_t* qTs = p.qT + ((int64_t)b * p.H + h) * HD * p.Lp;
-    const bf16_t* doTs = p.doT + ((int64_t)b * p.H + h) * HD * p.Lp;
     for (int qt = 0; qt < p.nW; ++qt) {
       if (!p.tileany[((int64_t)b * p.nW + qt) * p.nW + t]) continue;
       __syncthreads();
       stage_rm(Qs, qseq, p.ldq, qt * 64, p.L, tid);
-      stage_rm(Ds, doseq, p.ldo, qt * 64, p.L, tid);
-      stage_tr(Qt, qTs, p.Lp, qt * 64, tid);
-      stage_tr(Dt, doTs, p.Lp, qt * 64, tid);
+      stage_rm(Ds, doseq, p.ldo, qt * 64, p.L, tid);      // query rows past L repeat the last row: their mask words are 0
       if (tid < 64) {
         const int qr = qt * 64 + tid;
         const bool ok = qr < p.L;
@@ -530,10 +513,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
       const bf16x8_t sf0 = pack_p(ds[0], ds[1]), sf1 = pack_p(ds[2], ds[3]);
 #pragma unroll
       for (int d = 0; d < 8; ++d) {
-        dvt[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(Dt, d, 0, lane), pf0, dvt[d], 0, 0, 0);
-        dvt[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(Dt, d, 1, lane), pf1, dvt[d], 0, 0, 0);
-        dkt[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(Qt, d, 0, lane), sf0, dkt[d], 0, 0, 0);
-        dkt[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_tr(Qt, d, 1, lane), sf1, dkt[d], 0, 0, 0);
+        dvt[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_trr(Ds, d, 0, lane), pf0, dvt[d], 0, 0, 0);
+        dvt[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_trr(Ds, d, 1, lane), pf1, dvt[d], 0, 0, 0);
+        dkt[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_trr(Qs, d, 0, lane), sf0, dkt[d], 0, 0, 0);
+        dkt[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_trr(Qs, d, 1, lane), sf1, dkt[d], 0, 0, 0);
       }
     }
   }
@@ -670,14 +653,14 @@ extern "C" int ug_attn_transpose(const void* in, int64_t ld, void* out, int64_t 
   return UG_OK;
 }
 
-extern "C" int ug_attn_fwd(const void* q, const void* k, const void* v, int64_t ldq, const void* vT, void* o,
+extern "C" int ug_attn_fwd(const void* q, const void* k, const void* v, int64_t ldq, void* o,
                            int64_t ldo, float* lse, const uint64_t* bits, const uint8_t* tileany, int64_t B, int64_t L,
                            int64_t Lp, int H, int HKV, int head_dim, float scale, hipStream_t st) {
   if (int rc = check_common("ug_attn_fwd", B, L, Lp, H, HKV, head_dim, ldq)) return rc;
-  UG_REQUIRE(ug_aligned16(q) && ug_aligned16(k) && ug_aligned16(vT) && ((uintptr_t)o & 7) == 0 && ldo % 4 == 0,
+  UG_REQUIRE(ug_aligned16(q) && ug_aligned16(k) && ug_aligned16(v) && ((uintptr_t)o & 7) == 0 && ldo % 4 == 0,
              "ug_attn_fwd: alignment");
   AttnArgs a{};
-  a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.vT = (const bf16_t*)vT;
+  a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v;
   a.o = (bf16_t*)o; a.lse = lse; a.bits = bits; a.tileany = tileany;
   a.ldq = ldq; a.ldo = ldo; a.B = (int)B; a.L = (int)L; a.Lp = (int)Lp; a.nW = (int)((L + 63) / 64);
   a.H = H; a.HKV = HKV; a.scale = scale;
@@ -686,19 +669,17 @@ extern "C" int ug_attn_fwd(const void* q, const void* k, const void* v, int64_t 
   return UG_OK;
 }
 
-extern "C" int ug_attn_bwd(const void* q, const void* k, const void* v, int64_t ldq, const void* qT, const void* kT,
-                           const void* o, const void* dout, int64_t ldo, const void* doT, const float* lse,
+extern "C" int ug_attn_bwd(const void* q, const void* k, const void* v, int64_t ldq,
+                           const void* o, const void* dout, int64_t ldo, const float* lse,
                            float* delta, void* dq, void* dk, void* dv, int64_t ldg, const uint64_t* bits,
                            const uint8_t* tileany, int64_t B, int64_t L, int64_t Lp, int H, int HKV, int head_dim,
                            float scale, float* dkv_ws, hipStream_t st) {
   if (int rc = check_common("ug_attn_bwd", B, L, Lp, H, HKV, head_dim, ldq)) return rc;
   UG_REQUIRE(ug_aligned16(dkv_ws), "ug_attn_bwd: workspace alignment");
-  UG_REQUIRE(ug_aligned16(q) && ug_aligned16(k) && ug_aligned16(v) && ug_aligned16(qT) && ug_aligned16(kT) &&
-                 ug_aligned16(doT) && ug_aligned16(dout) && ldo % 8 == 0 && ldg % 4 == 0,
+  UG_REQUIRE(ug_aligned16(q) && ug_aligned16(k) && ug_aligned16(v) && ug_aligned16(dout) && ldo % 8 == 0 && ldg % 4 == 0,
              "ug_attn_bwd: alignment");
   AttnArgs a{};
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v;
-  a.qT = (const bf16_t*)qT; a.kT = (const bf16_t*)kT; a.doT = (const bf16_t*)doT;
   a.dout = (const bf16_t*)dout; a.lse = const_cast<float*>(lse); a.delta = delta;
   a.o = const_cast<bf16_t*>((const bf16_t*)o);
   a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.dkv_ws = dkv_ws;

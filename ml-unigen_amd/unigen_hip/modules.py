@@ -521,13 +521,22 @@ class _LinearFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x2, wb = ctx.saved_tensors
-        dy2 = dy.reshape(-1, dy.shape[-1]).to(torch.bfloat16).contiguous()
-        dx = ops.gemm(dy2, wb, b_kmajor=True).view(ctx.shp).to(ctx.in_dtype) if ctx.needs_input_grad[0] else None
-        dw = ops.gemm(dy2, x2, a_kmajor=True, b_kmajor=True, epilogue=ops.UG_EPI_F32)
+        N, K = wb.shape
+        dy2 = dy.reshape(-1, N).to(torch.bfloat16)
+        if N % 8:                 # 16-byte rows for the GEMM's loads: zero-padded columns (they meet zero-page weight rows)
+            pad = torch.zeros((dy2.shape[0], ops.round_up(N, 8)), dtype=torch.bfloat16, device=dy2.device)
+            pad[:, :N] = dy2
+            dy2 = pad
+        else:
+            dy2 = dy2.contiguous()
+        M = dy2.shape[0]
+        dx = (ops.gemm(dy2, wb, M=M, N=K, K=N, b_kmajor=True).view(ctx.shp).to(ctx.in_dtype)
+              if ctx.needs_input_grad[0] else None)
+        dw = ops.gemm(dy2, x2, M=N, N=K, K=M, a_kmajor=True, b_kmajor=True, epilogue=ops.UG_EPI_F32)
         db = None
         if ctx.has_bias:
-            db = torch.zeros(dy2.shape[1], dtype=torch.float32, device=dy2.device)
-            ops.colsum_(dy2, db)
+            db = torch.zeros(N, dtype=torch.float32, device=dy2.device)
+            ops.colsum_(dy2[:, :N], db)
         return dx, dw, db
 
 

@@ -331,10 +331,9 @@ def attn_fwd(qkv, mb, H, HKV, hd, scale=None):
     q = qkv[:, : H * hd]
     k = qkv[:, H * hd: (H + HKV) * hd]
     v = qkv[:, (H + HKV) * hd:]
-    vT = attn_transpose(v, B, L, Lp, HKV * hd)
     o = torch.empty((B * L, H * hd), dtype=torch.bfloat16, device=qkv.device)
     lse = torch.empty((B, H, L), dtype=torch.float32, device=qkv.device)
-    _l.check(_l.load().ug_attn_fwd(_p(q), _p(k), _p(v), qkv.stride(0), _p(vT), _p(o), o.stride(0), _p(lse), _p(mb.bits),
+    _l.check(_l.load().ug_attn_fwd(_p(q), _p(k), _p(v), qkv.stride(0), _p(o), o.stride(0), _p(lse), _p(mb.bits),
                                    _p(mb.tileany), B, L, Lp, H, HKV, hd, scale, _stream()), "ug_attn_fwd")
     return o, lse
 
@@ -358,17 +357,14 @@ def attn_bwd(qkv, o, lse, dout, mb, H, HKV, hd, scale=None, split_heads=True):
     q = qkv[:, : H * hd]
     k = qkv[:, H * hd: (H + HKV) * hd]
     v = qkv[:, (H + HKV) * hd:]
-    qT = attn_transpose(q, B, L, Lp, H * hd)
-    kT = attn_transpose(k, B, L, Lp, HKV * hd)
-    doT = attn_transpose(dout, B, L, Lp, H * hd)
     dqkv = torch.empty_like(qkv)
     dq = dqkv[:, : H * hd]
     dk = dqkv[:, H * hd: (H + HKV) * hd]
     dv = dqkv[:, (H + HKV) * hd:]
     delta = torch.empty((B, H, L), dtype=torch.float32, device=qkv.device)
     ws = _dkv_workspace(B * L, 2 * HKV * hd, qkv.device) if split_heads and H > HKV else None
-    _l.check(_l.load().ug_attn_bwd(_p(q), _p(k), _p(v), qkv.stride(0), _p(qT), _p(kT), _p(o), _p(dout), o.stride(0),
-                                   _p(doT), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), dqkv.stride(0), _p(mb.bits),
+    _l.check(_l.load().ug_attn_bwd(_p(q), _p(k), _p(v), qkv.stride(0), _p(o), _p(dout), o.stride(0),
+                                   _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), dqkv.stride(0), _p(mb.bits),
                                    _p(mb.tileany), B, L, Lp, H, HKV, hd, scale, _p(ws), _stream()), "ug_attn_bwd")
     return dqkv
 
