@@ -305,7 +305,7 @@ def main():
     decay = [p for n, p in model.named_parameters() if "bias" not in n]
     nodecay = [p for n, p in model.named_parameters() if "bias" in n]
     opt = FusedAdamW([{"params": decay, "weight_decay": 0.01}, {"params": nodecay, "weight_decay": 0.0}],
-                     lr=1e-4, betas=(0.9, 0.999), eps=1e-8)
+                     lr=1e-4, betas=(0.9, 0.999), eps=1e-8, overlap=True)     # update runs beside the next batch's tokenisation
     # N > 1: nothing to set up here -- the engine installs the flat-gradient exchange (unigen_hip/ddp.py) by itself on the
     # first backward of a process whose torch.distributed world is larger than one, and leaves the MEAN in the gradients
 

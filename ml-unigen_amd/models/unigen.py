@@ -57,6 +57,7 @@ def _load_llm_config(llm_model_path, ckpt_base_path=""):
 
 
 def _drop_anchor_from_state_dict(module, state_dict, prefix, local_metadata):
+    module.llm.engine.fp.wait_pending_update()             # an overlapped optimizer update must land before anyone reads the tensors
     state_dict.pop(prefix + "_ddp_anchor", None)          # not part of the reference checkpoint format
     return state_dict
 

@@ -28,6 +28,7 @@ class _EmbedFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, ids, engine):
         flat_ids = ids.reshape(-1).contiguous()
+        engine.fp.wait_pending_update()
         out = ops.embed_fwd(flat_ids, engine.fp.p("embed"), engine.err_flag)
         ctx.engine, ctx.ids = engine, flat_ids
         return out.view(*ids.shape, engine.dims.hidden_size)
@@ -36,6 +37,7 @@ class _EmbedFn(torch.autograd.Function):
     def backward(ctx, dout):
         eng = ctx.engine
         eng.begin_grad_pass()
+        eng.fp.ensure_zeroed("embed")
         ops.embed_bwd(ctx.ids, dout.reshape(-1, eng.dims.hidden_size).float().contiguous(), eng.fp.g("embed"))
         if eng.grad_ready_hook:
             eng.grad_ready_hook("embed")
@@ -130,6 +132,7 @@ class _HeadRowsFn(torch.autograd.Function):
         npad = ops.round_up(n, 8)
         dl = torch.zeros((R, npad), dtype=torch.bfloat16, device=dout.device)
         dl[:, :n] = dout
+        eng.fp.ensure_zeroed("embed")
         ops.gemm(dl, ctx.rows, out=eng.fp.g("embed")[v0:v1], M=n, N=H, K=R, a_kmajor=True, b_kmajor=True,
                  epilogue=ops.UG_EPI_F32, beta=1)
         drows = ops.gemm(dl, eng.fp.w("embed")[v0:v1], M=R, N=H, K=n, b_kmajor=True)
@@ -424,6 +427,7 @@ class TrainEngine(Qwen2Engine):
         (`optimizer.zero_grad(set_to_none=True)`, reference training/train.py:793) the flat buffer is
         cleared once and every Parameter gets its persistent grad view back.  The first segment of a backward pass also
         arms the data-parallel exchange and queues its completion on the autograd engine's end-of-backward callbacks."""
+        self.fp.wait_pending_update()
         views = self.__dict__.get("_grad_views", {})
         if any(p.grad is None for p, _ in views.values() if p.requires_grad):
             if all(p.grad is None for p, _ in views.values() if p.requires_grad):

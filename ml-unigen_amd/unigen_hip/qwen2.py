@@ -68,11 +68,14 @@ class FlatParams:
         self.grad = torch.zeros(n, dtype=torch.float32, device=device)
         self.bf16 = torch.zeros(n, dtype=torch.bfloat16, device=device)
         self._seen_version = -1
+        self.pending_update = None                 # event of an optimizer update running on a side stream (FusedAdamW overlap)
         ops.register_bf16_mirror(self)
         # gradients of the big per-layer matrices are written by exactly one GEMM per backward pass: after a
         # zero_grad they are not cleared but marked "fresh", and that GEMM overwrites (beta = 0) instead of adding
         self.fresh = set()
-        self._big = [k for k, shp in self.spec if len(shp) == 2 and k != "embed"]
+        # the tied embedding's gradient is first written by the lm-head weight-gradient GEMM (every vocabulary row), so it is
+        # "fresh" too: 983 MB that are neither zero-filled nor read back; writers that only ADD call ensure_zeroed first
+        self._big = [k for k, shp in self.spec if len(shp) == 2]
         big = set(self._big)
         self._small_runs = []                      # maximal runs of the remaining (small / multi-writer) tensors
         run = None
@@ -97,10 +100,17 @@ class FlatParams:
     def g(self, key):
         return self.view(self.grad, key)
 
+    def wait_pending_update(self):
+        """Order the current stream behind an overlapped optimizer update before it touches weights or gradients."""
+        if self.pending_update is not None:
+            torch.cuda.current_stream().wait_event(self.pending_update)
+            self.pending_update = None
+
     def clear_grads(self):
         """Start of a gradient pass after zero_grad: clear what is accumulated into (embedding, norms, biases) and
         mark the big matrices fresh (their single weight-gradient GEMM overwrites them): 5.2 of the 6.2 GB are never
         zero-filled nor read back."""
+        self.wait_pending_update()
         for lo, hi in self._small_runs:
             self.grad[lo:hi].zero_()
         self.fresh = set(self._big)
@@ -111,6 +121,13 @@ class FlatParams:
             self.fresh.discard(key)
             return 0
         return 1
+
+    def ensure_zeroed(self, key):
+        """For writers that accumulate into part of `key` (embedding scatter-add, a vocabulary slice of the head): if no
+        full overwrite has happened yet in this pass, clear it now."""
+        if key in self.fresh:
+            self.fresh.discard(key)
+            self.g(key).zero_()
 
     def flush_fresh(self):
         """End of the backbone's backward: a matrix that received no gradient in this pass must read as zero."""
@@ -124,6 +141,7 @@ class FlatParams:
     def refresh_compute_copies(self, force=False):
         """bf16 compute copy of the fp32 master weights (one HBM pass per optimizer step; dgrad / wgrad read
         the same copy through the GEMM's k-major operand mode, so no transposed copies exist)."""
+        self.wait_pending_update()
         ver = self.master._version
         if not force and ver == self._seen_version:
             return
@@ -311,7 +329,7 @@ class Qwen2Engine:
         R = hn_rows.shape[0]
         # dW[V,H] += dlogits^T hn : both k-major over the R selected rows (dlogits' leading dim is vocab_pad)
         ops.gemm(dlogits, hn_rows, out=fp.g("embed"), M=d.vocab_size, N=d.hidden_size, K=R, a_kmajor=True, b_kmajor=True,
-                 epilogue=ops.UG_EPI_F32, beta=1)
+                 epilogue=ops.UG_EPI_F32, beta=fp.beta_for("embed"))
         # dhn[R,H] = dlogits[R,V] W[V,H] : W read k-major; its rows >= V come from the zero page and the
         # dlogits pad columns are zero (ug_ce_bwd), so K = V needs no padding
         return ops.gemm(dlogits, fp.w("embed"), M=R, N=d.hidden_size, K=d.vocab_size, b_kmajor=True)

@@ -468,3 +468,34 @@ def test_gradient_accumulation_and_fresh_write_semantics(dev):
     run()
     for n in names:
         _check("params[n].grad", params[n].grad, once[n], 2e-3)
+
+
+def test_fused_adamw_overlapped_update_is_equivalent(dev):
+    """FusedAdamW(overlap=True) issues the flat-buffer update on a side stream; the engine orders every later weight /
+    gradient access behind it, so three steps (with unrelated work and an optimizer state_dict read in between) leave exactly
+    the weights, moments and losses of the in-stream update."""
+    from unigen_hip.optim import FusedAdamW
+    g = golden("g2_tiny_unigen.pt")
+    mask = additive(g["mask_allow"]).to(dev)
+    ids, labels = g["input_ids"].to(dev), g["labels"].to(dev)
+    results = []
+    for overlap in (False, True):
+        model, _ = _tiny_unigen(g, dev)
+        model.train()
+        opt = FusedAdamW(model.parameters(), lr=1e-3, overlap=overlap)
+        losses = []
+        busy = torch.randn(1024, 1024, device=dev)
+        for step in range(3):
+            _, l1, l2, l3 = model(input_ids=ids, attention_mask=mask, labels=labels, **g["kw"])
+            (l1 + 0.1 * l2 + l3).backward()
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            busy = busy @ busy.t() * 1e-3                       # the "next batch's tokenizer": independent of the backbone
+            losses.append(l1.item())
+        sd = opt.state_dict()
+        m0 = sd["state"][0]["exp_avg"].clone()
+        results.append((losses, {k: v.detach().clone() for k, v in model.state_dict().items()}, m0))
+        assert opt._pending is None or overlap
+    (la, wa, ma), (lb, wb, mb) = results
+    assert la == lb and torch.equal(ma, mb)
+    assert all(torch.equal(wa[k], wb[k]) for k in wa)
