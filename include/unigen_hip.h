@@ -256,6 +256,7 @@ int ug_ce_bwd(void* logits_inout, int64_t ld, int64_t R, int64_t V, const int64_
  * refreshes the bf16 compute copy (p_bf16 may be null).  grads are multiplied by grad_scale first. */
 int ug_adamw_flat(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr,
                   float beta1, float beta2, float eps, float weight_decay, int64_t step, float grad_scale,
+                  int max_blocks /* 0 = fill the chip; > 0 = grid cap for an update overlapped with other kernels */,
                   hipStream_t stream);
 
 /* ---- data-parallel gradient exchange staging ------------------------------------------------ */

@@ -507,13 +507,15 @@ extern "C" int ug_colsum_bf16(const void* in, int64_t ld, float* out, int64_t R,
 
 extern "C" int ug_adamw_flat(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, float lr,
                              float beta1, float beta2, float eps, float weight_decay, int64_t step, float grad_scale,
-                             hipStream_t st) {
+                             int max_blocks, hipStream_t st) {
   UG_REQUIRE(n > 0 && step >= 1, "ug_adamw_flat: n=%ld step=%ld", (long)n, (long)step);
   UG_REQUIRE(ug_aligned16(p) && ug_aligned16(g) && ug_aligned16(m) && ug_aligned16(v) && ((uintptr_t)p_bf16 & 7) == 0,
              "ug_adamw_flat: buffers must be 16B aligned");
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
-  dim3 grid(grid_for(n / 4 + 1)), block(256);
+  // max_blocks > 0: a deliberately small grid (one 4-wave, ~32-register workgroup per CU) for an update that runs on a
+  // side stream beside MFMA-bound kernels -- it leaves the register file and LDS to them and lives off spare HBM bandwidth
+  dim3 grid(max_blocks > 0 ? grid_for(n / 4 + 1, 256, max_blocks) : grid_for(n / 4 + 1)), block(256);
   hipLaunchKernelGGL(adamw_kernel, grid, block, 0, st, p, g, m, v, (bf16_t*)p_bf16, n, lr, beta1, beta2, eps,
                      weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale);
   UG_CHECK_LAUNCH("ug_adamw_flat");

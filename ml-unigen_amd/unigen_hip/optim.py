@@ -31,6 +31,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self._runs = None
         self._step = 0
         self.overlap = bool(overlap)
+        self.overlap_blocks = 256                  # one small workgroup per CU: the overlapped update yields registers / LDS
         self._side = None
         self._pending = None
 
@@ -134,7 +135,8 @@ class FusedAdamW(torch.optim.Optimizer):
                     side_used = True
                 stream = self._side
             rc = lib.ug_adamw_flat(r.p_ptr, g_ptr, r.m.data_ptr(), r.v.data_ptr(), mirror, r.numel, float(g["lr"]), b1, b2,
-                                   g["eps"], g["weight_decay"], self._step, float(grad_scale), stream.cuda_stream)
+                                   g["eps"], g["weight_decay"], self._step, float(grad_scale),
+                                   self.overlap_blocks if stream is not main else 0, stream.cuda_stream)
             ops._l.check(rc, "ug_adamw_flat")
             # the kernel wrote through a raw pointer: bump the (shared) version counter so the engine
             # knows its bf16 compute copies are stale
