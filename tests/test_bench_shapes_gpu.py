@@ -81,6 +81,23 @@ def test_decoder_layer_L771_left_pad_matches_oracle(dev):
     top2 = lo[:, -(n + 1):-1].topk(2, -1).values
     clear = (top2[..., 0] - top2[..., 1]) > 0.05
     assert torch.equal(got.argmax(-1)[clear], lo[:, -(n + 1):-1].argmax(-1)[clear]) and clear.float().mean() > 0.5
+    # north_star's 1e-3 on logits: two bf16 tensors that are roundings of fp32 values 1e-4 apart already differ by ~4e-3 in
+    # relative Frobenius norm (each flipped element moves a full bf16 ulp = 2^-8), so the bar is checked where it is
+    # meaningful -- on the PRE-ROUNDING fp32 logits (head GEMM with the fp32 epilogue on the HIP side, fp32 matmul of the
+    # bf16-rounded operands on the oracle side)
+    from unigen_hip import ops
+    with torch.no_grad():
+        hn_hip = model.llm.model(input_ids=seq.to(dev), attention_mask=mask.to(dev)).last_hidden_state        # bf16 [B, L, H]
+        rows = hn_hip[:, -(n + 1):-1].reshape(-1, hn_hip.shape[-1]).contiguous()
+        E = model.llm.engine.fp.w("embed")
+        pre_hip = ops.gemm(rows, E, epilogue=ops.UG_EPI_F32).cpu()
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            hn_ref = lm.backbone(seq, None, mask)
+        pre_ref = hn_ref[:, -(n + 1):-1].reshape(-1, hn_ref.shape[-1]).to(torch.bfloat16).float() @ \
+            lm.model.embed_tokens.weight.to(torch.bfloat16).float().t()
+    pre = _rel(pre_hip, pre_ref)
+    print(f"[L=771, 25% left pad] pre-rounding fp32 logits rel {pre:.2e} (gate 1e-3); bf16-rounded logits rel {rl:.2e}")
+    assert pre < 1e-3
 
 
 def test_decoder_layer_L1603_mmu_vit_mask_matches_oracle(dev):
