@@ -12,7 +12,7 @@ Memory plan (sized for 288 GB HBM3E, no activation recompute):
     stream, bf16 GEMM operands, fp32 accumulation / statistics / gradients.
 """
 import math
-import os
+
 import types
 
 import torch
@@ -186,9 +186,6 @@ class Qwen2Engine:
         self._rope_cache = {}
         self.err_flag = torch.zeros(1, dtype=torch.int32, device=device)
         self.grad_ready_hook = None      # callable(layer_index | 'embed' | 'norm') fired as grads complete (DDP)
-        self.overlap_wgrad = os.environ.get("UNIGEN_OVERLAP_WGRAD", "1") != "0"     # weight-gradient GEMMs on a side stream
-        self._wgrad_side = None
-        self._wgrad_stream = None
 
     # ---------------------------------------------------------------- helpers
     def rope(self, L):
@@ -278,31 +275,6 @@ class Qwen2Engine:
         return hn
 
     # ---------------------------------------------------------------- backward
-    # Weight gradients are leaves of the backward graph: nothing on the way to the layer input waits for them.  They run on
-    # a side stream, beside the critical path dgrad GEMM -> SwiGLU / RMSNorm / RoPE backward (HBM-bound) -> attention
-    # backward (LDS-bound) -> ..., so the matrix cores keep working while the main stream streams activations.  Each
-    # weight-gradient GEMM waits for the event recorded after its operand was produced; tensors it reads are handed to the
-    # allocator with record_stream so their memory is not reused under it.
-    def _wgrad(self, key, dy, x, after):
-        fp = self.fp
-        beta = fp.beta_for(key)
-        ws = self._wgrad_stream
-        if ws is None:
-            ops.gemm(dy, x, out=fp.g(key), a_kmajor=True, b_kmajor=True, epilogue=ops.UG_EPI_F32, beta=beta)
-            return
-        ws.wait_event(after)
-        dy.record_stream(ws)
-        x.record_stream(ws)
-        with torch.cuda.stream(ws):
-            ops.gemm(dy, x, out=fp.g(key), a_kmajor=True, b_kmajor=True, epilogue=ops.UG_EPI_F32, beta=beta)
-
-    def _mark(self):
-        if self._wgrad_stream is None:
-            return None
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream())
-        return ev
-
     def layer_bwd(self, i, s, dh, mb, L, dh_bf16=None):
         """dh fp32 [M,H]: grad w.r.t. the layer output on entry, w.r.t. the layer input on exit (in place).
         Weight gradients accumulate into the flat fp32 grad buffer.  dh_bf16: bf16(dh) if the producer already has it.
@@ -310,48 +282,37 @@ class Qwen2Engine:
         d, fp = self.dims, self.fp
         Hq, Hk, hd = d.num_attention_heads, d.num_key_value_heads, d.head_dim
         cos, sin = self.rope(L)
+        F32 = ops.UG_EPI_F32
         # ---- MLP   (wgrad: both operands k-major over the token axis; dgrad: weight read k-major)
         dyd = dh_bf16 if dh_bf16 is not None else ops.cast_bf16(dh)
-        self._wgrad(f"l{i}.wdown", dyd, s.act, self._mark())
+        ops.gemm(dyd, s.act, out=fp.g(f"l{i}.wdown"), a_kmajor=True, b_kmajor=True, epilogue=F32, beta=fp.beta_for(f"l{i}.wdown"))
         dact = ops.gemm(dyd, fp.w(f"l{i}.wdown"), b_kmajor=True)
         dgu = ops.swiglu_bwd(s.gu, dact)
-        self._wgrad(f"l{i}.wgu", dgu, s.xn2, self._mark())
+        ops.gemm(dgu, s.xn2, out=fp.g(f"l{i}.wgu"), a_kmajor=True, b_kmajor=True, epilogue=F32, beta=fp.beta_for(f"l{i}.wgu"))
         dxn2 = ops.gemm(dgu, fp.w(f"l{i}.wgu"), b_kmajor=True)
         dyo = ops.rmsnorm_bwd(dxn2, s.h_mid, s.rstd2, fp.p(f"l{i}.ln2"), dh, fp.g(f"l{i}.ln2"), want_bf16=True)
         # ---- attention
-        self._wgrad(f"l{i}.wo", dyo, s.o, self._mark())
+        ops.gemm(dyo, s.o, out=fp.g(f"l{i}.wo"), a_kmajor=True, b_kmajor=True, epilogue=F32, beta=fp.beta_for(f"l{i}.wo"))
         do = ops.gemm(dyo, fp.w(f"l{i}.wo"), b_kmajor=True)
         dqkv = ops.attn_bwd(s.qkv, s.o, s.lse, do, mb, Hq, Hk, hd)
         ops.rope_(dqkv, cos, sin, L, Hq + Hk, hd, backward=True)
         ops.colsum_(dqkv, fp.g(f"l{i}.bqkv"))
-        self._wgrad(f"l{i}.wqkv", dqkv, s.xn1, self._mark())
+        ops.gemm(dqkv, s.xn1, out=fp.g(f"l{i}.wqkv"), a_kmajor=True, b_kmajor=True, epilogue=F32, beta=fp.beta_for(f"l{i}.wqkv"))
         dxn1 = ops.gemm(dqkv, fp.w(f"l{i}.wqkv"), b_kmajor=True)
         dnext = ops.rmsnorm_bwd(dxn1, s.h, s.rstd1, fp.p(f"l{i}.ln1"), dh, fp.g(f"l{i}.ln1"), want_bf16=True)
         return dh, dnext
 
     def stack_bwd(self, saved, h_last, rstd_last, dhn, mb, L):
         """dhn bf16 [M,H] (grad of the final-norm output) -> dh0 fp32 [M,H]."""
-        if self.overlap_wgrad and h_last.is_cuda:
-            if self._wgrad_side is None:
-                self._wgrad_side = torch.cuda.Stream()
-            self._wgrad_stream = self._wgrad_side
-        else:
-            self._wgrad_stream = None
-        ws = self._wgrad_stream
         dh = torch.zeros_like(h_last)
         dh16 = ops.rmsnorm_bwd(dhn, h_last, rstd_last, self.fp.p("norm"), dh, self.fp.g("norm"), want_bf16=True)
         if self.grad_ready_hook:
             self.grad_ready_hook("norm")
         for i in reversed(range(self.dims.num_hidden_layers)):
             dh, dh16 = self.layer_bwd(i, saved[i], dh, mb, L, dh16)
-            saved[i] = None                       # release this layer's activations (record_stream keeps what the side stream reads)
+            saved[i] = None                       # release this layer's activations
             if self.grad_ready_hook:
-                if ws is not None:                # the exchange of this layer's bucket must see its weight gradients
-                    torch.cuda.current_stream().wait_stream(ws)
                 self.grad_ready_hook(i)
-        if ws is not None:
-            torch.cuda.current_stream().wait_stream(ws)
-        self._wgrad_stream = None
         self.fp.flush_fresh()
         return dh
 

@@ -90,7 +90,8 @@ def test_decoder_layer_L771_left_pad_matches_oracle(dev):
         hn_hip = model.llm.model(input_ids=seq.to(dev), attention_mask=mask.to(dev)).last_hidden_state        # bf16 [B, L, H]
         rows = hn_hip[:, -(n + 1):-1].reshape(-1, hn_hip.shape[-1]).contiguous()
         E = model.llm.engine.fp.w("embed")
-        pre_hip = ops.gemm(rows, E, epilogue=ops.UG_EPI_F32).cpu()
+        out32 = torch.empty((rows.shape[0], ops.round_up(V, 4)), dtype=torch.float32, device=dev)
+        pre_hip = ops.gemm(rows, E, out=out32, N=V, epilogue=ops.UG_EPI_F32)[:, :V].cpu()
         with torch.autocast("cpu", dtype=torch.bfloat16):
             hn_ref = lm.backbone(seq, None, mask)
         pre_ref = hn_ref[:, -(n + 1):-1].reshape(-1, hn_ref.shape[-1]).to(torch.bfloat16).float() @ \
