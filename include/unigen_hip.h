@@ -303,6 +303,12 @@ int ug_conv3x3_split(const float* x, const float* x_amax, const uint16_t* w_spli
  * rounded as ug_groupnorm_swish rounds them (common_modules.py:19-27). */
 int ug_groupnorm_stats(const float* x, double* stats_ws, float* mu_rstd, int64_t B, int64_t HW, int C, int groups,
                        float eps, hipStream_t stream);
+/* replaces: SigLipAttention.forward (siglip_encoder.py:196-260): softmax(q k^T * scale) v per (image, head) in one
+ * flash-style kernel, fp32 in / out, both contractions on the scaled two-way f16 split (fp32-accurate), scores never leave
+ * registers.  qkv: rows (b*T + t), q | k | v blocks of H*head_dim columns, row stride ld; qkv_amax: device fp32 bound of
+ * max|qkv| (ug_amax_f32) or null; out [B*T, H*head_dim] at row stride ldo.  head_dim % 4 == 0, <= 80. */
+int ug_siglip_attn_f32(const float* qkv, int64_t ld, const float* qkv_amax, float* out, int64_t ldo, int64_t B, int64_t T,
+                       int H, int head_dim, float scale, hipStream_t stream);
 /* ug_linear_f32 on the same split-f16 contraction (SigLIP q/k/v/out_proj, fc1/fc2: siglip_encoder.py:196-199,
  * 250-259): y = act(x W^T + bias) + residual with W^T packed as ug_conv2d_f32 weights of a 1x1 conv ([1][K][n_pad])
  * and split by ug_conv_split_weights. */

@@ -23,6 +23,7 @@ from unigen_hip import ops
 from unigen_hip.lib import UniGenHipError
 
 _SPLIT_LINEAR = os.environ.get("UNIGEN_CONV_FP32_MFMA", "0") != "1"
+_UNFUSED_ATTN = os.environ.get("UNIGEN_SIGLIP_UNFUSED_ATTN", "0") == "1"      # GEMM -> softmax -> GEMM with materialised scores (round-1 form, A/B)
 _SO400M = dict(hidden_size=1152, intermediate_size=4304, num_hidden_layers=27, num_attention_heads=16, num_channels=3,
                image_size=384, patch_size=14, layer_norm_eps=1e-6, hidden_act="gelu_pytorch_tanh")
 
@@ -210,13 +211,17 @@ class SigLipVisionTower(nn.Module):
 
             lin(xn, 0, wq, bq, out=qkv, M=B * T)
             ctx = torch.empty((B * T, D), dtype=torch.float32, device=h.device)
-            # all heads of all images per launch: batch = (head, image); scores [B, Hh, T, ldS]
-            s = torch.empty((B, Hh, T, ldS), dtype=torch.float32, device=h.device)
-            ops.gemm_f32_nested(qkv[:, 0:D], qkv[:, D:2 * D], s, b_is_nk=True, M=T, N=T, K=hd, batch_in=Hh, batch_out=B,
-                                lda=3 * D, ldb=3 * D, ldc=ldS, sa=(hd, T * 3 * D), sb=(hd, T * 3 * D), sc=(T * ldS, Hh * T * ldS))
-            ops.softmax_rows_(s.view(B * Hh * T, ldS), scale, cols=T)
-            ops.gemm_f32_nested(s, qkv[:, 2 * D:], ctx, b_is_nk=False, M=T, N=hd, K=Tp, batch_in=Hh, batch_out=B, lda=ldS,
-                                ldb=3 * D, ldc=D, sa=(T * ldS, Hh * T * ldS), sb=(hd, T * 3 * D), sc=(hd, T * D))
+            if hd % 4 == 0 and hd <= 80 and not _UNFUSED_ATTN:
+                # one flash-style kernel per layer: scores stay in registers, both contractions on the split-f16 path
+                ops.siglip_attn(qkv, ctx, B, T, Hh, hd, scale)
+            else:
+                # all heads of all images per launch: batch = (head, image); scores [B, Hh, T, ldS]
+                s = torch.empty((B, Hh, T, ldS), dtype=torch.float32, device=h.device)
+                ops.gemm_f32_nested(qkv[:, 0:D], qkv[:, D:2 * D], s, b_is_nk=True, M=T, N=T, K=hd, batch_in=Hh, batch_out=B,
+                                    lda=3 * D, ldb=3 * D, ldc=ldS, sa=(hd, T * 3 * D), sb=(hd, T * 3 * D), sc=(T * ldS, Hh * T * ldS))
+                ops.softmax_rows_(s.view(B * Hh * T, ldS), scale, cols=T)
+                ops.gemm_f32_nested(s, qkv[:, 2 * D:], ctx, b_is_nk=False, M=T, N=hd, K=Tp, batch_in=Hh, batch_out=B, lda=ldS,
+                                    ldb=3 * D, ldc=D, sa=(T * ldS, Hh * T * ldS), sb=(hd, T * 3 * D), sc=(hd, T * D))
             o = l.self_attn.out_proj
             h = lin(ctx, 1, o.weight.detach(), o.bias.detach(), residual=h)
             xn2 = ops.layernorm_f32(h, l.layer_norm2.weight.detach(), l.layer_norm2.bias.detach(), c.layer_norm_eps)

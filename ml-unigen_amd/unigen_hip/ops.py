@@ -744,6 +744,17 @@ def linear_split(x, w_split, n_pad, N, bias=None, residual=None, act=0, out=None
     return out
 
 
+def siglip_attn(qkv, out, B, T, H, hd, scale, qkv_amax=None):
+    """Fused fp32-accurate attention of the SigLIP tower: qkv fp32 [>= B*T, 3*H*hd] (q | k | v), out fp32 [B*T, H*hd];
+    see include/unigen_hip.h: ug_siglip_attn_f32.  qkv_amax: device scalar bounding max|qkv| (measured here if not given)."""
+    _need_cuda(qkv, out)
+    if qkv_amax is None:
+        qkv_amax = amax(qkv[:B * T])
+    _l.check(_l.load().ug_siglip_attn_f32(_p(qkv), qkv.stride(0), _p(qkv_amax), _p(out), out.stride(0), B, T, H, hd, float(scale),
+                                          _stream()), "ug_siglip_attn_f32")
+    return out
+
+
 def layernorm_f32(x2d, gamma, beta, eps):
     y = torch.empty_like(x2d)
     _l.check(_l.load().ug_layernorm_f32(_p(x2d), _p(gamma), _p(beta), _p(y), x2d.shape[0], x2d.shape[1], eps, _stream()),

@@ -1071,3 +1071,26 @@ def test_amax_and_saturating_bound(dev):
     ws, n_pad = ops.split_linear_weight(W.to(dev))
     y = ops.linear_split(x.to(dev), ws, n_pad, N, x_amax=ops.amax_const(4.0, dev)).cpu()
     assert torch.isfinite(y).all() and abs(float(y[1, 1]) - 3.0) < 1e-5 and float(y[0, 0]) < 1.0e6
+
+
+@pytest.mark.parametrize("B,T,H,hd", [(2, 729, 16, 72), (1, 16, 2, 72), (3, 130, 4, 64), (1, 65, 3, 40), (2, 200, 2, 80)])
+def test_siglip_fused_attention_matches_fp64(dev, B, T, H, hd):
+    """ug_siglip_attn_f32 (flash-style, scaled two-way f16 split in both contractions) vs fp64 softmax attention and vs the
+    materialised-scores path (fp32 MFMA GEMM -> row softmax -> GEMM): fp32-level accuracy, ragged last key tile, head_dim
+    not a multiple of 16 or 32, large / small operand magnitudes."""
+    ops = _ops()
+    gen = torch.Generator().manual_seed(B * 1000 + T + hd)
+    D = H * hd
+    for mag in (1.0, 300.0, 1e-3):
+        qkv = torch.randn(B * T, 3 * D, generator=gen) * mag
+        qkv[:, :D] *= 2.0 / mag if mag != 1.0 else 1.0              # keep the scores O(10) so softmax is not degenerate
+        scale = hd ** -0.5 / (mag if mag != 1.0 else 1.0) * (0.5 if mag != 1.0 else 1.0)
+        q = qkv[:, :D].double().view(B, T, H, hd).transpose(1, 2)
+        k = qkv[:, D:2 * D].double().view(B, T, H, hd).transpose(1, 2)
+        v = qkv[:, 2 * D:].double().view(B, T, H, hd).transpose(1, 2)
+        ref = (torch.softmax(q @ k.transpose(-1, -2) * scale, -1) @ v).transpose(1, 2).reshape(B * T, D)
+        out = torch.empty(B * T, D, device=dev)
+        ops.siglip_attn(qkv.to(dev), out, B, T, H, hd, scale)
+        err = (out.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+        print(f"    siglip attn B={B} T={T} H={H} hd={hd} |x|~{mag:g}: max err / max|ref| {err:.2e}")
+        assert err < 3e-6, (mag, err)
