@@ -73,6 +73,15 @@ int ug_transpose_cast(const void* in, int in_f32, int64_t ld_in, void* out, int6
                       int64_t ldT, int64_t R, int64_t C, hipStream_t stream);
 int ug_cast_f32_bf16(const float* in, void* out, int64_t n, hipStream_t stream);
 
+/* replaces: down_proj's input act_fn(gate_proj(x)) * up_proj(x) in Qwen2MLP.forward (modeling_qwen2.py:46-48) as ONE launch:
+ * the gate_up projection of x [M, K] with the fused weight w_gate_up [2I, K] (gate rows, then up rows) whose epilogue also
+ * writes act [M, I] = bf16(bf16(silu(gate)) * up).  gu [M, 2I] = [gate | up] is still written (the backward reads it).  A tile
+ * of the 256x256 kernel takes 128 gate rows and the same hidden units' 128 up rows of the weight, so both values of a hidden
+ * unit meet in one workgroup; values are bit-identical to ug_gemm_bf16 followed by ug_swiglu_fwd, which is also what this
+ * entry runs for shapes the 256x256 kernel is not used for (I % 128 != 0 or fewer than 200 tiles). */
+int ug_gemm_bf16_swiglu(const ug_handle* h, const void* x, int64_t ldx, const void* w_gate_up, int64_t ldw, void* gu,
+                        int64_t ld_gu, void* act, int64_t ld_act, int64_t M, int64_t I, int64_t K, hipStream_t stream);
+
 /* ---- Qwen2 decoder-layer row ops ----------------------------------------------------------- */
 /* replaces: transformers Qwen2RMSNorm.forward (modeling_qwen2.py:246-252) + the autocast bf16 cast
  * of the following Linear's input.  x fp32 [rows,cols]; y bf16 (or fp32 if out_f32); rstd optional. */

@@ -62,6 +62,10 @@ struct GemmArgs {
   float* tail_ws;
   int tail_private;        // 1: every k-slice stores its own [256][256] partial (no atomics); the finisher sums them
   int wide_epilogue;       // 256x256 kernel: LDS-transposed 16-byte stores (0 only for A/B runs, ug_gemm_set_tile_policy(100))
+  // fused SwiGLU (ug_gemm_bf16_swiglu): B = [gate rows | up rows] of the fused weight, I rows each; a tile's 256 columns are
+  // 128 gate columns and the SAME 128 hidden units' up columns; C = gu [M][2I], act [M][I] = bf16(bf16(silu(gate)) * up)
+  int swiglu_I;
+  bf16_t* act; int64_t ld_act;
 };
 
 __device__ __forceinline__ int swz_rowk(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
@@ -276,6 +280,58 @@ __device__ __forceinline__ void store_tile_lds(const GemmArgs& p, f32x4_t (&acc)
   }
 }
 
+// Fused SwiGLU epilogue of the gate_up projection (Qwen2MLP.forward, modeling_qwen2.py:46-48; numerics of swiglu_fwd_kernel:
+// act = bf16(bf16(silu(gate)) * up) on the bf16-ROUNDED gate / up, i.e. bit-identical to the separate kernel).  Waves with
+// wn = 0,1 hold 128 x 64 gate values, the waves wn + 2 of the same row group the up values of the same hidden units.  Per
+// 32-row chunk every wave writes its bf16 strip and stores its own gu piece with 16-byte row-segment stores; after a
+// workgroup barrier the gate waves read their partner's strip next to their own and store the activation.
+__device__ __forceinline__ float silu_gemm(float g) { return g / (1.f + __expf(-g)); }
+#define SW_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+__device__ __forceinline__ void store_tile_swiglu(const GemmArgs& p, f32x4_t (&acc)[8][4], char* lds, int wave, int grp, int wn,
+                                                  int mbase, int hbase /* hidden-unit column of this wave's 64 */, int lane) {
+  char* strip = lds + wave * EP_STRIP;
+  const char* partner = lds + (wave + 2) * EP_STRIP;          // meaningful for the gate waves (wn < 2)
+  const bool gate = wn < 2;
+  const int cbase = gate ? hbase : p.swiglu_I + hbase;         // column of gu
+  bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii) {
+      const int row = ii * 16 + (lane & 15);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4_t v = acc[2 * c + ii][j];
+        uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
+        *reinterpret_cast<uint2*>(strip + row * EP_PITCH_BF16 + (j * 16 + (lane >> 4) * 4) * 2) = o;
+      }
+    }
+    SW_BARRIER();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = q * 8 + (lane >> 3), ch = lane & 7;
+      const int m = mbase + c * EP_ROWS + row;
+      const uint4 mine = *reinterpret_cast<const uint4*>(strip + row * EP_PITCH_BF16 + ch * 16);
+      if (m < p.M) *reinterpret_cast<uint4*>(C + (int64_t)m * p.ldc + cbase + ch * 8) = mine;
+      if (gate) {
+        const uint4 up = *reinterpret_cast<const uint4*>(partner + row * EP_PITCH_BF16 + ch * 16);
+        const uint32_t gw[4] = {mine.x, mine.y, mine.z, mine.w}, uw[4] = {up.x, up.y, up.z, up.w};
+        uint32_t ow[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float g0 = __uint_as_float(gw[e] << 16), g1 = __uint_as_float(gw[e] & 0xffff0000u);
+          const float u0 = __uint_as_float(uw[e] << 16), u1 = __uint_as_float(uw[e] & 0xffff0000u);
+          const float s0 = bf2f(f2bf(silu_gemm(g0))), s1 = bf2f(f2bf(silu_gemm(g1)));
+          ow[e] = pack_bf2(s0 * u0, s1 * u1);
+        }
+        if (m < p.M) *reinterpret_cast<uint4*>(p.act + (int64_t)m * p.ld_act + hbase + ch * 8) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+      }
+    }
+    SW_BARRIER();
+  }
+}
+
 // DBUF = true : two LDS stages (64 KiB, 2 workgroups/CU), next tile's DMA overlaps this tile's MFMAs.
 // DBUF = false: one LDS stage (32 KiB, up to 4 workgroups/CU), overlap comes from the other workgroups.
 template <int EPI, bool AK, bool BKM, bool DBUF>
@@ -376,7 +432,8 @@ struct Stager32 {                // 256-row x 32-k operand tile, 8 waves: 2 one-
   const bf16_t* src[2];
   int64_t step[2];
   int kofs[2];
-  __device__ __forceinline__ void init(const bf16_t* X, int64_t ld, int row0, int rows_total, int wave, int lane) {
+  // split_rows > 0 (row-major only): tile rows 0..127 are operand rows row0.., rows 128..255 are operand rows split_rows + row0..
+  __device__ __forceinline__ void init(const bf16_t* X, int64_t ld, int row0, int rows_total, int wave, int lane, int split_rows = 0) {
     const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -384,7 +441,8 @@ struct Stager32 {                // 256-row x 32-k operand tile, 8 waves: 2 one-
       if constexpr (!KMAJOR) {                 // [256 rows][4 chunks]: 16 rows per instruction
         const int row = inst * 16 + (lane >> 2);
         const int chunk = swz_rowk32(row, lane & 3);
-        const int r = min(row0 + row, rows_total - 1);
+        const int grow = (split_rows > 0 && row >= 128) ? split_rows + row0 + row - 128 : row0 + row;
+        const int r = min(grow, rows_total - 1);
         src[i] = X + (int64_t)r * ld + chunk * 8;
         step[i] = PBK;
         kofs[i] = chunk * 8;
@@ -456,7 +514,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p8(GemmArgs p) {
 
   Stager32<AK> sa; Stager32<BKM> sb;
   sa.init(p.A, p.lda, m0, p.M, wave, lane);
-  sb.init(p.B, p.ldb, n0, p.N, wave, lane);
+  if constexpr (EPI == EPI_BF16 && !AK && !BKM) sb.init(p.B, p.ldb, p.swiglu_I > 0 ? tn * 128 : n0, p.N, wave, lane, p.swiglu_I);
+  else sb.init(p.B, p.ldb, n0, p.N, wave, lane);
 
   f32x4_t acc[8][4];
 #pragma unroll
@@ -534,6 +593,12 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p8(GemmArgs p) {
       }
     }
     return;
+  }
+  if constexpr (EPI == EPI_BF16 && !AK && !BKM) {
+    if (p.swiglu_I > 0) {
+      store_tile_swiglu(p, acc, lds, wave, grp, wn, m0 + grp * 128, tn * 128 + (wn & 1) * 64, lane);
+      return;
+    }
   }
   // interior column panel with 16-byte-addressable rows: wide stores through the (now idle) ring; ragged panels keep the
   // guarded element-wise form
@@ -708,6 +773,7 @@ extern "C" int ug_gemm_bf16(const ug_handle* h, const void* A, int64_t lda, int 
   a.bias = (const bf16_t*)bias; a.resid = resid; a.alpha_dev = alpha_dev;
   a.M = (int)M; a.N = (int)N; a.K = (int)K;
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = ldr; a.beta = beta;
+  a.swiglu_I = 0; a.act = nullptr; a.ld_act = 0;
   a.wide_epilogue = (policy >= 0 && (policy & UG_GEMM_NARROW_EPILOGUE)) ? 0 : 1;
   if (policy >= 0) policy &= ~UG_GEMM_NARROW_EPILOGUE;
   if (policy == UG_GEMM_POLICY_AUTO_BITS) policy = -1;
@@ -727,4 +793,33 @@ extern "C" int ug_gemm_bf16(const ug_handle* h, const void* A, int64_t lda, int 
                    a_kmajor, b_kmajor, epilogue);
       return UG_ERR_ARG;
   }
+}
+
+extern "C" int ug_swiglu_fwd(const void* gate_up, void* act, int64_t tokens, int64_t I, hipStream_t st);
+
+extern "C" int ug_gemm_bf16_swiglu(const ug_handle* h, const void* x, int64_t ldx, const void* w_gate_up, int64_t ldw, void* gu,
+                                   int64_t ld_gu, void* act, int64_t ld_act, int64_t M, int64_t I, int64_t K, hipStream_t stream) {
+  UG_REQUIRE(M > 0 && I > 0 && K > 0 && K % 8 == 0 && I % 8 == 0, "ug_gemm_bf16_swiglu: bad problem M=%ld I=%ld K=%ld", (long)M, (long)I, (long)K);
+  UG_REQUIRE(ldx % 8 == 0 && ldw % 8 == 0 && ld_gu % 8 == 0 && ld_act % 8 == 0 && ldx >= K && ldw >= K && ld_gu >= 2 * I && ld_act >= I,
+             "ug_gemm_bf16_swiglu: row strides must be multiples of 8 elements and cover the rows");
+  UG_REQUIRE(ug_aligned16(x) && ug_aligned16(w_gate_up) && ug_aligned16(gu) && ug_aligned16(act), "ug_gemm_bf16_swiglu: alignment");
+  UG_REQUIRE(M < (1 << 30) && I < (1 << 29) && K < (1 << 30), "ug_gemm_bf16_swiglu: dims too large");
+  const int64_t tiles = ((M + PBM - 1) / PBM) * (2 * I / PBN);
+  if (I % 128 != 0 || tiles < 200) {
+    // shapes the 256x256 kernel is not chosen for: the projection and the activation as two launches (identical values)
+    if (int rc = ug_gemm_bf16(h, x, ldx, 0, w_gate_up, ldw, 0, gu, ld_gu, M, 2 * I, K, EPI_BF16, nullptr, nullptr, 0, 0, nullptr, -1, stream))
+      return rc;
+    UG_REQUIRE(ld_gu == 2 * I && ld_act == I, "ug_gemm_bf16_swiglu: the two-launch form needs packed gu / act rows");
+    return ug_swiglu_fwd(gu, act, M, I, stream);
+  }
+  GemmArgs a{};
+  a.A = (const bf16_t*)x; a.B = (const bf16_t*)w_gate_up; a.C = gu;
+  a.M = (int)M; a.N = (int)(2 * I); a.K = (int)K;
+  a.lda = ldx; a.ldb = ldw; a.ldc = ld_gu;
+  a.tiles_m = (int)((M + PBM - 1) / PBM); a.tiles_n = (int)(2 * I / PBN);
+  a.full_tiles = a.tiles_m * a.tiles_n; a.tail_split = 1; a.tail_private = 1; a.wide_epilogue = 1;
+  a.swiglu_I = (int)I; a.act = (bf16_t*)act; a.ld_act = ld_act;
+  hipLaunchKernelGGL((gemm_kernel_p8<EPI_BF16, false, false>), dim3(a.full_tiles), dim3(512), 0, stream, a);
+  UG_CHECK_LAUNCH("ug_gemm_bf16_swiglu");
+  return UG_OK;
 }

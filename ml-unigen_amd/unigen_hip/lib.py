@@ -24,6 +24,7 @@ SIGNATURES = {
     "ug_create": [P],
     "ug_destroy": [P],
     "ug_gemm_bf16": [P, P, I64, I32, P, I64, I32, P, I64, I64, I64, I64, I32, P, P, I64, I32, P, I32, P],
+    "ug_gemm_bf16_swiglu": [P, P, I64, P, I64, P, I64, P, I64, I64, I64, I64, P],
     "ug_transpose_cast": [P, I32, I64, P, I64, P, I64, I64, I64, P],
     "ug_cast_f32_bf16": [P, P, I64, P],
     "ug_rmsnorm_fwd": [P, P, P, P, I64, I64, F32, I32, P],

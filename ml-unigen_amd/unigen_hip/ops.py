@@ -92,6 +92,26 @@ def gemm(a, b, out=None, *, M=None, N=None, K=None, a_kmajor=False, b_kmajor=Fal
     return out
 
 
+def gemm_swiglu(x, w_gate_up):
+    """x bf16 [M, K], fused weight bf16 [2I, K] (gate rows | up rows) -> (gu bf16 [M, 2I], act bf16 [M, I]): the gate_up
+    projection with the SwiGLU activation written by its epilogue (include/unigen_hip.h: ug_gemm_bf16_swiglu)."""
+    _need_cuda(x, w_gate_up)
+    M, K = x.shape
+    I = w_gate_up.shape[0] // 2
+    gu = torch.empty((M, 2 * I), dtype=torch.bfloat16, device=x.device)
+    act = torch.empty((M, I), dtype=torch.bfloat16, device=x.device)
+    prof = GEMM_PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _l.check(_l.load().ug_gemm_bf16_swiglu(_handle(), _p(x), x.stride(0), _p(w_gate_up), w_gate_up.stride(0), _p(gu), gu.stride(0),
+                                           _p(act), act.stride(0), M, I, K, _stream()), "ug_gemm_bf16_swiglu")
+    if prof is not None:
+        e1.record()
+        prof.append((e0, e1, 2.0 * M * 2 * I * K))
+    return gu, act
+
+
 def set_gemm_tile_policy(policy):
     """Kernel selection passed with every following GEMM call (include/unigen_hip.h: ug_gemm_bf16 `policy`): -1 auto, 0 / 2 =
     128x128 tiles with two / one LDS stages, 3 = staggered 256x256, 6 / 8 = k-sliced forms forced; 100 / 101 switch the 256x256

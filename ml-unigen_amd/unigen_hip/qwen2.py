@@ -212,8 +212,7 @@ class Qwen2Engine:
         o, lse = ops.attn_fwd(qkv, mb, Hq, Hk, hd)
         h_mid = ops.gemm_nt(o, fp.w(f"l{i}.wo"), epilogue=ops.UG_EPI_RESID, resid=h)
         xn2, rstd2 = ops.rmsnorm_fwd(h_mid, fp.p(f"l{i}.ln2"), d.rms_norm_eps)
-        gu = ops.gemm_nt(xn2, fp.w(f"l{i}.wgu"))
-        act = ops.swiglu_fwd(gu)
+        gu, act = ops.gemm_swiglu(xn2, fp.w(f"l{i}.wgu"))           # SwiGLU written by the projection's epilogue
         h_out = ops.gemm_nt(act, fp.w(f"l{i}.wdown"), epilogue=ops.UG_EPI_RESID, resid=h_mid)
         if save is not None:
             s = _Saved()
@@ -269,7 +268,7 @@ class Qwen2Engine:
             o_s = ops.gather_rows(o, sess.rows)
             h_mid = ops.gemm_nt(o_s, fp.w(f"l{i}.wo"), epilogue=ops.UG_EPI_RESID, resid=h)
             xn2, _ = ops.rmsnorm_fwd(h_mid, fp.p(f"l{i}.ln2"), d.rms_norm_eps, want_rstd=False)
-            act = ops.swiglu_fwd(ops.gemm_nt(xn2, fp.w(f"l{i}.wgu")))
+            _, act = ops.gemm_swiglu(xn2, fp.w(f"l{i}.wgu"))
             h = ops.gemm_nt(act, fp.w(f"l{i}.wdown"), epilogue=ops.UG_EPI_RESID, resid=h_mid)
         hn, _ = ops.rmsnorm_fwd(h, fp.p("norm"), d.rms_norm_eps, want_rstd=False)
         return hn

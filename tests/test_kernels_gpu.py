@@ -1094,3 +1094,21 @@ def test_siglip_fused_attention_matches_fp64(dev, B, T, H, hd):
         err = (out.cpu().double() - ref).abs().max().item() / ref.abs().max().item()
         print(f"    siglip attn B={B} T={T} H={H} hd={hd} |x|~{mag:g}: max err / max|ref| {err:.2e}")
         assert err < 3e-6, (mag, err)
+
+
+@pytest.mark.parametrize("M,I,K", [(12336, 8960, 1536), (4000, 4096, 512), (771, 512, 256), (300, 8960, 1536), (5000, 1000, 128)])
+def test_gemm_swiglu_fused_epilogue_is_bit_identical(dev, M, I, K):
+    """ug_gemm_bf16_swiglu (gate_up projection whose epilogue also writes act = bf16(bf16(silu(gate)) * up); a 256x256 tile =
+    128 gate + the same hidden units' 128 up weight rows) against the two-launch form GEMM -> ug_swiglu_fwd: gu and act
+    bit-identical -- fused path (first two shapes: >= 200 tiles, ragged M) and the fallback shapes alike."""
+    ops = _ops()
+    g = torch.Generator(device=dev).manual_seed(M + I)
+    x = (torch.randn(M, K, device=dev, generator=g)).to(torch.bfloat16)
+    w = (torch.randn(2 * I, K, device=dev, generator=g) * (K ** -0.5)).to(torch.bfloat16)
+    gu_ref = ops.gemm(x, w)
+    act_ref = ops.swiglu_fwd(gu_ref)
+    gu, act = ops.gemm_swiglu(x, w)
+    assert gu.shape == (M, 2 * I) and act.shape == (M, I)
+    assert torch.equal(gu, gu_ref) and torch.equal(act, act_ref)
+    ref32 = x.float() @ w.float().t()
+    assert _rel(gu, ref32) < 4e-3
