@@ -92,10 +92,16 @@ def gemm(a, b, out=None, *, M=None, N=None, K=None, a_kmajor=False, b_kmajor=Fal
     return out
 
 
+FUSED_SWIGLU = __import__("os").environ.get("UNIGEN_FUSED_SWIGLU", "1") != "0"
+
+
 def gemm_swiglu(x, w_gate_up):
     """x bf16 [M, K], fused weight bf16 [2I, K] (gate rows | up rows) -> (gu bf16 [M, 2I], act bf16 [M, I]): the gate_up
     projection with the SwiGLU activation written by its epilogue (include/unigen_hip.h: ug_gemm_bf16_swiglu)."""
     _need_cuda(x, w_gate_up)
+    if not FUSED_SWIGLU:                      # A/B switch (UNIGEN_FUSED_SWIGLU=0): projection and activation as two launches
+        gu = gemm(x, w_gate_up)
+        return gu, swiglu_fwd(gu)
     M, K = x.shape
     I = w_gate_up.shape[0] // 2
     gu = torch.empty((M, 2 * I), dtype=torch.bfloat16, device=x.device)
