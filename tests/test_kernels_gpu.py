@@ -1107,7 +1107,11 @@ def test_gemm_swiglu_fused_epilogue_is_bit_identical(dev, M, I, K):
     w = (torch.randn(2 * I, K, device=dev, generator=g) * (K ** -0.5)).to(torch.bfloat16)
     gu_ref = ops.gemm(x, w)
     act_ref = ops.swiglu_fwd(gu_ref)
-    gu, act = ops.gemm_swiglu(x, w)
+    was, ops.FUSED_SWIGLU = ops.FUSED_SWIGLU, True
+    try:
+        gu, act = ops.gemm_swiglu(x, w)
+    finally:
+        ops.FUSED_SWIGLU = was
     assert gu.shape == (M, 2 * I) and act.shape == (M, I)
     assert torch.equal(gu, gu_ref) and torch.equal(act, act_ref)
     ref32 = x.float() @ w.float().t()
