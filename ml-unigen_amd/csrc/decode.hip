@@ -600,7 +600,9 @@ __global__ __launch_bounds__(64) void gemv_ring_kernel(const bf16_t* __restrict_
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const bf16_t* src = W + (int64_t)min((grp0 + t) * 16 + roff[i], N - 1) * ldw + kc[i];
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile[t & 1] + i * 1024), 16, 0, 0);
+      // aux = 2: non-temporal -- every weight byte is read once per step by one CU; leaving it out of the caches shortens
+      // issue -> landed (guide, price list row nt-weights)
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile[t & 1] + i * 1024), 16, 0, 2);
     }
   };
   stage(0);
@@ -672,7 +674,7 @@ __global__ __launch_bounds__(64 * NW) void gemv_ring4_kernel(int R, const bf16_t
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const bf16_t* src = W + (int64_t)min((grp0 + t) * 16 + roff[i], N - 1) * ldw + kc[i];
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile[wave][t & 1] + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile[wave][t & 1] + i * 1024), 16, 0, 2);
     }
   };
   // operand loads of this wave's k-steps go out first, then the weight DMA
