@@ -502,3 +502,66 @@ def test_fused_adamw_overlapped_update_is_equivalent(dev):
     assert max(abs(a - b) for a, b in zip(la, lb)) < 1e-5 and torch.allclose(ma, mb, rtol=1e-4, atol=1e-7)
     bad = {k: (wa[k].float() - wb[k].float()).abs().max().item() for k in wa if not torch.allclose(wa[k], wb[k], rtol=1e-5, atol=1e-6)}
     assert not bad, bad
+
+
+def test_fused_adamw_state_dict_round_trip_and_torch_layout(dev):
+    """the optimizer state must survive the reference's checkpointing (`accelerator.save_state` /
+    utils/checkpoint.py:67-69 save optimizer.state_dict()).  FusedAdamW exports torch.optim.AdamW's layout: a fresh
+    FusedAdamW that loads it continues exactly; a torch.optim.AdamW that loads it takes the same next step; a param group
+    added after the first step keeps the moments of the existing groups."""
+    import copy
+    from unigen_hip.optim import FusedAdamW
+    g = golden("g2_tiny_unigen.pt")
+    mask = additive(g["mask_allow"]).to(dev)
+    ids, labels = g["input_ids"].to(dev), g["labels"].to(dev)
+
+    def grads(model):
+        model.zero_grad(set_to_none=True)
+        _, l1, l2, l3 = model(input_ids=ids, attention_mask=mask, labels=labels, **g["kw"])
+        (l1 + 0.1 * l2 + l3).backward()
+
+    model, _ = _tiny_unigen(g, dev)
+    model.train()
+    named = [(n, p) for n, p in model.named_parameters()]
+    groups = lambda: [{"params": [p for n, p in named if "bias" not in n], "weight_decay": 0.01},
+                      {"params": [p for n, p in named if "bias" in n], "weight_decay": 0.0}]
+    opt = FusedAdamW(groups(), lr=1e-3)
+    for _ in range(2):
+        grads(model)
+        opt.step()
+    sd = copy.deepcopy(opt.state_dict())
+    assert set(sd["state"][0]) >= {"step", "exp_avg", "exp_avg_sq"} and float(sd["state"][0]["step"]) == 2.0
+    w2 = {n: p.detach().clone() for n, p in named}
+    grads(model)                                               # the gradients every continuation below uses
+    gsave = {n: p.grad.detach().clone() for n, p in named}
+    opt.step()
+    want = {n: p.detach().clone() for n, p in named}
+
+    def restore():
+        with torch.no_grad():
+            for n, p in named:
+                p.copy_(w2[n])
+                p.grad = gsave[n].clone() if p.grad is None or p.grad.data_ptr() != gsave[n].data_ptr() else p.grad
+                p.grad.copy_(gsave[n])
+    # (a) a fresh FusedAdamW resumes from the state dict
+    restore()
+    opt2 = FusedAdamW(groups(), lr=1e-3)
+    opt2.load_state_dict(copy.deepcopy(sd))
+    opt2.step()
+    for n, p in named:
+        assert torch.allclose(p, want[n], rtol=1e-6, atol=1e-8), n
+    # (b) torch.optim.AdamW loads the same state dict and takes the same step
+    restore()
+    opt3 = torch.optim.AdamW(groups(), lr=1e-3)
+    opt3.load_state_dict(copy.deepcopy(sd))
+    opt3.step()
+    for n, p in named:
+        assert torch.allclose(p, want[n], rtol=2e-5, atol=1e-7), n
+    # (c) add_param_group after steps: existing moments are carried into the rebuilt runs
+    extra = torch.nn.Parameter(torch.ones(64, device=dev))
+    extra.grad = torch.full((64,), 0.5, device=dev)
+    m_before = opt.state[named[0][1]]["exp_avg"].clone()
+    opt.add_param_group({"params": [extra], "weight_decay": 0.0})
+    opt.step()
+    assert not torch.equal(opt.state[named[0][1]]["exp_avg"], torch.zeros_like(m_before)) and float(extra[0]) < 1.0
+    assert torch.allclose(opt.state[named[0][1]]["exp_avg"], m_before * 0.9 + 0.1 * named[0][1].grad, rtol=1e-4, atol=1e-7)
