@@ -66,8 +66,13 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
     const uint2* dyr = reinterpret_cast<const uint2*>(dy + (int64_t)row * cols);
     float4* dr = reinterpret_cast<float4*>(dres + (int64_t)row * cols);
     const float r = rstd[row];
-    float4 g[RN_MAXV], xh[RN_MAXV];
+    float4 g[RN_MAXV], xh[RN_MAXV], acc[RN_MAXV];
     float dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < RN_MAXV; ++k) {                      // the residual gradient this row adds to: in flight with x / dy
+      const int i = lane + k * 64;
+      if (i < nv) acc[k] = dr[i];
+    }
 #pragma unroll
     for (int k = 0; k < RN_MAXV; ++k) {
       const int i = lane + k * 64;
@@ -85,7 +90,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
     for (int k = 0; k < RN_MAXV; ++k) {
       const int i = lane + k * 64;
       if (i < nv) {
-        float4 o = dr[i];
+        float4 o = acc[k];
         o.x += r * (g[k].x - xh[k].x * dot); o.y += r * (g[k].y - xh[k].y * dot);
         o.z += r * (g[k].z - xh[k].z * dot); o.w += r * (g[k].w - xh[k].w * dot);
         dr[i] = o;
@@ -417,7 +422,7 @@ extern "C" int ug_rmsnorm_bwd(const void* dy, const float* x, const float* rstd,
              "ug_rmsnorm_bwd: cols=%ld unsupported (multiple of 4, <= %d)", (long)cols, 64 * 4 * RN_MAXV);
   UG_REQUIRE(ug_aligned16(x) && ug_aligned16(w) && ug_aligned16(dres) && ((uintptr_t)dy & 7) == 0,
              "ug_rmsnorm_bwd: pointers must be aligned");
-  const int rpb = 32;
+  const int rpb = 16;          // 771 workgroups for 12 336 rows: three per CU (32 left a third of the CUs with one)
   dim3 grid((unsigned)((rows + rpb - 1) / rpb)), block(256);
   UG_REQUIRE(((uintptr_t)dres_bf16 & 7) == 0, "ug_rmsnorm_bwd: dres_bf16 must be 8-byte aligned");
   hipLaunchKernelGGL(rmsnorm_bwd_kernel, grid, block, 0, st, (const bf16_t*)dy, x, rstd, w, dres, dw, (bf16_t*)dres_bf16,

@@ -541,8 +541,7 @@ def test_fused_adamw_state_dict_round_trip_and_torch_layout(dev):
         with torch.no_grad():
             for n, p in named:
                 p.copy_(w2[n])
-                p.grad = gsave[n].clone() if p.grad is None or p.grad.data_ptr() != gsave[n].data_ptr() else p.grad
-                p.grad.copy_(gsave[n])
+                p.grad.copy_(gsave[n])           # in place: the gradients stay the views of the flat buffer
     # (a) a fresh FusedAdamW resumes from the state dict
     restore()
     opt2 = FusedAdamW(groups(), lr=1e-3)
