@@ -206,10 +206,11 @@ __global__ __launch_bounds__(256) void attn_transpose_vec_kernel(const bf16_t* _
 
 // ------------------------------------------------------------------ tile staging helpers
 // row-major tile: 64 rows x 128 cols from global rows (row_first + r, clamped to L-1)
+template <int NT = 256>
 __device__ __forceinline__ void stage_rm(bf16_t* dst, const bf16_t* src_seq, int64_t ld, int row_first, int L, int tid) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = tid + i * 256;
+  for (int i = 0; i < 1024 / NT; ++i) {
+    const int c = tid + i * NT;
     const int r = c >> 4, ch = c & 15;
     const int gr = min(row_first + r, L - 1);
     const bf16x8_t v = *reinterpret_cast<const bf16x8_t*>(src_seq + (int64_t)gr * ld + ch * 8);
@@ -270,14 +271,17 @@ struct AttnArgs {
 };
 
 // ================================================================== forward
-// grid (nQtiles, H, B)
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
+// grid (ceil(L / (16 NW)), H, B).  NW = 4: one 64-row query tile per workgroup; NW = 8: two (128 rows) sharing every staged
+// K / V tile -- half the staging traffic and barriers per query row, same LDS, same registers per wave.  A wave whose own
+// 64-row tile sees nothing of a key tile skips the arithmetic but keeps the barriers.
+template <int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void attn_fwd_kernel(AttnArgs p) {
   __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * RM_LD];
   __shared__ __attribute__((aligned(16))) bf16_t Vs[64 * RM_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
   const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
   const int hk = h / (p.H / p.HKV);
-  const int qrow = qt * 64 + wave * 16 + (lane & 15);          // this lane's query (column of S^T)
+  const int qrow = qt * (16 * NW) + wave * 16 + (lane & 15);   // this lane's query (column of S^T)
   const int qrow_c = min(qrow, p.L - 1);
   const bf16_t* qseq = p.q + (int64_t)b * p.L * p.ldq + h * HD;
   const bf16_t* kseq = p.k + (int64_t)b * p.L * p.ldq + hk * HD;
@@ -293,14 +297,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs p) {
   for (int d = 0; d < 8; ++d) ot[d] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   float m_i = -INFINITY, l_i = 0.f;
   const uint64_t* wrow = p.bits + ((int64_t)b * p.L + qrow_c) * p.nW;
-  const uint8_t* tany = p.tileany + ((int64_t)b * p.nW + qt) * p.nW;
+  const int q64 = qt * (NW / 4) + (wave >> 2);                 // this wave's 64-row tile (its own row of tile flags)
+  const uint8_t* tany = p.tileany + ((int64_t)b * p.nW + min(q64, p.nW - 1)) * p.nW;
+  const uint8_t* tany2 = p.tileany + ((int64_t)b * p.nW + min(q64 ^ (NW == 8 ? 1 : 0), p.nW - 1)) * p.nW;   // the other half's
+  const bool have = q64 < p.nW, have2 = (q64 ^ (NW == 8 ? 1 : 0)) < p.nW;
 
   for (int t = 0; t < p.nW; ++t) {
-    if (!tany[t]) continue;                                     // uniform per block
+    const bool mine = have && tany[t];
+    if (!mine && !(NW == 8 && have2 && tany2[t])) continue;     // uniform per block: both halves evaluate the same pair
     __syncthreads();
-    stage_rm(Ks, kseq, p.ldq, t * 64, p.L, tid);
-    stage_rm(Vs, vseq, p.ldq, t * 64, p.L, tid);     // rows past L repeat the last key: their probabilities are exact zeros
+    stage_rm<64 * NW>(Ks, kseq, p.ldq, t * 64, p.L, tid);
+    stage_rm<64 * NW>(Vs, vseq, p.ldq, t * 64, p.L, tid);   // rows past L repeat the last key: their probabilities are exact zeros
     __syncthreads();
+    if (!mine) continue;                                        // wave-uniform: this 64-row tile sees none of these keys
 
     f32x4_t st[4];
 #pragma unroll
@@ -664,7 +673,11 @@ extern "C" int ug_attn_fwd(const void* q, const void* k, const void* v, int64_t 
   a.o = (bf16_t*)o; a.lse = lse; a.bits = bits; a.tileany = tileany;
   a.ldq = ldq; a.ldo = ldo; a.B = (int)B; a.L = (int)L; a.Lp = (int)Lp; a.nW = (int)((L + 63) / 64);
   a.H = H; a.HKV = HKV; a.scale = scale;
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(a.nW, H, (unsigned)B), dim3(256), 0, st, a);
+  // 128-row query tiles (eight waves share each staged K / V tile) once there are enough of them to fill the chip
+  if (L >= 256 && (int64_t)((L + 127) / 128) * H * B >= 512)
+    hipLaunchKernelGGL(attn_fwd_kernel<8>, dim3((unsigned)((L + 127) / 128), H, (unsigned)B), dim3(512), 0, st, a);
+  else
+    hipLaunchKernelGGL(attn_fwd_kernel<4>, dim3(a.nW, H, (unsigned)B), dim3(256), 0, st, a);
   UG_CHECK_LAUNCH("ug_attn_fwd");
   return UG_OK;
 }

@@ -338,8 +338,10 @@ def _ref_masks(B, L, kind, gen):
 
 
 @pytest.mark.parametrize("kind", ["causal", "t2i", "mmu", "random"])
-@pytest.mark.parametrize("B,L,H,HKV", [(2, 70, 2, 1), (1, 200, 12, 2), (2, 129, 6, 2)])
+@pytest.mark.parametrize("B,L,H,HKV", [(2, 70, 2, 1), (1, 200, 12, 2), (2, 129, 6, 2), (8, 333, 24, 4), (6, 400, 24, 4)])
 def test_attention_fwd_bwd(dev, kind, B, L, H, HKV):
+    """The last two shapes have >= 512 128-row query tiles, i.e. they run the eight-wave forward kernel (ragged last
+    tile at 333; at 400 the last 128-row tile has no second half)."""
     ops = _ops()
     from oracle.ops_ref import attention_ref
     hd = 128
