@@ -61,6 +61,7 @@ struct GemmArgs {
   int full_tiles, tail_split;
   float* tail_ws;
   int tail_private;        // 1: every k-slice stores its own [256][256] partial (no atomics); the finisher sums them
+  int one_barrier;         // 256x256 kernel: one barrier per k-tile (A/B runs; policy bit 0x200)
   int wide_epilogue;       // 256x256 kernel: LDS-transposed 16-byte stores (0 only for A/B runs, ug_gemm_set_tile_policy(100))
   // fused SwiGLU (ug_gemm_bf16_swiglu): B = [gate rows | up rows] of the fused weight, I rows each; a tile's 256 columns are
   // 128 gate columns and the SAME 128 hidden units' up columns; C = gu [M][2I], act [M][I] = bf16(bf16(silu(gate)) * up)
@@ -493,7 +494,21 @@ __device__ __forceinline__ bf16x8_t load_frag32(const char* tile, int r0, int la
 
 #define P_BARRIER() asm volatile("s_barrier" ::: "memory")
 
-template <int EPI, bool AK, bool BKM>
+// Phase timeline of workgroup 0 (probe builds only, -DUG_GEMM_TRACE; tools/probes/gemm_trace.py): s_memtime stamps of
+// waves 0 and 4 at the four boundaries of every k-tile iteration.
+#ifdef UG_GEMM_TRACE
+__device__ unsigned long long g_gemm_trace[2 * 4 * 512];
+#define P_STAMP(slot)                                                                                     \
+  do { if (blockIdx.x == 0 && wn == 0 && t < 512 && lane == 0)                                              \
+         g_gemm_trace[(grp * 512 + t) * 4 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int ug_gemm_trace_read(unsigned long long* host) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gemm_trace), sizeof(unsigned long long) * 2 * 4 * 512) == hipSuccess ? 0 : -1;
+}
+#else
+#define P_STAMP(slot) do {} while (0)
+#endif
+
+template <int EPI, bool AK, bool BKM, bool ONEBAR = false>
 __global__ __launch_bounds__(512, 2) void gemm_kernel_p8(GemmArgs p) {
   __shared__ __attribute__((aligned(16))) char lds[P_NST * P_STAGE];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -535,6 +550,82 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p8(GemmArgs p) {
     if (ragged && kt + 1 == nk_all) { sa.template issue<true>(kt, p.K, st, wave); sb.template issue<true>(kt, p.K, st + P_TILE, wave); }
     else { sa.template issue<false>(kt, p.K, st, wave); sb.template issue<false>(kt, p.K, st + P_TILE, wave); }
   };
+  if constexpr (ONEBAR) {
+    // One workgroup barrier per k-tile.  Interval t (between barriers t and t+1): a group-0 wave runs L(t) then M(t), the
+    // group-1 wave on the same SIMD runs M(t-1) (fragments kept in registers across the barrier) then L(t) -- the two halves
+    // of the interval still pair one wave's 32 MFMAs with the other's fragment reads, but nobody waits at a mid-interval
+    // barrier for the slower half.  Barrier t publishes tile t (every wave waited for its own DMA share at the end of
+    // interval t-1) and frees the slot of tile t-1 (last read by group 1 in interval t-1) for the DMA of tile t+3.
+    stage_in(0);
+    if (nk > 1) stage_in(1);
+    if (nk > 2) stage_in(2);
+    if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    bf16x8_t fa[8], fb[4];
+    auto L = [&](int t) {
+      const char* tA = lds + (t & (P_NST - 1)) * P_STAGE;
+      const char* tB = tA + P_TILE;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) fa[i] = load_frag32<AK>(tA, grp * 128 + i * 16, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = load_frag32<BKM>(tB, wn * 64 + j * 16, lane);
+      if (t + 3 < nk) stage_in(t + 3);
+    };
+    auto M = [&]() {
+      // group 1's M phase opens the interval and must not be starved by group 0's (older waves win the MFMA arbiter at equal
+      // priority: measured, group 1's 32 MFMAs stretched from 668 to 1152 clocks): it gets the higher priority
+      if (grp == 1) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    };
+    auto landed = [&](int t) {                   // this wave's share of tile t+1 (newer batches may stay in flight)
+      if (t + 3 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    if (grp == 0) {
+      for (int t = 0; t < nk; ++t) {
+        P_BARRIER();
+        P_STAMP(0);
+        L(t);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        P_STAMP(1);
+        __builtin_amdgcn_sched_barrier(0);
+        M();
+        __builtin_amdgcn_sched_barrier(0);
+        P_STAMP(2);
+        landed(t);
+        P_STAMP(3);
+      }
+      P_BARRIER();                               // interval nk: group 1's last M phase
+    } else {
+      P_BARRIER();
+      L(0);
+      landed(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      for (int t = 1; t < nk; ++t) {
+        P_BARRIER();
+        P_STAMP(0);
+        __builtin_amdgcn_sched_barrier(0);
+        M();
+        __builtin_amdgcn_sched_barrier(0);
+        P_STAMP(1);
+        L(t);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        P_STAMP(2);
+        landed(t);
+        P_STAMP(3);
+      }
+      P_BARRIER();
+      __builtin_amdgcn_sched_barrier(0);
+      M();
+    }
+  } else {
   // prologue: tiles 0..2 in flight, tile 0 landed
   stage_in(0);
   if (nk > 1) stage_in(1);
@@ -549,6 +640,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p8(GemmArgs p) {
     // ---------------- L phase: fragments of tile t into registers, DMA of tile t+3, retire tile t+1's DMA
     const char* tA = lds + (t & (P_NST - 1)) * P_STAGE;
     const char* tB = tA + P_TILE;
+    P_STAMP(0);
     bf16x8_t fa[8], fb[4];
 #pragma unroll
     for (int i = 0; i < 8; ++i) fa[i] = load_frag32<AK>(tA, grp * 128 + i * 16, lane);
@@ -561,8 +653,10 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p8(GemmArgs p) {
     else if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    P_STAMP(1);
     P_BARRIER();
     // ---------------- M phase
+    P_STAMP(2);
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -570,9 +664,11 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p8(GemmArgs p) {
       for (int j = 0; j < 4; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
     __builtin_amdgcn_s_setprio(0);
+    P_STAMP(3);
     P_BARRIER();
   }
   if (grp == 0) P_BARRIER();                    // balance the barrier count of the staggered group
+  }
 
   if (tail) {
     const int64_t slot = p.tail_private ? (int64_t)(tile_lin - p.full_tiles) * p.tail_split + tail_j % p.tail_split
@@ -718,7 +814,8 @@ int launch(GemmArgs a, const ug_handle* h, int policy, hipStream_t st) {
       a.tiles_m = (a.M + PBM - 1) / PBM; a.tiles_n = (a.N + PBN - 1) / PBN;
       a.full_tiles = 0; a.tail_split = sp; a.tail_private = 1;
       a.tail_ws = ws;
-      hipLaunchKernelGGL((gemm_kernel_p8<EPI, AK, BKM>), dim3(tiles_p8 * sp), dim3(512), 0, st, a);
+      if (a.one_barrier) hipLaunchKernelGGL((gemm_kernel_p8<EPI, AK, BKM, true>), dim3(tiles_p8 * sp), dim3(512), 0, st, a);
+      else hipLaunchKernelGGL((gemm_kernel_p8<EPI, AK, BKM>), dim3(tiles_p8 * sp), dim3(512), 0, st, a);
       UG_CHECK_LAUNCH("ug_gemm_bf16(p8 k-sliced)");
       hipLaunchKernelGGL((tail_finish_kernel<EPI>), dim3(tiles_p8 * 16), dim3(256), 0, st, a, tiles_p8);
       UG_CHECK_LAUNCH("ug_gemm_bf16(partial sum)");
@@ -730,7 +827,8 @@ int launch(GemmArgs a, const ug_handle* h, int policy, hipStream_t st) {
     a.full_tiles = tiles_p8 - tail_r; a.tail_split = tail_s;
     a.tail_private = 1;                          // private partials beat atomics here too (gate_up dgrad 886 -> see DESIGN)
     a.tail_ws = ws;
-    hipLaunchKernelGGL((gemm_kernel_p8<EPI, AK, BKM>), dim3(a.full_tiles + tail_r * tail_s), dim3(512), 0, st, a);
+    if (a.one_barrier) hipLaunchKernelGGL((gemm_kernel_p8<EPI, AK, BKM, true>), dim3(a.full_tiles + tail_r * tail_s), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((gemm_kernel_p8<EPI, AK, BKM>), dim3(a.full_tiles + tail_r * tail_s), dim3(512), 0, st, a);
     UG_CHECK_LAUNCH("ug_gemm_bf16(p8)");
     if (tail_s > 1) {
       hipLaunchKernelGGL((tail_finish_kernel<EPI>), dim3(tail_r * 16), dim3(256), 0, st, a, tail_r);
@@ -775,7 +873,12 @@ extern "C" int ug_gemm_bf16(const ug_handle* h, const void* A, int64_t lda, int 
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = ldr; a.beta = beta;
   a.swiglu_I = 0; a.act = nullptr; a.ld_act = 0;
   a.wide_epilogue = (policy >= 0 && (policy & UG_GEMM_NARROW_EPILOGUE)) ? 0 : 1;
-  if (policy >= 0) policy &= ~UG_GEMM_NARROW_EPILOGUE;
+  // main loop of the 256x256 kernel: one barrier per k-tile whenever an operand is k-major (its transposing fragment reads
+  // make L as long as M; measured +3..5 % dgrad, +10..13 % wgrad), two for the all-row-major forward (short L: -2 %)
+  a.one_barrier = (a_kmajor || b_kmajor) ? 1 : 0;
+  if (policy >= 0 && (policy & UG_GEMM_ONE_BARRIER)) a.one_barrier = 1;
+  if (policy >= 0 && (policy & UG_GEMM_TWO_BARRIERS)) a.one_barrier = 0;
+  if (policy >= 0) policy &= ~(UG_GEMM_NARROW_EPILOGUE | UG_GEMM_ONE_BARRIER | UG_GEMM_TWO_BARRIERS);
   if (policy == UG_GEMM_POLICY_AUTO_BITS) policy = -1;
   a.tiles_m = (int)((M + BM - 1) / BM); a.tiles_n = (int)((N + BN - 1) / BN);
   const int mode = (a_kmajor ? 2 : 0) | (b_kmajor ? 1 : 0);

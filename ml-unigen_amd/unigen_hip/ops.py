@@ -124,13 +124,18 @@ def gemm_swiglu(x, w_gate_up):
 def set_gemm_tile_policy(policy):
     """Kernel selection passed with every following GEMM call (include/unigen_hip.h: ug_gemm_bf16 `policy`): -1 auto, 0 / 2 =
     128x128 tiles with two / one LDS stages, 3 = staggered 256x256, 6 / 8 = k-sliced forms forced; 100 / 101 switch the 256x256
-    kernel's LDS-transposed wide epilogue off / on while leaving the selection automatic (A/B benchmarking and tests)."""
+    kernel's LDS-transposed wide epilogue off / on while leaving the selection automatic; 102 / 104 force its one- / two-barrier
+    main loop with automatic selection, 103 / 105 with the 256x256 kernel forced (A/B benchmarking and tests)."""
     global GEMM_POLICY
     policy = int(policy)
     if policy == 100:
         GEMM_POLICY = UG_GEMM_POLICY_AUTO_BITS | UG_GEMM_NARROW_EPILOGUE
     elif policy == 101:
         GEMM_POLICY = -1
+    elif policy in (102, 104):             # automatic selection, main loop forced to one / two barriers per k-tile
+        GEMM_POLICY = UG_GEMM_POLICY_AUTO_BITS | (0x200 if policy == 102 else 0x400)
+    elif policy in (103, 105):             # staggered 256x256 kernel forced, one / two barriers
+        GEMM_POLICY = 3 | (0x200 if policy == 103 else 0x400)
     else:
         GEMM_POLICY = policy
 

@@ -42,7 +42,7 @@ def test_probe_layouts(dev):
 
 
 # ------------------------------------------------------------------ GEMM
-@pytest.fixture(params=[0, 2, 3], ids=["two_lds_stages", "one_lds_stage", "staggered_256x256"])
+@pytest.fixture(params=[0, 2, 103, 105], ids=["two_lds_stages", "one_lds_stage", "staggered_256x256_one_barrier", "staggered_256x256_two_barriers"])
 def tile_policy(request):
     ops = _ops()
     ops.set_gemm_tile_policy(request.param)

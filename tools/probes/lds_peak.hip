@@ -6,6 +6,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 // TR: fragments through two ds_read_tr16_b64 (the k-major operand path) instead of one ds_read_b128
+#ifndef SWZ_OLD
+#define SWZ_OLD 0     // 1: round 1's row-quad map (0,1,2,3), 2-way conflicts on the real ds_read_b128 lane groups
+#endif
 template <int MFMA_PER_READ, bool TR = false>
 __global__ __launch_bounds__(512) void lds_read_kernel(float* __restrict__ out, int iters) {
   __shared__ __attribute__((aligned(16))) char tile[65536];
@@ -21,7 +24,7 @@ __global__ __launch_bounds__(512) void lds_read_kernel(float* __restrict__ out, 
       const int r = ((wave * 16 + u) * 16 + row + it) & 1023;                 // 1024 rows x 64 B
       bf16x8_t f;
       if constexpr (!TR) {
-        f = *reinterpret_cast<const bf16x8_t*>(tile + r * 64 + ((g ^ ((r >> 2) & 3)) << 4));
+        f = *reinterpret_cast<const bf16x8_t*>(tile + r * 64 + ((g ^ ((SWZ_OLD ? (r >> 2) : (0 - (r >> 2))) & 3)) << 4));
       } else {
         const char* p0 = tile + (((wave * 16 + u) * 1024 + it * 64) & 65535 & ~1023) + lane * 8;      // 512 contiguous bytes per read
         const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p0);
