@@ -463,7 +463,11 @@ struct Stager32 {                // 256-row x 32-k operand tile, 8 waves: 2 one-
     const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
+#ifdef UG_GEMM_ABLATE_SRC                       // probe builds only: every k-tile re-fetches tile kt & 1 (cache-resident source)
+      const bf16_t* s = src[i] + (kt & 1) * step[i];
+#else
       const bf16_t* s = src[i] + kt * step[i];
+#endif
       if constexpr (CHECK) {
         const bool past = kt * PBK + kofs[i] >= (KMAJOR ? K : ((K + 7) & ~7));
         s = reinterpret_cast<const bf16_t*>(past ? reinterpret_cast<uintptr_t>(zero) : reinterpret_cast<uintptr_t>(s));
@@ -545,6 +549,9 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p8(GemmArgs p) {
   if (nk <= 0) return;
   const bool ragged = (p.K % PBK) != 0;
   auto stage_in = [&](int lt) {                 // 4 DMA instructions per wave
+#ifdef UG_GEMM_ABLATE_DMA                       // probe builds only (tools/probes/gemm_ablate.py): the loop without its operand stream
+    if (lt > 2) return;
+#endif
     const int kt = kt0 + lt;
     char* st = lds + (lt & (P_NST - 1)) * P_STAGE;
     if (ragged && kt + 1 == nk_all) { sa.template issue<true>(kt, p.K, st, wave); sb.template issue<true>(kt, p.K, st + P_TILE, wave); }
