@@ -31,6 +31,7 @@
 // mode; M/N edges are clamped on load and guarded on store.  XCD-aware grouped tile order; operands
 // are passed swapped to the MFMA so each lane ends up with four consecutive output columns.
 #include "common.h"
+#include <type_traits>
 #include "unigen_hip.h"
 
 namespace {
@@ -557,82 +558,50 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p8(GemmArgs p) {
     if (ragged && kt + 1 == nk_all) { sa.template issue<true>(kt, p.K, st, wave); sb.template issue<true>(kt, p.K, st + P_TILE, wave); }
     else { sa.template issue<false>(kt, p.K, st, wave); sb.template issue<false>(kt, p.K, st + P_TILE, wave); }
   };
-  if constexpr (ONEBAR) {
-    // One workgroup barrier per k-tile.  Interval t (between barriers t and t+1): a group-0 wave runs L(t) then M(t), the
-    // group-1 wave on the same SIMD runs M(t-1) (fragments kept in registers across the barrier) then L(t) -- the two halves
-    // of the interval still pair one wave's 32 MFMAs with the other's fragment reads, but nobody waits at a mid-interval
-    // barrier for the slower half.  Barrier t publishes tile t (every wave waited for its own DMA share at the end of
-    // interval t-1) and frees the slot of tile t-1 (last read by group 1 in interval t-1) for the DMA of tile t+3.
-    stage_in(0);
-    if (nk > 1) stage_in(1);
-    if (nk > 2) stage_in(2);
-    if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  // Steady state (t + 4 < nk): tile t+3 is not the launch's last k-tile -- it exists and is never the ragged one -- so the
+  // iteration carries no scalar branch between the fragment reads and the barrier; the last four iterations take the checked
+  // form.  (Three to four branches per k-tile cost 5-10 % of the loop: measured when a run-time prefetch distance was tried.)
+  auto stage_whole = [&](int lt) {
+#ifdef UG_GEMM_ABLATE_DMA
+    return;
+#endif
+    char* st = lds + (lt & (P_NST - 1)) * P_STAGE;
+    sa.template issue<false>(kt0 + lt, p.K, st, wave);
+    sb.template issue<false>(kt0 + lt, p.K, st + P_TILE, wave);
+  };
+  const int nk_steady = max(nk - 4, 0);
+  bf16x8_t fa[8], fb[4];
+  auto read_frags = [&](int t) {
+    const char* tA = lds + (t & (P_NST - 1)) * P_STAGE;
+    const char* tB = tA + P_TILE;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fa[i] = load_frag32<AK>(tA, grp * 128 + i * 16, lane);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fb[j] = load_frag32<BKM>(tB, wn * 64 + j * 16, lane);
+  };
+  auto request = [&](int t, auto steady) {        // DMA of tile t+3
+    if constexpr (decltype(steady)::value) stage_whole(t + 3);
+    else if (t + 3 < nk) stage_in(t + 3);
+  };
+  auto landed = [&](int t, auto steady) {         // this wave's share of tile t+1 (the batches t+2, t+3 may stay in flight)
+    if constexpr (decltype(steady)::value) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (t + 3 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    bf16x8_t fa[8], fb[4];
-    auto L = [&](int t) {
-      const char* tA = lds + (t & (P_NST - 1)) * P_STAGE;
-      const char* tB = tA + P_TILE;
+  };
+  auto mfmas = [&](int prio) {
+    __builtin_amdgcn_sched_barrier(0);
+    if (prio == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) fa[i] = load_frag32<AK>(tA, grp * 128 + i * 16, lane);
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = load_frag32<BKM>(tB, wn * 64 + j * 16, lane);
-      if (t + 3 < nk) stage_in(t + 3);
-    };
-    auto M = [&]() {
-      // group 1's M phase opens the interval and must not be starved by group 0's (older waves win the MFMA arbiter at equal
-      // priority: measured, group 1's 32 MFMAs stretched from 668 to 1152 clocks): it gets the higher priority
-      if (grp == 1) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-    };
-    auto landed = [&](int t) {                   // this wave's share of tile t+1 (newer batches may stay in flight)
-      if (t + 3 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    };
-    if (grp == 0) {
-      for (int t = 0; t < nk; ++t) {
-        P_BARRIER();
-        P_STAMP(0);
-        L(t);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        P_STAMP(1);
-        __builtin_amdgcn_sched_barrier(0);
-        M();
-        __builtin_amdgcn_sched_barrier(0);
-        P_STAMP(2);
-        landed(t);
-        P_STAMP(3);
-      }
-      P_BARRIER();                               // interval nk: group 1's last M phase
-    } else {
-      P_BARRIER();
-      L(0);
-      landed(0);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      for (int t = 1; t < nk; ++t) {
-        P_BARRIER();
-        P_STAMP(0);
-        __builtin_amdgcn_sched_barrier(0);
-        M();
-        __builtin_amdgcn_sched_barrier(0);
-        P_STAMP(1);
-        L(t);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        P_STAMP(2);
-        landed(t);
-        P_STAMP(3);
-      }
-      P_BARRIER();
-      __builtin_amdgcn_sched_barrier(0);
-      M();
-    }
-  } else {
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  const std::true_type STEADY{};
+  const std::false_type CHECKED{};
   // prologue: tiles 0..2 in flight, tile 0 landed
   stage_in(0);
   if (nk > 1) stage_in(1);
@@ -640,41 +609,80 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p8(GemmArgs p) {
   if (nk > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   else if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  P_BARRIER();
-  if (grp == 1) P_BARRIER();                    // stagger: group 1 runs one phase behind group 0
-
-  for (int t = 0; t < nk; ++t) {
-    // ---------------- L phase: fragments of tile t into registers, DMA of tile t+3, retire tile t+1's DMA
-    const char* tA = lds + (t & (P_NST - 1)) * P_STAGE;
-    const char* tB = tA + P_TILE;
-    P_STAMP(0);
-    bf16x8_t fa[8], fb[4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) fa[i] = load_frag32<AK>(tA, grp * 128 + i * 16, lane);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) fb[j] = load_frag32<BKM>(tB, wn * 64 + j * 16, lane);
-    if (t + 3 < nk) stage_in(t + 3);
-    // this wave's share of tile t+1 must have landed before the barrier that opens the interval in which
-    // group 0 reads it; newer batches (t+2, t+3) may stay in flight
-    if (t + 3 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    P_STAMP(1);
+  if constexpr (ONEBAR) {
+    // One workgroup barrier per k-tile.  Interval t (between barriers t and t+1): a group-0 wave runs L(t) then M(t), the
+    // group-1 wave on the same SIMD runs M(t-1) (fragments kept in registers across the barrier) then L(t) -- the two halves
+    // of the interval still pair one wave's 32 MFMAs with the other's fragment reads, but nobody waits at a mid-interval
+    // barrier for the slower half.  Barrier t publishes tile t (every wave waited for its own DMA share at the end of
+    // interval t-1) and frees the slot of tile t-1 (last read by group 1 in interval t-1) for the DMA of tile t+3.
+    // Group 1's M phase opens the interval and must not be starved by group 0's (older waves win the MFMA arbiter at equal
+    // priority: measured, group 1's 32 MFMAs stretched from 668 to 1152 clocks): it runs at the higher priority.
+    if (grp == 0) {
+      auto interval = [&](int t, auto steady) {
+        P_BARRIER();
+        P_STAMP(0);
+        read_frags(t);
+        request(t, steady);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        P_STAMP(1);
+        mfmas(1);
+        P_STAMP(2);
+        landed(t, steady);
+        P_STAMP(3);
+      };
+      int t = 0;
+      for (; t < nk_steady; ++t) interval(t, STEADY);
+      for (; t < nk; ++t) interval(t, CHECKED);
+      P_BARRIER();                               // interval nk: group 1's last M phase
+    } else {
+      P_BARRIER();
+      read_frags(0);
+      request(0, CHECKED);
+      landed(0, CHECKED);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      auto interval = [&](int t, auto steady) {
+        P_BARRIER();
+        P_STAMP(0);
+        mfmas(2);
+        P_STAMP(1);
+        read_frags(t);
+        request(t, steady);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        P_STAMP(2);
+        landed(t, steady);
+        P_STAMP(3);
+      };
+      int t = 1;
+      for (; t < nk_steady; ++t) interval(t, STEADY);
+      for (; t < nk; ++t) interval(t, CHECKED);
+      P_BARRIER();
+      mfmas(2);
+    }
+  } else {
+    // Two barriers per k-tile: L(t) | M(t) with group 1 one phase behind group 0.
     P_BARRIER();
-    // ---------------- M phase
-    P_STAMP(2);
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    P_STAMP(3);
-    P_BARRIER();
-  }
-  if (grp == 0) P_BARRIER();                    // balance the barrier count of the staggered group
+    if (grp == 1) P_BARRIER();                    // stagger: group 1 runs one phase behind group 0
+    auto iteration = [&](int t, auto steady) {
+      // ---------------- L phase: fragments of tile t into registers, DMA of tile t+3, retire tile t+1's DMA
+      P_STAMP(0);
+      read_frags(t);
+      request(t, steady);
+      // this wave's share of tile t+1 must have landed before the barrier that opens the interval in which
+      // group 0 reads it; newer batches (t+2, t+3) may stay in flight
+      landed(t, steady);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      P_STAMP(1);
+      P_BARRIER();
+      // ---------------- M phase
+      P_STAMP(2);
+      mfmas(1);
+      P_STAMP(3);
+      P_BARRIER();
+    };
+    int t = 0;
+    for (; t < nk_steady; ++t) iteration(t, STEADY);
+    for (; t < nk; ++t) iteration(t, CHECKED);
+    if (grp == 0) P_BARRIER();                    // balance the barrier count of the staggered group
   }
 
   if (tail) {
