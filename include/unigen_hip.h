@@ -65,8 +65,8 @@ int ug_gemm_bf16(const ug_handle* h, const void* A, int64_t lda, int a_kmajor, c
  * 8 = k-sliced small outputs; UG_GEMM_POLICY_AUTO_BITS = automatic selection when only modifier bits are wanted;
  * | UG_GEMM_NARROW_EPILOGUE = element-wise instead of LDS-transposed 16-byte stores in the 256x256 kernel. */
 #define UG_GEMM_NARROW_EPILOGUE 0x100
-#define UG_GEMM_ONE_BARRIER 0x200     /* force the 256x256 kernel's one-barrier-per-k-tile main loop (default: k-major operands) */
-#define UG_GEMM_TWO_BARRIERS 0x400    /* force its two-barrier (L | M phase) main loop (default: both operands row-major) */
+#define UG_GEMM_ONE_BARRIER 0x200     /* force the 256x256 kernel's one-barrier-per-k-tile main loop (default: weight gradients, both operands k-major) */
+#define UG_GEMM_TWO_BARRIERS 0x400    /* force its two-barrier (L | M phase) main loop (default: forward and dgrad) */
 #define UG_GEMM_POLICY_AUTO_BITS 0xff
 
 /* in [R,C] (fp32 if in_f32 else bf16) -> out bf16 [R,C] (optional) and outT bf16 [C,ldT] with

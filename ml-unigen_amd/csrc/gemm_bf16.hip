@@ -888,9 +888,9 @@ extern "C" int ug_gemm_bf16(const ug_handle* h, const void* A, int64_t lda, int 
   a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.ldr = ldr; a.beta = beta;
   a.swiglu_I = 0; a.act = nullptr; a.ld_act = 0;
   a.wide_epilogue = (policy >= 0 && (policy & UG_GEMM_NARROW_EPILOGUE)) ? 0 : 1;
-  // main loop of the 256x256 kernel: one barrier per k-tile whenever an operand is k-major (its transposing fragment reads
-  // make L as long as M; measured +3..5 % dgrad, +10..13 % wgrad), two for the all-row-major forward (short L: -2 %)
-  a.one_barrier = (a_kmajor || b_kmajor) ? 1 : 0;
+  // main loop of the 256x256 kernel: one barrier per k-tile for the weight gradients (both operands through the transposing
+  // fragment reads make L half again as long as M: +10..13 %), two for forward and dgrad (short L: one barrier is -2..-3 %)
+  a.one_barrier = (a_kmajor && b_kmajor) ? 1 : 0;
   if (policy >= 0 && (policy & UG_GEMM_ONE_BARRIER)) a.one_barrier = 1;
   if (policy >= 0 && (policy & UG_GEMM_TWO_BARRIERS)) a.one_barrier = 0;
   if (policy >= 0) policy &= ~(UG_GEMM_NARROW_EPILOGUE | UG_GEMM_ONE_BARRIER | UG_GEMM_TWO_BARRIERS);
