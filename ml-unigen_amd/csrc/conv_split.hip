@@ -469,28 +469,61 @@ __global__ __launch_bounds__(512) void conv3x3_patch16_kernel(PatchArgs p) {
   stash_x(0);
   asm volatile("s_waitcnt vmcnt(2)" ::: "memory");            // tap 0's tile; tap 1's (two pieces per wave) may still be in flight
   RAW_BARRIER();
+  // Two wave groups (waves 0-3 / 4-7: one of each per SIMD) run every tap as L | M -- sixteen fragment reads + the DMA of the
+  // tile two taps ahead | 48 MFMAs -- one phase apart, so that on every SIMD one wave's MFMAs cover the other's LDS reads
+  // (the lock-stepped form had every wave read, then every wave multiply: matrix cores 0.45 busy).  The groups fall back into
+  // step at the end of a slab, where the next 32-channel patch replaces this one.
+  const int grp = wave >> 2;
   const int wrow = swz(wn * 64 + l16, g);
   for (int slab = 0; slab < p.kslabs; ++slab) {
+    if (grp == 1) RAW_BARRIER();                                // group 1 starts one phase behind
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       bf16_t* cur = tap % 3 == 0 ? W0 : tap % 3 == 1 ? W1 : W2;
-      bf16_t* two_ahead = (tap + 2) % 3 == 0 ? W0 : (tap + 2) % 3 == 1 ? W1 : W2;   // last read one tap ago
+      bf16_t* two_ahead = (tap + 2) % 3 == 0 ? W0 : (tap + 2) % 3 == 1 ? W1 : W2;   // last read one tap ago (by either group)
       const bool has2 = slab * 9 + tap + 2 < nkt;
       const bool next_slab = tap == 8 && slab + 1 < p.kslabs;
-      if (has2) dma_w(slab + (tap + 2 >= 9 ? 1 : 0), (tap + 2) % 9, two_ahead);
-      if (next_slab) fetch_x(slab + 1);
       const int dy = tap / 3, dx = tap % 3;
-      const bf16_t* xj[4];
+      // ---------------- L phase
+      h16x8_t w1[4], w2[4], x1[4], x2[4];
+      const bf16_t* wl = cur + wrow;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) xj[j] = Xp + swz((wm * 4 + j + dy) * PP_W + l16 + dx, g);
-      mma_slab<XQ>(cur + wrow, xj, acc);
-      if (next_slab) {
-        RAW_BARRIER();                 // every wave is done with this slab's patch
-        stash_x(slab + 1);
+      for (int i = 0; i < 4; ++i) {
+        w1[i] = *reinterpret_cast<const h16x8_t*>(wl + i * 16 * SBK);
+        w2[i] = *reinterpret_cast<const h16x8_t*>(wl + PLANE + i * 16 * SBK);
       }
-      // the next tap's tile (issued one tap ago) must have landed; the one issued in this tap may stay in flight
-      if (has2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bf16_t* xr = Xp + swz((wm * 4 + j + dy) * PP_W + l16 + dx, g);
+        x1[j] = *reinterpret_cast<const h16x8_t*>(xr);
+        x2[j] = *reinterpret_cast<const h16x8_t*>(xr + XQ);
+      }
+      if (has2) dma_w(slab + (tap + 2 >= 9 ? 1 : 0), (tap + 2) % 9, two_ahead);
+      if (next_slab) fetch_x(slab + 1);                         // six register loads behind the DMA: they stay in flight below
+      // this wave's share of the next tap's tile (issued one tap ago) has landed; newer requests may stay in flight
+      if (next_slab) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (has2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      RAW_BARRIER();
+      // ---------------- M phase: three partial products per block, the small ones first (same order as mma_slab)
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[i], x2[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2[i], x1[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[i], x1[j], acc[i][j], 0, 0, 0);
+        }
+      __builtin_amdgcn_s_setprio(0);
+      RAW_BARRIER();
+    }
+    if (grp == 0) RAW_BARRIER();                                // back in step: every wave is done with this slab's patch
+    if (slab + 1 < p.kslabs) {
+      stash_x(slab + 1);
       RAW_BARRIER();
     }
   }
