@@ -276,6 +276,11 @@ int ug_adamw_flat(float* p, const float* g, float* m, float* v, void* p_bf16, in
  * bf16(g * scale) (scale = 1 / world size: the mean is formed by the SUM all-reduce), exchanged by RCCL on the side
  * stream, and unpacked back in place.  Buffers 16-byte aligned; tails of any length. */
 int ug_grad_pack_bf16(const float* in, void* out_bf16, int64_t n, float scale, hipStream_t stream);
+/* Clear n_ranges spans of one fp32 buffer in ONE launch: ranges (device, int64) = {first element, element count} pairs, both
+ * multiples of 4; max_len = the longest count (sizes the grid).  Start of a gradient pass: the small accumulating gradients
+ * (norm weights, biases) that lie between the big "first write overwrites" matrices of the flat buffer -- 85 fill launches
+ * per step otherwise (torch's `zero_grad(set_to_none=False)` semantics for those tensors, reference training/train.py:773). */
+int ug_zero_ranges_f32(float* buf, const int64_t* ranges, int64_t n_ranges, int64_t max_len, hipStream_t stream);
 int ug_grad_unpack_bf16(const void* in_bf16, float* out, int64_t n, hipStream_t stream);
 
 /* ---- MAGVITv2 tokenizer (fp32, NHWC) ------------------------------------------------------- */

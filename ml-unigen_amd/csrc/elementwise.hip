@@ -5,6 +5,7 @@
 //
 // Numerics follow the reference's autocast(bf16) path (SURVEY.md §8a "precision modes", mode A):
 // fp32 residual stream and norm statistics, bf16 Linear inputs/outputs, fp32 master weights.
+#include <algorithm>
 #include "common.h"
 #include "unigen_hip.h"
 
@@ -540,6 +541,23 @@ extern "C" int ug_grad_pack_bf16(const float* in, void* out, int64_t n, float sc
   dim3 grid(grid_for(n / 8 + 1)), block(256);
   hipLaunchKernelGGL(grad_pack_kernel, grid, block, 0, st, in, (bf16_t*)out, n, scale);
   UG_CHECK_LAUNCH("ug_grad_pack_bf16");
+  return UG_OK;
+}
+
+// ranges[2 r] = first element, ranges[2 r + 1] = element count (both multiples of 4) of the r-th span of `buf` to clear
+__global__ __launch_bounds__(256) void zero_ranges_kernel(float* __restrict__ buf, const int64_t* __restrict__ ranges) {
+  const int64_t lo = ranges[2 * blockIdx.x], n4 = ranges[2 * blockIdx.x + 1] >> 2;
+  float4* dst = reinterpret_cast<float4*>(buf + lo);
+  for (int64_t i = blockIdx.y * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.y * blockDim.x)
+    dst[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+extern "C" int ug_zero_ranges_f32(float* buf, const int64_t* ranges, int64_t n_ranges, int64_t max_len, hipStream_t st) {
+  UG_REQUIRE(n_ranges > 0 && n_ranges < 65536 && max_len > 0 && ug_aligned16(buf) && ranges,
+             "ug_zero_ranges_f32: 1..65535 ranges, a 16-byte aligned buffer and a device range table required");
+  const unsigned per = (unsigned)std::min<int64_t>(64, (max_len / 4 + 255) / 256);
+  hipLaunchKernelGGL(zero_ranges_kernel, dim3((unsigned)n_ranges, per), dim3(256), 0, st, buf, ranges);
+  UG_CHECK_LAUNCH("ug_zero_ranges_f32");
   return UG_OK;
 }
 

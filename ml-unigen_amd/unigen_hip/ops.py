@@ -170,6 +170,12 @@ def cast_bf16(x, out=None):
     return out
 
 
+def zero_ranges_(buf, ranges, max_len):
+    """Clear the spans {first, count} (int64 device table [n, 2]) of the fp32 buffer `buf` with one launch."""
+    _l.check(_l.load().ug_zero_ranges_f32(_p(buf), _p(ranges), ranges.shape[0], int(max_len), _stream()), "ug_zero_ranges_f32")
+    return buf
+
+
 def grad_pack_bf16(g, out, scale):
     """out (bf16) = g (fp32) * scale: staging for the data-parallel bf16 all-reduce (unigen_hip/ddp.py)."""
     _need_cuda(g, out)

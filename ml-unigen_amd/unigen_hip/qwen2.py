@@ -89,6 +89,8 @@ class FlatParams:
                 self._small_runs.append(run)
             else:
                 run[1] = end
+        self._small_table = torch.tensor([[lo, hi - lo] for lo, hi in self._small_runs], dtype=torch.int64, device=device)
+        self._small_max = max(hi - lo for lo, hi in self._small_runs)
 
     def view(self, buf, key):
         o, shp = self.off[key]
@@ -111,8 +113,7 @@ class FlatParams:
         mark the big matrices fresh (their single weight-gradient GEMM overwrites them): 5.2 of the 6.2 GB are never
         zero-filled nor read back."""
         self.wait_pending_update()
-        for lo, hi in self._small_runs:
-            self.grad[lo:hi].zero_()
+        ops.zero_ranges_(self.grad, self._small_table, self._small_max)     # one launch instead of one fill per run
         self.fresh = set(self._big)
 
     def beta_for(self, key):

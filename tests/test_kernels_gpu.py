@@ -269,6 +269,21 @@ def test_colsum(dev):
     assert _rel(out, x.float().sum(0) + 1) < 1e-5
 
 
+def test_zero_ranges_clears_exactly_the_listed_spans(dev):
+    """ug_zero_ranges_f32: one launch clears the small accumulating gradients that lie between the big matrices of the flat
+    gradient buffer (ragged span lengths, a span longer than one workgroup pass); everything else is untouched."""
+    ops = _ops()
+    n = 1 << 20
+    buf = torch.arange(1, n + 1, dtype=torch.float32, device=dev)
+    spans = [(0, 64), (4096, 1536), (70000, 4), (300000, 200000), (n - 128, 128)]
+    table = torch.tensor([[lo, ln] for lo, ln in spans], dtype=torch.int64, device=dev)
+    ops.zero_ranges_(buf, table, max(ln for _, ln in spans))
+    want = torch.arange(1, n + 1, dtype=torch.float32)
+    for lo, ln in spans:
+        want[lo:lo + ln] = 0
+    assert torch.equal(buf.cpu(), want)
+
+
 def test_adamw_matches_torch(dev):
     ops = _ops()
     torch.manual_seed(4)

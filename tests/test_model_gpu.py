@@ -563,5 +563,5 @@ def test_fused_adamw_state_dict_round_trip_and_torch_layout(dev):
     m_before = opt.state[probe]["exp_avg"].clone()
     opt.add_param_group({"params": [extra], "weight_decay": 0.0})
     opt.step()
-    assert not torch.equal(opt.state[probe]["exp_avg"], torch.zeros_like(m_before)) and float(extra[0]) < 1.0
+    assert not torch.equal(opt.state[probe]["exp_avg"], torch.zeros_like(m_before)) and float(extra.detach()[0]) < 1.0
     assert torch.allclose(opt.state[probe]["exp_avg"], m_before * 0.9 + 0.1 * probe.grad, rtol=1e-4, atol=1e-7)
