@@ -215,8 +215,8 @@ constexpr int EP_ROWS = 32;
 constexpr int EP_PITCH_BF16 = 144, EP_PITCH_F32 = 272;
 constexpr int EP_STRIP = EP_ROWS * EP_PITCH_F32;            // 8704 B per wave (the bf16 strip needs 4608)
 
-template <int EPI>
-__device__ __forceinline__ void store_tile_lds(const GemmArgs& p, f32x4_t (&acc)[8][4], char* strip, int mbase, int nbase, int lane) {
+template <int EPI, int MF = 8>                              // MF = 16-row accumulator blocks of the wave (8, or 10 for 320-row tiles)
+__device__ __forceinline__ void store_tile_lds(const GemmArgs& p, f32x4_t (&acc)[MF][4], char* strip, int mbase, int nbase, int lane) {
   float alpha = 1.f;
   if constexpr (EPI == EPI_F32) { if (p.alpha_dev) alpha = *p.alpha_dev; }
   float bias4[4][4];
@@ -230,7 +230,7 @@ __device__ __forceinline__ void store_tile_lds(const GemmArgs& p, f32x4_t (&acc)
     }
   }
 #pragma unroll
-  for (int c = 0; c < 4; ++c) {                              // 32-row chunk = accumulator row blocks 2c, 2c+1
+  for (int c = 0; c < MF / 2; ++c) {                         // 32-row chunk = accumulator row blocks 2c, 2c+1
     // ---- registers -> strip (MFMA layout: lane holds rows lane&15, 4 consecutive columns per block)
 #pragma unroll
     for (int ii = 0; ii < 2; ++ii) {
@@ -724,6 +724,111 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p8(GemmArgs p) {
   store_tile<EPI>(p, reinterpret_cast<f32x4_t (&)[4][4]>(acc[4]), m0 + grp * 128 + 64, n0 + wn * 64, lane, false);
 }
 
+// =============================================================================================
+// 320 x 256 tiles for the token-count x 1536 outputs of the attention block (o forward, qkv / o dgrad: M = 12 336, K <= 2 048).
+// Their 49 x 6 = 294 tiles of 256 x 256 are 1.15 rounds of the chip and the contraction is too short for k-slices; 39 x 6 = 234
+// tiles of 320 x 256 are ONE round at 91 % occupancy.  Same two-barrier L | M schedule; a wave owns 160 x 64 (10 x 4 blocks,
+// 40 MFMAs per k-tile, 160 accumulator registers).  Restricted to what those launches need: A row-major, K % 32 == 0,
+// N % 256 == 0, bf16 / residual epilogues through the LDS strips, no k-slices.  The 20 A instructions of a k-tile go two
+// per wave plus a third for the waves of group 0, so the counted waits are per group (5 / 4 DMA instructions per tile).
+constexpr int QBM = 320;
+constexpr int Q_TILE_A = QBM * PBK * 2;        // 20 KiB
+constexpr int Q_STAGE = Q_TILE_A + P_TILE;     // 36 KiB; four stages = 144 KiB
+
+template <int EPI, bool BKM>
+__global__ __launch_bounds__(512, 2) void gemm_kernel_p10(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) char lds[P_NST * Q_STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, wn = wave & 3;
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int pid = xcd_remap((int)blockIdx.x, nwg);
+  const int per_group = GROUP_M * p.tiles_n;
+  const int gid = pid / per_group, first_m = gid * GROUP_M;
+  const int gsz = min(p.tiles_m - first_m, GROUP_M);
+  const int tm = first_m + (pid % per_group) % gsz;
+  const int tn = (pid % per_group) / gsz;
+  const int m0 = tm * QBM, n0 = tn * PBN;
+
+  const bf16_t* asrc[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int inst = min(i * 8 + wave, QBM / 16 - 1);          // (group 1's third slot is never issued)
+    const int row = inst * 16 + (lane >> 2);
+    const int r = min(m0 + row, p.M - 1);
+    asrc[i] = p.A + (int64_t)r * p.lda + swz_rowk32(row, lane & 3) * 8;
+  }
+  Stager32<BKM> sb;
+  sb.init(p.B, p.ldb, n0, p.N, wave, lane);
+
+  f32x4_t acc[10][4];
+#pragma unroll
+  for (int i = 0; i < 10; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int nk = p.K / PBK;
+
+  auto run = [&](auto group0) {
+    constexpr bool G0 = decltype(group0)::value;
+    auto stage_in = [&](int lt) {
+      char* st = lds + (lt & (P_NST - 1)) * Q_STAGE;
+#pragma unroll
+      for (int i = 0; i < (G0 ? 3 : 2); ++i)
+        __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + (int64_t)lt * PBK), (lptr_t)(st + (i * 8 + wave) * 1024), 16, 0, 0);
+      sb.template issue<false>(lt, p.K, st + Q_TILE_A, wave);
+    };
+    auto landed = [&](int in_flight) {            // batches of this wave's DMA that may stay in flight
+      if constexpr (G0) {
+        if (in_flight >= 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (in_flight == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
+        if (in_flight >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (in_flight == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    };
+    stage_in(0);
+    if (nk > 1) stage_in(1);
+    if (nk > 2) stage_in(2);
+    landed(min(nk, 3) - 1);
+    P_BARRIER();
+    if (!G0) P_BARRIER();                         // stagger: group 1 runs one phase behind group 0
+    auto iteration = [&](int t, auto steady) {
+      const char* tA = lds + (t & (P_NST - 1)) * Q_STAGE;
+      const char* tB = tA + Q_TILE_A;
+      bf16x8_t fa[10], fb[4];
+#pragma unroll
+      for (int i = 0; i < 10; ++i) fa[i] = load_frag32<false>(tA, grp * 160 + i * 16, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = load_frag32<BKM>(tB, wn * 64 + j * 16, lane);
+      if constexpr (decltype(steady)::value) {
+        stage_in(t + 3);
+        landed(2);
+      } else {
+        if (t + 3 < nk) stage_in(t + 3);
+        landed(min(nk - 1, t + 3) - (t + 1));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      P_BARRIER();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 10; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      P_BARRIER();
+    };
+    int t = 0;
+    for (; t + 4 < nk; ++t) iteration(t, std::true_type{});
+    for (; t < nk; ++t) iteration(t, std::false_type{});
+    if (G0) P_BARRIER();
+  };
+  if (grp == 0) run(std::true_type{}); else run(std::false_type{});
+  store_tile_lds<EPI, 10>(p, acc, lds + wave * EP_STRIP, m0 + grp * 160, n0 + wn * 64, lane);
+}
+
 // Epilogue of the k-sliced tail tiles: scratch -> C with the launch's epilogue, scratch re-zeroed.
 template <int EPI>
 __global__ __launch_bounds__(256) void tail_finish_kernel(GemmArgs p, int ntail) {
@@ -850,6 +955,19 @@ int launch(GemmArgs a, const ug_handle* h, int policy, hipStream_t st) {
       UG_CHECK_LAUNCH("ug_gemm_bf16(tail finish)");
     }
     return UG_OK;
+  }
+  // token-count x 1536 outputs with a short contraction (o forward, qkv / o dgrad): one round of 320 x 256 tiles
+  if constexpr (!AK && EPI != EPI_F32) {
+    const int tiles_q = ((a.M + QBM - 1) / QBM) * (a.N / PBN);
+    const bool aligned = a.N % PBN == 0 && a.K % PBK == 0 &&
+                         (EPI == EPI_BF16 ? (a.ldc % 8 == 0 && (!a.bias || (reinterpret_cast<uintptr_t>(a.bias) & 7) == 0))
+                                          : (a.ldc % 4 == 0 && a.ldr % 4 == 0));
+    if (aligned && (g_tile_policy == 10 || (g_tile_policy < 0 && tiles_p8 > 256 && tiles_q <= 256 && tiles_q >= 200))) {
+      a.tiles_m = (a.M + QBM - 1) / QBM; a.tiles_n = a.N / PBN;
+      hipLaunchKernelGGL((gemm_kernel_p10<EPI, BKM>), dim3(a.tiles_m * a.tiles_n), dim3(512), 0, st, a);
+      UG_CHECK_LAUNCH("ug_gemm_bf16(p10)");
+      return UG_OK;
+    }
   }
   bool dbuf = (!AK && !BKM && a.K >= 4096);
   if (g_tile_policy == 0) dbuf = true;

@@ -141,6 +141,35 @@ def test_gemm_bf16_small_weight_gradient_private_partials(dev):
         assert _rel(c32, rep * ref + 1.5) < 1e-5 * math.sqrt(K) + 1e-6, rep
 
 
+@pytest.mark.parametrize("M,N,K", [(12336, 1536, 1536), (12336, 1536, 2048), (700, 512, 96), (321, 256, 32), (1000, 768, 160)])
+def test_gemm_bf16_320_row_tiles(dev, M, N, K):
+    """320 x 256 tiles (one round for the token-count x 1536 outputs of the attention block): forward with bias, forward into
+    the fp32 residual, dgrad (B k-major); ragged M, 1 .. 64 k-tiles.  The two large shapes take the path by themselves
+    (auto policy), the small ones force it."""
+    ops = _ops()
+    g = torch.Generator(device=dev).manual_seed(M + N + K)
+    a = (torch.randn(M, K, device=dev, generator=g) * 0.5).to(torch.bfloat16)
+    b = (torch.randn(N, K, device=dev, generator=g) * 0.5).to(torch.bfloat16)
+    bias = torch.randn(N, device=dev, generator=g).to(torch.bfloat16)
+    res = torch.randn(M, N, device=dev, generator=g)
+    ref = a.float() @ b.float().t()
+    ops.set_gemm_tile_policy(-1 if M > 10000 else 10)
+    try:
+        out = ops.gemm(a, b, bias=bias)
+        assert _rel(out, ref + bias.float()) < 4e-3
+        r32 = torch.empty(M, N, dtype=torch.float32, device=dev)
+        ops.gemm(a, b, out=r32, epilogue=ops.UG_EPI_RESID, resid=res)
+        want = res + ref.to(torch.bfloat16).float()
+        assert ((r32 - want).abs() <= ref.abs() * 2.0 ** -7 + 1e-3).all()
+        out_d = ops.gemm(a, b.t().contiguous(), b_kmajor=True)
+        assert _rel(out_d, ref) < 4e-3
+        if M > 10000:                  # the same launches on the other kernels (policy 3 = 256 x 256 forced): same values up to
+            ops.set_gemm_tile_policy(3)     # the summation order inside a k-tile, which is identical -- bit-equal
+            assert torch.equal(ops.gemm(a, b, bias=bias), out)
+    finally:
+        ops.set_gemm_tile_policy(-1)
+
+
 def test_gemm_bf16_long_contraction_few_tiles(dev):
     """lm-head dgrad shape class: 48 output tiles, K = 70 000 -- every tile is cut along K over several rounds with private
     partials and a summing pass that applies the bf16 epilogue (auto policy).  Reference: fp32 matmul on the same device
