@@ -513,17 +513,17 @@ extern "C" int ug_gemm_trace_read(unsigned long long* host) {
 #define P_STAMP(slot) do {} while (0)
 #endif
 
-template <int EPI, bool AK, bool BKM, bool ONEBAR = false>
-__global__ __launch_bounds__(512, 2) void gemm_kernel_p8(GemmArgs p) {
-  __shared__ __attribute__((aligned(16))) char lds[P_NST * P_STAGE];
+// the workgroup `bid` of one launch (or of one problem of a grouped launch)
+template <int EPI, bool AK, bool BKM, bool ONEBAR>
+__device__ __forceinline__ void p8_body(const GemmArgs& p, const int bid, char* lds) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2, wn = wave & 3;
 
   const int nwg = p.tiles_m * p.tiles_n;
-  const bool tail = p.tail_split > 1 && (int)blockIdx.x >= p.full_tiles;
-  const int tail_j = tail ? (int)blockIdx.x - p.full_tiles : 0;
-  const int tile_lin = tail ? p.full_tiles + tail_j / p.tail_split : (int)blockIdx.x;
+  const bool tail = p.tail_split > 1 && bid >= p.full_tiles;
+  const int tail_j = tail ? bid - p.full_tiles : 0;
+  const int tile_lin = tail ? p.full_tiles + tail_j / p.tail_split : bid;
   const int pid = xcd_remap(tile_lin, nwg);
   const int per_group = GROUP_M * p.tiles_n;
   const int gid = pid / per_group, first_m = gid * GROUP_M;
@@ -722,6 +722,41 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p8(GemmArgs p) {
   }
   store_tile<EPI>(p, reinterpret_cast<f32x4_t (&)[4][4]>(acc[0]), m0 + grp * 128, n0 + wn * 64, lane, false);
   store_tile<EPI>(p, reinterpret_cast<f32x4_t (&)[4][4]>(acc[4]), m0 + grp * 128 + 64, n0 + wn * 64, lane, false);
+}
+
+template <int EPI, bool AK, bool BKM, bool ONEBAR = false>
+__global__ __launch_bounds__(512, 2) void gemm_kernel_p8(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) char lds[P_NST * P_STAGE];
+  p8_body<EPI, AK, BKM, ONEBAR>(p, (int)blockIdx.x, lds);
+}
+
+// Grouped weight gradients: the four dW = dY^T X of a decoder layer (gate_up 420 tiles, down 210, qkv 48, o 36 at 12 336 tokens)
+// share the contraction length, so their 256x256 tiles cost the same and ONE launch packs them into ceil(714 / 256) = 3 rounds
+// of the chip; launched one by one they take 2 + 1 rounds plus two k-sliced launches with their finishing passes.  Every
+// problem's first block index is a multiple of 8 (XCD round-robin as in the single launch); padding blocks return at once.
+constexpr int GROUP_MAX = 8;
+struct GroupProblem {
+  const bf16_t* A; const bf16_t* B; float* C;
+  int64_t lda, ldb, ldc;
+  int M, N, beta, tiles_m, tiles_n, start;
+};
+struct GroupArgs { GroupProblem pr[GROUP_MAX]; int n, K; };
+
+__global__ __launch_bounds__(512, 2) void gemm_kernel_p8_wgrad_group(GroupArgs g) {
+  __shared__ __attribute__((aligned(16))) char lds[P_NST * P_STAGE];
+  const int b = (int)blockIdx.x;
+  int q = 0;
+#pragma unroll
+  for (int i = 1; i < GROUP_MAX; ++i) if (i < g.n && b >= g.pr[i].start) q = i;
+  const GroupProblem& pr = g.pr[q];
+  const int local = b - pr.start;
+  if (local >= pr.tiles_m * pr.tiles_n) return;
+  GemmArgs p;
+  p.A = pr.A; p.B = pr.B; p.C = pr.C; p.bias = nullptr; p.resid = nullptr; p.alpha_dev = nullptr;
+  p.M = pr.M; p.N = pr.N; p.K = g.K; p.lda = pr.lda; p.ldb = pr.ldb; p.ldc = pr.ldc; p.ldr = 0; p.beta = pr.beta;
+  p.tiles_m = pr.tiles_m; p.tiles_n = pr.tiles_n; p.full_tiles = pr.tiles_m * pr.tiles_n; p.tail_split = 1;
+  p.tail_ws = nullptr; p.tail_private = 1; p.one_barrier = 1; p.wide_epilogue = 1; p.swiglu_I = 0; p.act = nullptr; p.ld_act = 0;
+  p8_body<EPI_F32, true, true, true>(p, local, lds);
 }
 
 // =============================================================================================
@@ -1029,6 +1064,33 @@ extern "C" int ug_gemm_bf16(const ug_handle* h, const void* A, int64_t lda, int 
                    a_kmajor, b_kmajor, epilogue);
       return UG_ERR_ARG;
   }
+}
+
+extern "C" int ug_gemm_bf16_wgrad_group(int n, const void* const* dy, const int64_t* ld_dy, const void* const* x, const int64_t* ld_x,
+                                        float* const* dw, const int64_t* ld_dw, const int64_t* rows, const int64_t* cols,
+                                        const int* beta, int64_t K, hipStream_t stream) {
+  UG_REQUIRE(n >= 1 && n <= GROUP_MAX && K > 0 && K < (1 << 30), "ug_gemm_bf16_wgrad_group: 1..%d problems and a positive K required", GROUP_MAX);
+  GroupArgs g;
+  g.n = n; g.K = (int)K;
+  int start = 0;
+  for (int i = 0; i < n; ++i) {
+    UG_REQUIRE(rows[i] > 0 && cols[i] > 0 && rows[i] < (1 << 30) && cols[i] < (1 << 30), "ug_gemm_bf16_wgrad_group: empty problem %d", i);
+    UG_REQUIRE(ld_dy[i] % 8 == 0 && ld_x[i] % 8 == 0 && ld_dy[i] >= rows[i] && ld_x[i] >= cols[i] && ld_dw[i] % 4 == 0 && ld_dw[i] >= cols[i],
+               "ug_gemm_bf16_wgrad_group: problem %d: token-major operands need leading dimensions that are multiples of 8 and cover "
+               "their rows; ld_dw a multiple of 4", i);
+    UG_REQUIRE(ug_aligned16(dy[i]) && ug_aligned16(x[i]) && ug_aligned16(dw[i]), "ug_gemm_bf16_wgrad_group: problem %d: 16-byte alignment", i);
+    GroupProblem& pr = g.pr[i];
+    pr.A = (const bf16_t*)dy[i]; pr.B = (const bf16_t*)x[i]; pr.C = dw[i];
+    pr.lda = ld_dy[i]; pr.ldb = ld_x[i]; pr.ldc = ld_dw[i];
+    pr.M = (int)rows[i]; pr.N = (int)cols[i]; pr.beta = beta[i];
+    pr.tiles_m = (pr.M + PBM - 1) / PBM; pr.tiles_n = (pr.N + PBN - 1) / PBN;
+    pr.start = start;
+    start += (pr.tiles_m * pr.tiles_n + 7) & ~7;
+  }
+  for (int i = n; i < GROUP_MAX; ++i) { g.pr[i] = g.pr[0]; g.pr[i].start = 1 << 30; }
+  hipLaunchKernelGGL(gemm_kernel_p8_wgrad_group, dim3(start), dim3(512), 0, stream, g);
+  UG_CHECK_LAUNCH("ug_gemm_bf16_wgrad_group");
+  return UG_OK;
 }
 
 extern "C" int ug_swiglu_fwd(const void* gate_up, void* act, int64_t tokens, int64_t I, hipStream_t st);

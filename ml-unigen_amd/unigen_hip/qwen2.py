@@ -284,22 +284,27 @@ class Qwen2Engine:
         cos, sin = self.rope(L)
         F32 = ops.UG_EPI_F32
         # ---- MLP   (wgrad: both operands k-major over the token axis; dgrad: weight read k-major)
+        # The four weight gradients (dW = dY^T X, both operands token-major) are leaves of the backward graph: they are
+        # collected and issued as ONE grouped launch at the end of the layer (3 rounds of the chip instead of 2 + 1 + two
+        # k-sliced launches, ops.gemm_wgrad_group).
+        wg = lambda key, dy, x: (dy, x, fp.g(key), fp.beta_for(key))
         dyd = dh_bf16 if dh_bf16 is not None else ops.cast_bf16(dh)
-        ops.gemm(dyd, s.act, out=fp.g(f"l{i}.wdown"), a_kmajor=True, b_kmajor=True, epilogue=F32, beta=fp.beta_for(f"l{i}.wdown"))
+        w_down = wg(f"l{i}.wdown", dyd, s.act)
         dact = ops.gemm(dyd, fp.w(f"l{i}.wdown"), b_kmajor=True)
         dgu = ops.swiglu_bwd(s.gu, dact)
-        ops.gemm(dgu, s.xn2, out=fp.g(f"l{i}.wgu"), a_kmajor=True, b_kmajor=True, epilogue=F32, beta=fp.beta_for(f"l{i}.wgu"))
+        w_gu = wg(f"l{i}.wgu", dgu, s.xn2)
         dxn2 = ops.gemm(dgu, fp.w(f"l{i}.wgu"), b_kmajor=True)
         dyo = ops.rmsnorm_bwd(dxn2, s.h_mid, s.rstd2, fp.p(f"l{i}.ln2"), dh, fp.g(f"l{i}.ln2"), want_bf16=True)
         # ---- attention
-        ops.gemm(dyo, s.o, out=fp.g(f"l{i}.wo"), a_kmajor=True, b_kmajor=True, epilogue=F32, beta=fp.beta_for(f"l{i}.wo"))
+        w_o = wg(f"l{i}.wo", dyo, s.o)
         do = ops.gemm(dyo, fp.w(f"l{i}.wo"), b_kmajor=True)
         dqkv = ops.attn_bwd(s.qkv, s.o, s.lse, do, mb, Hq, Hk, hd)
         ops.rope_(dqkv, cos, sin, L, Hq + Hk, hd, backward=True)
         ops.colsum_(dqkv, fp.g(f"l{i}.bqkv"))
-        ops.gemm(dqkv, s.xn1, out=fp.g(f"l{i}.wqkv"), a_kmajor=True, b_kmajor=True, epilogue=F32, beta=fp.beta_for(f"l{i}.wqkv"))
+        w_qkv = wg(f"l{i}.wqkv", dqkv, s.xn1)
         dxn1 = ops.gemm(dqkv, fp.w(f"l{i}.wqkv"), b_kmajor=True)
         dnext = ops.rmsnorm_bwd(dxn1, s.h, s.rstd1, fp.p(f"l{i}.ln1"), dh, fp.g(f"l{i}.ln1"), want_bf16=True)
+        ops.gemm_wgrad_group([w_gu, w_down, w_qkv, w_o])
         return dh, dnext
 
     def stack_bwd(self, saved, h_last, rstd_last, dhn, mb, L):

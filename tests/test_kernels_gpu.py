@@ -170,6 +170,37 @@ def test_gemm_bf16_320_row_tiles(dev, M, N, K):
         ops.set_gemm_tile_policy(-1)
 
 
+@pytest.mark.parametrize("K,shapes", [(12336, [(17920, 1536), (1536, 8960), (2048, 1536), (1536, 1536)]),
+                                      (1000, [(300, 520), (64, 64), (777, 256), (256, 40), (130, 1000)])])
+def test_gemm_wgrad_group_matches_single_launches(dev, K, shapes):
+    """The grouped weight-gradient launch (a decoder layer's four dW = dY^T X in one grid) against the same problems launched
+    one by one: first-write (beta 0) and accumulating (beta 1) outputs, ragged rows / columns / K, padded leading dimensions.
+    Same tiles, same k order: the 256x256 kernel is bit-equal; problems the single launch k-slices agree to fp32 rounding."""
+    ops = _ops()
+    g = torch.Generator(device=dev).manual_seed(K)
+    probs, refs = [], []
+    for n, (rows, cols) in enumerate(shapes):
+        dy = (torch.randn(K, ops.round_up(rows, 8) + 8, device=dev, generator=g) * 0.1).to(torch.bfloat16)[:, :rows]
+        x = (torch.randn(K, ops.round_up(cols, 8), device=dev, generator=g) * 0.5).to(torch.bfloat16)[:, :cols]
+        beta = n % 2
+        dw = torch.full((rows, ops.round_up(cols, 4) + 4), 0.25, dtype=torch.float32, device=dev)[:, :cols]
+        probs.append((dy, x, dw, beta))
+        refs.append(dy.float().t() @ x.float() + (0.25 if beta else 0.0))
+    old = ops.WGRAD_GROUP_MIN_TILES
+    ops.WGRAD_GROUP_MIN_TILES = 0
+    try:
+        ops.gemm_wgrad_group(probs)
+    finally:
+        ops.WGRAD_GROUP_MIN_TILES = old
+    for (dy, x, dw, beta), ref in zip(probs, refs):
+        assert _rel(dw, ref) < 1e-5 * math.sqrt(K) + 1e-6, (tuple(dw.shape), beta)
+        single = torch.full_like(dw, 0.25)
+        ops.set_gemm_tile_policy(3)                    # whole 256x256 tiles, no k-slices: the same arithmetic
+        ops.gemm(dy, x, out=single, a_kmajor=True, b_kmajor=True, epilogue=ops.UG_EPI_F32, beta=beta)
+        ops.set_gemm_tile_policy(-1)
+        assert torch.equal(single, dw), tuple(dw.shape)
+
+
 def test_gemm_bf16_long_contraction_few_tiles(dev):
     """lm-head dgrad shape class: 48 output tiles, K = 70 000 -- every tile is cut along K over several rounds with private
     partials and a summing pass that applies the bf16 epilogue (auto policy).  Reference: fp32 matmul on the same device
