@@ -1,5 +1,6 @@
-"""Every distinct bf16 GEMM of one training step exactly once (the 12 per-layer launches at M = 12336 tokens + the
-lm-head trio on 4096 label rows), for rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes: HBM-side traffic per launch."""
+"""Every distinct bf16 GEMM launch of one training step exactly once (per layer at M = 12336 tokens: four forward, four dgrad
+and the grouped weight-gradient launch; + the lm-head trio on 4096 label rows), for rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+passes: HBM-side traffic per launch.  o forward runs with its fp32 residual epilogue, down forward too, as in the step."""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ml-unigen_amd"))
 import torch
@@ -23,10 +24,14 @@ which = sys.argv[1] if len(sys.argv) > 1 else "all"      # "layers" | "head" | "
 ops._handle()                                            # the stream's workspace exists before the counted launches
 torch.cuda.synchronize()
 if which in ("layers", "all"):
-    for x, w, dy, gw in bufs:
-        ops.gemm(x, w)
+    for name, (x, w, dy, gw) in zip(shapes, bufs):
+        if name in ("o", "down"):
+            res = torch.randn(M, w.shape[0], device=dev)
+            ops.gemm(x, w, out=torch.empty_like(res), epilogue=ops.UG_EPI_RESID, resid=res)
+        else:
+            ops.gemm(x, w)
         ops.gemm(dy, w, b_kmajor=True)
-        ops.gemm(dy, x, out=gw, a_kmajor=True, b_kmajor=True, epilogue=ops.UG_EPI_F32, beta=1)
+    ops.gemm_wgrad_group([(dy, x, gw, 1) for x, w, dy, gw in bufs])
 if which in ("head", "all"):
     ops.gemm(hn, emb, out=logits, N=V, K=H)
     ops.gemm(logits, hn, out=gemb, M=V, N=H, K=R, a_kmajor=True, b_kmajor=True, epilogue=ops.UG_EPI_F32, beta=1)

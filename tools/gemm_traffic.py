@@ -44,7 +44,7 @@ for group, w in WEIGHT.items():
             launches += w                                   # a finishing pass belongs to its GEMM launch
 src = open(os.path.join(ROOT, "ml-unigen_amd", "csrc", "gemm_bf16.hip"), "rb").read()
 rec = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 tools/gemm_step_mix.py {layers,head}; "
-                 "bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024; step = 28 x the 12 per-layer launches + the lm-head trio",
+                 "bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024; step = 28 x the 9 per-layer launches (4 forward, 4 dgrad, the grouped weight gradients) + the lm-head trio",
        "gemm_src_sha256": hashlib.sha256(src).hexdigest(), "launches_per_step": launches,
        "traffic_bytes_per_step": tot_bytes, "traffic_bytes_per_launch": round(tot_bytes / launches), "per_dispatch": per}
 out = os.path.join(base, "gemm_traffic_current.json")
