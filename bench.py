@@ -371,7 +371,7 @@ def main():
             with open(os.path.join(ROOT, "ml-unigen_amd", "csrc", "gemm_bf16.hip"), "rb") as fh:
                 if rec_t.get("gemm_src_sha256") == hashlib.sha256(fh.read()).hexdigest():
                     traffic = rec_t.get("traffic_bytes_per_launch")
-        roof = {"bound": "mfma", "kernel": "gemm_nt_kernel (bf16 MFMA GEMM)", "achieved": round(ach, 1), "peak": 2500.0,
+        roof = {"bound": "mfma", "kernel": "ug_gemm_bf16 family: gemm_kernel_p8 / _p8_wgrad_group / _p10 / gemm_kernel (bf16 MFMA GEMM)", "achieved": round(ach, 1), "peak": 2500.0,
                 "unit": "TFLOP/s", "frac": round(ach / 2500.0, 4), "traffic": traffic,
                 "launches_per_step": len(rec), "avg_launch_ms": round(tot_ms / len(rec), 4),
                 "flops_per_launch": round(tot_fl / len(rec) / 1e9, 2), "gemm_ms_per_step": round(tot_ms, 2),

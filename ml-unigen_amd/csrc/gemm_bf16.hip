@@ -934,6 +934,21 @@ int launch(GemmArgs a, const ug_handle* h, int policy, hipStream_t st) {
   const int tiles_p8 = ((a.M + PBM - 1) / PBM) * ((a.N + PBN - 1) / PBN);
   const int rounds = (tiles_p8 + 255) / 256;
   const bool p8_fits = (tiles_p8 <= 256) ? (tiles_p8 >= 200) : (4 * tiles_p8 >= 3 * rounds * 256);
+  // token-count x 1536 outputs (o / down forward, qkv / o / gate_up dgrad): one round of 320 x 256 tiles instead of 1.15 rounds
+  // of 256 x 256 -- also ahead of the k-sliced tail where the contraction is long (down forward 954 -> 1065, gate_up dgrad
+  // 1188 -> 1354 TF/s)
+  if constexpr (!AK && EPI != EPI_F32) {
+    const int tiles_q = ((a.M + QBM - 1) / QBM) * (a.N / PBN);
+    const bool aligned = a.N % PBN == 0 && a.K % PBK == 0 &&
+                         (EPI == EPI_BF16 ? (a.ldc % 8 == 0 && (!a.bias || (reinterpret_cast<uintptr_t>(a.bias) & 7) == 0))
+                                          : (a.ldc % 4 == 0 && a.ldr % 4 == 0));
+    if (aligned && (g_tile_policy == 10 || (g_tile_policy < 0 && tiles_p8 > 256 && tiles_q <= 256 && tiles_q >= 200))) {
+      a.tiles_m = (a.M + QBM - 1) / QBM; a.tiles_n = a.N / PBN;
+      hipLaunchKernelGGL((gemm_kernel_p10<EPI, BKM>), dim3(a.tiles_m * a.tiles_n), dim3(512), 0, st, a);
+      UG_CHECK_LAUNCH("ug_gemm_bf16(p10)");
+      return UG_OK;
+    }
+  }
   // A partial last round of 256x256 tiles is cut along K instead: r = tiles mod 256 leftover tiles x s slices fill
   // the chip once more for 1/s of a tile time (fp32 atomics into a scratch, then tail_finish applies the epilogue).
   int tail_r = 0, tail_s = 1;
@@ -990,19 +1005,6 @@ int launch(GemmArgs a, const ug_handle* h, int policy, hipStream_t st) {
       UG_CHECK_LAUNCH("ug_gemm_bf16(tail finish)");
     }
     return UG_OK;
-  }
-  // token-count x 1536 outputs with a short contraction (o forward, qkv / o dgrad): one round of 320 x 256 tiles
-  if constexpr (!AK && EPI != EPI_F32) {
-    const int tiles_q = ((a.M + QBM - 1) / QBM) * (a.N / PBN);
-    const bool aligned = a.N % PBN == 0 && a.K % PBK == 0 &&
-                         (EPI == EPI_BF16 ? (a.ldc % 8 == 0 && (!a.bias || (reinterpret_cast<uintptr_t>(a.bias) & 7) == 0))
-                                          : (a.ldc % 4 == 0 && a.ldr % 4 == 0));
-    if (aligned && (g_tile_policy == 10 || (g_tile_policy < 0 && tiles_p8 > 256 && tiles_q <= 256 && tiles_q >= 200))) {
-      a.tiles_m = (a.M + QBM - 1) / QBM; a.tiles_n = a.N / PBN;
-      hipLaunchKernelGGL((gemm_kernel_p10<EPI, BKM>), dim3(a.tiles_m * a.tiles_n), dim3(512), 0, st, a);
-      UG_CHECK_LAUNCH("ug_gemm_bf16(p10)");
-      return UG_OK;
-    }
   }
   bool dbuf = (!AK && !BKM && a.K >= 4096);
   if (g_tile_policy == 0) dbuf = true;
