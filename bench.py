@@ -350,10 +350,14 @@ def main():
     value = B * world / (dt / args.steps)
 
     roof = None
-    if rank == 0 and not args.no_roofline:
-        ops.GEMM_PROFILE = []
+    if not args.no_roofline:
+        # one more step with HIP events around every GEMM launch (on the launch stream): EVERY rank runs it -- the step
+        # contains the gradient exchange -- and rank 0 records
+        if rank == 0:
+            ops.GEMM_PROFILE = []
         step()
         torch.cuda.synchronize()
+    if rank == 0 and not args.no_roofline:
         rec = ops.GEMM_PROFILE
         ops.GEMM_PROFILE = None
         tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in rec)
