@@ -81,3 +81,20 @@ def test_two_ranks_on_one_gpu_match_single_process(dev, tmp_path, reduce):
             assert torch.equal(r0["accum_grad"], r1["accum_grad"])                             # ... averaged sum afterwards
         else:
             assert r0["sync"]["bytes"] == 3 * per_step
+
+
+def test_bench_runs_end_to_end_with_two_ranks(dev):
+    """bench.py exactly as the driver launches it for N > 1 (torch.distributed.run, one JSON line from rank 0), with both ranks
+    on cuda:0 over gloo (RCCL refuses two ranks on one device): every rank must run every step that contains the gradient
+    exchange -- including the instrumented roofline step -- or rank 0 waits for its peers forever."""
+    import json
+    env = dict(os.environ, UNIGEN_DIST_BACKEND="gloo", UNIGEN_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", _free_port(), os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, (res.stdout + res.stderr)[-3000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 32 and out["config"]["parallelism"] == "dp2"
+    assert out["roofline"]["launches_per_step"] > 0 and out["cpu_baseline"] is None
