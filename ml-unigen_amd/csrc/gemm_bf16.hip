@@ -39,6 +39,12 @@ namespace {
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;   // 16 KiB per operand tile (either layout)
 constexpr int GROUP_M = 8;
+#ifndef UG_P8_GROUP_M
+#define UG_P8_GROUP_M 4
+#endif
+constexpr int P8_GROUP_M = UG_P8_GROUP_M;    // row panels per column sweep of the 256-wide kernels: the four 786 KB A panels of a
+                                             // K = 1536 launch stay in an XCD's 4 MB L2 while its 32 workgroups walk the columns
+                                             // (8: 8192^3 1325 -> 1385, gate_up forward / weight gradients +1..2 %; probe builds override it)
 
 enum Epi { EPI_BF16 = 0, EPI_F32 = 1, EPI_RESID = 2 };
 
@@ -525,9 +531,9 @@ __device__ __forceinline__ void p8_body(const GemmArgs& p, const int bid, char* 
   const int tail_j = tail ? bid - p.full_tiles : 0;
   const int tile_lin = tail ? p.full_tiles + tail_j / p.tail_split : bid;
   const int pid = xcd_remap(tile_lin, nwg);
-  const int per_group = GROUP_M * p.tiles_n;
-  const int gid = pid / per_group, first_m = gid * GROUP_M;
-  const int gsz = min(p.tiles_m - first_m, GROUP_M);
+  const int per_group = P8_GROUP_M * p.tiles_n;
+  const int gid = pid / per_group, first_m = gid * P8_GROUP_M;
+  const int gsz = min(p.tiles_m - first_m, P8_GROUP_M);
   const int tm = first_m + (pid % per_group) % gsz;
   const int tn = (pid % per_group) / gsz;
   const int m0 = tm * PBM, n0 = tn * PBN;
@@ -778,9 +784,9 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p10(GemmArgs p) {
   const int grp = wave >> 2, wn = wave & 3;
   const int nwg = p.tiles_m * p.tiles_n;
   const int pid = xcd_remap((int)blockIdx.x, nwg);
-  const int per_group = GROUP_M * p.tiles_n;
-  const int gid = pid / per_group, first_m = gid * GROUP_M;
-  const int gsz = min(p.tiles_m - first_m, GROUP_M);
+  const int per_group = P8_GROUP_M * p.tiles_n;
+  const int gid = pid / per_group, first_m = gid * P8_GROUP_M;
+  const int gsz = min(p.tiles_m - first_m, P8_GROUP_M);
   const int tm = first_m + (pid % per_group) % gsz;
   const int tn = (pid % per_group) / gsz;
   const int m0 = tm * QBM, n0 = tn * PBN;
@@ -875,9 +881,9 @@ __global__ __launch_bounds__(256) void tail_finish_kernel(GemmArgs p, int ntail)
   for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     const int tl = (int)(idx / per_tile), q = (int)(idx % per_tile);
     const int pid = xcd_remap(p.full_tiles + tl, nwg);
-    const int per_group = GROUP_M * p.tiles_n;
-    const int gid = pid / per_group, first_m = gid * GROUP_M;
-    const int gsz = min(p.tiles_m - first_m, GROUP_M);
+    const int per_group = P8_GROUP_M * p.tiles_n;
+    const int gid = pid / per_group, first_m = gid * P8_GROUP_M;
+    const int gsz = min(p.tiles_m - first_m, P8_GROUP_M);
     const int tm = first_m + (pid % per_group) % gsz;
     const int tn = (pid % per_group) / gsz;
     const int ml = q / (PBN / 4), nl = (q % (PBN / 4)) * 4;
