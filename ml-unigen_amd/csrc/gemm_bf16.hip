@@ -772,6 +772,10 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p8_wgrad_group(GroupArgs g
 // 40 MFMAs per k-tile, 160 accumulator registers).  Restricted to what those launches need: A row-major, K % 32 == 0,
 // N % 256 == 0, bf16 / residual epilogues through the LDS strips, no k-slices.  The 20 A instructions of a k-tile go two
 // per wave plus a third for the waves of group 0, so the counted waits are per group (5 / 4 DMA instructions per tile).
+#ifndef UG_P10_GROUP_M
+#define UG_P10_GROUP_M 4
+#endif
+constexpr int P10_GROUP_M = UG_P10_GROUP_M;
 constexpr int QBM = 320;
 constexpr int Q_TILE_A = QBM * PBK * 2;        // 20 KiB
 constexpr int Q_STAGE = Q_TILE_A + P_TILE;     // 36 KiB; four stages = 144 KiB
@@ -784,9 +788,9 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p10(GemmArgs p) {
   const int grp = wave >> 2, wn = wave & 3;
   const int nwg = p.tiles_m * p.tiles_n;
   const int pid = xcd_remap((int)blockIdx.x, nwg);
-  const int per_group = P8_GROUP_M * p.tiles_n;
-  const int gid = pid / per_group, first_m = gid * P8_GROUP_M;
-  const int gsz = min(p.tiles_m - first_m, P8_GROUP_M);
+  const int per_group = P10_GROUP_M * p.tiles_n;
+  const int gid = pid / per_group, first_m = gid * P10_GROUP_M;
+  const int gsz = min(p.tiles_m - first_m, P10_GROUP_M);
   const int tm = first_m + (pid % per_group) % gsz;
   const int tn = (pid % per_group) / gsz;
   const int m0 = tm * QBM, n0 = tn * PBN;

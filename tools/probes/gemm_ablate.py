@@ -22,7 +22,7 @@ out = os.path.join(ROOT, "gpurun_out", "ablate")
 os.makedirs(out, exist_ok=True)
 variant = sys.argv[1] if len(sys.argv) > 1 else "full"
 flags = {"full": [], "nodma": ["-DUG_GEMM_ABLATE_DMA"], "hotsrc": ["-DUG_GEMM_ABLATE_SRC"],
-         "gm2": ["-DUG_P8_GROUP_M=2"], "gm8": ["-DUG_P8_GROUP_M=8"], "gm6": ["-DUG_P8_GROUP_M=6"], "gm16": ["-DUG_P8_GROUP_M=16"]}[variant]
+         "q2": ["-DUG_P10_GROUP_M=2"], "q4": ["-DUG_P10_GROUP_M=4"], "q8": ["-DUG_P10_GROUP_M=8"], "q3": ["-DUG_P10_GROUP_M=3"], "q6": ["-DUG_P10_GROUP_M=6"], "gm2": ["-DUG_P8_GROUP_M=2"], "gm8": ["-DUG_P8_GROUP_M=8"], "gm6": ["-DUG_P8_GROUP_M=6"], "gm16": ["-DUG_P8_GROUP_M=16"]}[variant]
 so = os.path.join(out, f"libunigen_hip_{variant}.so")
 objs = []
 for f in sorted(os.listdir(src)):
@@ -43,8 +43,11 @@ assert L.load()._name == so
 dev = torch.device("cuda:0")
 T = 12336
 cases = [("sq8192", 8192, 8192, 8192, "fwd"), ("gu_f", T, 17920, 1536, "fwd"), ("down_d", T, 8960, 1536, "dgrad"), ("gu_w", 17920, 1536, T, "wgrad"),
-         ("qkv_f", T, 2048, 1536, "fwd"), ("head_f", 4096, 159872, 1536, "fwd"), ("gu_d", T, 1536, 17920, "dgrad")]
-pols = {"two-barrier": 105, "one-barrier": 103}
+         ("qkv_f", T, 2048, 1536, "fwd"), ("head_f", 4096, 159872, 1536, "fwd"), ("gu_d", T, 1536, 17920, "dgrad"),
+         ("qkv_d", T, 1536, 2048, "dgrad"), ("o_f", T, 1536, 1536, "fwd")]
+if variant.startswith("q"):
+    cases = [c for c in cases if c[0] in ("gu_f", "gu_d", "qkv_d", "o_f")]
+pols = {"two-barrier": 105, "one-barrier": 103} if not variant.startswith("q") else {"auto": -1}
 for name, M, N, K, mode in cases:
     g = torch.Generator(device=dev).manual_seed(1)
     rnd = lambda *s: (torch.rand(*s, device=dev, generator=g) * 2 - 1).to(torch.bfloat16)
