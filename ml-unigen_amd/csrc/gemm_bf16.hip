@@ -10,7 +10,16 @@
 //   dgrad    dx = dy W        : A = dy  RowK, B = W  KRow   (W is [N_out][K_in] = [k][row])
 //   wgrad    dW = dy^T x      : A = dy  KRow, B = x  KRow   (contraction over tokens)
 //
-// Structure: 128x128 tile, BK=64, 4 waves (2x2, 64x64 per wave = 4x4 mfma_f32_16x16x32_bf16
+// Kernels in this file (the launcher picks per shape, see launch<>() and DESIGN.md section 4.1):
+//   gemm_kernel             128x128 tiles, 4 waves, 1-2 LDS stages: small / ragged problems
+//   gemm_kernel_p8          256x256 tiles, 8 waves in two groups that alternate fragment reads (L) and MFMAs (M), 4-stage
+//                           LDS-DMA ring; two barriers per k-tile (forward, dgrad) or one (weight gradients); k-sliced forms
+//                           for partial last rounds and small outputs
+//   gemm_kernel_p8_wgrad_group   the same loop over the tiles of up to 8 weight-gradient problems sharing K (one launch
+//                           per decoder layer)
+//   gemm_kernel_p10         320x256 tiles (A row-major): outputs whose 256-row tiling leaves a mostly empty round
+//
+// The 128x128 kernel: BK=64, 4 waves (2x2, 64x64 per wave = 4x4 mfma_f32_16x16x32_bf16
 // fragments), operands staged HBM->LDS with 16-byte LDS-DMA (global_load_lds).  Two pipelining
 // modes, chosen per launch (measured on MI355X, tools/gemm_bench.py):
 //   single LDS stage (32 KiB, <=128 VGPRs -> 4 workgroups/CU): latency is hidden by the other resident
