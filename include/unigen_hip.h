@@ -292,6 +292,11 @@ int ug_grad_pack_bf16(const float* in, void* out_bf16, int64_t n, float scale, h
  * per step otherwise (torch's `zero_grad(set_to_none=False)` semantics for those tensors, reference training/train.py:773). */
 int ug_zero_ranges_f32(float* buf, const int64_t* ranges, int64_t n_ranges, int64_t max_len, hipStream_t stream);
 int ug_grad_unpack_bf16(const void* in_bf16, float* out, int64_t n, hipStream_t stream);
+/* bf16 on the wire, fp32 arithmetic: after an all-to-all of the packed bucket, `shards` holds every rank's bf16 copy of THIS
+ * rank's slice (shard r at shards + r * stride elements, stride % 8 == 0).  out[i] = bf16(scale * sum_r float(shards[r][i])),
+ * summed in fp32 in rank order (identical on every rank), rounded once; the slices are then all-gathered and unpacked. */
+int ug_grad_sum_shards_bf16(const void* shards_bf16, int world, int64_t stride, void* out_bf16, int64_t n, float scale,
+                            hipStream_t stream);
 
 /* ---- MAGVITv2 tokenizer (fp32, NHWC) ------------------------------------------------------- */
 /* replaces: torch.nn.Conv2d in VQGANEncoder/Decoder, ResnetBlock, Downsample (asymmetric pad via

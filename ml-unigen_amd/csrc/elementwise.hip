@@ -365,6 +365,32 @@ __global__ __launch_bounds__(256) void grad_pack_kernel(const float* __restrict_
   const int64_t ti = (n8 << 3) + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (ti < n) out[ti] = f2bf(in[ti] * scale);
 }
+// out[i] = bf16( (sum_{r < world} float(shards[r * stride + i])) * scale ): rank-ordered fp32 sum of the bf16 copies of ONE slice
+// that an all-to-all collected from every rank (FlatGradSync reduce = "bf16_fp32acc": bf16 on the wire, fp32 arithmetic).
+__global__ __launch_bounds__(256) void grad_sum_shards_kernel(const bf16_t* __restrict__ shards, int world, int64_t stride,
+                                                              bf16_t* __restrict__ out, int64_t n, float scale) {
+  const int64_t n8 = n >> 3;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < world; ++r) {
+      const uint4 v = reinterpret_cast<const uint4*>(shards + r * stride)[i];
+      acc[0] += __uint_as_float(v.x << 16); acc[1] += __uint_as_float(v.x & 0xffff0000u);
+      acc[2] += __uint_as_float(v.y << 16); acc[3] += __uint_as_float(v.y & 0xffff0000u);
+      acc[4] += __uint_as_float(v.z << 16); acc[5] += __uint_as_float(v.z & 0xffff0000u);
+      acc[6] += __uint_as_float(v.w << 16); acc[7] += __uint_as_float(v.w & 0xffff0000u);
+    }
+    uint4 o;
+    o.x = pack_bf2(acc[0] * scale, acc[1] * scale); o.y = pack_bf2(acc[2] * scale, acc[3] * scale);
+    o.z = pack_bf2(acc[4] * scale, acc[5] * scale); o.w = pack_bf2(acc[6] * scale, acc[7] * scale);
+    reinterpret_cast<uint4*>(out)[i] = o;
+  }
+  const int64_t ti = (n8 << 3) + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (ti < n) {
+    float a = 0.f;
+    for (int r = 0; r < world; ++r) a += bf2f(shards[r * stride + ti]);
+    out[ti] = f2bf(a * scale);
+  }
+}
 // out = float(in): the reduced bf16 bucket back into the flat fp32 gradient buffer.
 __global__ __launch_bounds__(256) void grad_unpack_kernel(const bf16_t* __restrict__ in, float* __restrict__ out, int64_t n) {
   const int64_t n8 = n >> 3;
@@ -566,6 +592,15 @@ extern "C" int ug_grad_unpack_bf16(const void* in, float* out, int64_t n, hipStr
   dim3 grid(grid_for(n / 8 + 1)), block(256);
   hipLaunchKernelGGL(grad_unpack_kernel, grid, block, 0, st, (const bf16_t*)in, out, n);
   UG_CHECK_LAUNCH("ug_grad_unpack_bf16");
+  return UG_OK;
+}
+
+extern "C" int ug_grad_sum_shards_bf16(const void* shards, int world, int64_t stride, void* out, int64_t n, float scale, hipStream_t st) {
+  UG_REQUIRE(n > 0 && world >= 1 && world <= 1024 && stride >= n && stride % 8 == 0 && ug_aligned16(shards) && ug_aligned16(out),
+             "ug_grad_sum_shards_bf16: n > 0, 1..1024 shards, stride >= n and a multiple of 8, 16-byte aligned buffers required");
+  dim3 grid(grid_for(n / 8 + 1)), block(256);
+  hipLaunchKernelGGL(grad_sum_shards_kernel, grid, block, 0, st, (const bf16_t*)shards, world, stride, (bf16_t*)out, n, scale);
+  UG_CHECK_LAUNCH("ug_grad_sum_shards_bf16");
   return UG_OK;
 }
 

@@ -19,6 +19,7 @@ Behavioural notes (all mirror the reference unless stated):
 """
 import json
 import os
+import weakref
 from typing import Optional
 
 import torch
@@ -145,7 +146,7 @@ class UniGen(ModelMixin, ConfigMixin):
         self._ddp_anchor = torch.nn.Parameter(torch.zeros(1, device=eng.device))
         eng._anchor = self._ddp_anchor
         eng.extra_grad_params = self._ordinary_grad_params
-        self.__dict__["_ddp_wrapped"] = False
+        self.__dict__["_ddp_wrapper"] = None          # weakref to the DistributedDataParallel instance wrapping this model, if any
         self._register_state_dict_hook(_drop_anchor_from_state_dict)
         self.register_load_state_dict_post_hook(_forgive_missing_anchor)
         if w_und_encoder:
@@ -160,17 +161,22 @@ class UniGen(ModelMixin, ConfigMixin):
     @property
     def _ddp_params_and_buffers_to_ignore(self):
         """Read by torch's DistributedDataParallel constructor (nn/parallel/distributed.py: parameters_to_ignore): every
-        name under which a flat-view parameter is reachable, including the tied `llm.lm_head.weight`.  Reading it also
-        records that a DDP wrapper exists, i.e. that the ordinary parameters (mm_projector, ...) are averaged by DDP's
-        own reducer and FlatGradSync only has to move the flat buffer."""
-        self.__dict__["_ddp_wrapped"] = True
-        self.llm.engine._dp_sync()          # the wrapper is being built: align the flat weights to rank 0 now, like DDP does for its own
+        name under which a flat-view parameter is reachable, including the tied `llm.lm_head.weight`.  Side-effect free:
+        whether a wrapper exists is recorded by `_note_ddp_wrapper` below when DistributedDataParallel registers this model
+        as its `.module`, and the flat weights are aligned to rank 0 at the first training forward (`TrainEngine._dp_sync`),
+        which every rank reaches together."""
         flat = self._flat_view_ids()
         return [f"{mn}.{pn}" if mn else pn for mn, m in self.named_modules() for pn, p in m.named_parameters(recurse=False)
                 if id(p) in flat]
 
+    def _is_ddp_wrapped(self):
+        """True while a live DistributedDataParallel instance holds this model: its reducer then averages the ordinary
+        parameters (mm_projector, gen_*) and FlatGradSync only moves the flat buffer."""
+        ref = self.__dict__.get("_ddp_wrapper")
+        return ref is not None and ref() is not None
+
     def _ordinary_grad_params(self):
-        if self.__dict__.get("_ddp_wrapped"):
+        if self._is_ddp_wrapped():
             return []
         flat = self._flat_view_ids()
         return [p for p in self.parameters() if id(p) not in flat and p is not self._ddp_anchor and p.requires_grad]
@@ -834,3 +840,15 @@ class UniGen(ModelMixin, ConfigMixin):
             if eot_token is not None and idx_next.cpu() == eot_token:
                 break
         return result
+
+
+def _note_ddp_wrapper(parent, name, sub):
+    """Global module-registration hook: `DistributedDataParallel.__init__` does `self.module = module` (reference:
+    accelerator.prepare, training/train.py:492).  The weak reference dies with the wrapper, so a model that is unwrapped
+    again goes back to averaging its ordinary parameters itself."""
+    if isinstance(sub, UniGen) and isinstance(parent, torch.nn.parallel.DistributedDataParallel):
+        sub.__dict__["_ddp_wrapper"] = weakref.ref(parent)
+    return None
+
+
+torch.nn.modules.module.register_module_module_registration_hook(_note_ddp_wrapper)

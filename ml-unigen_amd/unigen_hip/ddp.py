@@ -8,11 +8,15 @@ gradient buffer, issued bucket by bucket on a side HIP stream while backward is 
     backward (main stream)   ... layer 5 | layer 4 | layer 3 | layer 2 | ...
     side stream                          [pack 5-4][RCCL all-reduce 5-4][unpack]   [pack 3-2][all-reduce 3-2] ...
 
-* reduce = "bf16" (default on the GPU): a bucket is packed as bf16(g / world) by `ug_grad_pack_bf16`, summed by RCCL
-  over xGMI, and unpacked in place -- half the bytes on the links (3.1 GB instead of 6.2 GB per step for the 1.5B
-  model) and half the time the collective's workgroups compete with the backward GEMMs for CUs.
-* reduce = "fp32" (`UNIGEN_DDP_REDUCE=fp32`; always on CPU tensors): the bucket itself is all-reduced (AVG on RCCL, SUM and
-  a scale on gloo) -- bit-for-bit what DDP's reducer computes.
+* reduce = "fp32" (default): the bucket itself is all-reduced (AVG on RCCL, SUM and a scale on gloo) -- bit-for-bit
+  what DDP's reducer computes; 6.2 GB per step on the links for the 1.5B model.
+* reduce = "bf16_fp32acc" (`UNIGEN_DDP_REDUCE=bf16_fp32acc`): bf16 on the wire, fp32 arithmetic.  Each rank packs
+  bf16(g), an all-to-all hands rank r every rank's copy of slice r, the slice is summed in fp32 in rank order and scaled
+  (`ug_grad_sum_shards_bf16`), rounded to bf16 ONCE and all-gathered: two bf16 roundings per element whatever the world
+  size (worst element 2^-8 relative), 3.1 GB on the links.
+* reduce = "bf16" (`UNIGEN_DDP_REDUCE=bf16`): bf16(g / world) summed by the collective itself in bf16 -- the cheapest
+  form and the least accurate one: a ring adds world - 1 bf16 roundings of partial sums on top of the packing
+  (tests/test_ddp_cpu.py::test_bf16_exchange_error_by_world_size measures every mode at 2 / 4 / 8 ranks).
 
 After `finish()` every gradient holds the MEAN over ranks, exactly what DDP leaves in `.grad`: the caller's unchanged
 `accelerator.clip_grad_norm_` and any stock torch optimizer see the same values as in the reference (no grad_scale
@@ -35,15 +39,23 @@ class FlatGradSync:
     def __init__(self, engine, process_group=None, layers_per_bucket=2, reduce=None, extra_params=None):
         self.engine, self.pg = engine, process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # UNIGEN_DDP_FORCE=1: run the exchange at world size 1 too (the mean of one rank is the gradient itself) -- lets a
+        # one-GPU box drive pack -> RCCL -> unpack on the side stream (tests/test_ddp_gpu.py)
+        self.active = self.world > 1 or (dist.is_initialized() and os.environ.get("UNIGEN_DDP_FORCE", "0") == "1")
         self.layers_per_bucket = max(1, int(layers_per_bucket))
         self.cuda = engine.fp.grad.is_cuda
         if reduce is None:
-            reduce = os.environ.get("UNIGEN_DDP_REDUCE", "bf16" if self.cuda else "fp32")
-        if reduce not in ("bf16", "fp32"):
-            raise ValueError(f"FlatGradSync: reduce must be 'bf16' or 'fp32' (got {reduce!r})")
-        if reduce == "bf16" and not self.cuda:
-            raise ValueError("FlatGradSync: the bf16 exchange packs with a HIP kernel; CPU tensors use reduce='fp32'")
+            reduce = os.environ.get("UNIGEN_DDP_REDUCE", "fp32")
+        if reduce not in ("bf16", "bf16_fp32acc", "fp32"):
+            raise ValueError(f"FlatGradSync: reduce must be 'fp32', 'bf16_fp32acc' or 'bf16' (got {reduce!r})")
+        if reduce != "fp32" and not self.cuda:
+            raise ValueError("FlatGradSync: the bf16 exchanges pack with a HIP kernel; CPU tensors use reduce='fp32'")
         self.reduce = reduce
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        # largest bucket handed to one collective, in elements (the tied embedding, 245.6 M elements for the 1.5B model, is
+        # otherwise ONE exposed collective at the end of backward): UNIGEN_DDP_MAX_BUCKET_MB of fp32
+        self.max_bucket = max(1 << 16, int(float(os.environ.get("UNIGEN_DDP_MAX_BUCKET_MB", "512")) * (1 << 20) / 4))
+        self._overlap = True
         self.backend = dist.get_backend(process_group) if dist.is_initialized() else "none"
         self.stream = torch.cuda.Stream() if self.cuda else None
         self.extra_params = extra_params
@@ -55,15 +67,17 @@ class FlatGradSync:
         self._starts = {i: fp.off[f"l{i}.wqkv"][0] for i in range(n)}
         self._numel = fp.grad.numel()
         self._stage = None              # bf16 staging buffer, sized for the largest bucket on first use
+        self._gather = None
         self.bytes_on_wire = 0          # payload handed to the collective since construction (tests / bench reporting)
         engine.grad_ready_hook = self.on_ready
 
     # ------------------------------------------------------------------ one bucket
     def _stage_for(self, n):
-        if self._stage is None or self._stage.numel() < n:
-            cap = max(n, self._starts.get(0, n))           # the embedding table (everything before layer 0) is the largest bucket
-            self._stage = torch.empty(cap, dtype=torch.bfloat16, device=self.engine.fp.grad.device)
-        return self._stage[:n]
+        """bf16 staging: [send n_pad | recv n_pad] for the largest bucket this object will ever hand over"""
+        if self._stage is None or self._stage.numel() < 2 * n:
+            cap = max(n, min(self.max_bucket, self._starts.get(0, n)) + 8 * self.world)
+            self._stage = torch.empty(2 * cap, dtype=torch.bfloat16, device=self.engine.fp.grad.device)
+        return self._stage
 
     def _allreduce_mean_(self, buf):
         """in-place mean over ranks of an fp32 tensor on the current stream / host"""
@@ -73,9 +87,42 @@ class FlatGradSync:
             dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg)
             buf.mul_(1.0 / self.world)
 
-    def _flush(self, lo, hi):
-        if self.world == 1 or hi <= lo or not self.enabled:
+    def _exchange_bf16_fp32acc(self, buf):
+        """bf16 on the wire, fp32 arithmetic (see the module docstring); runs on the current (side) stream"""
+        from . import ops
+        n, W = buf.numel(), self.world
+        chunk = -(-n // (8 * W)) * 8                 # slice length per rank, 16-byte rows
+        n_pad = chunk * W
+        stage = self._stage_for(n_pad)
+        send, recv = stage[:n_pad], stage[n_pad:2 * n_pad]
+        if n_pad > n:
+            send[n:].zero_()
+        ops.grad_pack_bf16(buf, send[:n], 1.0)
+        if self.backend != "nccl":
+            # rehearsal transports (gloo moves device tensors through the host and has no all-to-all for them): every rank
+            # gathers every packed bucket and sums all of it -- W times the bytes, the same arithmetic in the same order
+            if self._gather is None or self._gather.numel() < W * n_pad:
+                self._gather = torch.empty(W * n_pad, dtype=torch.bfloat16, device=buf.device)
+            parts = list(self._gather[:W * n_pad].view(W, n_pad).unbind(0))
+            dist.all_gather(parts, send, group=self.pg)
+            ops.grad_sum_shards_bf16(self._gather, W, n_pad, recv, 1.0 / W)
+            ops.grad_unpack_bf16(recv[:n], buf)
+            self.bytes_on_wire += W * n_pad * 2
             return
+        dist.all_to_all_single(recv, send, group=self.pg)                  # recv[j] = rank j's copy of my slice
+        mine = send[self.rank * chunk:(self.rank + 1) * chunk]            # (my own packed slice is no longer needed)
+        ops.grad_sum_shards_bf16(recv, W, chunk, mine, 1.0 / W)
+        dist.all_gather_into_tensor(recv, mine, group=self.pg)
+        ops.grad_unpack_bf16(recv[:n], buf)
+        self.bytes_on_wire += 2 * n_pad * 2
+
+    def _flush(self, lo, hi):
+        if not self.active or hi <= lo or not self.enabled:
+            return
+        for a in range(lo, hi, self.max_bucket):                            # (one piece unless the span is the embedding table)
+            self._flush_piece(a, min(hi, a + self.max_bucket))
+
+    def _flush_piece(self, lo, hi):
         buf = self.engine.fp.grad[lo:hi]
         if not self.cuda:
             self.bytes_on_wire += buf.numel() * 4
@@ -87,11 +134,13 @@ class FlatGradSync:
         with torch.cuda.stream(self.stream):
             self.stream.wait_event(ev)
             if self.reduce == "bf16":
-                stage = self._stage_for(hi - lo)
+                stage = self._stage_for(hi - lo)[:hi - lo]
                 ops.grad_pack_bf16(buf, stage, 1.0 / self.world)
                 dist.all_reduce(stage, op=dist.ReduceOp.SUM, group=self.pg)
                 ops.grad_unpack_bf16(stage, buf)
                 self.bytes_on_wire += stage.numel() * 2
+            elif self.reduce == "bf16_fp32acc":
+                self._exchange_bf16_fp32acc(buf)
             else:
                 self._allreduce_mean_(buf)
                 self.bytes_on_wire += buf.numel() * 4
@@ -102,29 +151,38 @@ class FlatGradSync:
         exchanged, gradients keep accumulating locally."""
         self.enabled = bool(enabled)
         self._hi = None
+        self._overlap = True
+
+    def set_overlap(self, on):
+        """Called at the start of every decoder-stack segment of a backward pass: only the LAST segment that writes the
+        layers' gradients may hand them over while it runs (a forward that ran the stack twice -- chosen / rejected, two
+        micro-batches under one backward -- has an earlier segment whose hooks must be ignored)."""
+        self._overlap = bool(on)
 
     def on_ready(self, tag):
-        """tag: 'norm' (first), layer index N-1 .. 0, then 'embed' (last)."""
-        if not self.enabled:
+        """tag: 'norm' (first), layer index N-1 .. 0, then 'embed' (any number of times, last).
+        The embedding table is NEVER handed over from here: a forward may look embeddings up several times (the reference's
+        callers do: training/train.py:602-609,633,671 -- text, t2i and mmu parts), the tied head writes the same table, and
+        only the end of backward (finish) knows that no writer is left."""
+        if not self.enabled or not self._overlap:
             return
         if tag == "norm":
             self._hi = self._numel
             return
         if tag == "embed":
-            self._flush(0, self._hi if self._hi is not None else self._numel)
-            self._hi = 0
             return
         i = int(tag)
-        if i % self.layers_per_bucket == 0:
+        if self._hi is not None and i % self.layers_per_bucket == 0:
             lo = self._starts[i]
-            self._flush(lo, self._hi if self._hi is not None else self._numel)
-            self._hi = lo
+            if lo < self._hi:
+                self._flush(lo, self._hi)
+                self._hi = lo
 
     def finish(self):
-        """End of backward: flush what no hook has covered (the embedding table when the caller passed embeddings, or
-        everything if no hook fired), average the ordinary parameters' gradients, and make the current stream (the host,
-        on CPU) wait for every outstanding bucket."""
-        if not self.enabled or self.world == 1:
+        """End of backward: flush what no hook has covered (always the embedding table; everything if no hook fired or
+        overlapping was off), average the ordinary parameters' gradients, and make the current stream (the host, on CPU)
+        wait for every outstanding bucket."""
+        if not self.enabled or not self.active:
             self._hi = None
             return
         if self._hi is None:

@@ -66,6 +66,7 @@ SIGNATURES = {
     "ug_grad_pack_bf16": [P, P, I64, F32, P],
     "ug_zero_ranges_f32": [P, P, I64, I64, P],
     "ug_grad_unpack_bf16": [P, P, I64, P],
+    "ug_grad_sum_shards_bf16": [P, I32, I64, P, I64, F32, P],
     "ug_conv2d_f32": [P, P, P, P, P, I64, I32, I32, I32, I32, I32, I32, I32, I32, I32, I32, I32, I32, P],
     "ug_conv_split_weights": [P, P, I32, I32, I32, P],
     "ug_amax_f32": [P, I64, I64, I64, P, P],

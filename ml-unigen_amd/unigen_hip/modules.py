@@ -51,7 +51,8 @@ class _StackFn(torch.autograd.Function):
         need = any(ctx.needs_input_grad)
         saved = [] if need else None
         if need:
-            engine._dp_sync()               # world > 1: install the gradient exchange / align the replicas before step 1
+            engine._forward_entry()         # world > 1: install the gradient exchange / align the replicas before step 1
+            engine._stack_graphs_live += 1  # decoder-stack segments waiting for their backward (see _StackFn.backward)
         h_last, hn, rstd = engine.stack_fwd(h0.reshape(B * L, H).float().contiguous(), mb, L, saved)
         if need:
             ctx.engine, ctx.saved, ctx.h_last, ctx.rstd, ctx.mb, ctx.shape = engine, saved, h_last, rstd, mb, (B, L, H)
@@ -62,6 +63,12 @@ class _StackFn(torch.autograd.Function):
         eng = ctx.engine
         B, L, H = ctx.shape
         eng.begin_grad_pass()
+        # layer gradients may be handed to the data-parallel exchange as this segment retires them only if no other
+        # recorded stack segment (a second forward under the same backward) can still add to them
+        last_writer = eng._stack_graphs_live <= 1
+        eng._stack_graphs_live = max(0, eng._stack_graphs_live - 1)
+        if eng.grad_sync is not None:
+            eng.grad_sync.set_overlap(last_writer)
         dhn = dhn.reshape(B * L, H).to(torch.bfloat16).contiguous()
         dh0 = eng.stack_bwd(ctx.saved, ctx.h_last, ctx.rstd, dhn, ctx.mb, L)
         ctx.saved = None
@@ -227,7 +234,7 @@ class HipEmbedding(nn.Module):
     def forward(self, ids):
         eng = self.__dict__["_engine"]
         if torch.is_grad_enabled():
-            eng._dp_sync()                  # world > 1: replicas aligned to rank 0 before the first training lookup
+            eng._forward_entry()            # world > 1: replicas aligned to rank 0 before the first training lookup
         return _EmbedFn.apply(eng._anchor, ids.to(eng.device), eng)
 
 
@@ -374,6 +381,7 @@ class TrainEngine(Qwen2Engine):
         self.require_grad_sync = True        # False inside UniGen.no_sync(): gradient-accumulation micro-steps
         self.extra_grad_params = None        # callable -> ordinary Parameters to average when no DDP wrapper does it
         self._in_backward = False
+        self._stack_graphs_live = 0
 
     def named_param_views(self):
         if self._params is None:
@@ -395,7 +403,9 @@ class TrainEngine(Qwen2Engine):
         manages, and the flat views are deliberately hidden from it (`UniGen._ddp_params_and_buffers_to_ignore`)."""
         if self.grad_sync is None and self.auto_data_parallel:
             import torch.distributed as dist
-            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            import os
+            forced = os.environ.get("UNIGEN_DDP_FORCE", "0") == "1"
+            if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or forced):
                 from .ddp import FlatGradSync
                 self.grad_sync = FlatGradSync(self, extra_params=lambda: self.extra_grad_params() if self.extra_grad_params else [])
                 with torch.no_grad():
@@ -404,6 +414,13 @@ class TrainEngine(Qwen2Engine):
                         dist.broadcast(p.data, 0)
                 self.fp._seen_version = -1
         return self.grad_sync
+
+    def _forward_entry(self):
+        """Start of a training forward.  A backward that raised after arming the exchange (OOM, a device-side check,
+        KeyboardInterrupt in a retry loop) never ran its end-of-backward callback: a forward is proof that no backward
+        pass is in flight any more, so the next one arms again."""
+        self._in_backward = False
+        return self._dp_sync()
 
     def _sync_this_pass(self):
         """False on a gradient-accumulation micro-step: inside `UniGen.no_sync()`, or when accelerate's shared
@@ -419,6 +436,7 @@ class TrainEngine(Qwen2Engine):
 
     def _end_of_backward(self):
         self._in_backward = False
+        self._stack_graphs_live = 0          # graphs that were built and dropped without a backward do not count against the next pass
         if self.grad_sync is not None:
             self.grad_sync.finish()
 

@@ -221,6 +221,13 @@ def grad_unpack_bf16(src, g):
     _l.check(_l.load().ug_grad_unpack_bf16(_p(src), _p(g), g.numel(), _stream()), "ug_grad_unpack_bf16")
 
 
+def grad_sum_shards_bf16(shards, world, stride, out, scale):
+    """out (bf16 [n]) = bf16(scale * sum over the `world` bf16 shards of n elements, `stride` apart), fp32 sum in rank order."""
+    _need_cuda(shards, out)
+    _l.check(_l.load().ug_grad_sum_shards_bf16(_p(shards), int(world), int(stride), _p(out), out.numel(), float(scale), _stream()),
+             "ug_grad_sum_shards_bf16")
+
+
 # ------------------------------------------------------------------------------------ row ops
 def rmsnorm_fwd(x, w, eps, out_f32=False, want_rstd=True, out=None):
     _need_cuda(x, w)

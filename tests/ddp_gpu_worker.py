@@ -9,6 +9,10 @@ callback, optimizer -- is the one an 8-GPU run executes).  mode:
   ddp     the model wrapped in torch DistributedDataParallel exactly as accelerator.prepare does (train.py:492), stock
           torch.optim.AdamW, clip_grad_norm_ between backward and step (train.py:775-780)
   bare    no wrapper (bench.py's situation), FusedAdamW, plus a gradient-accumulation step under UniGen.no_sync()
+  multi   no wrapper; every forward looks embeddings up TWICE (two parts concatenated, as the reference's callers do,
+          training/train.py:602-609,633,671) and every backward covers TWO decoder-stack segments (the local batch as two
+          micro-batches under one backward) -- ADVICE r2 (high): the embedding bucket must be exchanged once, after its last
+          writer, and layer buckets only by the last segment
 """
 import os
 import sys
@@ -67,7 +71,7 @@ def groups(named):
 net = model
 if mode == "ddp":
     net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0])
-    assert model.__dict__["_ddp_wrapped"]
+    assert model._is_ddp_wrapped()
     opt = torch.optim.AdamW(groups(net.named_parameters()), lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
 else:
     from unigen_hip.optim import FusedAdamW
@@ -80,6 +84,14 @@ params = dict(model.named_parameters())
 
 
 def loss_of(seq, mask, labels, feats):
+    if mode == "multi":
+        total, h = 0.0, seq.shape[0] // 2
+        for sl in (slice(0, h), slice(h, seq.shape[0])):
+            emb = torch.cat([model.llm.model.embed_tokens(seq[sl, :17]), model.llm.model.embed_tokens(seq[sl, 17:])], 1)
+            _, l1, _, _ = net(input_ids=seq[sl], input_embeddings=emb, attention_mask=mask[sl], labels=labels[sl], batch_size_t2i=h,
+                              max_seq_length=L - n - 3, num_vq_tokens=n)
+            total = total + 0.5 * l1
+        return total
     if W_UND:                                              # projector output replaces 6 text embeddings: ordinary parameters
         emb = model.llm.model.embed_tokens(seq)            # on the graph next to the flat ones
         emb = torch.cat([emb[:, :10], model.mm_projector(feats).to(emb.dtype), emb[:, 16:]], 1)

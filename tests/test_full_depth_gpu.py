@@ -1,0 +1,153 @@
+"""Full-depth parity (VERDICT r2 "What's weak" 2): bf16 rounding divergence compounds per layer, and the headline number is a
+28-layer model.  ONE t2i sample of the benchmarked shape -- L = 771 with left padding, the real vocabulary V = 159 867 -- runs
+forward + backward through the WHOLE 1.5B backbone (28 layers, seeded weights from oracle/weights.py) on the HIP path and on the
+pinned CPU oracle under bf16 autocast (the reference's training mode):
+
+    loss                         <= 1e-3 relative   (north_star)
+    logits of the 256 label rows    as close to the oracle's fp32 logits as the reference's bf16 path is (helpers.fp32_yardstick)
+    every parameter's gradient      norm within 3e-2 of the oracle's; relative Frobenius error against the oracle's bf16-mode
+                                    gradient <= 6e-2; and -- the bar that means something at this depth -- as close to the
+                                    EXACT (fp32) gradient as the reference-mode gradient is (see below)
+
+With V = 159 867 and random weights the softmax is nearly flat (p ~ 6e-6): d(logits) carries few significant bits in bf16, and
+the reference-mode gradient of EVERY layer (the last one included: it is not a depth effect) sits 3-4 % from the exact gradient.
+Two bf16 evaluations with different summation orders are then 3.3e-2 .. 4.5e-2 apart, tensor by tensor, layer 27 like layer 0.
+So the oracle also runs forward + backward WITHOUT autocast, and every HIP gradient tensor must be within 1.15 x (median over
+tensors within 1.03 x) of the reference-mode tensor's distance to the fp32 gradient.
+
+The oracle needs ~30 s per forward + backward on the GPU box's host cores (two passes); set UNIGEN_SKIP_FULL_DEPTH=1 to skip it
+on a small host."""
+import os
+import time
+
+import pytest
+import torch
+
+from helpers import additive, fp32_yardstick, llm_config_dir, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TV, CB, NVQ, L = 151674, 8192, 256, 771
+V = TV + CB + 1
+PAD, SOI, EOI, MASK = 151643, 151665, 151666, V - 1
+SEED = 93
+# relative Frobenius error of a whole gradient tensor, by kind.  Depth does not loosen the per-tensor gates of the one- and
+# two-layer tests: the error of dW is dominated by the bf16 roundings of its own two operands, not by the layers above.
+GATES = {"weight": 6e-2, "bias": 6e-2, "norm": 6e-2, "embed": 6e-2, "norm_ratio": 3e-2}
+TRUTH_WORST, TRUTH_MEDIAN = 1.15, 1.03
+
+
+def _oracle_full_depth(cfg, sd):
+    """RefCausalLM built on the meta device (no 1.5 B-element default init) and bound to the SAME host tensors as the state dict"""
+    from oracle import qwen2_ref
+    with torch.device("meta"):
+        lm = qwen2_ref.RefCausalLM(qwen2_ref.Qwen2Cfg(**cfg))
+    lm.load_state_dict(sd, strict=False, assign=True)
+    lm.lm_head.weight = lm.model.embed_tokens.weight
+    for p in lm.parameters():
+        p.requires_grad_(True)
+    return lm
+
+
+@pytest.mark.skipif(os.environ.get("UNIGEN_SKIP_FULL_DEPTH") == "1", reason="UNIGEN_SKIP_FULL_DEPTH=1")
+def test_28_layer_1p5b_step_matches_oracle(dev):
+    from models import UniGen
+    from oracle import host_ref, qwen2_ref, weights
+    t0 = time.time()
+    cfg = dict(qwen2_ref.QWEN25_1P5B, vocab_size=V)
+    model = UniGen(w_und_encoder=False, vocab_size=V, llm_vocab_size=TV, llm_model_path=llm_config_dir(cfg), codebook_size=CB,
+                   num_vq_tokens=NVQ, load_from_pretrained=True, device=dev, init_seed=-1).train()
+    names = [(n, tuple(p.shape)) for n, p in model.llm.named_parameters()]
+    sd = weights.synth_llm_state(names, seed=SEED)
+    model.llm.load_state_dict(sd, strict=False)
+    lm = _oracle_full_depth(cfg, sd)
+    t_build = time.time() - t0
+
+    g = torch.Generator().manual_seed(11)
+    seq = torch.randint(0, 151643, (1, L), generator=g)
+    seq[0, :97] = PAD                                            # left padding that ends inside a 64-key tile
+    seq[:, -(NVQ + 2)] = SOI
+    seq[:, -1] = EOI
+    img = torch.randint(TV, TV + CB, (1, NVQ), generator=g)
+    msk = torch.rand(1, NVQ, generator=g) < 0.65
+    msk[:, 0] = True
+    seq[:, -(NVQ + 1):-1] = torch.where(msk, MASK, img)
+    labels = torch.full((1, L), -100)
+    labels[:, -(NVQ + 1):-1] = torch.where(msk, img, -100)
+    mask = additive(host_ref.mask_predict_next_ref(seq, PAD, SOI, EOI, rm_pad_in_image=True))
+
+    # ---- HIP path
+    logits, l1, _, _ = model(input_ids=seq.to(dev), attention_mask=mask.to(dev), labels=labels.to(dev), batch_size_t2i=1,
+                             max_seq_length=L - NVQ - 3, num_vq_tokens=NVQ)
+    model.llm.engine.check_errors()
+    l1.backward()
+    got = logits[:, -(NVQ + 1):-1, :].float().cpu()
+    torch.cuda.synchronize()
+
+    # ---- oracle, bf16 autocast (the reference's mode), forward + backward
+    t0 = time.time()
+    lo, r1, _, _ = qwen2_ref.unigen_forward_ref(lm, seq, mask, labels, batch_size_t2i=1, num_vq_tokens=NVQ, autocast=True)
+    r1.backward()
+    lo = lo[:, -(NVQ + 1):-1].clone()
+    t_ref = time.time() - t0
+    lerr = abs(l1.item() - r1.item()) / abs(r1.item())
+    print(f"\n[28 layers, L={L}, V={V}] build {t_build:.0f} s, oracle fwd+bwd {t_ref:.0f} s on {torch.get_num_threads()} threads")
+    print(f"    loss {l1.item():.6f} vs oracle {r1.item():.6f}: rel {lerr:.2e} (gate 1e-3)")
+    assert lerr < 1e-3
+
+    # ---- exact arithmetic: the same step without autocast (fp32 logits of the label rows, fp32 gradients)
+    g16 = {}
+    for n, p_ in lm.named_parameters():
+        g16[n], p_.grad = p_.grad, None
+    t0 = time.time()
+    lo32, r32, _, _ = qwen2_ref.unigen_forward_ref(lm, seq, mask, labels, batch_size_t2i=1, num_vq_tokens=NVQ, autocast=False)
+    r32.backward()
+    lo32 = lo32[:, -(NVQ + 1):-1].detach().clone()
+    print(f"    oracle fp32 fwd+bwd {time.time() - t0:.0f} s; fp32 loss {r32.item():.6f}")
+
+    # ---- gradients, tensor by tensor
+    ref_p = dict(lm.named_parameters())
+    per_layer, ratios = {}, []
+    worst = {"weight": (0.0, None), "bias": (0.0, None), "norm": (0.0, None), "embed": (0.0, None), "norm_ratio": (0.0, None)}
+    worst_truth = (0.0, None, 0.0, 0.0)
+    for n, p in model.llm.named_parameters():
+        rg, r32g = g16[n], ref_p[n].grad
+        hg = p.grad.float().cpu()
+        e = rel_err(hg, rg)
+        ratio = abs(hg.norm().item() / max(rg.norm().item(), 1e-30) - 1.0)
+        d_ref, d_hip = rel_err(rg, r32g), rel_err(hg, r32g)
+        ratios.append(d_hip / max(d_ref, 1e-30))
+        if ratios[-1] > worst_truth[0]:
+            worst_truth = (ratios[-1], n, d_hip, d_ref)
+        kind = "embed" if "embed_tokens" in n else "norm" if n.endswith("norm.weight") else "bias" if n.endswith(".bias") else "weight"
+        if e > worst[kind][0]:
+            worst[kind] = (e, n)
+        if ratio > worst["norm_ratio"][0]:
+            worst["norm_ratio"] = (ratio, n)
+        if ".layers." in n:
+            li = int(n.split(".layers.")[1].split(".")[0])
+            cur = per_layer.get(li, (0.0, 0.0, 0.0))
+            per_layer[li] = (max(cur[0], e), max(cur[1], d_hip), max(cur[2], d_ref))
+        g16[n] = None
+        ref_p[n].grad = None
+    print("    layer: worst HIP-vs-reference-mode | HIP-vs-fp32 | reference-mode-vs-fp32 (relative Frobenius error of a gradient tensor)")
+    for i in sorted(per_layer):
+        print(f"      {i:2d}: {per_layer[i][0]:.2e} | {per_layer[i][1]:.2e} | {per_layer[i][2]:.2e}")
+    for k, (e, n) in worst.items():
+        print(f"    worst {k}: {e:.2e} ({n}), gate {GATES[k]:.0e}")
+    med = sorted(ratios)[len(ratios) // 2]
+    print(f"    distance to the fp32 gradient, HIP / reference mode: median over {len(ratios)} tensors {med:.3f} (gate {TRUTH_MEDIAN}), worst "
+          f"{worst_truth[0]:.3f} ({worst_truth[1]}: {worst_truth[2]:.2e} vs {worst_truth[3]:.2e}; gate {TRUTH_WORST})")
+    for k, (e, n) in worst.items():
+        assert e < GATES[k], (k, n, e)
+    assert med <= TRUTH_MEDIAN and worst_truth[0] <= TRUTH_WORST
+
+    # ---- logits: HIP vs reference-mode bf16, and both against the exact (fp32) logits of the same weights
+    rl = rel_err(got, lo)
+    print(f"    logits of the {NVQ} label rows: HIP vs oracle bf16 rel {rl:.2e}")
+    top2 = lo.topk(2, -1).values
+    clear = (top2[..., 0] - top2[..., 1]) > 0.05
+    agree = (got.argmax(-1)[clear] == lo.argmax(-1)[clear]).float().mean().item() if bool(clear.any()) else 1.0
+    print(f"    argmax agreement where the oracle's top-2 margin > 0.05 ({clear.float().mean().item():.0%} of rows): {agree:.4f}")
+    fp32_yardstick("28 layers", got, lo, lo32)
+    assert agree == 1.0

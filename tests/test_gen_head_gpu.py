@@ -7,7 +7,7 @@ import math
 import pytest
 import torch
 
-from helpers import additive, golden, llm_config_dir
+from helpers import additive, fp32_yardstick, golden, llm_config_dir
 
 pytestmark = pytest.mark.gpu
 
@@ -35,7 +35,7 @@ def _model(g, dev, use_dim):
 def test_gen_projector_forward_backward_matches_reference(dev, use_dim):
     g = golden("g12_gen_head.pt")
     want = g[f"dim{int(use_dim)}"]
-    model, _ = _model(g, dev, use_dim)
+    model, sd = _model(g, dev, use_dim)
     model.train()
     assert sorted(k for k, _ in model.named_parameters() if not k.startswith("llm.") and k != "_ddp_anchor") == sorted(want["grad_norms_gen"])
     mask = additive(g["mask_allow"]).to(dev)
@@ -55,6 +55,16 @@ def test_gen_projector_forward_backward_matches_reference(dev, use_dim):
     print(f"[gen_proj use_gen_dim={use_dim}] loss rel {lerr:.2e} (gate 1e-3); img_logits rel {rl:.2e}; grad-norm worst rel {worst:.2e}; "
           f"gen-module gradients rel {rows:.2e}")
     assert lerr < 1e-3 and rl < 1e-2 and worst < 2e-2 and rows < 3e-2
+    # fp32 logits of the same weights from the oracle's gen-branch forward (bit-identical to the reference, tools/make_golden.py)
+    from oracle import qwen2_ref
+    lm = qwen2_ref.RefCausalLM(qwen2_ref.Qwen2Cfg(**g["cfg"]))
+    lm.load_state_dict({k[4:]: v for k, v in sd.items() if k.startswith("llm.")}, strict=False)
+    gen = qwen2_ref.GenHeadRef(g["cfg"]["hidden_size"], g["codebook"], depth=2, use_gen_dim=use_dim, gen_input_dim=16)
+    gen.load_state_dict({k: v for k, v in sd.items() if not k.startswith("llm.") and k != "_ddp_anchor"})
+    with torch.no_grad():
+        lo32 = qwen2_ref.unigen_forward_gen_ref(lm, gen, g["input_ids"], additive(g["mask_allow"]), None,
+                                                batch_size_t2i=g["kw"]["batch_size_t2i"], num_vq_tokens=g["n"], autocast=False)
+    fp32_yardstick(f"G12 img_logits use_gen_dim={use_dim}", img_logits, want["img_logits"], lo32)
     # labels=None returns the img_head logits of the t2i rows (reference :264-265)
     only = model(input_ids=ids, attention_mask=mask, batch_size_t2i=g["kw"]["batch_size_t2i"], num_vq_tokens=g["n"])
     assert torch.equal(only, img_logits)

@@ -42,7 +42,8 @@ def test_probe_layouts(dev):
 
 
 # ------------------------------------------------------------------ GEMM
-@pytest.fixture(params=[0, 2, 103, 105], ids=["two_lds_stages", "one_lds_stage", "staggered_256x256_one_barrier", "staggered_256x256_two_barriers"])
+@pytest.fixture(params=[0, 2, 103, 105, 12], ids=["two_lds_stages", "one_lds_stage", "staggered_256x256_one_barrier", "staggered_256x256_two_barriers",
+                                                  "register_blocked_4_waves"])
 def tile_policy(request):
     ops = _ops()
     ops.set_gemm_tile_policy(request.param)

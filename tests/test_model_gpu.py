@@ -8,7 +8,7 @@ import os
 import pytest
 import torch
 
-from helpers import additive, golden, llm_config_dir, oracle_lm
+from helpers import additive, fp32_yardstick, golden, llm_config_dir, oracle_lm
 
 pytestmark = pytest.mark.gpu
 
@@ -59,6 +59,7 @@ def test_tiny_unigen_step_matches_reference_golden(dev):
     _check("dense", dense, want["logits"], 1e-2)
     sl = logits[:2, -17:-1, 312:-1].float().cpu()
     _check("sl", sl, want["logits"][:2, -17:-1, 312:-1], 1e-2)
+    fp32_yardstick("G2 dense logits", dense, want["logits"], g["fp32"]["logits"])
     loss = 1.0 * l1 + 0.1 * l2 + 1.0 * l3
     loss.backward()
     params = dict(model.llm.named_parameters())
@@ -127,6 +128,9 @@ def test_tiny_unigen_vs_cpu_oracle_fresh_batch(dev):
     assert l2 == 0. and l3 == 0.
     assert abs(l1.item() - r1.item()) / r1.item() < 1e-3
     _check("logits[:", logits[:, -(n + 1):-1].float(), lo[:, -(n + 1):-1], 1e-2)
+    with torch.no_grad():
+        lo32 = qwen2_ref.unigen_forward_ref(lm, seq, mask, None, autocast=False)
+    fp32_yardstick("tiny fresh batch", logits[:, -(n + 1):-1].float(), lo[:, -(n + 1):-1], lo32[:, -(n + 1):-1])
     top2 = lo[:, -(n + 1):-1].topk(2, -1).values
     clear = (top2[..., 0] - top2[..., 1]) > 0.05
     am = logits[:, -(n + 1):-1].float().argmax(-1).cpu()
@@ -280,6 +284,13 @@ def test_wide_layer_matches_reference_golden(dev):
     assert abs(l1.item() - g["loss"].item()) < 1e-3 * g["loss"].item(), (l1.item(), g["loss"].item())
     got = logits[:, -257:-1, :].float().cpu()[:, ::8]
     _check("got", got, g["logits_rows"], 1e-2)
+    # the fixture holds the real reference's bf16 logits; its fp32 logits come from the oracle (bit-identical to the reference
+    # on CPU, tools/make_golden.py) with the same seeded weights
+    from oracle import qwen2_ref
+    lm, _ = oracle_lm(cfg, g["weight_seed"])
+    with torch.no_grad():
+        lo32 = qwen2_ref.unigen_forward_ref(lm, g["input_ids"], additive(g["mask_allow"]), None, autocast=False)[:, -257:-1][:, ::8]
+    fp32_yardstick("G3 wide layer", got, g["logits_rows"], lo32)
     l1.backward()
     params = dict(m.llm.named_parameters())
     for n, v in g["grad_norms"].items():
