@@ -563,10 +563,8 @@ class UniGen(ModelMixin, ConfigMixin):
         only works when both embedding tensors are supplied; ids are accepted here too
         and embedded, which is what its callers intend."""
         from unigen_hip.qwen2 import DecodeState
-        if self._use_gen():
-            raise UniGenHipError("t2i_generate_ar with gen_proj_depth > 0 (img_head / gen_projector per step, reference :487-498,"
-                                 "513-515) is not implemented; the training forward and t2i_generate are")
-        n = image_token_num_per_image
+        gen = self._use_gen()          # gen_projector path (reference :486-495,512-514): img_head on the last hidden state, the next
+        n = image_token_num_per_image  # input is gen_projector(gen_embed(raw code)); no text-vocabulary offset anywhere
         embed = self.llm.model.embed_tokens
         eng = self.llm.engine
         dev = eng.device
@@ -590,7 +588,8 @@ class UniGen(ModelMixin, ConfigMixin):
         x = torch.empty((R, eng.dims.hidden_size), dtype=torch.float32, device=dev)      # static: next token's embedding
         tok = torch.zeros((bsz, 1), dtype=torch.long, device=dev)                        # static: last sampled token
         V = code_hi - code_lo
-        fused = R <= 32 and eng.dims.hidden_size >= 256 and eng.dims.hidden_size % 32 == 0 and not kwargs.get("torch_sampler", False)
+        fused = (R <= 32 and eng.dims.hidden_size >= 256 and eng.dims.hidden_size % 32 == 0 and not kwargs.get("torch_sampler", False)
+                 and not gen)
         if fused:
             # lm-head as a weight-streaming GEMV into a raw fp32 accumulator + ONE sampling kernel per step (CFG mix,
             # temperature, softmax, inverse-CDF draw on uniforms taken from `generator` up front, next input embedding)
@@ -606,15 +605,19 @@ class UniGen(ModelMixin, ConfigMixin):
                                text_vocab_size, tok, out_tokens, x)
         else:
             def sample(hn):
-                lg = eng.head_slice(hn, code_lo, code_hi).float()
+                # (gen path: the reference mixes the bf16 img_head outputs in bf16 under autocast, :498-500)
+                lg = self._img_head(hn) if gen else eng.head_slice(hn, code_lo, code_hi).float()
                 cond, uncond = lg[:bsz], lg[bsz:]
-                lg = uncond + guidance_scale * (cond - uncond)
+                lg = (uncond + guidance_scale * (cond - uncond)).float()
                 if greedy:
                     nxt = lg.argmax(-1, keepdim=True)
                 else:
                     nxt = torch.multinomial(torch.softmax(lg / temperature, dim=-1), num_samples=1, generator=generator)
                 tok.copy_(nxt)
-                x.copy_(embed(torch.cat([nxt, nxt]) + text_vocab_size)[:, 0])
+                if gen:
+                    x.copy_(self.get_gen_embed(torch.cat([nxt, nxt]))[:, 0])
+                else:
+                    x.copy_(embed(torch.cat([nxt, nxt]) + text_vocab_size)[:, 0])
 
         sample(eng.prefill(st, prefix, key_valid))
         if not fused:

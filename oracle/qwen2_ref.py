@@ -268,10 +268,12 @@ def unigen_forward_gen_ref(lm, gen, input_ids, attention_mask, labels=None, batc
     return f(img_logits), f(loss_t2i), f(loss_lm), f(loss_mmu)
 
 
-def ar_generate_ref(lm, cond_embeds, uncond_embeds, n_tokens, guidance_scale, text_vocab, key_valid=None, autocast=True):
+def ar_generate_ref(lm, cond_embeds, uncond_embeds, n_tokens, guidance_scale, text_vocab, key_valid=None, autocast=True, gen=None):
     """Greedy (argmax) version of UniGen.t2i_generate_ar (models/unigen.py:457-521): prefix = embeddings with the
     last n+1 positions already cut off; KV cache grown by concatenation like DynamicCache; CFG
     `uncond + s * (cond - uncond)` on logits[text_vocab:-1]; next token embedded for both halves.
+    gen (a GenHeadRef): the gen_proj_depth > 0 branch (:486-495,512-514) -- img_head on the last hidden state (codebook-wide
+    logits, no slicing, no text-vocabulary offset), next input gen_projector(gen_embed(token)).
     Returns (tokens [B, n], top-2 margin of the mixed logits per step [B, n])."""
     B = cond_embeds.shape[0]
     x = torch.cat([cond_embeds, uncond_embeds])
@@ -297,15 +299,16 @@ def ar_generate_ref(lm, cond_embeds, uncond_embeds, n_tokens, guidance_scale, te
                     allow = allow & kv[:, None, None, :]
                 mask = torch.where(allow, 0.0, float("-inf"))
             h = lm.backbone(inputs_embeds=x, mask=mask, caches=caches, pos_offset=pos)
-            logits = lm.lm_head(h[:, -1]).float()[:, text_vocab:-1]
+            # (gen branch: the img_head output stays in the autocast dtype, the CFG mix below is bf16 arithmetic there, :498-500)
+            logits = gen.img_head(h[:, -1]) if gen is not None else lm.lm_head(h[:, -1]).float()[:, text_vocab:-1]
             cond, uncond = logits[:B], logits[B:]
-            mixed = uncond + guidance_scale * (cond - uncond)
+            mixed = (uncond + guidance_scale * (cond - uncond)).float()
             top2 = mixed.topk(2, -1).values
             nxt = mixed.argmax(-1, keepdim=True)
             toks.append(nxt)
             margins.append(top2[:, 0] - top2[:, 1])
             pos = total
-            x = lm.model.embed_tokens(torch.cat([nxt, nxt]) + text_vocab)
+            x = gen.gen_projector(gen.gen_embed(torch.cat([nxt, nxt]))) if gen is not None else lm.model.embed_tokens(torch.cat([nxt, nxt]) + text_vocab)
     return torch.cat(toks, 1), torch.stack(margins, 1)
 
 

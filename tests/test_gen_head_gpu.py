@@ -110,3 +110,38 @@ def test_gen_projector_maskgit_round_matches_oracle(dev):
                               noise_schedule=sched, generator=torch.Generator().manual_seed(1), image_token_num_per_image=n,
                               text_vocab_size=g["ids"]["text_vocab"], incremental=False).cpu()
     assert full.shape == (N, n) and int(full.min()) >= 0 and int(full.max()) < CB
+
+
+@pytest.mark.parametrize("use_dim", [False, True])
+def test_ar_generation_gen_head_matches_reference_trajectory(dev, use_dim):
+    """G13: t2i_generate_ar on the gen_projector path (img_head on the last hidden state, gen_projector(gen_embed(token)) as the
+    next input, reference models/unigen.py:486-495,512-514) against the tokens of the REAL reference (bf16 autocast, CFG 2.5,
+    left-padded prompts, 2-D mask), step by step until the reference's own top-2 margin drops below bf16 noise; eager and with
+    the captured decode graph."""
+    from models import UniGen
+    from oracle import weights
+    g = golden("g13_ar_gen_head.pt")
+    cfg, ids = g["cfg"], g["ids"]
+    m = UniGen(w_und_encoder=False, vocab_size=cfg["vocab_size"], llm_vocab_size=ids["text_vocab"], llm_model_path=llm_config_dir(cfg),
+               codebook_size=g["codebook"], num_vq_tokens=g["n"], load_from_pretrained=True, gen_proj_depth=2, use_gen_dim=use_dim,
+               gen_input_dim=16, device=dev, init_seed=1)
+    names = [(k, tuple(p.shape)) for k, p in m.named_parameters() if k != "_ddp_anchor"]
+    res = m.load_state_dict(weights.synth_llm_state(names, seed=g["weight_seed"], std=g["weight_std"]), strict=False)
+    assert not res.unexpected_keys
+    m.eval()
+    want, margin = g[f"dim{int(use_dim)}"]["bf16"]["tokens"], g[f"dim{int(use_dim)}"]["bf16"]["margin"]
+    for use_graph in (False, True):
+        got = m.t2i_generate_ar(input_ids=g["cond"].to(dev), uncond_input_ids=g["uncond"].to(dev), attention_mask=g["attention_mask"].to(dev),
+                                guidance_scale=g["scale"], temperature=1.0, text_vocab_size=ids["text_vocab"],
+                                image_token_num_per_image=g["n"], greedy=True, use_graph=use_graph).cpu()
+        assert got.shape == want.shape and int(got.min()) >= 0 and int(got.max()) < g["codebook"]
+        compared = 0
+        for b in range(want.shape[0]):
+            for i in range(want.shape[1]):
+                if margin[b, i] < 0.1:
+                    break
+                assert int(got[b, i]) == int(want[b, i]), (use_graph, b, i, got[b].tolist(), want[b].tolist())
+                compared += 1
+        print(f"AR on the gen_projector path vs reference golden (use_gen_dim={use_dim}, graph={use_graph}): {compared}/{want.numel()} "
+              f"tokens compared, all equal")
+        assert compared >= 8, compared

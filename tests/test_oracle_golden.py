@@ -146,3 +146,26 @@ def test_gen_projector_oracle_matches_reference():
         lo, r1, _, _ = qwen2_ref.unigen_forward_gen_ref(lm, gen, g["input_ids"], mask, g["labels"], autocast=True, **kw)
         want = g[f"dim{int(use_dim)}"]
         assert torch.equal(lo.to(torch.bfloat16), want["img_logits"]) and r1.item() == want["loss"].item()
+
+
+def test_ar_generation_gen_head_oracle_matches_reference():
+    """G13: ar_generate_ref(gen=...) returns the tokens of the real reference's t2i_generate_ar on a gen_proj_depth = 2 model
+    (models/unigen.py:486-495,512-514), both use_gen_dim settings, fp32 and bf16 autocast."""
+    from oracle import qwen2_ref, weights
+    g = golden("g13_ar_gen_head.pt")
+    cfg = qwen2_ref.Qwen2Cfg(**g["cfg"])
+    P, n, tv = g["P"], g["n"], g["ids"]["text_vocab"]
+    for use_dim in (False, True):
+        lm = qwen2_ref.RefCausalLM(cfg)
+        gen = qwen2_ref.GenHeadRef(g["cfg"]["hidden_size"], g["codebook"], depth=2, use_gen_dim=use_dim, gen_input_dim=16)
+        names = [("llm." + k, tuple(p.shape)) for k, p in lm.named_parameters()] + [(k, tuple(p.shape)) for k, p in gen.named_parameters()]
+        sd = weights.synth_llm_state(names, seed=g["weight_seed"], std=g["weight_std"])
+        lm.load_state_dict({k[4:]: v for k, v in sd.items() if k.startswith("llm.")}, strict=False)
+        gen.load_state_dict({k: v for k, v in sd.items() if not k.startswith("llm.")})
+        with torch.no_grad():
+            ce, ue = lm.model.embed_tokens(g["cond"][:, :P]), lm.model.embed_tokens(g["uncond"][:, :P])
+        for mode, ac in (("fp32", False), ("bf16", True)):
+            tok, margin = qwen2_ref.ar_generate_ref(lm, ce, ue, n, g["scale"], tv, key_valid=g["attention_mask"][:, :P], autocast=ac, gen=gen)
+            want = g[f"dim{int(use_dim)}"][mode]
+            assert torch.equal(tok.long(), want["tokens"]) and torch.allclose(margin, want["margin"])
+            assert len(set(tok[0].tolist())) > 4 and int(tok.max()) < g["codebook"]

@@ -678,3 +678,77 @@ def golden_gen_head():
 
 if __name__ == "__main__" and "gen_head" in sys.argv[1:]:
     golden_gen_head()
+
+
+# ------------------------------------------------------------------ G13: AR image tokens on the gen_projector path (models/unigen.py:486-495,512-514)
+def golden_ar_gen_head():
+    """The real reference's `t2i_generate_ar` on a model built with gen_proj_depth = 2 (img_head on the last hidden state of
+    `llm.model`, gen_projector(gen_embed(token)) as the next input), deterministic through temperature 1e-6 as in G9; both
+    use_gen_dim settings, fp32 and bf16-autocast.  The oracle's ar_generate_ref(gen=...) must return the same tokens.
+    Under autocast the reference mixes cond / uncond logits in bf16, where the two largest values can TIE (its multinomial then
+    draws among them from the global RNG): the prompt seed is the first one whose trajectories have no tie in any mode."""
+    from models import UniGen
+    g2 = torch.load(os.path.join(OUT, "g2_tiny_unigen.pt"), weights_only=False)
+    cfgd, ids = g2["cfg"], g2["ids"]
+    V, TV, CB, n, B, P = cfgd["vocab_size"], ids["text_vocab"], 20, 16, 2, 30
+    cfg = qwen2_ref.Qwen2Cfg(**cfgd)
+    d = ref_shims.write_llm_config_dir(cfg.to_hf_dict())
+    STD = 0.15
+    built = {}
+    for use_dim in (False, True):
+        torch.manual_seed(0)
+        model = UniGen(w_und_encoder=False, vocab_size=V, llm_vocab_size=TV, llm_model_path=d, codebook_size=CB, num_vq_tokens=n,
+                       load_from_pretrained=True, gen_proj_depth=2, use_gen_dim=use_dim, gen_input_dim=16).eval()
+        names = [(k, tuple(p.shape)) for k, p in model.named_parameters()]
+        sd = weights.synth_llm_state(names, seed=78, std=STD)
+        assert not model.load_state_dict(sd, strict=False).unexpected_keys
+        lm = qwen2_ref.RefCausalLM(cfg)
+        lm.load_state_dict({k[4:]: v for k, v in sd.items() if k.startswith("llm.")}, strict=False)
+        gen = qwen2_ref.GenHeadRef(cfgd["hidden_size"], CB, depth=2, use_gen_dim=use_dim, gen_input_dim=16)
+        gen.load_state_dict({k: v for k, v in sd.items() if not k.startswith("llm.")})
+        built[use_dim] = (model, lm, gen)
+    for prompt_seed in range(6, 60):
+        gen_ = torch.Generator().manual_seed(prompt_seed)
+        cond = torch.randint(0, 290, (B, P + n + 1), generator=gen_)
+        uncond = torch.randint(0, 290, (B, P + n + 1), generator=gen_)
+        cond[1, :9] = ids["pad"]
+        uncond[:, :18] = ids["pad"]
+        am = torch.cat([cond != ids["pad"], uncond != ids["pad"]]).long()
+        am[:, P:] = 1
+        out = {"cfg": cfgd, "weight_seed": 78, "weight_std": STD, "ids": ids, "codebook": CB, "n": n, "P": P, "scale": 2.5,
+               "cond": cond, "uncond": uncond, "attention_mask": am, "prompt_seed": prompt_seed}
+        tie = False
+        for use_dim in (False, True):
+            model, lm, gen = built[use_dim]
+            rec = {}
+            for mode, ac in (("fp32", False), ("bf16", True)):
+                with torch.no_grad():
+                    mine, margin = qwen2_ref.ar_generate_ref(lm, lm.model.embed_tokens(cond[:, :P]), lm.model.embed_tokens(uncond[:, :P]), n,
+                                                             2.5, TV, key_valid=am[:, :P], autocast=ac, gen=gen)
+                if margin.min() <= 0:
+                    tie = True
+                    break
+                ctx = torch.autocast("cpu", dtype=torch.bfloat16) if ac else torch.autocast("cpu", enabled=False)
+                with torch.no_grad(), ctx:
+                    ce, ue = model.llm.model.embed_tokens(cond), model.llm.model.embed_tokens(uncond)
+                    ref_tok = model.t2i_generate_ar(input_ids=cond, uncond_input_ids=uncond, input_embeddings=ce, uncond_input_embeddings=ue,
+                                                    attention_mask=am, guidance_scale=2.5, temperature=1e-6, text_vocab_size=TV,
+                                                    image_token_num_per_image=n)
+                same = torch.equal(ref_tok.long(), mine.long())
+                print(f"G13 AR gen head[prompt seed {prompt_seed}, use_gen_dim={use_dim}, {mode}] reference tokens {ref_tok.tolist()}  "
+                      f"oracle equal: {same}  min margin {margin.min():.3f}")
+                assert same, "oracle ar_generate_ref(gen=...) != reference t2i_generate_ar on the gen_projector path"
+                rec[mode] = {"tokens": ref_tok.long(), "margin": margin}
+            if tie:
+                break
+            out[f"dim{int(use_dim)}"] = rec
+        if not tie:
+            torch.save(out, os.path.join(OUT, "g13_ar_gen_head.pt"))
+            print("G13 AR generation on the gen_projector path: captured (oracle == reference)")
+            return
+        print(f"G13: prompt seed {prompt_seed} has a bf16 tie, trying the next one")
+    raise RuntimeError("G13: no tie-free prompt seed found")
+
+
+if __name__ == "__main__" and "ar_gen_head" in sys.argv[1:]:
+    golden_ar_gen_head()
