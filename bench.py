@@ -47,37 +47,24 @@ FLOP_SAMPLE = 3 * FLOP_LLM_FWD + 0.3551e12     # fwd+bwd + MAGVITv2 encode (fwd 
 PEAK_BF16 = 2.5e15
 
 
-def device_mask_predict_next(seq, pad_id, soi_id, eoi_id):
-    """Caller-side glue: the dense additive mask of training/prompting_utils.py:975-1020
-    (rm_pad_in_image=True) built with vectorised device ops; fp32 like mask_dtype under DDP."""
-    B, L = seq.shape
-    dev = seq.device
-    is_pad = seq == pad_id
-    start, end = seq == soi_id, seq == eoi_id
-    in_img = (start.cumsum(1) > end.cumsum(1)) | start | end
-    r = torch.arange(L, device=dev)
-    causal = (r[None, :] <= r[:, None])[None]
-    allow = torch.where(in_img[:, :, None], torch.ones((), dtype=torch.bool, device=dev), causal)
-    last_pad = torch.where(is_pad.any(1), (is_pad * r[None, :]).max(1).values, torch.full((B,), -1, device=dev))
-    cut = (r[None, :, None] > last_pad[:, None, None]) & (r[None, None, :] <= last_pad[:, None, None])
-    allow = allow & ~(cut & ~in_img[:, :, None])
-    allow = allow & ~(in_img[:, :, None] & is_pad[:, None, :])
-    neg = torch.full((), float(torch.iinfo(torch.int64).min), device=dev)
-    return torch.where(allow, torch.zeros((), device=dev), neg)[:, None]
+def t2i_rows(ops, text, image_in, image_labels):
+    """Caller-side glue on the device, through the product's own kernels (both are pinned against the
+    real reference: `ug_t2i_assemble` against UniversalPromptingQwen2.t2i_prompt's ids / labels, golden G2 layout, and
+    `ug_attn_mask_from_ids` against create_attention_mask_predict_next(rm_pad_in_image=True), golden G4):
+      [<|im_start|><|t2i|> text ... | <|soi|> 256 image ids <|eoi|>] (training/prompting_utils.py:59-111; the text fills
+      max_seq_length, no padding), labels on the image slots, and the compressed attention mask straight from the ids."""
+    B, T = text.shape
+    dev = text.device
+    key = (B, T, str(dev))
+    if _GLUE.get("key") != key:
+        _GLUE.update(key=key, offs=torch.arange(B + 1, device=dev, dtype=torch.int64) * T,
+                     head=torch.tensor([IM_START, T2I], device=dev, dtype=torch.int64), tail=torch.zeros(0, device=dev, dtype=torch.int64))
+    L = 2 + T + image_in.shape[1] + 2
+    ids, _, labels = ops.t2i_assemble((text.reshape(-1), _GLUE["offs"]), image_in, image_labels, L, PAD, SOI, EOI, _GLUE["head"], _GLUE["tail"])
+    return ids, labels, ops.mask_from_ids(ids, PAD, SOI, EOI, ops.MASK_T2I)
 
 
-def t2i_layout(text_ids, image_ids, labels_img):
-    """[<|im_start|><|t2i|> text ... | <|soi|> 256 image ids <|eoi|>] (prompting_utils.py:59-111, no padding:
-    the text fills max_seq_length)."""
-    B = text_ids.shape[0]
-    dev = text_ids.device
-    head = torch.tensor([IM_START, T2I], device=dev).expand(B, 2)
-    soi = torch.full((B, 1), SOI, device=dev)
-    eoi = torch.full((B, 1), EOI, device=dev)
-    ids = torch.cat([head, text_ids, soi, image_ids, eoi], 1)
-    ign = torch.full((B, 2 + text_ids.shape[1]), -100, device=dev)
-    labels = torch.cat([ign, soi, labels_img, eoi], 1)
-    return ids, labels
+_GLUE = {}
 
 
 def init_magvit_device(vq, seed):
@@ -173,29 +160,40 @@ def ar_decode_bench(model, dev, n_img=8, prefix=138, reps=2):
                                                                       "frac": round(floor_ms / (best / NVQ * 1e3), 4)}}
 
 
-def extra_cases(model, vq, opt, dev, args, steps=3):
-    """Secondary cases reported next to the headline (not `value`):
+def extra_cases(model, vq, opt, dev, args, steps=2):
+    """Secondary cases reported next to the headline (not `value`): the other BASELINE.json configs at their per-GPU shapes.
       * `t2i_L771_real_mask_ratio`: the headline step with the masking the reference applies (data/masking.py through the
-        device kernel: t ~ U(0,1), cosine schedule, round(256 p) masked positions per sample) instead of mask_prob = 1 --
-        fewer label rows reach the head + CE;
-      * `pt1_mixed_L387`: the stage-1 pretraining batch of configs/unigen_1_5b/unigen_pt1.yaml:87-93 -- 16 t2i + 8 mmu rows at
-        L = 387 (128 text + 256 image + 3), VQ tokens on both sides, t2i + mmu losses, 24 images through MAGVITv2."""
+        device kernel: t ~ U(0,1), cosine schedule, round(256 p) masked positions per sample) instead of mask_prob = 1;
+      * `pt1_mixed_L387` (configs[1] as trained): configs/unigen_1_5b/unigen_pt1.yaml:87-93 -- 16 t2i + 8 mmu rows at L = 387;
+      * `sft_L1603` (configs[2], per GPU): unigen_sft.yaml:69,96-98 -- 3 t2i + 1 lm + 4 mmu rows at L = 1603, SigLIP so400m
+        tower on the 4 mmu images (384^2 -> 729 tokens), mm_projector, MAGVITv2 on the 3 t2i images;
+      * `dpo_L387` (configs[4], per GPU): unigen_dpo.yaml:80, training/train_dpo.py:573-647 -- 10 chosen + 10 rejected image
+        sequences, frozen reference-model forward, policy forward + get_batch_logps + backward + AdamW;
+      * `maskgit_50_rounds` (configs[3]'s sibling sampler, scripts/run_evaluation.sh:195-197): UniGen.t2i_generate, 10 images with
+        CFG 6 (20 rows), 50 rounds."""
     import types
+    import torch.nn.functional as F
     from data.masking import mask_or_random_replace_tokens
+    from models import UniGen
     from models.sampling import cosine_schedule
+    from unigen_hip import ops
+    from unigen_hip.dpo import get_batch_logps
     cfg = types.SimpleNamespace(training=types.SimpleNamespace(min_masking_rate=0.0, get=lambda k, d=None: d),
                                 model=types.SimpleNamespace(codebook_size=CODEBOOK))
     g = torch.Generator(device=dev).manual_seed(SEED + 7)
     out = {}
 
-    def timed(fn):
+    def timed(fn, n=steps):
         fn()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for _ in range(n):
             fn()
         torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / steps * 1e3
+        return (time.perf_counter() - t0) / n * 1e3
+
+    def cat_masks(*ms):
+        return ops.MaskBits(torch.cat([m.bits for m in ms]), torch.cat([m.tileany for m in ms]), sum(m.B for m in ms), ms[0].L)
 
     # ---- headline shape, real mask ratios
     B = args.batch
@@ -206,8 +204,7 @@ def extra_cases(model, vq, opt, dev, args, steps=3):
     def step_real():
         codes = vq.get_code(images) + TEXT_VOCAB
         ids_img, lab_img, _, _ = mask_or_random_replace_tokens(codes, MASK_ID, cfg, cosine_schedule)
-        ids, labels = t2i_layout(text, ids_img, lab_img)
-        mask = device_mask_predict_next(ids, PAD, SOI, EOI)
+        ids, labels, mask = t2i_rows(ops, text, ids_img, lab_img)
         _, l, _, _ = model(input_ids=ids, attention_mask=mask, labels=labels, batch_size_t2i=B, max_seq_length=args.text_len + 1,
                            num_vq_tokens=NVQ)
         l.backward()
@@ -225,21 +222,17 @@ def extra_cases(model, vq, opt, dev, args, steps=3):
     text_t = torch.randint(0, 151643, (Bt, T - 1), device=dev, generator=g)
     text_m = torch.randint(0, 151643, (Bm, L - NVQ - 4), device=dev, generator=g)
     MMU = 151670
-    r = torch.arange(L, device=dev)
 
     def step_pt1():
         codes = vq.get_code(images) + TEXT_VOCAB
         ids_img, lab_img, _, _ = mask_or_random_replace_tokens(codes[:Bt], MASK_ID, cfg, cosine_schedule)
-        ids_t, lab_t = t2i_layout(text_t, ids_img, lab_img)
+        ids_t, lab_t, m_t = t2i_rows(ops, text_t, ids_img, lab_img)
         col = lambda v: torch.full((Bm, 1), v, device=dev)
         ids_m = torch.cat([col(IM_START), col(MMU), col(SOI), codes[Bt:], col(EOI), text_m], 1)       # mmu_prompt layout
         lab_m = ids_m.clone()
         lab_m[:, :NVQ + 4] = -100
-        m_t = device_mask_predict_next(ids_t, PAD, SOI, EOI)
-        allow = (r[None, :] <= r[:, None]) | (r[None, :] <= NVQ + 3)                                    # create_attention_mask_for_mmu
-        neg = torch.full((), float(torch.iinfo(torch.int64).min), device=dev)
-        m_m = torch.where(allow, torch.zeros((), device=dev), neg)[None, None].expand(Bm, 1, L, L)
-        _, l_t, _, l_m = model(input_ids=torch.cat([ids_t, ids_m]), attention_mask=torch.cat([m_t, m_m]), labels=torch.cat([lab_t, lab_m]),
+        m_m = ops.mask_from_ids(ids_m, PAD, SOI, EOI, ops.MASK_MMU)                                     # create_attention_mask_for_mmu
+        _, l_t, _, l_m = model(input_ids=torch.cat([ids_t, ids_m]), attention_mask=cat_masks(m_t, m_m), labels=torch.cat([lab_t, lab_m]),
                                batch_size_t2i=Bt, batch_size_mmu=Bm, max_seq_length=T, num_vq_tokens=NVQ)
         (l_t + l_m).backward()
         opt.step()
@@ -250,6 +243,110 @@ def extra_cases(model, vq, opt, dev, args, steps=3):
     fl = Bt * (3.475e12 + 0.3551e12) + Bm * (3 * (1.0141e12 + 0.0186e12 + 386 / 256 * 0.1257e12) + 0.3551e12)
     out["pt1_mixed_L387"] = {"ms_per_step": round(ms, 2), "samples_per_s": round((Bt + Bm) / ms * 1e3, 2), "rows": f"{Bt} t2i + {Bm} mmu",
                              "seq_len": L, "step_frac_of_bf16_peak": round(fl / (ms * 1e-3) / PEAK_BF16, 4)}
+
+    # ---- DPO: 10 pairs at L = 387 (a second, frozen copy of the model as the reference policy)
+    pairs, beta = 10, 0.1
+    Bd = 2 * pairs
+    ref = UniGen(w_und_encoder=False, vocab_size=VOCAB, llm_vocab_size=TEXT_VOCAB, llm_model_path="Qwen2.5-1.5B-Instruct",
+                 codebook_size=CODEBOOK, num_vq_tokens=NVQ, load_from_pretrained=True, device=dev, init_seed=-1)
+    ref.llm.init_weights_device(SEED)
+    ref.eval().requires_grad_(False)
+    images = torch.rand(Bd, 3, 256, 256, device=dev, generator=g) * 2 - 1                # chosen | rejected
+    ids_d = torch.randint(0, 151643, (Bd, L), device=dev, generator=g)
+    ids_d[pairs:, :L - NVQ - 2] = ids_d[:pairs, :L - NVQ - 2]                            # a pair shares its prompt
+    ids_d[:, -(NVQ + 2)] = SOI
+    ids_d[:, -1] = EOI
+    dpo_loss = []
+
+    def step_dpo():
+        codes = vq.get_code(images) + TEXT_VOCAB
+        msk = torch.rand(pairs, NVQ, device=dev, generator=g) < 0.6
+        msk = torch.cat([msk, msk])                                                      # same masked positions within a pair
+        ids_d[:, -(NVQ + 1):-1] = torch.where(msk, torch.full_like(codes, MASK_ID), codes)
+        labels = torch.full((Bd, L), -100, device=dev)
+        labels[:, -(NVQ + 1):-1] = torch.where(msk, codes, torch.full_like(codes, -100))
+        mb = ops.mask_from_ids(ids_d, PAD, SOI, EOI, ops.MASK_T2I)
+        with torch.no_grad():
+            ref_lp = get_batch_logps(ref(input_ids=ids_d, attention_mask=mb, batch_size_t2i=Bd), labels, num_vq_tokens=NVQ)
+        lp = get_batch_logps(model(input_ids=ids_d, attention_mask=mb, batch_size_t2i=Bd), labels, num_vq_tokens=NVQ)
+        logits = (lp[:pairs] - lp[pairs:]) - (ref_lp[:pairs] - ref_lp[pairs:])
+        loss = -F.logsigmoid(beta * logits).mean()
+        loss.backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        dpo_loss.append(loss.detach())
+    ms = timed(step_dpo)
+    out["dpo_L387"] = {"ms_per_step": round(ms, 2), "pairs_per_s": round(pairs / ms * 1e3, 2), "pairs": pairs, "seq_len": L,
+                       "loss": round(float(dpo_loss[-1]), 4)}
+    del ref
+    torch.cuda.empty_cache()
+
+    # ---- MaskGIT generation: 10 images, CFG 6, 50 rounds
+    model.eval()
+    n_img, prefix, rounds = 10, 138, 50
+    Lg = prefix + NVQ + 1
+    ids_g = torch.randint(0, 151643, (n_img, Lg), device=dev, generator=g)
+    ids_g[:, prefix - 1] = SOI
+    ids_g[:, -1] = EOI
+    ids_g[:, prefix:-1] = MASK_ID
+    un = ids_g.clone()
+    un[:, :prefix - 10] = PAD
+    mb = ops.mask_from_ids(torch.cat([ids_g, un]), PAD, SOI, EOI, ops.MASK_T2I)
+
+    def gen():
+        with torch.no_grad():
+            return model.t2i_generate(input_ids=ids_g, uncond_input_ids=un, attention_mask=mb, guidance_scale=6.0, temperature=1.0,
+                                      timesteps=rounds, generator=torch.Generator(device=dev).manual_seed(3),
+                                      image_token_num_per_image=NVQ, text_vocab_size=TEXT_VOCAB)
+    ms = timed(gen, n=1)
+    out["maskgit_50_rounds"] = {"seconds_per_batch": round(ms / 1e3, 3), "images_per_s": round(n_img / ms * 1e3, 2), "images": n_img,
+                                "rows_with_cfg": 2 * n_img, "rounds": rounds, "ms_per_round": round(ms / rounds, 2),
+                                "img_tokens_per_s": round(n_img * NVQ / ms * 1e3, 1)}
+    model.train()
+
+    # ---- SFT mix at L = 1603 with the SigLIP tower (the projector joins the model and the optimizer here)
+    from models.multimodal_encoder.siglip_encoder import SigLipVisionConfig, SigLipVisionTower
+    Ls, bt, bl, bm, n_tok = 1603, 3, 1, 4, 729
+    model.add_mm_projector(2, 1152)
+    opt.add_param_group({"params": list(model.mm_projector.parameters()), "weight_decay": 0.01})
+    tower = SigLipVisionTower("siglip-so400m-patch14-384", config=SigLipVisionConfig(patch_size=14)).to(dev).eval()
+    with torch.no_grad():
+        for p_ in tower.parameters():
+            p_.normal_(0, 0.02, generator=g)
+    images = torch.rand(bt, 3, 256, 256, device=dev, generator=g) * 2 - 1
+    images_mmu = torch.rand(bm, 3, 384, 384, device=dev, generator=g) * 2 - 1
+    ids_s = torch.randint(0, 151643, (bt + bl + bm, Ls), device=dev, generator=g)
+    ids_s[:bt, -(NVQ + 2)] = SOI
+    ids_s[:bt, -1] = EOI
+    ids_s[:bt, -(NVQ + 1):-1] = MASK_ID
+    embed = model.llm.model.embed_tokens
+    r = torch.arange(Ls, device=dev)
+    allow_lm = (r[None, :] <= r[:, None])[None].expand(bl, Ls, Ls)
+    allow_mmu = ((r[None, :] <= r[:, None]) | ((r[None, :] >= 20) & (r[None, :] < 20 + n_tok)))[None].expand(bm, Ls, Ls)    # mmu_vit mask
+    rest = ops.mask_compress(torch.cat([allow_lm, allow_mmu]))
+    sft_loss = []
+
+    def step_sft():
+        codes = vq.get_code(images) + TEXT_VOCAB
+        labels = torch.full((bt + bl + bm, Ls), -100, device=dev)
+        labels[:bt, -(NVQ + 1):-1] = codes
+        labels[bt:bt + bl] = ids_s[bt:bt + bl]
+        labels[bt + bl:, 20 + n_tok:] = ids_s[bt + bl:, 20 + n_tok:]
+        with torch.no_grad():
+            feats = tower(images_mmu)                                       # [bm, 729, 1152] fp32
+        img_h = model.mm_projector(feats)
+        e = embed(ids_s)
+        e = torch.cat([e[:bt + bl], torch.cat([e[bt + bl:, :20], img_h.float(), e[bt + bl:, 20 + n_tok:]], 1)])
+        mb = cat_masks(ops.mask_from_ids(ids_s[:bt], PAD, SOI, EOI, ops.MASK_T2I), rest)
+        _, l1, l2, l3 = model(input_ids=None, input_embeddings=e, attention_mask=mb, labels=labels, batch_size_t2i=bt,
+                              batch_size_lm=bl, batch_size_mmu=bm, max_seq_length=Ls - NVQ - 3, num_vq_tokens=NVQ)
+        (l1 + l2 + l3).backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        sft_loss.append(torch.stack([l1.detach(), l2.detach(), l3.detach()]))
+    ms = timed(step_sft)
+    out["sft_L1603"] = {"ms_per_step": round(ms, 2), "samples_per_s": round((bt + bl + bm) / ms * 1e3, 2), "rows": f"{bt} t2i + {bl} lm + {bm} mmu",
+                        "seq_len": Ls, "siglip_images": bm, "losses": [round(float(x), 3) for x in sft_loss[-1]]}
     model.llm.engine.check_errors()
     return out
 
@@ -263,7 +360,7 @@ def main():
     ap.add_argument("--text-len", type=int, default=511, help="text tokens after the 2 template tokens (513 total)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the secondary cases (pt1 mixed batch, real MaskGIT mask ratios)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary cases (pt1 mixed batch, real mask ratios, SFT, DPO, MaskGIT)")
     ap.add_argument("--no-ar", action="store_true", help="skip the AR image-token generation measurement (second half of the metric)")
     args = ap.parse_args()
 
@@ -318,8 +415,7 @@ def main():
     def step():
         codes = vq.get_code(images) + TEXT_VOCAB
         masked = torch.full_like(codes, MASK_ID)                    # mask_prob = 1: every image token is a label
-        ids, labels = t2i_layout(text, masked, codes)
-        mask = device_mask_predict_next(ids, PAD, SOI, EOI)
+        ids, labels, mask = t2i_rows(ops, text, masked, codes)
         _, l_t2i, _, _ = model(input_ids=ids, attention_mask=mask, labels=labels, batch_size_t2i=B,
                                max_seq_length=args.text_len + 1, num_vq_tokens=NVQ)
         l_t2i.backward()
@@ -353,10 +449,13 @@ def main():
     if not args.no_roofline:
         # one more step with HIP events around every GEMM launch (on the launch stream): EVERY rank runs it -- the step
         # contains the gradient exchange -- and rank 0 records
+        from unigen_hip import lib as ug_lib
         if rank == 0:
             ops.GEMM_PROFILE = []
+            ug_lib.PROFILE = {}
         step()
         torch.cuda.synchronize()
+        fam_rec, ug_lib.PROFILE = ug_lib.PROFILE, None
     if rank == 0 and not args.no_roofline:
         rec = ops.GEMM_PROFILE
         ops.GEMM_PROFILE = None
@@ -380,12 +479,27 @@ def main():
                 "launches_per_step": len(rec), "avg_launch_ms": round(tot_ms / len(rec), 4),
                 "flops_per_launch": round(tot_fl / len(rec) / 1e9, 2), "gemm_ms_per_step": round(tot_ms, 2),
                 "step_frac_of_bf16_peak": round(value / world * FLOP_SAMPLE / PEAK_BF16, 4)}
-    extra = None
-    if rank == 0 and world == 1 and not args.no_extra:
-        extra = extra_cases(model, vq, opt, dev, args)
+        # launch time by kernel family in the same instrumented step (HIP events around every library launch, on the launch
+        # stream) against each family's own bound; algorithmic work per step from SURVEY.md section 8d
+        fam_ms = {k: sum(e0.elapsed_time(e1) for e0, e1, _ in v) for k, v in (fam_rec or {}).items()}
+        n_par = model.llm.engine.fp.numel
+        work = {"gemm": ("mfma", tot_fl, 2.5e15), "attention": ("mfma", 3 * B * 0.0569e12, 2.5e15),
+                "tokenizer_and_towers": ("mfma f16 x 3 split products", B * 0.3551e12, 2.5e15 / 3),
+                "adamw": ("hbm", 28.0 * n_par, 8e12), "elementwise": ("hbm", None, 8e12)}
+        by_family = {}
+        for k, t_ms in sorted(fam_ms.items(), key=lambda kv: -kv[1]):
+            bound, w, peak = work[k]
+            e = {"bound": bound, "ms_per_step": round(t_ms, 2), "launches": len(fam_rec[k])}
+            if w is not None:
+                e.update(achieved=round(w / (t_ms * 1e-3) / 1e12, 2), unit="TFLOP/s" if bound != "hbm" else "TB/s", frac=round(w / (t_ms * 1e-3) / peak, 4))
+            by_family[k] = e
+        roof["by_family"] = by_family
     ar = None
     if rank == 0 and world == 1 and not args.no_ar:
         ar = ar_decode_bench(model, dev)
+    extra = None
+    if rank == 0 and world == 1 and not args.no_extra:
+        extra = extra_cases(model, vq, opt, dev, args)           # (last: the SFT case adds the projector to the model)
     if rank == 0:
         out = {"metric": "train-step samples/s (1.5B, 256^2 img)", "value": round(value, 3), "unit": "samples/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2),

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define UG_ABI_VERSION 2
+#define UG_ABI_VERSION 3
 
 /* ---- library ---------------------------------------------------------------------------- */
 const char* ug_last_error(void);
@@ -70,10 +70,6 @@ int ug_gemm_bf16(const ug_handle* h, const void* A, int64_t lda, int a_kmajor, c
 #define UG_GEMM_TWO_BARRIERS 0x400    /* force its two-barrier (L | M phase) main loop (default: forward and dgrad) */
 #define UG_GEMM_POLICY_AUTO_BITS 0xff
 
-/* in [R,C] (fp32 if in_f32 else bf16) -> out bf16 [R,C] (optional) and outT bf16 [C,ldT] with
- * columns R..ldT-1 zero-filled (layout utility; the training path no longer needs it). */
-int ug_transpose_cast(const void* in, int in_f32, int64_t ld_in, void* out, int64_t ld_out, void* outT,
-                      int64_t ldT, int64_t R, int64_t C, hipStream_t stream);
 int ug_cast_f32_bf16(const float* in, void* out, int64_t n, hipStream_t stream);
 
 /* replaces: down_proj's input act_fn(gate_proj(x)) * up_proj(x) in Qwen2MLP.forward (modeling_qwen2.py:46-48) as ONE launch:
@@ -138,10 +134,6 @@ int ug_attn_mask_compress(const void* mask, int mask_dtype, int64_t stride_b, in
                           hipStream_t stream);
 int ug_attn_mask_causal(const uint8_t* key_valid /* [B,L] or null */, uint64_t* bits, uint8_t* tileany,
                         int64_t B, int64_t L, hipStream_t stream);
-/* in rows (b*L+t), C columns at stride ld  ->  out[b][c][t], t zero-padded to Lp (multiple of 64).  (No attention kernel
- * needs it any more -- they transpose in LDS with ds_read_b64_tr_b16; kept as a utility.) */
-int ug_attn_transpose(const void* in, int64_t ld, void* out, int64_t B, int64_t L, int64_t Lp, int64_t C,
-                      hipStream_t stream);
 /* replaces: torch SDPA in Qwen2Attention.forward (modeling_qwen2.py:196-234), GQA H:HKV, head_dim 128.
  * q/k/v: row (b*L+t), head h at column h*128, row stride ldq.
  * o: [tokens, ldo] bf16, lse: [B][H][L] fp32. */
@@ -174,18 +166,11 @@ int ug_attn_decode(const void* q, int64_t ldq, const void* cache_k, const void* 
  * models/unigen.py:496-502).  The decode path keeps row-major accumulators (acc_stride_n = 1). */
 int ug_gemv_bf16(const void* x, int64_t ldx, int64_t R, const void* W, int64_t ldw, float* acc, int64_t acc_stride_r,
                  int64_t acc_stride_n, int64_t N, int64_t K, hipStream_t stream);
-/* fused finishers of one decode step (Qwen2DecoderLayer.forward with a one-token query, transformers
- * modeling_qwen2.py as driven by models/unigen.py:496-502).  Each consumes a row-major fp32 accumulator
- * (acc[r*ldacc + n]) filled by ug_gemv_bf16 and leaves it zeroed for the next step.
- *   qkv:        + bias -> bf16, RoPE at *pos_dev on q and k heads, q -> q_out, k/v -> cache[:, :, *pos_dev]
- *   resid_norm: x += bf16round(acc);  xn = bf16(rmsnorm(x) * w)   (o_proj / down_proj + the following RMSNorm)
- *   swiglu:     act = bf16(bf16(silu(bf16 gate)) * bf16 up)       (gate_up projection + SiLU-mul) */
-int ug_decode_finish_qkv(float* acc, int64_t ldacc, const void* bias, const float* cos_tab, const float* sin_tab,
-                         const int* pos_dev, void* q_out, int64_t ldq, void* cache_k, void* cache_v, int64_t rows, int Hq,
-                         int Hkv, int head_dim, int64_t Tmax, int64_t max_pos, hipStream_t stream);
+/* last launch of a decode step (Qwen2Model.norm after the last layer's down_proj, models/unigen.py:496-502): consumes the
+ * row-major fp32 accumulator acc[r*ldacc + n] a decode GEMV filled and leaves it zeroed for the next step:
+ *   x += bf16round(acc);  xn = bf16(rmsnorm(x) * w) */
 int ug_decode_finish_resid_norm(float* acc, int64_t ldacc, float* x, const float* w, void* xn, int64_t rows, int64_t cols,
                                 float eps, hipStream_t stream);
-int ug_decode_finish_swiglu(float* acc, int64_t ldacc, void* act, int64_t rows, int64_t I, hipStream_t stream);
 /* Five-launch decode layer (what UniGen.t2i_generate_ar's per-token forward, models/unigen.py:496-502, runs).  A decode
  * step is bound by the ~4 us floor of every launch, so all finishing work moves to the CONSUMER of each accumulator
  * and kernel boundaries are the only synchronisation:
@@ -297,6 +282,35 @@ int ug_grad_unpack_bf16(const void* in_bf16, float* out, int64_t n, hipStream_t 
  * summed in fp32 in rank order (identical on every rank), rounded once; the slices are then all-gathered and unpacked. */
 int ug_grad_sum_shards_bf16(const void* shards_bf16, int world, int64_t stride, void* out_bf16, int64_t n, float scale,
                             hipStream_t stream);
+
+/* ---- data-parallel gradient exchange over RCCL ------------------------------------------------ */
+/* replaces: the DistributedDataParallel reducer behind accelerator.prepare / accelerator.backward (training/train.py:492,775)
+ * for hosts that do not bring torch.distributed (the shipped Python host keeps torch.distributed as its default transport and
+ * switches to these entry points with UNIGEN_DDP_TRANSPORT=ug_comm).  One ug_comm per rank = one process per GPU.  RCCL is
+ * resolved with dlopen at ug_comm_init time (the copy already mapped into the process, else UNIGEN_RCCL_LIB / librccl.so.1).
+ *   ug_comm_unique_id       rank 0 creates the 128-byte rendezvous id; the host hands it to every rank (any side channel)
+ *   ug_comm_init            ncclCommInitRank + the communicator's side stream, events and bf16 staging for buckets of up to
+ *                           max_bucket_elems elements
+ *   ug_comm_allreduce_bucket  MEAN over ranks of grad[0..n) in place.  Ordered after everything queued on `producer` at the
+ *                           time of the call (an event is recorded there); pack / collective(s) / unpack run on the
+ *                           communicator's side stream, so the producer stream continues with backward.  mode:
+ *                             UG_COMM_FP32          ncclAllReduce(fp32, AVG): DDP's arithmetic, 4 bytes per element on the links
+ *                             UG_COMM_BF16_FP32ACC  bf16 on the links, fp32 sum in rank order, one final bf16 rounding
+ *                             UG_COMM_BF16          bf16(g / world) summed by ncclAllReduce in bf16 (least accurate)
+ *   ug_comm_wait            `consumer` waits for every bucket issued so far (end of backward, before clipping / the optimizer)
+ *   ug_comm_bytes_on_wire   payload handed to the collectives since init (reporting)
+ * No call synchronises the host.  Buckets must be 16-byte aligned. */
+typedef struct ug_comm ug_comm;
+#define UG_COMM_ID_BYTES 128
+#define UG_COMM_FP32 0
+#define UG_COMM_BF16_FP32ACC 1
+#define UG_COMM_BF16 2
+int ug_comm_unique_id(void* id128);
+int ug_comm_init(ug_comm** out, int world, int rank, const void* id128, int64_t max_bucket_elems);
+int ug_comm_allreduce_bucket(ug_comm* comm, float* grad, int64_t n, int mode, hipStream_t producer);
+int ug_comm_wait(ug_comm* comm, hipStream_t consumer);
+int ug_comm_destroy(ug_comm* comm);
+int64_t ug_comm_bytes_on_wire(const ug_comm* comm);
 
 /* ---- MAGVITv2 tokenizer (fp32, NHWC) ------------------------------------------------------- */
 /* replaces: torch.nn.Conv2d in VQGANEncoder/Decoder, ResnetBlock, Downsample (asymmetric pad via

@@ -154,56 +154,6 @@ __global__ __launch_bounds__(256) void mask_tiles_kernel(const uint64_t* __restr
   if (lane == 0) tileany[wid] = any ? 1 : 0;
 }
 
-// ------------------------------------------------------------------ batched slice transpose
-// in: rows (b*L + t), columns [0, C) at row stride ld  ->  out[b][c][t], t padded to Lp with zeros
-__global__ __launch_bounds__(256) void attn_transpose_kernel(const bf16_t* __restrict__ in, int64_t ld,
-                                                             bf16_t* __restrict__ out, int L, int Lp, int C) {
-  __shared__ bf16_t tile[64][66];
-  const int b = blockIdx.z;
-  const int t0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  for (int i = ty; i < 64; i += 4) {
-    const int t = t0 + i, c = c0 + tx;
-    tile[i][tx] = (t < L && c < C) ? in[((int64_t)b * L + t) * ld + c] : (bf16_t)0;
-  }
-  __syncthreads();
-  for (int i = ty; i < 64; i += 4) {
-    const int c = c0 + i, t = t0 + tx;
-    if (c < C && t < Lp) out[((int64_t)b * C + c) * Lp + t] = tile[tx][i];
-  }
-}
-
-// same transpose with 16-byte global accesses (C, ld, Lp multiples of 8, 16-byte aligned bases): rows go to LDS as
-// loaded, every thread then gathers eight tokens of one column (conflict-free 2-byte reads: a wave spans 64 columns of
-// one token row) and stores them as one 16-byte piece of the transposed row
-__global__ __launch_bounds__(256) void attn_transpose_vec_kernel(const bf16_t* __restrict__ in, int64_t ld,
-                                                                 bf16_t* __restrict__ out, int L, int Lp, int C) {
-  __shared__ __attribute__((aligned(16))) bf16_t tile[64][72];
-  const int b = blockIdx.z;
-  const int t0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
-  const int tid = threadIdx.x;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int e = tid + i * 256, r = e >> 3, ch = e & 7;
-    const int t = t0 + r, c = c0 + ch * 8;
-    bf16x8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (t < L && c < C) v = *reinterpret_cast<const bf16x8_t*>(in + ((int64_t)b * L + t) * ld + c);
-    *reinterpret_cast<bf16x8_t*>(&tile[r][ch * 8]) = v;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int c = tid & 63, tc = (tid >> 6) + i * 4;             // column, token chunk of eight
-    const int t = t0 + tc * 8;
-    if (c0 + c < C && t < Lp) {
-      bf16x8_t v;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] = (short)tile[tc * 8 + k][c];
-      *reinterpret_cast<bf16x8_t*>(out + ((int64_t)b * C + c0 + c) * Lp + t) = v;
-    }
-  }
-}
-
 // ------------------------------------------------------------------ tile staging helpers
 // row-major tile: 64 rows x 128 cols from global rows (row_first + r, clamped to L-1)
 template <int NT = 256>
@@ -647,18 +597,6 @@ extern "C" int ug_attn_mask_from_ids(const int64_t* ids, int64_t B, int64_t L, i
   const int64_t ntile = B * nW * nW;
   hipLaunchKernelGGL(mask_tiles_kernel, dim3((unsigned)((ntile + 3) / 4)), dim3(256), 0, st, bits, tileany, (int)B, (int)L, nW);
   UG_CHECK_LAUNCH("ug_attn_mask_from_ids(tiles)");
-  return UG_OK;
-}
-
-extern "C" int ug_attn_transpose(const void* in, int64_t ld, void* out, int64_t B, int64_t L, int64_t Lp, int64_t C,
-                                 hipStream_t st) {
-  UG_REQUIRE(B > 0 && L > 0 && C > 0 && Lp >= L, "ug_attn_transpose: bad args");
-  dim3 grid((unsigned)((C + 63) / 64), (unsigned)((Lp + 63) / 64), (unsigned)B), block(256);
-  if (C % 8 == 0 && ld % 8 == 0 && Lp % 8 == 0 && ug_aligned16(in) && ug_aligned16(out))
-    hipLaunchKernelGGL(attn_transpose_vec_kernel, grid, block, 0, st, (const bf16_t*)in, ld, (bf16_t*)out, (int)L, (int)Lp, (int)C);
-  else
-    hipLaunchKernelGGL(attn_transpose_kernel, grid, block, 0, st, (const bf16_t*)in, ld, (bf16_t*)out, (int)L, (int)Lp, (int)C);
-  UG_CHECK_LAUNCH("ug_attn_transpose");
   return UG_OK;
 }
 

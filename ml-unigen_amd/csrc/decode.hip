@@ -409,15 +409,6 @@ __device__ __forceinline__ void finish_qkv_tile(float* __restrict__ acc, int64_t
   }
 }
 
-__global__ __launch_bounds__(64) void finish_qkv_kernel(float* __restrict__ acc, int64_t lda, const bf16_t* __restrict__ bias,
-                                                        const float* __restrict__ cs, const float* __restrict__ sn_tab,
-                                                        const int* __restrict__ pos_dev, bf16_t* __restrict__ q_out,
-                                                        int64_t ldq, bf16_t* __restrict__ ck, bf16_t* __restrict__ cv, int Hq,
-                                                        int Hk, int Tmax, int max_pos) {
-  finish_qkv_tile(acc, lda, bias, cs, sn_tab, *pos_dev, q_out, ldq, ck, cv, Hq, Hk, Tmax, max_pos, blockIdx.x, blockIdx.y,
-                  threadIdx.x);
-}
-
 // o / down projection:  x[r] += bf16round(acc[r]);  xn[r] = bf16(rmsnorm(x[r]) * w)   (next sub-block's input).
 // One wave per row, the same per-lane accumulation order as rmsnorm_fwd_kernel so both paths agree bit for bit.
 template <int MAXV>
@@ -484,14 +475,6 @@ __device__ __forceinline__ void finish_swiglu_quad(float* __restrict__ acc, int6
   }
   uint2 ov; ov.x = pack_bf2(o[0], o[1]); ov.y = pack_bf2(o[2], o[3]);
   *reinterpret_cast<uint2*>(act + (int64_t)r * I + c) = ov;
-}
-
-__global__ __launch_bounds__(256) void finish_swiglu_kernel(float* __restrict__ acc, int64_t lda, bf16_t* __restrict__ act,
-                                                            int R, int I) {
-  const int per_row = I >> 2;
-  const int64_t total = (int64_t)R * per_row;
-  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x)
-    finish_swiglu_quad(acc, lda, act, I, (int)(idx / per_row), (int)(idx % per_row) * 4);
 }
 
 // One wave per workgroup owns ONE 256-wide k-slab and KW consecutive 16-row weight groups.  The
@@ -877,18 +860,6 @@ extern "C" int ug_decode_gemv_swiglu(const float* gate_up_acc, int64_t ld_gu, co
   return UG_OK;
 }
 
-extern "C" int ug_decode_finish_qkv(float* acc, int64_t ldacc, const void* bias, const float* cos_tab, const float* sin_tab,
-                                    const int* pos_dev, void* q_out, int64_t ldq, void* cache_k, void* cache_v, int64_t rows,
-                                    int Hq, int Hkv, int head_dim, int64_t Tmax, int64_t max_pos, hipStream_t st) {
-  UG_REQUIRE(rows > 0 && head_dim == DHD && Hq > 0 && Hkv > 0 && pos_dev && acc && q_out && cache_k && cache_v,
-             "ug_decode_finish_qkv: bad args");
-  hipLaunchKernelGGL(finish_qkv_kernel, dim3(Hq + 2 * Hkv, (unsigned)rows), dim3(64), 0, st, acc, ldacc, (const bf16_t*)bias,
-                     cos_tab, sin_tab, pos_dev, (bf16_t*)q_out, ldq, (bf16_t*)cache_k, (bf16_t*)cache_v, Hq, Hkv, (int)Tmax,
-                     (int)max_pos);
-  UG_CHECK_LAUNCH("ug_decode_finish_qkv");
-  return UG_OK;
-}
-
 extern "C" int ug_decode_finish_resid_norm(float* acc, int64_t ldacc, float* x, const float* w, void* xn, int64_t rows,
                                            int64_t cols, float eps, hipStream_t st) {
   UG_REQUIRE(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= 4096 && ldacc % 4 == 0 && acc && x && w && xn,
@@ -902,16 +873,6 @@ extern "C" int ug_decode_finish_resid_norm(float* acc, int64_t ldacc, float* x, 
     hipLaunchKernelGGL(finish_resid_norm_kernel<16>, dim3((unsigned)rows), dim3(64), 0, st, acc, ldacc, x, w, (bf16_t*)xn,
                        (int)cols, eps);
   UG_CHECK_LAUNCH("ug_decode_finish_resid_norm");
-  return UG_OK;
-}
-
-extern "C" int ug_decode_finish_swiglu(float* acc, int64_t ldacc, void* act, int64_t rows, int64_t I, hipStream_t st) {
-  UG_REQUIRE(rows > 0 && I > 0 && I % 4 == 0 && ldacc % 4 == 0 && acc && act && ug_aligned16(acc) && ((uintptr_t)act & 7) == 0,
-             "ug_decode_finish_swiglu: bad args");
-  const int64_t total = rows * (I / 4);
-  int64_t g = (total + 255) / 256; if (g > 4096) g = 4096;
-  hipLaunchKernelGGL(finish_swiglu_kernel, dim3((unsigned)g), dim3(256), 0, st, acc, ldacc, (bf16_t*)act, (int)rows, (int)I);
-  UG_CHECK_LAUNCH("ug_decode_finish_swiglu");
   return UG_OK;
 }
 

@@ -1,5 +1,5 @@
 // HBM-bound row/elementwise kernels of the Qwen2.5 backbone for gfx950: RMSNorm fwd/bwd, RoPE,
-// SwiGLU, transpose/cast, embedding gather / scatter-add, column sums, fused AdamW.
+// SwiGLU, cast, embedding gather / scatter-add, column sums, fused AdamW.
 // All are one pass over their operands with 16-byte per-lane accesses and wave64 shuffles for the
 // row reductions (no LDS round trip unless a cross-wave sum is needed).
 //
@@ -221,36 +221,6 @@ __global__ __launch_bounds__(256) void gelu_kernel(const bf16_t* __restrict__ x,
       else o[k] = (short)f2bf(bf2f((bf16_t)g[k]) * (cdf + f * 0.3989422804014327f * __expf(-0.5f * f * f)));
     }
     reinterpret_cast<bf16x8_t*>(out)[i] = o;
-  }
-}
-
-// =========================================================================== transpose / cast
-// in [R, C] (fp32 or bf16, row stride ld_in)  ->  out bf16 [R, C] (optional, stride ld_out)
-//                                               outT bf16 [C, ldT] with columns R..ldT-1 zeroed
-// 64x64 tiles through LDS (+1 padding), 256 threads.
-template <typename TIn>
-__global__ __launch_bounds__(256) void transpose_kernel(const TIn* __restrict__ in, int64_t ld_in,
-                                                        bf16_t* __restrict__ out, int64_t ld_out,
-                                                        bf16_t* __restrict__ outT, int64_t ldT, int R, int C) {
-  __shared__ bf16_t tile[64][66];
-  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  for (int i = ty; i < 64; i += 4) {
-    const int r = r0 + i, c = c0 + tx;
-    bf16_t v = 0;
-    if (r < R && c < C) {
-      if constexpr (sizeof(TIn) == 4) v = f2bf(in[(int64_t)r * ld_in + c]);
-      else v = in[(int64_t)r * ld_in + c];
-      if (out) out[(int64_t)r * ld_out + c] = v;
-    }
-    tile[i][tx] = v;
-  }
-  __syncthreads();
-  if (outT) {
-    for (int i = ty; i < 64; i += 4) {
-      const int c = c0 + i, r = r0 + tx;
-      if (c < C && r < ldT) outT[(int64_t)c * ldT + r] = tile[tx][i];
-    }
   }
 }
 
@@ -495,18 +465,6 @@ extern "C" int ug_gelu(const void* x, const void* dy_or_null, void* out, int64_t
   dim3 grid(grid_for(n / 8)), block(256);
   hipLaunchKernelGGL(gelu_kernel, grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)dy_or_null, (bf16_t*)out, n / 8);
   UG_CHECK_LAUNCH("ug_gelu");
-  return UG_OK;
-}
-
-extern "C" int ug_transpose_cast(const void* in, int in_f32, int64_t ld_in, void* out, int64_t ld_out, void* outT,
-                                 int64_t ldT, int64_t R, int64_t C, hipStream_t st) {
-  UG_REQUIRE(R > 0 && C > 0, "ug_transpose_cast: empty");
-  UG_REQUIRE(outT == nullptr || ldT >= R, "ug_transpose_cast: ldT=%ld < R=%ld", (long)ldT, (long)R);
-  const int64_t rext = outT ? ldT : R;   // sweep the zero padding too
-  dim3 grid((unsigned)((C + 63) / 64), (unsigned)((rext + 63) / 64)), block(256);
-  if (in_f32) hipLaunchKernelGGL(transpose_kernel<float>, grid, block, 0, st, (const float*)in, ld_in, (bf16_t*)out, ld_out, (bf16_t*)outT, ldT, (int)R, (int)C);
-  else hipLaunchKernelGGL(transpose_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)in, ld_in, (bf16_t*)out, ld_out, (bf16_t*)outT, ldT, (int)R, (int)C);
-  UG_CHECK_LAUNCH("ug_transpose_cast");
   return UG_OK;
 }
 

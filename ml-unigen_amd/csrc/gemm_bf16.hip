@@ -883,7 +883,9 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p10(GemmArgs p) {
   store_tile_lds<EPI, 10>(p, acc, lds + wave * EP_STRIP, m0 + grp * 160, n0 + wn * 64, lane);
 }
 
+#ifdef UG_GEMM_R4
 // =============================================================================================
+// PROBE BUILDS ONLY (-DUG_GEMM_R4, tools/probes/gemm_r4_ablate.py; measured and not shipped).
 // Register-blocked kernel: 256 x 256 tile, FOUR waves (one per SIMD), each wave 128 x 128 = 4 x 4 blocks of
 // v_mfma_f32_32x32x16_bf16 (256 accumulator registers).  One wave per SIMD issues that instruction back to back (32 clocks each:
 // tools/probes/mfma_peak.py measures the same 2.5 PF on zeros / 1.75 PF on random operands from one wave per SIMD as from two),
@@ -1157,38 +1159,69 @@ __device__ __forceinline__ void r4_body(const GemmArgs& p, const int bid, char* 
   read_frags(0, 0);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
+  // one MFMA of k-step ks: block (i, j) of the wave's 4 x 4
+  auto mfma1 = [&](int ks, int i, int j) {
+    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(hwbf16x8_t, fb[ks][j]), __builtin_bit_cast(hwbf16x8_t, fa[ks][i]),
+                                                        acc[i][j], 0, 0, 0);
+  };
   auto iteration = [&](int t, auto steady) {
     constexpr bool ST = decltype(steady)::value;
-    // ---------------- phase A: k-step 0 of tile t; fragments of k-step 1 arrive under it
+    const char* tA = lds + (t & (P_NST - 1)) * P_STAGE;
+    const char* tB = tA + P_TILE;
+    const char* nA = lds + ((t + 1) & (P_NST - 1)) * P_STAGE;
+    const char* nB = nA + P_TILE;
+    char* dA = lds + (t & (P_NST - 1)) * P_STAGE;            // slot of tile t+4 == slot of tile t
+    const bool have_next = ST || (t + 1 < nk);
+    const bool do_dma = ST || (t + 4 < nk);
+    const bool dma_checked = !ST && ragged && (kt0 + t + 4 + 1 == nk_all);
+    // ---------------- phase A: k-step 0 of tile t; fragments of k-step 1 arrive under it (one per MFMA gap, pinned)
     __builtin_amdgcn_sched_barrier(0);
-    read_frags(t, 1);
-    mfmas(0);
 #pragma unroll
-    for (int g = 0; g < 8; ++g) { R4_GROUP(0x008, 1); R4_GROUP(0x100, DSR / 8); }
-    R4_GROUP(0x008, 8);
-    __builtin_amdgcn_sched_barrier(0);
+    for (int g = 0; g < 16; ++g) {
+      mfma1(0, g >> 2, g & 3);
+#ifndef UG_R4_ABLATE_READS
+      if (g < 4) fa[1][g] = ma.load(tA, 1, g);
+      else if (g < 8) fb[1][g - 4] = mb.load(tB, 1, g - 4);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+    }
     // own DMA share of tile t+1 landed (the two newer tiles may stay in flight); every wave past its reads of tile t
     if constexpr (ST) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else if (t + 3 < nk) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifndef UG_R4_ABLATE_BARRIER
     P_BARRIER();
-    // ---------------- phase B: k-step 1 of tile t; DMA of tile t+4 into tile t's slot, k-step-0 fragments of tile t+1
+#endif
+    // ---------------- phase B: k-step 1 of tile t; per MFMA gap one DMA instruction of tile t+4 (into tile t's slot) and one
+    // k-step-0 fragment of tile t+1
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (ST) {
-      stage_whole(t + 4);
-      read_frags(t + 1, 0);
-      mfmas(1);
 #pragma unroll
-      for (int g = 0; g < 8; ++g) { R4_GROUP(0x008, 1); R4_GROUP(0x020, 1); R4_GROUP(0x100, DSR / 8); }
-      R4_GROUP(0x008, 8);
-    } else {
-      if (t + 4 < nk) stage_in(t + 4);
-      if (t + 1 < nk) read_frags(t + 1, 0);
-      mfmas(1);
+    for (int g = 0; g < 16; ++g) {
+      mfma1(1, g >> 2, g & 3);
+#ifndef UG_R4_ABLATE_DMA
+      if (g < 8 && do_dma) {
+        const int kt = kt0 + t + 4;
+        if (g < 4) {
+          const bf16_t* sp = sa.src[g] + kt * sa.step[g];
+          if (dma_checked && kt * PBK + sa.kofs[g] >= (AK ? p.K : ((p.K + 7) & ~7))) sp = reinterpret_cast<const bf16_t*>(g_zero_page);
+          __builtin_amdgcn_global_load_lds((gptr_t)sp, (lptr_t)(dA + (g * R_NW + wave) * 1024), 16, 0, 0);
+        } else {
+          const bf16_t* sp = sb.src[g - 4] + kt * sb.step[g - 4];
+          if (dma_checked && kt * PBK + sb.kofs[g - 4] >= (BKM ? p.K : ((p.K + 7) & ~7))) sp = reinterpret_cast<const bf16_t*>(g_zero_page);
+          __builtin_amdgcn_global_load_lds((gptr_t)sp, (lptr_t)(dA + P_TILE + ((g - 4) * R_NW + wave) * 1024), 16, 0, 0);
+        }
+      }
+#endif
+#ifndef UG_R4_ABLATE_READS
+      if (have_next) {
+        if (g < 4) fa[0][g] = ma.load(nA, 0, g);
+        else if (g < 8) fb[0][g - 4] = mb.load(nB, 0, g - 4);
+      }
+#endif
+      __builtin_amdgcn_sched_barrier(0);
     }
-    __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   };
   {
@@ -1225,6 +1258,7 @@ __global__ __launch_bounds__(256, 1) void gemm_kernel_r4(GemmArgs p) {
   __shared__ __attribute__((aligned(16))) char lds[P_NST * P_STAGE];
   r4_body<EPI, AK, BKM>(p, (int)blockIdx.x, lds);
 }
+#endif  // UG_GEMM_R4
 
 // Epilogue of the k-sliced tail tiles: scratch -> C with the launch's epilogue, scratch re-zeroed.
 template <int EPI>
@@ -1357,6 +1391,7 @@ int launch(GemmArgs a, const ug_handle* h, int policy, hipStream_t st) {
       return UG_OK;
     }
   }
+#ifdef UG_GEMM_R4
   if (g_tile_policy == 12) {                      // register-blocked 4-wave kernel, whole tiles only (A/B runs)
     a.tiles_m = (a.M + PBM - 1) / PBM; a.tiles_n = (a.N + PBN - 1) / PBN;
     a.full_tiles = tiles_p8; a.tail_split = 1; a.tail_private = 1; a.tail_ws = ws;
@@ -1364,6 +1399,7 @@ int launch(GemmArgs a, const ug_handle* h, int policy, hipStream_t st) {
     UG_CHECK_LAUNCH("ug_gemm_bf16(r4)");
     return UG_OK;
   }
+#endif
   if (g_tile_policy == 3 || g_tile_policy == 6 || (g_tile_policy < 0 && (p8_fits || tail_s > 1))) {
     a.tiles_m = (a.M + PBM - 1) / PBM; a.tiles_n = (a.N + PBN - 1) / PBN;
     a.full_tiles = tiles_p8 - tail_r; a.tail_split = tail_s;

@@ -501,9 +501,17 @@ class UniGen(ModelMixin, ConfigMixin):
         seg_start = L - n - 2                        # <soi> | n image tokens | <eoi>
         # Prefix rows (padding + text) must not see the image segment for their keys / values to be round-invariant;
         # true for every mask the reference builds (create_attention_mask_predict_next), checked on the mask given.
-        incremental = bool(kwargs.get("incremental", True)) and not torch.is_grad_enabled() and attention_mask is not None \
-            and torch.is_tensor(attention_mask) and attention_mask.dim() == 4 \
-            and not bool((attention_mask[:, 0, :seg_start, seg_start:] == 0).any())
+        incremental = bool(kwargs.get("incremental", True)) and not torch.is_grad_enabled() and attention_mask is not None
+        if incremental and isinstance(attention_mask, ops.MaskBits):
+            # compressed mask (ops.mask_from_ids): no bit of a prefix row may be set at or beyond the segment's first column
+            w0, sh = seg_start // 64, seg_start % 64
+            words = attention_mask.bits[:, :seg_start, w0:]
+            keep = torch.full((words.shape[-1],), -1, dtype=torch.int64, device=words.device)
+            keep[0] = -1 << sh                           # the straddling word: only columns >= seg_start count
+            incremental = not bool(((words & keep) != 0).any())
+        elif incremental:
+            incremental = torch.is_tensor(attention_mask) and attention_mask.dim() == 4 \
+                and not bool((attention_mask[:, 0, :seg_start, seg_start:] == 0).any())
         sess = None
         trace = kwargs.get("trace", None)
         for step in range(timesteps):

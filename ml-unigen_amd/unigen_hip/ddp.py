@@ -18,6 +18,10 @@ gradient buffer, issued bucket by bucket on a side HIP stream while backward is 
   form and the least accurate one: a ring adds world - 1 bf16 roundings of partial sums on top of the packing
   (tests/test_ddp_cpu.py::test_bf16_exchange_error_by_world_size measures every mode at 2 / 4 / 8 ranks).
 
+Transport: `torch.distributed` collectives by default (backend "nccl" IS RCCL on ROCm); `UNIGEN_DDP_TRANSPORT=ug_comm` moves
+the buckets through the library's own RCCL entry points instead (include/unigen_hip.h: ug_comm_*; csrc/comm.hip) -- the same
+wire formats on the communicator's own side stream, torch.distributed only carries the 128-byte rendezvous id.
+
 After `finish()` every gradient holds the MEAN over ranks, exactly what DDP leaves in `.grad`: the caller's unchanged
 `accelerator.clip_grad_norm_` and any stock torch optimizer see the same values as in the reference (no grad_scale
 argument is needed any more; `grad_scale` stays as a constant 1.0 for older callers).
@@ -56,6 +60,10 @@ class FlatGradSync:
         # otherwise ONE exposed collective at the end of backward): UNIGEN_DDP_MAX_BUCKET_MB of fp32
         self.max_bucket = max(1 << 16, int(float(os.environ.get("UNIGEN_DDP_MAX_BUCKET_MB", "512")) * (1 << 20) / 4))
         self._overlap = True
+        self.transport = os.environ.get("UNIGEN_DDP_TRANSPORT", "torch")
+        if self.transport not in ("torch", "ug_comm"):
+            raise ValueError(f"FlatGradSync: UNIGEN_DDP_TRANSPORT must be 'torch' or 'ug_comm' (got {self.transport!r})")
+        self._comm = None
         self.backend = dist.get_backend(process_group) if dist.is_initialized() else "none"
         self.stream = torch.cuda.Stream() if self.cuda else None
         self.extra_params = extra_params
@@ -70,6 +78,42 @@ class FlatGradSync:
         self._gather = None
         self.bytes_on_wire = 0          # payload handed to the collective since construction (tests / bench reporting)
         engine.grad_ready_hook = self.on_ready
+        if self.transport == "ug_comm":
+            if not self.cuda:
+                raise ValueError("FlatGradSync: the ug_comm transport (RCCL) moves device buffers only")
+            self._comm_init()
+
+    # ------------------------------------------------------------------ the library's own RCCL transport
+    def _comm_init(self):
+        import ctypes
+        from . import lib as _l
+        L = _l.load()
+        ident = ctypes.create_string_buffer(128)
+        if self.rank == 0:
+            _l.check(L.ug_comm_unique_id(ident), "ug_comm_unique_id")
+        box = [bytes(ident.raw)]
+        if self.world > 1:
+            dist.broadcast_object_list(box, src=0, group=self.pg)           # the only use of torch.distributed on this transport
+        cap = min(self.max_bucket, self._numel)
+        handle = ctypes.c_void_p()
+        _l.check(L.ug_comm_init(ctypes.byref(handle), self.world, self.rank, ctypes.create_string_buffer(box[0], 128), int(cap)), "ug_comm_init")
+        self._comm, self._lib = handle, L
+        self.backend = "ug_comm(rccl)"
+        self._mode = {"fp32": 0, "bf16_fp32acc": 1, "bf16": 2}[self.reduce]
+
+    def _comm_bucket(self, buf, mode=None):
+        from . import lib as _l
+        _l.check(self._lib.ug_comm_allreduce_bucket(self._comm, buf.data_ptr(), buf.numel(), self._mode if mode is None else mode,
+                                                    torch.cuda.current_stream().cuda_stream), "ug_comm_allreduce_bucket")
+        self.bytes_on_wire = int(self._lib.ug_comm_bytes_on_wire(self._comm))
+
+    def __del__(self):
+        if getattr(self, "_comm", None) is not None:
+            try:
+                self._lib.ug_comm_destroy(self._comm)
+            except Exception:
+                pass
+            self._comm = None
 
     # ------------------------------------------------------------------ one bucket
     def _stage_for(self, n):
@@ -127,6 +171,9 @@ class FlatGradSync:
         if not self.cuda:
             self.bytes_on_wire += buf.numel() * 4
             self._pending.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), buf))
+            return
+        if self._comm is not None:
+            self._comm_bucket(buf)
             return
         from . import ops
         ev = torch.cuda.Event()
@@ -191,7 +238,18 @@ class FlatGradSync:
             self._flush(0, self._hi)
         self._hi = None
         extra = [p for p in (self.extra_params() if self.extra_params is not None else []) if p.grad is not None]
-        if self.cuda:
+        if self._comm is not None:
+            from . import lib as _l
+            flat = torch.cat([p.grad.reshape(-1).float() for p in extra]) if extra else None
+            if flat is not None:
+                self._comm_bucket(flat, mode=0)
+            _l.check(self._lib.ug_comm_wait(self._comm, torch.cuda.current_stream().cuda_stream), "ug_comm_wait")
+            o = 0
+            for p in extra:
+                n = p.grad.numel()
+                p.grad.copy_(flat[o:o + n].view_as(p.grad))
+                o += n
+        elif self.cuda:
             if extra:
                 with torch.cuda.stream(self.stream):
                     self.stream.wait_stream(torch.cuda.current_stream())

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
 LIB_PATH = os.path.join(CSRC_DIR, "libunigen_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 P = ctypes.c_void_p
 I64 = ctypes.c_int64
 I32 = ctypes.c_int
@@ -25,7 +25,6 @@ SIGNATURES = {
     "ug_destroy": [P],
     "ug_gemm_bf16": [P, P, I64, I32, P, I64, I32, P, I64, I64, I64, I64, I32, P, P, I64, I32, P, I32, P],
     "ug_gemm_bf16_swiglu": [P, P, I64, P, I64, P, I64, P, I64, I64, I64, I64, P],
-    "ug_transpose_cast": [P, I32, I64, P, I64, P, I64, I64, I64, P],
     "ug_cast_f32_bf16": [P, P, I64, P],
     "ug_rmsnorm_fwd": [P, P, P, P, I64, I64, F32, I32, P],
     "ug_rmsnorm_bwd": [P, P, P, P, P, P, P, I64, I64, P],
@@ -39,7 +38,6 @@ SIGNATURES = {
     "ug_colsum_bf16": [P, I64, P, I64, I64, P],
     "ug_attn_mask_compress": [P, I32, I64, I64, P, P, I64, I64, P, P],
     "ug_attn_mask_causal": [P, P, P, I64, I64, P],
-    "ug_attn_transpose": [P, I64, P, I64, I64, I64, I64, P],
     "ug_attn_fwd": [P, P, P, I64, P, I64, P, P, P, I64, I64, I64, I32, I32, I32, F32, P],
     "ug_attn_bwd": [P, P, P, I64, P, P, I64, P, P, P, P, P, I64, P, P, I64, I64, I64, I32, I32, I32, F32, P, P],
     "ug_kv_store": [P, I64, I64, I64, P, P, I64, I64, I32, I32, I64, P, I32, P],
@@ -50,9 +48,7 @@ SIGNATURES = {
     "ug_decode_gemv_resid_norm": [P, P, I64, P, P, P, I64, P, I64, P, I64, I64, I64, P, I64, P, I64, P, P],
     "ug_decode_gemv_swiglu": [P, I64, P, F32, I64, I64, P, I64, P, I64, I64, I64, P, I64, P, I64, P, P],
     "ug_attn_decode_fused": [P, I64, P, F32, I64, P, P, P, P, P, P, P, P, I64, I64, I32, I32, I32, I64, I64, F32, P],
-    "ug_decode_finish_qkv": [P, I64, P, P, P, P, P, I64, P, P, I64, I32, I32, I32, I64, I64, P],
     "ug_decode_finish_resid_norm": [P, I64, P, P, P, I64, I64, F32, P],
-    "ug_decode_finish_swiglu": [P, I64, P, I64, I64, P],
     "ug_t2i_assemble": [P, P, P, I64, P, I64, P, P, I64, I64, I64, I64, I64, I64, I64, P, P, P, P],
     "ug_attn_mask_from_ids": [P, I64, I64, I64, I64, I64, I32, P, P, P, P, P],
     "ug_maskgit_train_mask": [P, P, P, I64, I64, I64, I64, P, P, P],
@@ -64,6 +60,12 @@ SIGNATURES = {
     "ug_adamw_flat": [P, P, P, P, P, I64, F32, F32, F32, F32, F32, I64, F32, I32, P],
     "ug_gemm_bf16_wgrad_group": [I32, P, P, P, P, P, P, P, P, P, I64, P],
     "ug_grad_pack_bf16": [P, P, I64, F32, P],
+    "ug_comm_unique_id": [P],
+    "ug_comm_init": [P, I32, I32, P, I64],
+    "ug_comm_allreduce_bucket": [P, P, I64, I32, P],
+    "ug_comm_wait": [P, P],
+    "ug_comm_destroy": [P],
+    "ug_comm_bytes_on_wire": [P],
     "ug_zero_ranges_f32": [P, P, I64, I64, P],
     "ug_grad_unpack_bf16": [P, P, I64, P],
     "ug_grad_sum_shards_bf16": [P, I32, I64, P, I64, F32, P],
@@ -89,6 +91,45 @@ SIGNATURES = {
 }
 
 _lib = None
+
+# Launch-time breakdown by kernel family (bench.py's `roofline_by_family`): when PROFILE is a dict, every entry point that
+# launches on the caller's stream is bracketed by a pair of HIP events recorded on torch's current stream -- the stream every
+# op passes down (or the explicit stream of an overlapped launch, e.g. the optimizer update) -- and filed under its family.  None (the default) costs one global read per call.
+PROFILE = None
+
+
+def family_of(name):
+    if name.startswith("ug_gemm_bf16"):
+        return "gemm"
+    if name in ("ug_attn_fwd", "ug_attn_bwd"):
+        return "attention"
+    if name.startswith(("ug_conv", "ug_groupnorm", "ug_amax", "ug_lfq", "ug_nchw", "ug_nhwc", "ug_gemm_f32", "ug_softmax_rows", "ug_linear_",
+                        "ug_layernorm", "ug_siglip")):
+        return "tokenizer_and_towers"
+    if name == "ug_adamw_flat":
+        return "adamw"
+    return "elementwise"
+
+
+def _profiled(name, fn):
+    fam = family_of(name)
+
+    def call(*args):
+        prof = PROFILE
+        if prof is None:
+            return fn(*args)
+        import torch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        sp = args[-1]                                  # every launching entry point takes its stream last
+        sp = getattr(sp, "value", sp) or 0
+        st = torch.cuda.current_stream() if sp == torch.cuda.current_stream().cuda_stream else torch.cuda.ExternalStream(sp)
+        e0.record(st)
+        rc = fn(*args)
+        e1.record(st)
+        prof.setdefault(fam, []).append((e0, e1, name))
+        return rc
+    call.__name__ = name
+    return call
 
 
 class UniGenHipError(RuntimeError):
@@ -125,7 +166,10 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)   # AttributeError here = header/library mismatch: fail loudly
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_int
+        fn.restype = ctypes.c_int64 if name == "ug_comm_bytes_on_wire" else ctypes.c_int
+        if name.startswith("ug_comm_") or name in ("ug_abi_version", "ug_create", "ug_destroy"):
+            continue
+        setattr(lib, name, _profiled(name, fn))
     if lib.ug_abi_version() != ABI_VERSION:
         raise UniGenHipError(f"ABI version mismatch: library reports {lib.ug_abi_version()}, binding expects {ABI_VERSION}")
     _lib = lib

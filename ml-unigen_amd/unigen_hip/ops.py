@@ -179,23 +179,6 @@ def gemm_nt(a, b, out=None, **kw):
     return gemm(a, b, out, **kw)
 
 
-def transpose_cast(x, R=None, C=None, *, want_out=False, want_T=True, ldT=None):
-    """x [R,C] fp32|bf16 -> (out bf16 [R,C] | None, outT bf16 [C, ldT] zero padded)."""
-    _need_cuda(x)
-    R = x.shape[0] if R is None else R
-    C = x.shape[1] if C is None else C
-    out = torch.empty((R, C), dtype=torch.bfloat16, device=x.device) if want_out else None
-    outT = None
-    if want_T:
-        ldT = round_up(R, 64) if ldT is None else ldT
-        outT = torch.empty((C, ldT), dtype=torch.bfloat16, device=x.device)
-    lib = _l.load()
-    rc = lib.ug_transpose_cast(_p(x), 1 if x.dtype == torch.float32 else 0, x.stride(0), _p(out),
-                               out.stride(0) if out is not None else 0, _p(outT), ldT if want_T else 0, R, C, _stream())
-    _l.check(rc, "ug_transpose_cast")
-    return out, outT
-
-
 def cast_bf16(x, out=None):
     _need_cuda(x)
     if out is None:
@@ -386,8 +369,8 @@ def t2i_assemble(text_ids, image_in, image_labels, max_seq_len, pad_id, soi_id, 
         flat = torch.tensor([v for t in text_ids for v in t] or [0], dtype=torch.int64)
         offs = torch.tensor(offs, dtype=torch.int64)
     flat, offs = flat.to(dev), offs.to(dev)
-    cs = torch.as_tensor(list(conv_start), dtype=torch.int64).to(dev)
-    ce = torch.as_tensor(list(conv_end), dtype=torch.int64).to(dev)
+    as_dev = lambda v: v.to(device=dev, dtype=torch.int64) if torch.is_tensor(v) else torch.as_tensor(list(v), dtype=torch.int64).to(dev)
+    cs, ce = as_dev(conv_start), as_dev(conv_end)
     B, n = image_in.shape
     ids = torch.empty((B, max_seq_len), dtype=torch.int64, device=dev)
     labels = torch.empty_like(ids)
@@ -396,13 +379,6 @@ def t2i_assemble(text_ids, image_in, image_labels, max_seq_len, pad_id, soi_id, 
                                        _p(image_labels.to(torch.int64).contiguous()), B, n, max_seq_len, int(pad_id), int(soi_id),
                                        int(eoi_id), int(ignore_id), _p(ids), _p(labels), _p(attn), _stream()), "ug_t2i_assemble")
     return ids, attn, labels
-
-
-def attn_transpose(x, B, L, Lp, C):
-    """x: rows (b*L+t), C columns starting at x's first column (row stride x.stride(0)) -> [B, C, Lp]."""
-    out = torch.empty((B, C, Lp), dtype=torch.bfloat16, device=x.device)
-    _l.check(_l.load().ug_attn_transpose(_p(x), x.stride(0), _p(out), B, L, Lp, C, _stream()), "ug_attn_transpose")
-    return out
 
 
 def attn_fwd(qkv, mb, H, HKV, hd, scale=None):
@@ -495,23 +471,10 @@ def gemv_acc_(x, w, acc):
     return acc
 
 
-def decode_finish_qkv_(acc, bias, cos, sin, pos_dev, q_out, cache_k, cache_v, rows, H, HKV, hd, Tmax):
-    _l.check(_l.load().ug_decode_finish_qkv(_p(acc), acc.stride(0), _p(bias), _p(cos), _p(sin), _p(pos_dev), _p(q_out),
-                                            q_out.stride(0), _p(cache_k), _p(cache_v), rows, H, HKV, hd, Tmax, cos.shape[0],
-                                            _stream()), "ug_decode_finish_qkv")
-    return q_out
-
-
 def decode_finish_resid_norm_(acc, x, w, xn, eps):
     _l.check(_l.load().ug_decode_finish_resid_norm(_p(acc), acc.stride(0), _p(x), _p(w), _p(xn), x.shape[0], x.shape[1], eps,
                                                    _stream()), "ug_decode_finish_resid_norm")
     return xn
-
-
-def decode_finish_swiglu_(acc, act):
-    _l.check(_l.load().ug_decode_finish_swiglu(_p(acc), acc.stride(0), _p(act), act.shape[0], act.shape[1], _stream()),
-             "ug_decode_finish_swiglu")
-    return act
 
 
 def _clr(t):

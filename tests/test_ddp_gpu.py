@@ -121,7 +121,9 @@ from models import UniGen
 from oracle import weights
 g = golden("g2_tiny_unigen.pt"); cfg = g["cfg"]; dev = torch.device("cuda:0")
 res = {}
-for reduce in ("off", "fp32", "bf16_fp32acc", "bf16"):
+for case in ("off", "fp32", "bf16_fp32acc", "bf16", "ug_comm:fp32", "ug_comm:bf16_fp32acc", "ug_comm:bf16"):
+    reduce = case.split(":")[-1]
+    os.environ["UNIGEN_DDP_TRANSPORT"] = "ug_comm" if case.startswith("ug_comm") else "torch"
     os.environ["UNIGEN_DDP_REDUCE"] = "fp32" if reduce == "off" else reduce
     os.environ["UNIGEN_DDP_FORCE"] = "0" if reduce == "off" else "1"
     m = UniGen(w_und_encoder=False, vocab_size=cfg["vocab_size"], llm_vocab_size=312, llm_model_path=llm_config_dir(cfg), codebook_size=20,
@@ -132,8 +134,9 @@ for reduce in ("off", "fp32", "bf16_fp32acc", "bf16"):
     (l1 + l2 + l3).backward()
     torch.cuda.synchronize()
     eng = m.llm.engine
-    res[reduce] = dict(grad=eng.fp.grad.detach().cpu().clone(), bytes=0 if eng.grad_sync is None else eng.grad_sync.bytes_on_wire,
-                       backend=None if eng.grad_sync is None else eng.grad_sync.backend)
+    res[case] = dict(grad=eng.fp.grad.detach().cpu().clone(), bytes=0 if eng.grad_sync is None else eng.grad_sync.bytes_on_wire,
+                     backend=None if eng.grad_sync is None else eng.grad_sync.backend)
+    eng.grad_sync = None
 torch.save(res, sys.argv[2])
 dist.destroy_process_group()
 """
@@ -144,15 +147,18 @@ dist.destroy_process_group()
     res = torch.load(out, weights_only=False)
     base = res["off"]["grad"]
     assert res["off"]["bytes"] == 0
-    for k in ("fp32", "bf16_fp32acc", "bf16"):
-        assert res[k]["backend"] == "nccl" and res[k]["bytes"] > 0, (k, res[k]["backend"], res[k]["bytes"])
     # (two runs of the same backward differ in the last bits: the embedding scatter-add and the dK / dV finish use fp32 atomics)
     rel = lambda a, b: ((a - b).norm() / b.norm()).item()
-    assert rel(res["fp32"]["grad"], base) < 1e-5
-    for k in ("bf16_fp32acc", "bf16"):
-        g = res[k]["grad"]
-        assert torch.equal(g, g.to(torch.bfloat16).float()) and rel(g, base) < 2.0 ** -8, (k, rel(g, base))
-    print(f"[RCCL, world 1] bytes handed to the collectives: " + ", ".join(f"{k} {res[k]['bytes']}" for k in ("fp32", "bf16_fp32acc", "bf16")))
+    for pre, backend in (("", "nccl"), ("ug_comm:", "ug_comm(rccl)")):      # torch.distributed's RCCL | the library's own ug_comm_* entry points
+        for k in ("fp32", "bf16_fp32acc", "bf16"):
+            r = res[pre + k]
+            assert r["backend"] == backend and r["bytes"] > 0, (pre + k, r["backend"], r["bytes"])
+        assert rel(res[pre + "fp32"]["grad"], base) < 1e-5
+        for k in ("bf16_fp32acc", "bf16"):
+            g = res[pre + k]["grad"]
+            assert torch.equal(g, g.to(torch.bfloat16).float()) and rel(g, base) < 2.0 ** -8, (pre + k, rel(g, base))
+        print(f"[{backend}, world 1] bytes handed to the collectives: " + ", ".join(f"{k} {res[pre + k]['bytes']}" for k in ("fp32", "bf16_fp32acc", "bf16")))
+    assert res["ug_comm:fp32"]["bytes"] == res["fp32"]["bytes"] and res["ug_comm:bf16"]["bytes"] == res["bf16"]["bytes"]
 
 
 def test_bench_runs_end_to_end_with_two_ranks(dev):

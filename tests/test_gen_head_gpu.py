@@ -138,7 +138,7 @@ def test_ar_generation_gen_head_matches_reference_trajectory(dev, use_dim):
         compared = 0
         for b in range(want.shape[0]):
             for i in range(want.shape[1]):
-                if margin[b, i] < 0.1:
+                if margin[b, i] < 0.3:      # the mix is bf16 arithmetic here: margins come in steps of one bf16 ulp (0.06 .. 0.13)
                     break
                 assert int(got[b, i]) == int(want[b, i]), (use_graph, b, i, got[b].tolist(), want[b].tolist())
                 compared += 1

@@ -180,3 +180,28 @@ def test_maskgit_every_round_matches_oracle(dev, incremental):
                     assert torch.equal(got[b], want[b])
     print(f"MaskGIT (incremental={incremental}): {rounds_checked}/{3 * N * T} image-rounds followed to exact agreement")
     assert rounds_checked >= 3 * N * T // 2, rounds_checked
+
+
+def test_maskgit_accepts_the_compressed_mask_from_ids(dev):
+    """t2i_generate with the compressed mask `ops.mask_from_ids` builds straight from the ids (what
+    bench.py's MaskGIT case passes) takes the same incremental path and returns the same tokens as with the dense additive
+    mask of create_attention_mask_predict_next (golden G2's mask)."""
+    from unigen_hip import ops
+    g = golden("g2_tiny_unigen.pt")
+    model = _model(g, dev)
+    m, ids = g["maskgit"], g["ids"]
+    n = 16
+    both = torch.cat([m["input_ids"], m["uncond_ids"]]).to(dev)
+    mb = ops.mask_from_ids(both, ids["pad"], ids["soi"], ids["eoi"], ops.MASK_T2I)
+    L = both.shape[1]
+    cols = torch.arange(mb.nW * 64, device=dev)
+    allow = ((mb.bits[:, :, cols // 64] >> (cols % 64)) & 1).bool()[:, :, :L]
+    assert torch.equal(allow.cpu(), m["mask_allow"])
+    sched = lambda t: torch.cos(t * math.pi * 0.5)
+    outs = []
+    for mask in (additive(m["mask_allow"]).to(dev), mb):
+        outs.append(model.t2i_generate(input_ids=m["input_ids"].to(dev), uncond_input_ids=m["uncond_ids"].to(dev), attention_mask=mask,
+                                       guidance_scale=m["scale"], temperature=1.0, timesteps=4, noise_schedule=sched,
+                                       generator=torch.Generator(device=dev).manual_seed(5), image_token_num_per_image=n,
+                                       text_vocab_size=ids["text_vocab"]).cpu())
+    assert torch.equal(outs[0], outs[1])

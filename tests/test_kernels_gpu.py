@@ -42,8 +42,7 @@ def test_probe_layouts(dev):
 
 
 # ------------------------------------------------------------------ GEMM
-@pytest.fixture(params=[0, 2, 103, 105, 12], ids=["two_lds_stages", "one_lds_stage", "staggered_256x256_one_barrier", "staggered_256x256_two_barriers",
-                                                  "register_blocked_4_waves"])
+@pytest.fixture(params=[0, 2, 103, 105], ids=["two_lds_stages", "one_lds_stage", "staggered_256x256_one_barrier", "staggered_256x256_two_barriers"])
 def tile_policy(request):
     ops = _ops()
     ops.set_gemm_tile_policy(request.param)
@@ -226,16 +225,6 @@ def test_gemm_rejects_bad_args(dev):
         ops.gemm(a, a, K=68)                                # both row-major: K must be a multiple of 8
     with pytest.raises(UniGenHipError):
         ops.gemm(a, a, epilogue=ops.UG_EPI_RESID)           # residual epilogue without a residual
-
-
-def test_transpose_cast(dev):
-    ops = _ops()
-    for dt in (torch.float32, torch.bfloat16):
-        x = torch.randn(203, 130).to(dt)
-        out, outT = ops.transpose_cast(x.to(dev), want_out=True, ldT=256)
-        assert torch.equal(out.cpu(), x.to(torch.bfloat16))
-        assert torch.equal(outT[:, :203].cpu(), x.to(torch.bfloat16).t())
-        assert outT[:, 203:].abs().max().item() == 0
 
 
 # ------------------------------------------------------------------ row ops
@@ -778,28 +767,14 @@ def test_attn_decode_matches_reference(dev, R, Tmax, length):
 @pytest.mark.gpu
 @pytest.mark.parametrize("R", [16, 5, 24])
 def test_decode_fused_finishers_match_unfused_kernels(dev, R):
-    """the fused decode finishers are bit-identical to the separate kernels they replace and re-zero the accumulator"""
+    """the residual + RMSNorm finisher of the decode step is bit-identical to the separate kernels it replaces and re-zeroes
+    the accumulator"""
     ops = _ops()
     Hq, Hk, hd, H, I, Tmax, pos = 12, 2, 128, 1536, 8960, 40, 17
     g = torch.Generator().manual_seed(R)
     cos, sin = ops.rope_tables(Tmax, hd, 1e6, dev)
     pos_dev = torch.tensor([pos], dtype=torch.int32, device=dev)
-    # ---- qkv
-    nq = (Hq + 2 * Hk) * hd
-    a = torch.randn(R, nq, generator=g) * 3
-    bias = torch.randn(nq, generator=g).to(torch.bfloat16).to(dev)
-    acc = a.clone().to(dev)
-    q = torch.empty(R, Hq * hd, dtype=torch.bfloat16, device=dev)
-    ck = torch.zeros(R, Hk, Tmax, hd, dtype=torch.bfloat16, device=dev); cv = torch.zeros_like(ck)
-    ops.decode_finish_qkv_(acc, bias, cos, sin, pos_dev, q, ck, cv, R, Hq, Hk, hd, Tmax)
-    qkv = torch.empty(R, nq, dtype=torch.bfloat16, device=dev)
     lib = ops._l.load()
-    ops._l.check(lib.ug_skinny_finish(ops._p(a.to(dev).contiguous()), ops._p(bias), ops._p(qkv), None, R, nq, 0, ops._stream()), "fin")
-    ops.rope_at_(qkv, cos, sin, Hq + Hk, hd, pos_dev)
-    ck2 = torch.zeros_like(ck); cv2 = torch.zeros_like(cv)
-    ops.kv_store(qkv, ck2, cv2, R, 1, Hq, Hk, hd, Tmax, pos_dev, 0)
-    assert torch.equal(q, qkv[:, :Hq * hd]) and torch.equal(ck, ck2) and torch.equal(cv, cv2)
-    assert float(acc.abs().max()) == 0.0
     # ---- residual + rmsnorm
     a = torch.randn(R, H, generator=g)
     x0 = torch.randn(R, H, generator=g)
@@ -812,12 +787,6 @@ def test_decode_fused_finishers_match_unfused_kernels(dev, R):
     ops._l.check(lib.ug_skinny_finish(ops._p(a.to(dev).contiguous()), None, None, ops._p(x2), R, H, 1, ops._stream()), "fin")
     xn2, _ = ops.rmsnorm_fwd(x2, w, 1e-6, want_rstd=False)
     assert torch.equal(x, x2) and torch.equal(xn, xn2) and float(acc.abs().max()) == 0.0
-    # ---- swiglu
-    a = torch.randn(R, 2 * I, generator=g) * 2
-    acc = a.clone().to(dev)
-    act = torch.empty(R, I, dtype=torch.bfloat16, device=dev)
-    ops.decode_finish_swiglu_(acc, act)
-    assert torch.equal(act, ops.swiglu_fwd(a.to(torch.bfloat16).to(dev))) and float(acc.abs().max()) == 0.0
 
 
 @pytest.mark.gpu
