@@ -93,8 +93,6 @@ class UniGen(ModelMixin, ConfigMixin):
             **kwargs,
     ):
         super().__init__()
-        if scaling_factor != 1:
-            raise UniGenHipError("rope scaling is not used by any shipped config and is not implemented")
         device = kwargs.get("device", None) or torch.device("cuda", torch.cuda.current_device())
         self.vocab_size = vocab_size
         self.num_vq_tokens = num_vq_tokens
@@ -103,6 +101,8 @@ class UniGen(ModelMixin, ConfigMixin):
         llm_cfg["vocab_size"] = vocab_size          # reference: config.vocab_size = vocab_size / resize_token_embeddings
         if rope_theta is not None:
             llm_cfg["rope_theta"] = rope_theta
+        if scaling_factor != 1:                       # reference :63-64
+            llm_cfg["rope_scaling"] = {"factor": float(scaling_factor), "type": rope_type}
         dims = Qwen2Dims(**llm_cfg)
         seed = kwargs.get("init_seed", None)
         if seed is None:

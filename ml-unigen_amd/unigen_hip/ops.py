@@ -232,10 +232,30 @@ def rmsnorm_bwd(dy, x, rstd, w, dres, dw, want_bf16=False):
     return out
 
 
-def rope_tables(L, head_dim, theta, device):
+def rope_inv_freq(head_dim, theta, scaling=None, seq_len=None):
+    """inv_freq of transformers' Qwen2RotaryEmbedding (modeling_rope_utils.py ROPE_INIT_FUNCTIONS): "default";
+    "linear" (positions divided by `factor`, i.e. inv_freq / factor); "dynamic" (NTK: the base grows once seq_len exceeds
+    max_position_embeddings).  scaling = {"type" | "rope_type", "factor", "max_position_embeddings"} or None -- what the
+    reference puts into config.rope_scaling (models/unigen.py:61-64)."""
+    base = float(theta)
+    kind = (scaling or {}).get("rope_type", (scaling or {}).get("type", "default"))
+    factor = float((scaling or {}).get("factor", 1.0))
+    if kind == "dynamic":
+        max_pos = int((scaling or {}).get("max_position_embeddings", 32768))
+        sl = torch.tensor(max(int(seq_len or 0), max_pos))       # (an int64 tensor in transformers: the new base is fp32 arithmetic)
+        base = base * ((factor * sl / max_pos) - (factor - 1)) ** (head_dim / (head_dim - 2))
+    elif kind not in ("default", "linear"):
+        raise _l.UniGenHipError(f"rope_type {kind!r} is not implemented (default, linear and dynamic are)")
+    inv_freq = 1.0 / (base ** (torch.arange(0, head_dim, 2, dtype=torch.float) / head_dim))
+    if kind == "linear":
+        inv_freq = inv_freq / factor
+    return inv_freq
+
+
+def rope_tables(L, head_dim, theta, device, scaling=None):
     """cos/sin [L, head_dim/2] fp32, built with the same fp32 ops as transformers'
-    Qwen2RotaryEmbedding (modeling_qwen2.py:80-102): inv_freq = 1/theta^(2i/d); freqs = inv_freq*pos."""
-    inv_freq = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float) / head_dim))
+    Qwen2RotaryEmbedding (modeling_qwen2.py:80-102): inv_freq = 1/theta^(2i/d) (see rope_inv_freq); freqs = inv_freq*pos."""
+    inv_freq = rope_inv_freq(head_dim, theta, scaling, L)
     pos = torch.arange(L, dtype=torch.float)
     freqs = (inv_freq[None, :, None] @ pos[None, None, :]).transpose(1, 2)[0]     # [L, d/2]
     return freqs.cos().contiguous().to(device), freqs.sin().contiguous().to(device)

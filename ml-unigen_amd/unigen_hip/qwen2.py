@@ -25,7 +25,7 @@ from .lib import UniGenHipError
 class Qwen2Dims:
     def __init__(self, vocab_size, hidden_size=1536, intermediate_size=8960, num_hidden_layers=28,
                  num_attention_heads=12, num_key_value_heads=2, rope_theta=1e6, rms_norm_eps=1e-6,
-                 initializer_range=0.02, **_unused):
+                 initializer_range=0.02, rope_scaling=None, max_position_embeddings=32768, **_unused):
         self.vocab_size = int(vocab_size)
         self.hidden_size = hidden_size
         self.intermediate_size = intermediate_size
@@ -34,6 +34,9 @@ class Qwen2Dims:
         self.num_key_value_heads = num_key_value_heads
         self.head_dim = hidden_size // num_attention_heads
         self.rope_theta = float(rope_theta)
+        self.rope_scaling = None
+        if rope_scaling:
+            self.rope_scaling = dict(rope_scaling, max_position_embeddings=int(max_position_embeddings))
         self.rms_norm_eps = float(rms_norm_eps)
         self.initializer_range = initializer_range
         if self.head_dim != 128:
@@ -191,7 +194,7 @@ class Qwen2Engine:
     # ---------------------------------------------------------------- helpers
     def rope(self, L):
         if L not in self._rope_cache:
-            self._rope_cache[L] = ops.rope_tables(L, self.dims.head_dim, self.dims.rope_theta, self.device)
+            self._rope_cache[L] = ops.rope_tables(L, self.dims.head_dim, self.dims.rope_theta, self.device, self.dims.rope_scaling)
         return self._rope_cache[L]
 
     def check_errors(self):

@@ -29,7 +29,7 @@ from .ops_ref import rope_ref
 class Qwen2Cfg:
     def __init__(self, vocab_size, hidden_size=1536, intermediate_size=8960, num_hidden_layers=28,
                  num_attention_heads=12, num_key_value_heads=2, head_dim=None, rope_theta=1e6, rms_norm_eps=1e-6,
-                 initializer_range=0.02):
+                 initializer_range=0.02, rope_scaling=None, max_position_embeddings=32768):
         self.vocab_size = vocab_size
         self.hidden_size = hidden_size
         self.intermediate_size = intermediate_size
@@ -40,6 +40,8 @@ class Qwen2Cfg:
         self.rope_theta = rope_theta
         self.rms_norm_eps = rms_norm_eps
         self.initializer_range = initializer_range
+        self.rope_scaling = rope_scaling            # {"factor": f, "type": "linear" | "dynamic"} (models/unigen.py:63-64) or None
+        self.max_position_embeddings = max_position_embeddings
 
     def to_hf_dict(self):
         return dict(architectures=["Qwen2ForCausalLM"], model_type="qwen2", vocab_size=self.vocab_size,
@@ -143,7 +145,15 @@ class RefCausalLM(nn.Module):
 
     def rope(self, L, dtype, offset=0):
         c = self.cfg
-        inv_freq = 1.0 / (c.rope_theta ** (torch.arange(0, c.head_dim, 2, dtype=torch.float) / c.head_dim))
+        base, sc = c.rope_theta, (c.rope_scaling or {})
+        kind, factor = sc.get("rope_type", sc.get("type", "default")), float(sc.get("factor", 1.0))
+        if kind == "dynamic":           # modeling_rope_utils._compute_dynamic_ntk_parameters; the sequence length arrives as an
+            # int64 TENSOR (max(position_ids) + 1), so the new base is fp32 tensor arithmetic, not Python doubles
+            sl = torch.maximum(torch.tensor(offset + L), torch.tensor(c.max_position_embeddings))
+            base = base * ((factor * sl / c.max_position_embeddings) - (factor - 1)) ** (c.head_dim / (c.head_dim - 2))
+        inv_freq = 1.0 / (base ** (torch.arange(0, c.head_dim, 2, dtype=torch.float) / c.head_dim))
+        if kind == "linear":            # _compute_linear_scaling_rope_parameters
+            inv_freq = inv_freq / factor
         pos = torch.arange(offset, offset + L, dtype=torch.float)
         with torch.autocast("cpu", enabled=False):
             freqs = (inv_freq[None, :, None].float() @ pos[None, None, :].float()).transpose(1, 2)

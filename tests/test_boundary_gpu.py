@@ -8,7 +8,7 @@ import types
 import pytest
 import torch
 
-from helpers import GOLDEN, golden, llm_config_dir
+from helpers import GOLDEN, additive, fp32_yardstick, golden, llm_config_dir
 
 pytestmark = pytest.mark.gpu
 
@@ -147,3 +147,30 @@ def test_generate_matches_reference_generate(dev):
                          generator=torch.Generator(device=dev).manual_seed(1))
     assert smp.shape == (2, P + 4) and int(smp.max()) < g["cfg"]["vocab_size"]
     print(f"generate vs reference: {compared}/{2 * new} tokens compared, all equal")
+
+
+@pytest.mark.parametrize("kind", ["linear", "dynamic"])
+def test_rope_scaling_arguments_match_reference(dev, kind):
+    """UniGen(scaling_factor=2.0, rope_type=...) (reference models/unigen.py:38-40,61-64 -> config.rope_scaling) against the REAL
+    reference's outputs (golden G14; max_position_embeddings = 16 < L = 40 so 'dynamic' takes its NTK branch): the three losses
+    <= 1e-3, logits as close to the reference's fp32 logits as its own bf16 path."""
+    from models import UniGen
+    from oracle import weights
+    g, g2 = golden("g14_rope_scaling.pt"), golden("g2_tiny_unigen.pt")
+    cfg, ids = dict(g["cfg"], max_position_embeddings=g["max_position_embeddings"]), g["ids"]
+    m = UniGen(w_und_encoder=False, vocab_size=cfg["vocab_size"], llm_vocab_size=ids["text_vocab"], llm_model_path=llm_config_dir(cfg),
+               codebook_size=20, num_vq_tokens=16, load_from_pretrained=True, scaling_factor=g["factor"], rope_type=kind, device=dev,
+               init_seed=1).train()
+    names = [(n, tuple(p.shape)) for n, p in m.llm.named_parameters()]
+    m.llm.load_state_dict(weights.synth_llm_state(names, seed=g["weight_seed"]), strict=False)
+    logits, l1, l2, l3 = m(input_ids=g2["input_ids"].to(dev), attention_mask=additive(g2["mask_allow"]).to(dev), labels=g2["labels"].to(dev),
+                           **g2["kw"])
+    m.llm.engine.check_errors()
+    got = torch.stack([l1, l2, l3]).float().cpu()
+    want = g[kind]["bf16"]
+    rel = ((got - want["losses"]).abs() / want["losses"]).max().item()
+    print(f"    [rope_type={kind}] losses rel {rel:.2e} (gate 1e-3)")
+    assert rel < 1e-3
+    fp32_yardstick(f"G14 rope_type={kind}", logits.materialize().float().cpu(), want["logits"], g[kind]["fp32"]["logits"])
+    # and the unscaled model is measurably somewhere else (the arguments are not ignored)
+    assert ((logits.materialize().float().cpu() - g2["bf16"]["logits"].float()).norm() / g2["bf16"]["logits"].float().norm()).item() > 2e-2

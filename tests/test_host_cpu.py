@@ -124,3 +124,28 @@ def test_prepare_inputs_for_mmu_host_logic_matches_reference():
             w = g[f"mmu_{mode}_{tag}"]
             assert torch.equal(am, w["attention_mask"]) and torch.equal(lab, w["labels"]) and torch.equal(p1, w["part1"]), (mode, tag)
             assert e.shape[:2] == w["embeddings"].shape[:2]
+
+
+def test_masking_options_match_reference_golden():
+    """G15: data/masking.py's optional branches (reference :20-22 `eval_mask_ratios`, :33-66 `mask_contiguous_region_prob`) draw
+    from Python's `random` only, so the drop-in reproduces the REAL reference's rectangles and ratios bit for bit -- host logic,
+    no kernel involved."""
+    import math
+    import random
+    import types
+    from data.masking import mask_or_random_replace_tokens
+    g = torch.load(os.path.join(ROOT, "tests", "golden", "g15_masking_options.pt"), weights_only=False)
+
+    class Node(dict):
+        __getattr__ = dict.__getitem__
+    for c in g["cases"]:
+        cfg = types.SimpleNamespace(training=Node(min_masking_rate=0.0, eval_mask_ratios=[0.25, 0.5, 0.9], mask_contiguous_region_prob=1.0),
+                                    model=types.SimpleNamespace(codebook_size=8192))
+        random.seed(c["seed"])
+        ids, labels, lw, mp = mask_or_random_replace_tokens(c["tokens"], 159866, cfg, lambda t: torch.cos(t * math.pi * 0.5), is_train=False)
+        assert lw is None and torch.equal(ids, c["input_ids"]) and torch.equal(labels, c["labels"]) and torch.equal(mp, c["mask_prob"])
+        res = int(c["n"] ** 0.5)
+        m = (labels != -100).view(-1, res, res)
+        for b in range(m.shape[0]):                       # every mask is one filled rectangle
+            rows, cols = m[b].any(1).nonzero().flatten(), m[b].any(0).nonzero().flatten()
+            assert int(m[b].sum()) == len(rows) * len(cols) and rows[-1] - rows[0] + 1 == len(rows) and cols[-1] - cols[0] + 1 == len(cols)

@@ -61,3 +61,31 @@ def test_masking_module_is_a_drop_in(dev):
     w_ids, w_lab, w_mp = host_ref.maskgit_train_mask_ref(toks.cpu(), 159866, ts.cpu(), sc.cpu(), cosine)
     assert lw is None and torch.equal(ids.cpu(), w_ids) and torch.equal(labels.cpu(), w_lab)
     assert torch.allclose(mp.cpu(), w_mp, atol=1e-6)
+
+
+def test_masking_options_on_the_device(dev):
+    """The optional branches with device tensors: `eval_mask_ratios` through the masking kernel (exactly round(n * ratio) masked
+    positions per row, ratios from the configured list), and the training-time contiguous-region branch (one filled rectangle per
+    image covering at least the requested number of positions); golden G15 pins both against the real reference on the host."""
+    import random
+    from data.masking import mask_or_random_replace_tokens
+
+    class Node(dict):
+        __getattr__ = dict.__getitem__
+    toks = torch.randint(151674, 151674 + 8192, (12, 256), device=dev)
+    cfg = types.SimpleNamespace(training=Node(min_masking_rate=0.0, eval_mask_ratios=[0.25, 0.5, 0.9]), model=types.SimpleNamespace(codebook_size=8192))
+    random.seed(3)
+    ids, labels, lw, mp = mask_or_random_replace_tokens(toks, 159866, cfg, cosine, is_train=False)
+    assert lw is None and set(round(float(v), 2) for v in mp.cpu()) <= {0.25, 0.5, 0.9}
+    assert torch.equal((labels != -100).sum(1).cpu(), (256 * mp).round().long().cpu())
+    assert torch.equal(torch.where(labels != -100, labels, ids).cpu(), toks.cpu()) and bool(((ids == 159866) == (labels != -100)).all())
+    cfg = types.SimpleNamespace(training=Node(min_masking_rate=0.0, mask_contiguous_region_prob=1.0), model=types.SimpleNamespace(codebook_size=8192))
+    random.seed(4)
+    torch.manual_seed(4)
+    ids, labels, lw, mp = mask_or_random_replace_tokens(toks, 159866, cfg, cosine)
+    m = (labels != -100).view(12, 16, 16).cpu()
+    want = (256 * mp).round().clamp(min=1).cpu()
+    for b in range(12):
+        rows, cols = m[b].any(1).nonzero().flatten(), m[b].any(0).nonzero().flatten()
+        assert int(m[b].sum()) == len(rows) * len(cols) >= min(int(want[b]), 256) - 16
+    assert bool(((ids == 159866) == (labels != -100)).all())

@@ -169,3 +169,24 @@ def test_ar_generation_gen_head_oracle_matches_reference():
             want = g[f"dim{int(use_dim)}"][mode]
             assert torch.equal(tok.long(), want["tokens"]) and torch.allclose(margin, want["margin"])
             assert len(set(tok[0].tolist())) > 4 and int(tok.max()) < g["codebook"]
+
+
+def test_rope_scaling_oracle_matches_reference():
+    """G14: the oracle's rope with config.rope_scaling = {"factor": 2.0, "type": "linear" | "dynamic"} (reference
+    models/unigen.py:38-40,61-64; max_position_embeddings = 16 < L so the dynamic-NTK base applies) reproduces the real
+    reference's logits and losses bit for bit, fp32 and bf16 autocast."""
+    from oracle import host_ref, qwen2_ref, weights
+    g, g2 = golden("g14_rope_scaling.pt"), golden("g2_tiny_unigen.pt")
+    mask = host_ref.to_additive(g2["mask_allow"]).float()
+    kw = {k: v for k, v in g2["kw"].items() if k != "max_seq_length"}
+    for kind in ("linear", "dynamic"):
+        lm = qwen2_ref.RefCausalLM(qwen2_ref.Qwen2Cfg(**g["cfg"], rope_scaling={"factor": g["factor"], "type": kind},
+                                                      max_position_embeddings=g["max_position_embeddings"]))
+        names = [(n, tuple(p.shape)) for n, p in lm.named_parameters()]
+        lm.load_state_dict(weights.synth_llm_state(names, seed=g["weight_seed"]), strict=False)
+        for mode, ac in (("fp32", False), ("bf16", True)):
+            with torch.no_grad():
+                lo, r1, r2, r3 = qwen2_ref.unigen_forward_ref(lm, g2["input_ids"], mask, g2["labels"], autocast=ac, **kw)
+            assert torch.equal(lo, g[kind][mode]["logits"].float())
+            assert torch.equal(torch.stack([r1, r2, r3]).float(), g[kind][mode]["losses"])
+        assert not torch.equal(g[kind]["fp32"]["logits"], g2["fp32"]["logits"])

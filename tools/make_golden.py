@@ -752,3 +752,97 @@ def golden_ar_gen_head():
 
 if __name__ == "__main__" and "ar_gen_head" in sys.argv[1:]:
     golden_ar_gen_head()
+
+
+# ------------------------------------------------------------------ G14: RoPE scaling arguments (models/unigen.py:38-40,61-64)
+def golden_rope_scaling():
+    """The real reference UniGen built with scaling_factor = 2.0 and rope_type 'linear' / 'dynamic' (config.rope_scaling =
+    {"factor", "type"}; the tiny config says max_position_embeddings = 16 so that the 40-token batch of G2 is past it and the
+    dynamic-NTK base applies): logits and the three losses under bf16 autocast and in fp32; the oracle must be bit-identical."""
+    from models import UniGen
+    import transformers
+    # Third-party API shim (the reference pins transformers 4.51.0, this container has 5.x): in 4.51 `config.rope_scaling =
+    # {"factor", "type"}` (models/unigen.py:64) sits NEXT to config.rope_theta; in 5.x `rope_scaling` aliases the whole
+    # `rope_parameters` dict, so the same assignment drops rope_theta / rope_type and Qwen2RotaryEmbedding raises.  The shim
+    # turns the legacy assignment into the 5.x form of the same request; the rotary arithmetic itself is transformers'.
+    cfg_cls = transformers.Qwen2Config
+    orig_setattr = cfg_cls.__setattr__
+
+    def legacy_rope_scaling(self, key, value):
+        if key == "rope_scaling" and isinstance(value, dict) and "type" in value and "rope_type" not in value:
+            theta = (self.__dict__.get("rope_parameters") or {}).get("rope_theta", 10000.0)
+            value = {"rope_type": value["type"], "factor": value["factor"], "rope_theta": theta}
+            key = "rope_parameters"
+        orig_setattr(self, key, value)
+    cfg_cls.__setattr__ = legacy_rope_scaling
+    g2 = torch.load(os.path.join(OUT, "g2_tiny_unigen.pt"), weights_only=False)
+    cfgd, ids = dict(g2["cfg"]), g2["ids"]
+    V, TV = cfgd["vocab_size"], ids["text_vocab"]
+    mask = host_ref.to_additive(g2["mask_allow"]).float()
+    kw = {k: v for k, v in g2["kw"].items() if k != "max_seq_length"}
+    out = {"cfg": cfgd, "weight_seed": g2["weight_seed"], "ids": ids, "factor": 2.0, "max_position_embeddings": 16}
+    for kind in ("linear", "dynamic"):
+        hf = qwen2_ref.Qwen2Cfg(**cfgd).to_hf_dict()
+        hf["max_position_embeddings"] = 16
+        d = ref_shims.write_llm_config_dir(hf)
+        torch.manual_seed(0)
+        model = UniGen(w_und_encoder=False, vocab_size=V, llm_vocab_size=TV, llm_model_path=d, codebook_size=20, num_vq_tokens=16,
+                       load_from_pretrained=True, scaling_factor=2.0, rope_type=kind).eval()
+        names = [(n, tuple(p.shape)) for n, p in model.llm.named_parameters()]
+        sd = weights.synth_llm_state(names, seed=g2["weight_seed"])
+        model.llm.load_state_dict(sd, strict=False)
+        lm = qwen2_ref.RefCausalLM(qwen2_ref.Qwen2Cfg(**cfgd, rope_scaling={"factor": 2.0, "type": kind}, max_position_embeddings=16))
+        lm.load_state_dict(sd, strict=False)
+        rec = {}
+        for mode, ac in (("fp32", False), ("bf16", True)):
+            ctx = torch.autocast("cpu", dtype=torch.bfloat16) if ac else torch.autocast("cpu", enabled=False)
+            with torch.no_grad(), ctx:
+                logits, l1, l2, l3 = model(input_ids=g2["input_ids"], attention_mask=mask, labels=g2["labels"], **g2["kw"])
+            with torch.no_grad():
+                lo, r1, r2, r3 = qwen2_ref.unigen_forward_ref(lm, g2["input_ids"], mask, g2["labels"], autocast=ac, **kw)
+            dl = maxdiff(lo, logits.float())
+            print(f"G14 rope_type={kind} [{mode}] oracle vs reference: logits {dl:.3e} losses {abs(float(l1) - float(r1)):.1e}")
+            assert dl == 0, "oracle rope scaling is not bit-identical to the reference"
+            rec[mode] = {"logits": logits.detach().to(torch.bfloat16 if ac else torch.float32),
+                         "losses": torch.stack([l1.float(), l2.float(), l3.float()]).detach()}
+        # the scaling must change something: compare with the unscaled G2 logits
+        assert maxdiff(rec["fp32"]["logits"], g2["fp32"]["logits"]) > 1e-3
+        out[kind] = rec
+    cfg_cls.__setattr__ = orig_setattr
+    torch.save(out, os.path.join(OUT, "g14_rope_scaling.pt"))
+    print("G14 rope scaling: captured (oracle == reference)")
+
+
+if __name__ == "__main__" and "rope_scaling" in sys.argv[1:]:
+    golden_rope_scaling()
+
+
+# ------------------------------------------------------------------ G15: optional branches of data/masking.py (:20-22, :33-66)
+def golden_masking_options():
+    """The real reference's mask_or_random_replace_tokens at evaluation time with `eval_mask_ratios` and
+    `mask_contiguous_region_prob = 1`: every draw comes from Python's `random` (ratios, rectangle bounds), none from torch, so a
+    seeded call is reproducible on any device."""
+    import random
+    from data.masking import mask_or_random_replace_tokens as ref_mask
+    out = {"cases": []}
+    for n, B, seed in ((256, 6, 7), (16, 4, 11), (1024, 3, 5)):
+        cfg = types.SimpleNamespace(training=_Cfg(min_masking_rate=0.0, eval_mask_ratios=[0.25, 0.5, 0.9], mask_contiguous_region_prob=1.0),
+                                    model=types.SimpleNamespace(codebook_size=8192))
+        g = torch.Generator().manual_seed(seed)
+        toks = torch.randint(151674, 151674 + 8192, (B, n), generator=g)
+        random.seed(seed)
+        ids, labels, lw, mp = ref_mask(toks, 159866, cfg, lambda t: torch.cos(t * 3.141592653589793 * 0.5), is_train=False)
+        assert lw is None
+        out["cases"].append({"n": n, "B": B, "seed": seed, "tokens": toks, "input_ids": ids, "labels": labels, "mask_prob": mp})
+        print(f"G15 n={n}: masked per row {[int(v) for v in (labels != -100).sum(1)]} ratios {mp.tolist()}")
+    torch.save(out, os.path.join(OUT, "g15_masking_options.pt"))
+    print("G15 masking options: captured")
+
+
+class _Cfg(dict):
+    """OmegaConf-like node: attribute access + .get (what data/masking.py touches)"""
+    __getattr__ = dict.__getitem__
+
+
+if __name__ == "__main__" and "masking_options" in sys.argv[1:]:
+    golden_masking_options()
