@@ -184,14 +184,26 @@ class MAGVITv2(ModelMixin, ConfigMixin):
         LDS-resident-patch kernel, which applies the normalisation on its load path."""
         p = self._pk(conv, pad_cin_to)
         if p.ws is not None and p.k == 3 and not upsample and not asym:
-            gn = None
+            gn, bound = None, None
             if norm is not None:
                 gn = (ops.groupnorm_stats(x, groups=32, eps=norm.eps), norm.weight.detach(), norm.bias.detach(), 32, swish)
-            return ops.conv3x3_nhwc(x, p.ws, p.cpad, p.bias, p.cout, residual=residual, gn=gn)
+                bound = self._gn_bound(norm, (x.shape[3] // 32) * x.shape[1] * x.shape[2])
+            return ops.conv3x3_nhwc(x, p.ws, p.cpad, p.bias, p.cout, residual=residual, gn=gn, gn_bound=bound)
         if norm is not None:
             x = self._norm(x, norm, swish)
         return ops.conv2d_nhwc(x, p.w, p.cpad, p.bias, p.cout, p.k, stride=2 if asym else 1, asym_pad=asym,
                                upsample=upsample, residual=residual, w_split=p.ws)
+
+    def _gn_bound(self, norm, group_elems):
+        """scale bound of swish?(norm(x)) for the split convolution that applies `norm` on its load path, from the layer's own
+        gamma / beta (two device reads per weight version, cached like the packed conv weights)"""
+        key = ("gn", id(norm))
+        ver = (norm.weight._version, norm.bias._version)
+        hit = self._packed.get(key)
+        if hit is None or hit[0] != ver:
+            hit = (ver, float(norm.weight.detach().abs().max()), float(norm.bias.detach().abs().max()))
+            self._packed[key] = hit
+        return ops.gn_out_bound(hit[1], hit[2], group_elems)
 
     @staticmethod
     def _norm(x, gn, swish=True):

@@ -746,19 +746,28 @@ def groupnorm_stats(x, *, groups=32, eps=1e-6):
     return mr
 
 
-GN_OUT_BOUND = 256.0      # |gamma * xhat + beta| stays below 2 x this for any |xhat| <= 500 with |gamma| <= 1, |beta| <= 12
+def gn_out_bound(gamma_absmax, beta_absmax, group_elems):
+    """Upper bound of |gamma * xhat + beta| for a GroupNorm output, from the layer's ACTUAL affine parameters: a normalised
+    group of n elements cannot exceed sqrt(n - 1) in magnitude (one outlier carrying all of the variance), swish only shrinks
+    magnitudes.  Rounded up to a power of two (only the binade matters to the split convolutions, and few distinct device
+    constants are cached).  The caller computes it once per weight version (models/multimodal_encoder/magvitv2.py)."""
+    b = float(gamma_absmax) * math.sqrt(max(float(group_elems) - 1.0, 1.0)) + float(beta_absmax)
+    return 2.0 ** math.ceil(math.log2(max(b, 1e-30)))
 
 
-def conv3x3_nhwc(x, w_split, cout_pad, bias, cout, *, residual=None, gn=None, x_amax=None):
+def conv3x3_nhwc(x, w_split, cout_pad, bias, cout, *, residual=None, gn=None, x_amax=None, gn_bound=None):
     """3x3 / stride 1 / pad 1 convolution of NHWC fp32 x with split weights (`split_conv_weight`), input patch resident
-    in LDS.  gn = (mu_rstd, gamma, beta, groups, swish): apply swish?(GroupNorm(x)) on the load path; the scale bound of
-    the normalised tensor is then a constant (a unit-variance group cannot exceed sqrt(group size) <= 512; values past the
-    bound's binade saturate at 1023 instead of overflowing).  Without gn the bound is measured unless `x_amax` is given."""
+    in LDS.  gn = (mu_rstd, gamma, beta, groups, swish): apply swish?(GroupNorm(x)) on the load path; the scale bound of the
+    normalised tensor, `gn_bound`, is then known without a pass over it: `gn_out_bound` of the layer's gamma / beta (required
+    with gn -- a fixed constant would silently saturate activations of a checkpoint with larger affine parameters).  Without
+    gn the bound is measured unless `x_amax` is given."""
     B, H, W, Cin = x.shape
     y = torch.empty((B, H, W, cout), dtype=torch.float32, device=x.device)
     mr, ga, be, groups, swish = gn if gn is not None else (None, None, None, 0, 0)
     if x_amax is None:
-        x_amax = amax_const(GN_OUT_BOUND, x.device) if gn is not None else amax(x.view(-1, Cin))
+        if gn is not None and gn_bound is None:
+            raise _l.UniGenHipError("conv3x3_nhwc: GroupNorm on the load path needs gn_bound (ops.gn_out_bound of the layer's gamma / beta)")
+        x_amax = amax_const(gn_bound, x.device) if gn is not None else amax(x.view(-1, Cin))
     _l.check(_l.load().ug_conv3x3_split(_p(x), _p(x_amax), _p(w_split), _p(bias), _p(residual), _p(y), B, H, W, Cin, cout,
                                         cout_pad, _p(mr), _p(ga), _p(be), groups, int(swish), _stream()), "ug_conv3x3_split")
     return y

@@ -173,4 +173,8 @@ def test_rope_scaling_arguments_match_reference(dev, kind):
     assert rel < 1e-3
     fp32_yardstick(f"G14 rope_type={kind}", logits.materialize().float().cpu(), want["logits"], g[kind]["fp32"]["logits"])
     # and the unscaled model is measurably somewhere else (the arguments are not ignored)
-    assert ((logits.materialize().float().cpu() - g2["bf16"]["logits"].float()).norm() / g2["bf16"]["logits"].float().norm()).item() > 2e-2
+    dense = logits.materialize().float().cpu()
+    d_scaled = ((dense - want["logits"].float()).norm() / want["logits"].float().norm()).item()
+    d_plain = ((dense - g2["bf16"]["logits"].float()).norm() / g2["bf16"]["logits"].float().norm()).item()
+    print(f"    [rope_type={kind}] distance to the scaled reference {d_scaled:.2e}, to the unscaled one {d_plain:.2e}")
+    assert d_scaled < 0.7 * d_plain

@@ -549,13 +549,44 @@ def test_conv3x3_patch_matches_fp64(dev, cin, cout, H, W, gn):
     x_nhwc = x.permute(0, 2, 3, 1).contiguous().to(dev)
     res_d = res.permute(0, 2, 3, 1).contiguous().to(dev)
     fused_gn = (ops.groupnorm_stats(x_nhwc), g.to(dev), be.to(dev), 32, True) if gn else None
-    got = ops.conv3x3_nhwc(x_nhwc, ws, cpad, bias.to(dev), cout, residual=res_d, gn=fused_gn)
+    # scale bound of the normalised tensor from the layer's actual gamma / beta (here N(0,1) draws: |gamma| up to ~3.5)
+    bound = ops.gn_out_bound(g.abs().max().item(), be.abs().max().item(), (cin // 32) * H * W) if gn else None
+    got = ops.conv3x3_nhwc(x_nhwc, ws, cpad, bias.to(dev), cout, residual=res_d, gn=fused_gn, gn_bound=bound)
     xn = ops.groupnorm_swish(x_nhwc, g.to(dev), be.to(dev), swish=True) if gn else x_nhwc
     unfused = ops.conv2d_nhwc(xn, wp, cpad, bias.to(dev), cout, 3, residual=res_d, w_split=ws)
     got64 = got.permute(0, 3, 1, 2).cpu().double()
     assert got64.shape == ref.shape
     assert (got64 - ref).abs().max().item() < 3e-5
     assert _maxabs(got, unfused) < 3e-5
+
+
+def test_conv3x3_groupnorm_on_load_with_large_affine_parameters(dev):
+    """the GroupNorm-on-load convolution took a FIXED bound (|gamma| <= 1, |beta| <= 12) for the scale of the
+    normalised tensor, so a checkpoint with larger affine parameters would have saturated silently.  The bound now comes
+    from the layer's own gamma / beta (ops.gn_out_bound): gamma ~ 60 N(0,1), beta ~ 30 N(0,1) stays fp32-accurate."""
+    ops = _ops()
+    gen = torch.Generator().manual_seed(9)
+    cin, cout, H, W, B = 128, 128, 32, 32, 2
+    x = torch.randn(B, cin, H, W, generator=gen) * 2.0 + 0.3
+    x[0, 5, 3, 4] = 400.0                                  # an outlier: its normalised value is far beyond the bulk
+    w = torch.randn(cout, cin, 3, 3, generator=gen) / math.sqrt(cin * 9)
+    bias = torch.randn(cout, generator=gen)
+    g, be = 60.0 * torch.randn(cin, generator=gen), 30.0 * torch.randn(cin, generator=gen)
+    xin = F.group_norm(x.double(), 32, g.double(), be.double(), eps=1e-6)
+    xin = xin * torch.sigmoid(xin)
+    ref = F.conv2d(xin, w.double(), bias.double(), padding=1)
+    wp, cpad = ops.pack_conv_weight(w.to(dev))
+    ws = ops.split_conv_weight(wp)
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    bound = ops.gn_out_bound(g.abs().max().item(), be.abs().max().item(), (cin // 32) * H * W)
+    assert bound >= xin.abs().max().item()
+    got = ops.conv3x3_nhwc(x_nhwc, ws, cpad, bias.to(dev), cout, gn=(ops.groupnorm_stats(x_nhwc), g.to(dev), be.to(dev), 32, True),
+                           gn_bound=bound)
+    err = (got.permute(0, 3, 1, 2).cpu().double() - ref).abs().max().item()
+    print(f"    large-affine GroupNorm on load: max err vs fp64 {err:.2e} at max|ref| {ref.abs().max().item():.1f}, bound {bound:.0f}")
+    assert err < 3e-5 * max(1.0, ref.abs().max().item())
+    with pytest.raises(Exception):
+        ops.conv3x3_nhwc(x_nhwc, ws, cpad, bias.to(dev), cout, gn=(ops.groupnorm_stats(x_nhwc), g.to(dev), be.to(dev), 32, True))
 
 
 @pytest.mark.parametrize("M,N,K,act", [(300, 1152, 1152, 0), (257, 4304, 1152, 1), (129, 1152, 4304, 0), (64, 68, 36, 1)])
@@ -620,7 +651,8 @@ def test_conv_split_randomised_shapes(dev):
         tol = 2e-5 * max(1.0, ref.abs().max().item())
         assert got.shape == ref.shape and _maxabs(got, ref) < tol, (case, cin, cout, k, H, W, mode, _maxabs(got, ref))
         if k == 3 and mode == "plain":
-            got3 = ops.conv3x3_nhwc(x, ws, cpad, bias, cout, residual=res, gn=gn)
+            bound = ops.gn_out_bound(ga.abs().max().item(), be.abs().max().item(), (cin // 32) * H * W) if use_gn else None
+            got3 = ops.conv3x3_nhwc(x, ws, cpad, bias, cout, residual=res, gn=gn, gn_bound=bound)
             assert _maxabs(got3, ref) < tol, (case, cin, cout, H, W, use_gn, _maxabs(got3, ref))
 
 
