@@ -386,6 +386,22 @@ int ug_linear_f32(const float* x, int64_t ldx, const float* W, int64_t ldw, cons
 /* replaces: nn.LayerNorm(eps 1e-6) (siglip_encoder.py:267-269) */
 int ug_layernorm_f32(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int64_t cols,
                      float eps, hipStream_t stream);
+/* Backward pieces of the tower for the UNFROZEN case (reference models/unigen.py:111 freeze=False; training/train_w_clip_vit.py:
+ * 282,311-312).  The contractions of the backward run on ug_gemm_f32 / ug_gemm_f32_nested (exact fp32); these are the row-wise /
+ * element-wise derivatives:
+ *   ug_layernorm_bwd_f32      dx = [dres_in +] LayerNorm'(dy) (statistics recomputed from x); dgamma, dbeta ACCUMULATE
+ *   ug_gelu_tanh_f32          dy_or_null == null: out = gelu_pytorch_tanh(pre); else out = dy * gelu'(pre)
+ *   ug_softmax_bwd_rows_f32   in place on dP: dS = scale * P * (dP - sum_j dP_j P_j), padding columns [cols, ld) zeroed
+ *   ug_colsum_f32             out[c] += sum_r x[r, c]   (bias / position-embedding gradients) */
+int ug_layernorm_bwd_f32(const float* dy, const float* x, const float* gamma, const float* dres_in, float* dx, float* dgamma,
+                         float* dbeta, int64_t rows, int64_t cols, float eps, hipStream_t stream);
+int ug_gelu_tanh_f32(const float* pre, const float* dy_or_null, float* out, int64_t n, hipStream_t stream);
+int ug_softmax_bwd_rows_f32(const float* P, float* dP, int64_t rows, int64_t cols, int64_t ld, float scale, hipStream_t stream);
+int ug_colsum_f32(const float* x, int64_t ld, float* out, int64_t rows, int64_t cols, hipStream_t stream);
+/* out[z][c][r] = in[z][r][c] for z < batch (operands z * stride apart); output rows ld_out >= rows long, their tail zero-filled:
+ * the transposed activations / probabilities are the row-major A operand of the weight-gradient and dK / dV contractions */
+int ug_transpose_f32(const float* in, int64_t ld_in, int64_t stride_in, float* out, int64_t ld_out, int64_t stride_out,
+                     int64_t rows, int64_t cols, int64_t batch, hipStream_t stream);
 int ug_nchw_to_nhwc(const float* in, float* out, int64_t B, int C, int64_t HW, int c_pad, hipStream_t stream);
 int ug_nhwc_to_nchw(const float* in, float* out, int64_t B, int C, int64_t HW, int c_pad, hipStream_t stream);
 /* replaces: LFQuantizer.get_indices / get_codebook_entry, magvitv2.py:210-230 */

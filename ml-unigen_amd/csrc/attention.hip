@@ -220,6 +220,28 @@ struct AttnArgs {
   float scale;
 };
 
+// Workgroup -> (tile, head, batch).  Consecutive workgroup ids of a launch go round-robin over the 8 XCDs, each with a private
+// 4 MB L2; with a (tile, head, batch) grid every XCD meets every (batch, kv head) and re-fetches ALL K / V rows (12.6 MB at
+// 16 x 771 tokens) through its own L2 -- 387 MB of L2 fills per forward launch for 12.6 MB of distinct data.  Here every
+// workgroup that reads the K / V rows of one (batch, kv head) pair -- its G query heads x nT tiles -- runs on ONE XCD (4 pairs
+// of 395 KB per XCD at the training shape).  1-D grid of 8 * ceil(pairs / 8) * nT * G workgroups; surplus ones exit.
+struct WgCoord { int tile, h, b; bool ok; };
+__device__ __forceinline__ WgCoord wg_coord(int wid, int nT, int H, int HKV, int B) {
+  const int G = H / HKV, per_pair = nT * G, P = B * HKV;
+  const int xcd = wid & 7, idx = wid >> 3;
+  const int pair = (idx / per_pair) * 8 + xcd, rem = idx % per_pair;
+  WgCoord c;
+  c.ok = pair < P;
+  c.b = pair / HKV;
+  c.h = (pair % HKV) * G + rem / nT;
+  c.tile = rem % nT;
+  return c;
+}
+static inline unsigned wg_grid(int64_t nT, int H, int HKV, int64_t B) {
+  const int64_t P = B * HKV;
+  return (unsigned)(8 * ((P + 7) / 8) * nT * (H / HKV));
+}
+
 // ================================================================== forward
 // grid (ceil(L / (16 NW)), H, B).  NW = 4: one 64-row query tile per workgroup; NW = 8: two (128 rows) sharing every staged
 // K / V tile -- half the staging traffic and barriers per query row, same LDS, same registers per wave.  A wave whose own
@@ -229,7 +251,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void attn_fwd_kernel(Attn
   __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * RM_LD];
   __shared__ __attribute__((aligned(16))) bf16_t Vs[64 * RM_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
-  const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const WgCoord wc = wg_coord((int)blockIdx.x, (p.L + 16 * NW - 1) / (16 * NW), p.H, p.HKV, p.B);
+  if (!wc.ok) return;
+  const int qt = wc.tile, h = wc.h, b = wc.b;
   const int hk = h / (p.H / p.HKV);
   const int qrow = qt * (16 * NW) + wave * 16 + (lane & 15);   // this lane's query (column of S^T)
   const int qrow_c = min(qrow, p.L - 1);
@@ -319,7 +343,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
   __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * RM_LD];
   __shared__ __attribute__((aligned(16))) bf16_t Vs[64 * RM_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
-  const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+  const WgCoord wc = wg_coord((int)blockIdx.x, p.nW, p.H, p.HKV, p.B);
+  if (!wc.ok) return;
+  const int qt = wc.tile, h = wc.h, b = wc.b;
   const int hk = h / (p.H / p.HKV);
   const int qrow = qt * 64 + wave * 16 + (lane & 15);
   const int qrow_c = min(qrow, p.L - 1);
@@ -412,9 +438,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
   __shared__ __attribute__((aligned(16))) float lse_s[64], dl_s[64];
   __shared__ uint64_t word_s[64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
-  const int t = blockIdx.x, b = blockIdx.z;
   const int grp = p.H / p.HKV;
-  const int hk = SPLIT ? blockIdx.y / grp : blockIdx.y;
+  const WgCoord wc = wg_coord((int)blockIdx.x, p.nW, SPLIT ? p.H : p.HKV, p.HKV, p.B);       // (not SPLIT: one workgroup per kv head)
+  if (!wc.ok) return;
+  const int t = wc.tile, b = wc.b;
+  const int hk = SPLIT ? wc.h / grp : wc.h;
   const int krow = t * 64 + wave * 16 + (lane & 15);
   const int krow_c = min(krow, p.L - 1);
   const bf16_t* kseq = p.k + (int64_t)b * p.L * p.ldq + hk * HD;
@@ -430,7 +458,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
   for (int d = 0; d < 8; ++d) { dkt[d] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dvt[d] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
   const int kbit = wave * 16 + (lane & 15);
 
-  for (int hh = SPLIT ? blockIdx.y % grp : 0; hh < (SPLIT ? blockIdx.y % grp + 1 : grp); ++hh) {
+  for (int hh = SPLIT ? wc.h % grp : 0; hh < (SPLIT ? wc.h % grp + 1 : grp); ++hh) {
     const int h = hk * grp + hh;
     const bf16_t* qseq = p.q + (int64_t)b * p.L * p.ldq + h * HD;
     const bf16_t* doseq = p.dout + (int64_t)b * p.L * p.ldo + h * HD;
@@ -613,9 +641,9 @@ extern "C" int ug_attn_fwd(const void* q, const void* k, const void* v, int64_t 
   a.H = H; a.HKV = HKV; a.scale = scale;
   // 128-row query tiles (eight waves share each staged K / V tile) once there are enough of them to fill the chip
   if (L >= 256 && (int64_t)((L + 127) / 128) * H * B >= 512)
-    hipLaunchKernelGGL(attn_fwd_kernel<8>, dim3((unsigned)((L + 127) / 128), H, (unsigned)B), dim3(512), 0, st, a);
+    hipLaunchKernelGGL(attn_fwd_kernel<8>, dim3(wg_grid((L + 127) / 128, H, HKV, B)), dim3(512), 0, st, a);
   else
-    hipLaunchKernelGGL(attn_fwd_kernel<4>, dim3(a.nW, H, (unsigned)B), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(attn_fwd_kernel<4>, dim3(wg_grid(a.nW, H, HKV, B)), dim3(256), 0, st, a);
   UG_CHECK_LAUNCH("ug_attn_fwd");
   return UG_OK;
 }
@@ -637,17 +665,17 @@ extern "C" int ug_attn_bwd(const void* q, const void* k, const void* v, int64_t 
   a.bits = bits; a.tileany = tileany;
   a.ldq = ldq; a.ldo = ldo; a.ldg = ldg; a.B = (int)B; a.L = (int)L; a.Lp = (int)Lp; a.nW = (int)((L + 63) / 64);
   a.H = H; a.HKV = HKV; a.scale = scale;
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(a.nW, H, (unsigned)B), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(wg_grid(a.nW, H, HKV, B)), dim3(256), 0, st, a);
   UG_CHECK_LAUNCH("ug_attn_bwd(dq)");
   if (dkv_ws) {
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, dim3(a.nW, H, (unsigned)B), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, dim3(wg_grid(a.nW, H, HKV, B)), dim3(256), 0, st, a);
     UG_CHECK_LAUNCH("ug_attn_bwd(dkv split)");
     const int64_t total = B * L * (2 * HKV * HD / 4);
     int64_t gsz = (total + 255) / 256; if (gsz > 4096) gsz = 4096;
     hipLaunchKernelGGL(dkv_finish_kernel, dim3((unsigned)gsz), dim3(256), 0, st, dkv_ws, a.dk, a.dv, ldg, B * L, HKV * HD);
     UG_CHECK_LAUNCH("ug_attn_bwd(dkv finish)");
   } else {
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, dim3(a.nW, HKV, (unsigned)B), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, dim3(wg_grid(a.nW, HKV, HKV, B)), dim3(256), 0, st, a);
     UG_CHECK_LAUNCH("ug_attn_bwd(dkv)");
   }
   return UG_OK;

@@ -8,8 +8,9 @@ last one, :573) of pre-LayerNorm(eps 1e-6) attention (16 heads x 72, fp32 softma
 tanh-GELU MLP (:247-259); the pooling head is replaced by Identity and `forward` returns
 `hidden_states[-1]`, i.e. the output of the last kept layer BEFORE `post_layernorm` (:579-590).
 The tower is frozen fp32 in every shipped config (it runs outside autocast), so everything here is
-fp32 on the f32 matrix cores: linears via `ug_linear_f32` (bias / GELU / residual in the epilogue),
-attention as two batched fp32 GEMMs around a row softmax, LayerNorm one wave per row.  torch modules
+fp32: linears on the fp32-accurate split-f16 contraction (`ug_linear_split`; `ug_linear_f32` with UNIGEN_CONV_FP32_MFMA=1),
+one flash-style fp32 attention kernel, LayerNorm one wave per row.  An UNFROZEN tower (reference models/unigen.py:111
+`freeze=False`) trains through a hand-written fp32 backward (`_TowerFn` / `_backward`, csrc/siglip_bwd.hip).  torch modules
 only HOLD the parameters under the reference checkpoint's names
 (`vision_tower.vision_model.encoder.layers.N.self_attn.q_proj.weight`, ...).
 """
@@ -114,6 +115,24 @@ class SigLipVisionModel(nn.Module):
         self.vision_model = vm
 
 
+class _TowerFn(torch.autograd.Function):
+    """SigLipVisionTower.forward for a tower with trainable parameters: forward = `_encode` keeping per-layer activations,
+    backward = `_backward` (hand-written, fp32).  The parameters are inputs so that autograd routes their gradients."""
+
+    @staticmethod
+    def forward(ctx, tower, images, *params):
+        saved = []
+        out = tower._encode(images, save=saved)
+        ctx.tower, ctx.images, ctx.saved, ctx.params = tower, images, saved, params
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        grads = ctx.tower._backward(ctx.images, ctx.saved, dout.contiguous())
+        ctx.saved = None
+        return (None, None) + tuple(grads[p].to(p.dtype) if p in grads else None for p in ctx.params)
+
+
 class SigLipVisionTower(nn.Module):
     def __init__(self, vision_tower, vision_tower_cfg=None, freeze=True, delay_load=False, config=None):
         super().__init__()
@@ -178,7 +197,9 @@ class SigLipVisionTower(nn.Module):
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
-    def _encode(self, images):
+    def _encode(self, images, save=None):
+        """save: a list that receives, per encoder layer, the tensors the backward of an UNFROZEN tower needs (layer input, q|k|v,
+        attention context, post-attention residual stream, fc1 pre-activation); None = inference (nothing is kept)."""
         c = self.config
         vm = self.vision_tower.vision_model
         pk = self._pack()
@@ -192,6 +213,7 @@ class SigLipVisionTower(nn.Module):
         pos_b = pos.unsqueeze(0).expand(B, T, D).contiguous().view(B, g, g, D)
         h = ops.conv2d_nhwc(x, pk["patch_w"], pk["patch_cpad"], pk["patch_b"], D, c.patch_size, stride=c.patch_size, pad=0,
                             residual=pos_b).view(B * T, D)
+        train = save is not None
         ldS = ops.round_up(T, 4)
         scale = float(hd) ** -0.5
         # q|k|v of every token, reused by all layers.  Four slack rows that stay zero: the P.V contraction runs over
@@ -200,6 +222,10 @@ class SigLipVisionTower(nn.Module):
         qkv[B * T:].zero_()
         Tp = ops.round_up(T, 4)
         for li, l in enumerate(vm.encoder.layers):
+            if train and li > 0:                      # every layer keeps its own q|k|v when a backward follows
+                qkv = torch.empty((B * T + 4, 3 * D), dtype=torch.float32, device=h.device)
+                qkv[B * T:].zero_()
+            h_in = h
             xn = ops.layernorm_f32(h, l.layer_norm1.weight.detach(), l.layer_norm1.bias.detach(), c.layer_norm_eps)
             wq, bq = pk["qkv"][li]
             sp = pk["split"][li] if pk["split"] else None
@@ -225,20 +251,133 @@ class SigLipVisionTower(nn.Module):
             o = l.self_attn.out_proj
             h = lin(ctx, 1, o.weight.detach(), o.bias.detach(), residual=h)
             xn2 = ops.layernorm_f32(h, l.layer_norm2.weight.detach(), l.layer_norm2.bias.detach(), c.layer_norm_eps)
-            m = lin(xn2, 2, l.mlp.fc1.weight.detach(), l.mlp.fc1.bias.detach(), act=1)
+            if train:                                 # the GELU's derivative needs the pre-activation: activation as its own pass
+                pre = lin(xn2, 2, l.mlp.fc1.weight.detach(), l.mlp.fc1.bias.detach())
+                m = ops.gelu_tanh_f32(pre)
+                save.append((h_in, qkv, ctx, h, pre))
+            else:
+                m = lin(xn2, 2, l.mlp.fc1.weight.detach(), l.mlp.fc1.bias.detach(), act=1)
             h = lin(m, 3, l.mlp.fc2.weight.detach(), l.mlp.fc2.bias.detach(), residual=h)
         return h.view(B, T, D)
 
+    # ------------------------------------------------------------------ backward (unfrozen tower)
+    @torch.no_grad()
+    def _backward(self, images, saved, dout):
+        """Gradient of every tower parameter for d(loss)/d(output) = dout [B, T, D] (reference: autograd through
+        SigLipVisionModel when `freeze=False`, models/unigen.py:111, training/train_w_clip_vit.py:282,311-312).  fp32; every
+        contraction on the exact fp32 MFMA GEMM with its operands brought into [rows][k] form by `ug_transpose_f32`;
+        LayerNorm / GELU / softmax derivatives in csrc/siglip_bwd.hip; scores are recomputed per layer (not stored).
+        -> {parameter: gradient tensor}."""
+        c = self.config
+        vm = self.vision_tower.vision_model
+        B = images.shape[0]
+        D, Hh, I = c.hidden_size, c.num_attention_heads, c.intermediate_size
+        hd = D // Hh
+        g = c.image_size // c.patch_size
+        T = g * g
+        M = B * T
+        Tp = ops.round_up(T, 4)
+        scale = float(hd) ** -0.5
+        dev = dout.device
+        eps = c.layer_norm_eps
+        grads = {}
+        z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
+
+        def mm(a, bt, Mr, N, K, lda=None, ldb=None):
+            """a [Mr, K] (row stride lda) @ bt[N, K]^T (row stride ldb) -> [Mr, N]; K a multiple of 4 (zero-padded operands)"""
+            return ops.gemm_f32(a, bt, b_is_nk=True, M=Mr, N=N, K=K, lda=a.stride(0) if lda is None else lda,
+                                ldb=bt.stride(0) if ldb is None else ldb)[0]
+
+        def linear_bwd(dy, x, W, n_out, n_in):
+            """y = x W^T + b -> (dx, dW, db); dy [M, n_out], x [M, n_in]"""
+            dyT = ops.transpose_f32(dy, M, n_out)[0]                       # [n_out, Mp], zero tail
+            xT = ops.transpose_f32(x, M, n_in)[0]                          # [n_in, Mp]
+            dW = mm(dyT, xT, n_out, n_in, dyT.shape[1])
+            db = ops.colsum_f32_(dy, z(n_out))
+            WT = ops.transpose_f32(W.detach().float().contiguous(), n_out, n_in)[0]     # [n_in, n_out_p]
+            dyp = dy
+            if n_out % 4:                                                  # contraction over n_out: zero-padded copy of dy
+                dyp = z(M, WT.shape[1])
+                dyp[:, :n_out] = dy
+            dx = mm(dyp, WT, M, n_in, WT.shape[1])
+            return dx, dW, db
+
+        dh = dout.reshape(M, D).float().contiguous()
+        for li in reversed(range(len(vm.encoder.layers))):
+            l = vm.encoder.layers[li]
+            h_in, qkv, ctx, h_mid, pre = saved[li]
+            a = l.self_attn
+            # ---- MLP: h_out = h_mid + fc2(gelu(fc1(LN2(h_mid))))
+            m = ops.gelu_tanh_f32(pre)
+            dm, grads[l.mlp.fc2.weight], grads[l.mlp.fc2.bias] = linear_bwd(dh, m, l.mlp.fc2.weight, D, I)
+            dpre = ops.gelu_tanh_f32(pre, dm)
+            xn2 = ops.layernorm_f32(h_mid, l.layer_norm2.weight.detach(), l.layer_norm2.bias.detach(), eps)
+            dxn2, grads[l.mlp.fc1.weight], grads[l.mlp.fc1.bias] = linear_bwd(dpre, xn2, l.mlp.fc1.weight, I, D)
+            grads[l.layer_norm2.weight], grads[l.layer_norm2.bias] = z(D), z(D)
+            dh_mid = ops.layernorm_bwd_f32(dxn2, h_mid, l.layer_norm2.weight.detach().float(), eps, grads[l.layer_norm2.weight],
+                                           grads[l.layer_norm2.bias], dres_in=dh)
+            # ---- attention output projection: h_mid = h_in + out_proj(ctx)
+            dctx, grads[a.out_proj.weight], grads[a.out_proj.bias] = linear_bwd(dh_mid, ctx, a.out_proj.weight, D, D)
+            # ---- attention core, all heads of all images per launch: batch = (head, image)
+            ldS = ops.round_up(T, 4)
+            P = torch.empty((B, Hh, T, ldS), dtype=torch.float32, device=dev)
+            nest = dict(batch_in=Hh, batch_out=B)
+            ops.gemm_f32_nested(qkv[:, 0:D], qkv[:, D:2 * D], P, b_is_nk=True, M=T, N=T, K=hd, lda=3 * D, ldb=3 * D, ldc=ldS,
+                                sa=(hd, T * 3 * D), sb=(hd, T * 3 * D), sc=(T * ldS, Hh * T * ldS), **nest)
+            ops.softmax_rows_(P.view(B * Hh * T, ldS), scale, cols=T)
+            dP = torch.empty_like(P)                                       # dP = dctx_h V_h^T
+            ops.gemm_f32_nested(dctx, qkv[:, 2 * D:], dP, b_is_nk=True, M=T, N=T, K=hd, lda=D, ldb=3 * D, ldc=ldS,
+                                sa=(hd, T * D), sb=(hd, T * 3 * D), sc=(T * ldS, Hh * T * ldS), **nest)
+            PT = ops.transpose_f32(P, T, T, batch=B * Hh, ld_in=ldS, stride_in=T * ldS)                  # [B*Hh, Tk, Tp(q)]
+            ops.softmax_bwd_rows_(P.view(B * Hh * T, ldS), dP.view(B * Hh * T, ldS), scale, T)           # dP becomes dS (x scale)
+            dST = ops.transpose_f32(dP, T, T, batch=B * Hh, ld_in=ldS, stride_in=T * ldS)
+            dqkv = torch.empty((M, 3 * D), dtype=torch.float32, device=dev)
+            # per-head transposes of q, k and dctx ([T, hd] -> [hd, Tp]) as the [N][K] operands of the three contractions
+            qT = torch.empty((B, Hh, hd, Tp), dtype=torch.float32, device=dev)
+            kT, dcT = torch.empty_like(qT), torch.empty_like(qT)
+            for b in range(B):
+                qT[b] = ops.transpose_f32(qkv[b * T:, 0:D], T, hd, batch=Hh, ld_in=3 * D, stride_in=hd)
+                kT[b] = ops.transpose_f32(qkv[b * T:, D:2 * D], T, hd, batch=Hh, ld_in=3 * D, stride_in=hd)
+                dcT[b] = ops.transpose_f32(dctx[b * T:], T, hd, batch=Hh, ld_in=D, stride_in=hd)
+            tk = dict(M=T, N=hd, K=Tp, ldb=Tp, ldc=3 * D, sb=(hd * Tp, Hh * hd * Tp), sc=(hd, T * 3 * D), **nest)
+            ops.gemm_f32_nested(dP, kT, dqkv[:, 0:D], b_is_nk=True, lda=ldS, sa=(T * ldS, Hh * T * ldS), **tk)          # dQ = dS K
+            ops.gemm_f32_nested(dST, qT, dqkv[:, D:2 * D], b_is_nk=True, lda=Tp, sa=(T * Tp, Hh * T * Tp), **tk)        # dK = dS^T Q
+            ops.gemm_f32_nested(PT, dcT, dqkv[:, 2 * D:], b_is_nk=True, lda=Tp, sa=(T * Tp, Hh * T * Tp), **tk)         # dV = P^T dctx
+            del P, dP, PT, dST
+            # ---- fused q|k|v projection and the first LayerNorm
+            xn = ops.layernorm_f32(h_in, l.layer_norm1.weight.detach(), l.layer_norm1.bias.detach(), eps)
+            wq = torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight]).detach().float().contiguous()
+            dxn, dWq, dbq = linear_bwd(dqkv, xn, wq, 3 * D, D)
+            for j, proj in enumerate((a.q_proj, a.k_proj, a.v_proj)):
+                grads[proj.weight], grads[proj.bias] = dWq[j * D:(j + 1) * D], dbq[j * D:(j + 1) * D]
+            grads[l.layer_norm1.weight], grads[l.layer_norm1.bias] = z(D), z(D)
+            dh = ops.layernorm_bwd_f32(dxn, h_in, l.layer_norm1.weight.detach().float(), eps, grads[l.layer_norm1.weight],
+                                       grads[l.layer_norm1.bias], dres_in=dh_mid)
+        # ---- embeddings: h0 = conv14x14/14(images) + position embedding (non-overlapping patches: a plain GEMM over [B*T, 3*p*p])
+        pe, ps = vm.embeddings.patch_embedding, c.patch_size
+        grads[vm.embeddings.position_embedding.weight] = ops.colsum_f32_(dh.view(B, T * D), z(T * D)).view(T, D)
+        grads[pe.bias] = ops.colsum_f32_(dh, z(D))
+        # (a stride-14 convolution without padding never reads the last image_size - g * 14 rows / columns: 384 -> 378)
+        patches = images.float()[:, :, :g * ps, :g * ps].reshape(B, c.num_channels, g, ps, g, ps).permute(0, 2, 4, 1, 3, 5).reshape(
+            M, c.num_channels * ps * ps)
+        dhT = ops.transpose_f32(dh, M, D)[0]
+        pT = ops.transpose_f32(patches.contiguous(), M, patches.shape[1])[0]
+        grads[pe.weight] = mm(dhT, pT, D, patches.shape[1], dhT.shape[1]).view(pe.weight.shape)
+        return grads
+
     def forward(self, images):
-        # The tower has no backward here: every shipped config freezes it (configs/*: model.vision_tower.freeze true).
-        # Training it (mm_tunable_parts containing 'mm_vision_tower', train_w_clip_vit.py:311-312) must not silently
-        # train nothing.
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.vision_tower.parameters()):
-            raise UniGenHipError("SigLipVisionTower: training the vision tower is not implemented (forward only); freeze it "
-                                 "(`vision_tower.requires_grad_(False)`, config model.vision_tower.freeze) or run under no_grad")
         if type(images) is list:
-            return [self._encode(im.to(device=self.device, dtype=self.dtype).unsqueeze(0)).to(im.dtype) for im in images]
-        return self._encode(images.to(device=self.device, dtype=self.dtype)).to(images.dtype)
+            return [self._forward_one(im.to(device=self.device, dtype=self.dtype).unsqueeze(0)).to(im.dtype) for im in images]
+        return self._forward_one(images.to(device=self.device, dtype=self.dtype)).to(images.dtype)
+
+    def _forward_one(self, images):
+        # Frozen (every shipped config: model.vision_tower.freeze true) or under no_grad: inference kernels, nothing kept.
+        # Unfrozen (mm_tunable_parts containing 'mm_vision_tower', train_w_clip_vit.py:311-312): the same forward with the
+        # activations a backward needs, on the autograd graph through _TowerFn.
+        params = [p for p in self.vision_tower.parameters() if p.requires_grad]
+        if torch.is_grad_enabled() and params:
+            return _TowerFn.apply(self, images, *params)
+        return self._encode(images)
 
     # ------------------------------------------------------------------ reference properties
     @property

@@ -9,7 +9,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
-LIB_PATH = os.path.join(CSRC_DIR, "libunigen_hip.so")
+LIB_PATH = os.environ.get("UNIGEN_HIP_LIB") or os.path.join(CSRC_DIR, "libunigen_hip.so")     # (probe builds: tools/probes/_build/*.so)
 
 ABI_VERSION = 3
 P = ctypes.c_void_p
@@ -83,6 +83,11 @@ SIGNATURES = {
     "ug_softmax_rows_f32": [P, I64, I64, I64, F32, P],
     "ug_linear_f32": [P, I64, P, I64, P, P, I64, P, I64, I64, I64, I64, I32, P],
     "ug_layernorm_f32": [P, P, P, P, I64, I64, F32, P],
+    "ug_layernorm_bwd_f32": [P, P, P, P, P, P, P, I64, I64, F32, P],
+    "ug_gelu_tanh_f32": [P, P, P, I64, P],
+    "ug_softmax_bwd_rows_f32": [P, P, I64, I64, I64, F32, P],
+    "ug_colsum_f32": [P, I64, P, I64, I64, P],
+    "ug_transpose_f32": [P, I64, I64, P, I64, I64, I64, I64, I64, P],
     "ug_nchw_to_nhwc": [P, P, I64, I32, I64, I32, P],
     "ug_nhwc_to_nchw": [P, P, I64, I32, I64, I32, P],
     "ug_lfq_pack": [P, I64, P, I64, I32, P],

@@ -835,6 +835,47 @@ def layernorm_f32(x2d, gamma, beta, eps):
     return y
 
 
+def layernorm_bwd_f32(dy, x, gamma, eps, dgamma, dbeta, dres_in=None):
+    """dx = [dres_in +] LayerNorm'(dy); dgamma / dbeta (fp32 [cols]) accumulate."""
+    dx = torch.empty_like(x)
+    _l.check(_l.load().ug_layernorm_bwd_f32(_p(dy), _p(x), _p(gamma), _p(dres_in), _p(dx), _p(dgamma), _p(dbeta), x.shape[0], x.shape[1],
+                                            eps, _stream()), "ug_layernorm_bwd_f32")
+    return dx
+
+
+def gelu_tanh_f32(pre, dy=None):
+    """gelu_pytorch_tanh(pre), or dy * gelu'(pre) when dy is given; fp32."""
+    out = torch.empty_like(pre)
+    _l.check(_l.load().ug_gelu_tanh_f32(_p(pre), _p(dy), _p(out), pre.numel(), _stream()), "ug_gelu_tanh_f32")
+    return out
+
+
+def softmax_bwd_rows_(P2d, dP2d, scale, cols):
+    """in place on dP2d: dS = scale * P * (dP - rowsum(dP * P)) over the first `cols` columns, padding columns zeroed"""
+    _l.check(_l.load().ug_softmax_bwd_rows_f32(_p(P2d), _p(dP2d), P2d.shape[0], cols, P2d.stride(0), scale, _stream()),
+             "ug_softmax_bwd_rows_f32")
+    return dP2d
+
+
+def colsum_f32_(x2d, out):
+    """out[c] += sum_r x2d[r, c] (fp32)"""
+    _l.check(_l.load().ug_colsum_f32(_p(x2d), x2d.stride(0), _p(out), x2d.shape[0], x2d.shape[1], _stream()), "ug_colsum_f32")
+    return out
+
+
+def transpose_f32(x, rows=None, cols=None, *, batch=1, ld_in=None, stride_in=0, pad_to=4):
+    """out[z][c][r] = x[z][r][c]; output rows are round_up(rows, pad_to) long with a zero tail.  x: 2-D [rows, cols] (batch 1) or
+    any buffer described by (ld_in, stride_in).  -> [batch, cols, ld_out]."""
+    rows = x.shape[-2] if rows is None else rows
+    cols = x.shape[-1] if cols is None else cols
+    ld_in = x.stride(-2) if ld_in is None else ld_in
+    ld_out = round_up(rows, pad_to)
+    out = torch.empty((batch, cols, ld_out), dtype=torch.float32, device=x.device)
+    _l.check(_l.load().ug_transpose_f32(_p(x), ld_in, stride_in, _p(out), ld_out, cols * ld_out, rows, cols, batch, _stream()),
+             "ug_transpose_f32")
+    return out
+
+
 def nchw_to_nhwc(x, c_pad):
     B, C, H, W = x.shape
     out = torch.empty((B, H, W, c_pad), dtype=torch.float32, device=x.device)
