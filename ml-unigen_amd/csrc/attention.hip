@@ -15,6 +15,7 @@
 // with 16-byte loads, and no transposed copy exists in HBM or LDS.
 #include "common.h"
 #include "unigen_hip.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -193,8 +194,9 @@ __device__ __forceinline__ bf16x8_t pack_p(const f32x4_t& a, const f32x4_t& b) {
 // integer-sequence RNE packing (what pack_p was before the hardware converter).  The dQ kernel keeps it: measured in one
 // session, 216.6 us with this sequence vs 255 us with v_cvt_pk_bf16_f32 (the forward and dK/dV kernels go the other way).
 __device__ __forceinline__ bf16_t f2bf_sw(float f) {
+  // branch-free: the NaN test of round 2 compiled to an exec-mask branch per element (60 scalar instructions per key tile);
+  // a quiet NaN (0x7fc00000 + 0x7fff) still rounds to a NaN
   uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
   u += 0x7fffu + ((u >> 16) & 1u);
   return (bf16_t)(u >> 16);
 }
@@ -337,6 +339,206 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 4) void attn_fwd_kernel(Attn
   }
 }
 
+// ================================================================== forward, 32 query rows per wave (round 3)
+// The same S^T formulation on v_mfma_f32_32x32x16_bf16: a wave owns 32 query rows (lane = query column n = lane & 31, key half
+// hh = lane >> 5), a workgroup of NW waves 32 * NW rows.  Against the 16-row kernel above, per query row: half the LDS fragment
+// reads (every K / V fragment feeds a 32-row MFMA), one cross-lane exchange per row statistic instead of two, the softmax in the
+// exp2 domain (one fma + one exp per score), and the K / V tiles arrive by LDS-DMA into a two-slot ring one visible tile ahead
+// with ONE workgroup barrier per tile (the 16-row kernel stages through registers between two barriers).
+//   LDS tile image [64 rows][16 chunks of 16 B], chunk_l = chunk ^ swz16(row): the 16 rows of a ds_read_b128 lane group and the
+//   4 keys x 4 chunks of a transposing half-wave both fall on 16 distinct 16-byte bank groups.
+//   k-slot mapping of the P.V contraction (k-step j of 32-key block kb): slot e of lane half hh <-> key 16 j + 8 (e / 4) + 4 hh
+//   + e % 4 -- exactly the rows the S^T accumulator holds in registers 8 j .. 8 j + 7, so probabilities feed the B operand
+//   without a shuffle and the V^T fragment is two transposing reads of 4 consecutive keys each.
+typedef __attribute__((ext_vector_type(8))) __bf16 hwbf16x8_t;
+typedef const __attribute__((address_space(1))) void* a_gptr_t;
+typedef __attribute__((address_space(3))) void* a_lptr_t;
+__device__ __forceinline__ int swz16(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+constexpr int T32_BYTES = 64 * 256;
+
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void attn_fwd32_kernel(AttnArgs p) {
+  __shared__ __attribute__((aligned(16))) char ring[2 * 2 * T32_BYTES];       // [slot][K | V]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 31, hh = lane >> 5, i16 = lane & 15, grp = (lane >> 4) & 1;
+  constexpr int ROWS = 32 * NW;
+  const WgCoord wc = wg_coord((int)blockIdx.x, (p.L + ROWS - 1) / ROWS, p.H, p.HKV, p.B);
+  if (!wc.ok) return;
+  const int qt = wc.tile, h = wc.h, b = wc.b;
+  const int hk = h / (p.H / p.HKV);
+  const int qrow = qt * ROWS + wave * 32 + n;
+  const int qrow_c = min(qrow, p.L - 1);
+  const bf16_t* qseq = p.q + (int64_t)b * p.L * p.ldq + h * HD;
+  const bf16_t* kseq = p.k + (int64_t)b * p.L * p.ldq + hk * HD;
+  const bf16_t* vseq = p.v + (int64_t)b * p.L * p.ldq + hk * HD;
+
+  bf16x8_t qf[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks)
+    qf[ks] = *reinterpret_cast<const bf16x8_t*>(qseq + (int64_t)qrow_c * p.ldq + ks * 16 + hh * 8);
+  f32x16_t ot[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ot[d][r] = 0.f;
+  float m_i = -INFINITY, l_i = 0.f;                    // running maximum of the RAW scores, running sum
+  const float c1 = p.scale * 1.4426950408889634f;      // exp(scale * s) = exp2(c1 * s)
+  const uint64_t* wrow = p.bits + ((int64_t)b * p.L + qrow_c) * p.nW;
+  // 64-row tile flags (nW <= 64 tiles), fetched ONCE: bit t of `vis` = some row of the workgroup sees key tile t (uniform),
+  // bit t of `minem` = this wave's 32 rows do.  (A flag byte fetched per tile right before its use was a dependent global
+  // load on every iteration's critical path.)
+  const int q64_0 = qt * (ROWS / 64), q64_w = q64_0 + (wave >> 1);
+  uint64_t vis, minem;
+  {
+    bool v = false, m = false;
+    if (lane < p.nW) {
+#pragma unroll
+      for (int i = 0; i < ROWS / 64; ++i)
+        if (q64_0 + i < p.nW) v = v || p.tileany[((int64_t)b * p.nW + q64_0 + i) * p.nW + lane];
+      if (q64_w < p.nW) m = p.tileany[((int64_t)b * p.nW + q64_w) * p.nW + lane];
+    }
+    vis = __ballot(v);
+    minem = __ballot(m);
+  }
+  auto next_visible = [&](int t) {
+    const uint64_t rest = t < 64 ? vis >> t : 0ull;
+    return rest ? t + __builtin_ctzll(rest) : p.nW;
+  };
+  // LDS-DMA of one K / V tile pair: 16 one-KiB instructions per operand, 16 / NW per wave
+  auto stage = [&](int t, int slot) {
+    char* base = ring + slot * 2 * T32_BYTES;
+#pragma unroll
+    for (int i = 0; i < 16 / NW; ++i) {
+      const int inst = i * NW + wave;
+      const int row = inst * 4 + (lane >> 4);
+      const int chunk = (lane & 15) ^ swz16(row);
+      const int64_t goff = (int64_t)min(t * 64 + row, p.L - 1) * p.ldq + chunk * 8;
+      __builtin_amdgcn_global_load_lds((a_gptr_t)(kseq + goff), (a_lptr_t)(base + inst * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((a_gptr_t)(vseq + goff), (a_lptr_t)(base + T32_BYTES + inst * 1024), 16, 0, 0);
+    }
+  };
+  // per-lane fragment offsets inside a tile
+  int koff[8], voff[4][2];
+  {
+    const int sw = swz16(n);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) koff[ks] = n * 256 + (((ks * 2 + hh) ^ sw) << 4);
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int key = 4 * hh + (i16 >> 2) + 8 * e;                    // + 16 j + 32 kb: multiples of 16 leave swz16 unchanged
+        const int chunk = d * 4 + grp * 2 + ((i16 & 3) >> 1);
+        voff[d][e] = key * 256 + ((chunk ^ swz16(key)) << 4) + (i16 & 1) * 8;
+      }
+  }
+
+  int t = next_visible(0);
+  if (t < p.nW) stage(t, 0);
+  uint64_t wcur = t < p.nW ? wrow[t] : 0ull;             // the mask word of a tile is requested one tile ahead, like its K / V rows
+  for (int it = 0; t < p.nW; ++it) {
+    const int tn = next_visible(t + 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of tile t has landed
+    asm volatile("s_barrier" ::: "memory");               // ... everyone's has; everyone is past its reads of the other slot
+    if (tn < p.nW) stage(tn, (it + 1) & 1);
+    const uint64_t wnext = tn < p.nW ? wrow[tn] : 0ull;
+    const bool mine = (minem >> t) & 1ull;
+    if (mine) {
+      const char* Ks = ring + (it & 1) * 2 * T32_BYTES;
+      const char* Vs = Ks + T32_BYTES;
+      f32x16_t st[2];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
+      // the two key blocks alternate: consecutive MFMAs never wait for each other's result (a 32x32x16 issues every 32 clocks
+      // and delivers after 64)
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(Ks + kb * 8192 + koff[ks]);
+          st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(hwbf16x8_t, a), __builtin_bit_cast(hwbf16x8_t, qf[ks]),
+                                                           st[kb], 0, 0, 0);
+        }
+      // keys of this lane: 32 kb + 8 (r / 4) + 4 hh + r % 4.  A tile every row of the wave sees completely (below the causal
+      // diagonal; image rows) skips the three instructions per score of the bit test -- wave-uniform branch.
+      float mloc = -INFINITY;
+      if (__ballot(wcur != ~0ull) != 0ull) {
+        const uint64_t w2 = wcur >> (hh * 4);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const bool on = (w2 >> (kb * 32 + (r >> 2) * 8 + (r & 3))) & 1ull;
+            st[kb][r] = on ? st[kb][r] : -INFINITY;
+          }
+      }
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, st[kb][r]);
+      mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+      const float m_new = fmaxf(m_i, mloc);
+      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+      const float alpha = __builtin_amdgcn_exp2f((m_i - m_use) * c1);      // v_exp_f32: arguments are <= 0, results in [0, 1]
+      const float mc = m_use * c1;
+      float rs = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(st[kb][r], c1, -mc)); st[kb][r] = e; rs += e; }
+      rs += __shfl_xor(rs, 32, 64);
+      l_i = l_i * alpha + rs;
+      m_i = m_new;
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[d][r] *= alpha;
+      bf16x8_t pf[2][2];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          uint4 u;
+          u.x = pack_bf2(st[kb][j * 8 + 0], st[kb][j * 8 + 1]); u.y = pack_bf2(st[kb][j * 8 + 2], st[kb][j * 8 + 3]);
+          u.z = pack_bf2(st[kb][j * 8 + 4], st[kb][j * 8 + 5]); u.w = pack_bf2(st[kb][j * 8 + 6], st[kb][j * 8 + 7]);
+          pf[kb][j] = __builtin_bit_cast(bf16x8_t, u);
+        }
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {                    // four independent accumulators in turn
+            const char* vb = Vs + kb * 8192 + j * 4096;
+            const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vb + voff[d][0]));
+            const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vb + voff[d][1]));
+            const bf16x8_t a = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(hwbf16x8_t, a), __builtin_bit_cast(hwbf16x8_t, pf[kb][j]),
+                                                            ot[d], 0, 0, 0);
+          }
+    }
+    t = tn;
+    wcur = wnext;
+  }
+  if (qrow < p.L) {
+    const float inv = (l_i > 0.f) ? 1.f / l_i : 0.f;
+    bf16_t* orow = p.o + ((int64_t)b * p.L + qrow) * p.ldo + h * HD;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        uint2 w;
+        w.x = pack_bf2(ot[d][q * 4 + 0] * inv, ot[d][q * 4 + 1] * inv);
+        w.y = pack_bf2(ot[d][q * 4 + 2] * inv, ot[d][q * 4 + 3] * inv);
+        *reinterpret_cast<uint2*>(orow + d * 32 + q * 8 + hh * 4) = w;
+      }
+    if (hh == 0) p.lse[((int64_t)b * p.H + h) * p.L + qrow] = (l_i > 0.f) ? m_i * p.scale + __logf(l_i) : INFINITY;
+  }
+}
+
 // ================================================================== backward: dQ  (also delta = rowsum(dO * O))
 // grid (nQtiles, H, B)
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
@@ -379,6 +581,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
   f32x4_t dqt[8];
 #pragma unroll
   for (int d = 0; d < 8; ++d) dqt[d] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const float c1 = p.scale * 1.4426950408889634f, lse2 = lse * 1.4426950408889634f, dls = dl * p.scale;
   const uint64_t* wrow = p.bits + ((int64_t)b * p.L + qrow_c) * p.nW;
   const uint8_t* tany = p.tileany + ((int64_t)b * p.nW + qt) * p.nW;
 
@@ -399,19 +602,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
         s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rm(Ks, j, ks, lane), qf[ks], s, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rm(Vs, j, ks, lane), dof[ks], dp, 0, 0, 0);
       }
+      // p = exp(scale s - lse) = exp2(c1 s - lse2); dS = p (dP - delta) scale = p fma(dP, scale, -delta scale): two + two
+      // instructions per score (the exp() / three-factor form took seven).  (A wave-uniform "tile fully visible" branch around
+      // the bit test was measured SLOWER: +9 % on the full mask -- the branch keeps the next block's MFMAs from overlapping.)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const bool on = ((j < 2 ? mlo : mhi) >> ((j & 1) * 16 + r)) & 1u;
-        const float pr = on ? __expf(s[r] * p.scale - lse) : 0.f;
-        ds[j][r] = pr * (dp[r] - dl) * p.scale;
+        const float pr = on ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c1, -lse2)) : 0.f;
+        ds[j][r] = pr * __builtin_fmaf(dp[r], p.scale, -dls);
       }
     }
     const bf16x8_t sf0 = pack_p_sw(ds[0], ds[1]), sf1 = pack_p_sw(ds[2], ds[3]);
 #pragma unroll
-    for (int d = 0; d < 8; ++d) {
-      dqt[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_trr(Ks, d, 0, lane), sf0, dqt[d], 0, 0, 0);
-      dqt[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_trr(Ks, d, 1, lane), sf1, dqt[d], 0, 0, 0);
-    }
+    for (int d = 0; d < 8; ++d) dqt[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_trr(Ks, d, 0, lane), sf0, dqt[d], 0, 0, 0);
+#pragma unroll
+    for (int d = 0; d < 8; ++d) dqt[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_trr(Ks, d, 1, lane), sf1, dqt[d], 0, 0, 0);
   }
   if (qrow < p.L) {
     bf16_t* drow = p.dq + ((int64_t)b * p.L + qrow) * p.ldg + h * HD;
@@ -435,7 +640,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
   __shared__ __attribute__((aligned(16))) bf16_t QD[2 * 64 * RM_LD];  // Q rows | dO rows (one array: reused as the
   bf16_t* Qs = QD;                                                    // SPLIT epilogue's fp32 transpose scratch)
   bf16_t* Ds = QD + 64 * RM_LD;
-  __shared__ __attribute__((aligned(16))) float lse_s[64], dl_s[64];
+  __shared__ __attribute__((aligned(16))) float lse_s[64], dl_s[64];       // lse log2(e) | delta scale of the staged query rows
   __shared__ uint64_t word_s[64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4;
   const int grp = p.H / p.HKV;
@@ -457,6 +662,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
 #pragma unroll
   for (int d = 0; d < 8; ++d) { dkt[d] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dvt[d] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
   const int kbit = wave * 16 + (lane & 15);
+  const float c1 = p.scale * 1.4426950408889634f;
 
   for (int hh = SPLIT ? wc.h % grp : 0; hh < (SPLIT ? wc.h % grp + 1 : grp); ++hh) {
     const int h = hk * grp + hh;
@@ -471,9 +677,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
         const int qr = qt * 64 + tid;
         const bool ok = qr < p.L;
         const int qc = min(qr, p.L - 1);
-        lse_s[tid] = p.lse[((int64_t)b * p.H + h) * p.L + qc];
-        dl_s[tid] = p.delta[((int64_t)b * p.H + h) * p.L + qc];
-        word_s[tid] = ok ? p.bits[((int64_t)b * p.L + qc) * p.nW + t] : 0ull;   // rows past L contribute nothing
+        lse_s[tid] = p.lse[((int64_t)b * p.H + h) * p.L + qc] * 1.4426950408889634f;       // exp2 domain
+        dl_s[tid] = p.delta[((int64_t)b * p.H + h) * p.L + qc] * p.scale;                  // delta scale
+        word_s[tid] = ok ? p.bits[((int64_t)b * p.L + qc) * p.nW + t] : 0ull;              // rows past L contribute nothing
       }
       __syncthreads();
       f32x4_t pr[4], ds[4];
@@ -491,18 +697,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
         for (int r = 0; r < 4; ++r) {
           const int ql = j * 16 + g * 4 + r;
           const bool on = (word_s[ql] >> kbit) & 1ull;
-          const float e = on ? __expf(s[r] * p.scale - ls[r]) : 0.f;
+          const float e = on ? __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c1, -ls[r])) : 0.f;
           pr[j][r] = e;
-          ds[j][r] = e * (dp[r] - dl4[r]) * p.scale;
+          ds[j][r] = e * __builtin_fmaf(dp[r], p.scale, -dl4[r]);
         }
       }
       const bf16x8_t pf0 = pack_p(pr[0], pr[1]), pf1 = pack_p(pr[2], pr[3]);
       const bf16x8_t sf0 = pack_p(ds[0], ds[1]), sf1 = pack_p(ds[2], ds[3]);
 #pragma unroll
-      for (int d = 0; d < 8; ++d) {
+      for (int d = 0; d < 8; ++d) {                         // (16 independent accumulators per pass: no MFMA waits for its predecessor)
         dvt[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_trr(Ds, d, 0, lane), pf0, dvt[d], 0, 0, 0);
-        dvt[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_trr(Ds, d, 1, lane), pf1, dvt[d], 0, 0, 0);
         dkt[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_trr(Qs, d, 0, lane), sf0, dkt[d], 0, 0, 0);
+      }
+#pragma unroll
+      for (int d = 0; d < 8; ++d) {
+        dvt[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_trr(Ds, d, 1, lane), pf1, dvt[d], 0, 0, 0);
         dkt[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_trr(Qs, d, 1, lane), sf1, dkt[d], 0, 0, 0);
       }
     }
@@ -640,7 +849,10 @@ extern "C" int ug_attn_fwd(const void* q, const void* k, const void* v, int64_t 
   a.ldq = ldq; a.ldo = ldo; a.B = (int)B; a.L = (int)L; a.Lp = (int)Lp; a.nW = (int)((L + 63) / 64);
   a.H = H; a.HKV = HKV; a.scale = scale;
   // 128-row query tiles (eight waves share each staged K / V tile) once there are enough of them to fill the chip
-  if (L >= 256 && (int64_t)((L + 127) / 128) * H * B >= 512)
+  static const int use32 = [] { const char* e = getenv("UNIGEN_ATTN_FWD32"); return e ? atoi(e) : 1; }();
+  if (use32 && L >= 256 && L <= 4096 && (int64_t)((L + 127) / 128) * H * B >= 512)
+    hipLaunchKernelGGL(attn_fwd32_kernel<4>, dim3(wg_grid((L + 127) / 128, H, HKV, B)), dim3(256), 0, st, a);
+  else if (L >= 256 && (int64_t)((L + 127) / 128) * H * B >= 512)
     hipLaunchKernelGGL(attn_fwd_kernel<8>, dim3(wg_grid((L + 127) / 128, H, HKV, B)), dim3(512), 0, st, a);
   else
     hipLaunchKernelGGL(attn_fwd_kernel<4>, dim3(wg_grid(a.nW, H, HKV, B)), dim3(256), 0, st, a);
