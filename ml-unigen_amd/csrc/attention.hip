@@ -628,6 +628,165 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnArgs p) {
   }
 }
 
+// ================================================================== backward: dQ on 32-row waves (round 3)
+// The forward's 32-row structure (attn_fwd32_kernel: LDS-DMA ring, one barrier per visible key tile, swizzled tile image) with
+// the dQ arithmetic: per key block of 32, S^T = K Q^T and dP^T = V dO^T (two independent accumulator chains), dS = P (dP - delta)
+// scale in the exp2 / fma form, then dQ^T += K^T dS^T with K^T fragments read transposed from the SAME staged K tile.  Also
+// publishes delta = rowsum(dO * O) for the dK / dV kernel that runs next.
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq32_kernel(AttnArgs p) {
+  __shared__ __attribute__((aligned(16))) char ring[2 * 2 * T32_BYTES];       // [slot][K | V]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 31, hh = lane >> 5, i16 = lane & 15, grp = (lane >> 4) & 1;
+  constexpr int ROWS = 32 * NW;
+  const WgCoord wc = wg_coord((int)blockIdx.x, (p.L + ROWS - 1) / ROWS, p.H, p.HKV, p.B);
+  if (!wc.ok) return;
+  const int qt = wc.tile, h = wc.h, b = wc.b;
+  const int hk = h / (p.H / p.HKV);
+  const int qrow = qt * ROWS + wave * 32 + n;
+  const int qrow_c = min(qrow, p.L - 1);
+  const bf16_t* qseq = p.q + (int64_t)b * p.L * p.ldq + h * HD;
+  const bf16_t* kseq = p.k + (int64_t)b * p.L * p.ldq + hk * HD;
+  const bf16_t* vseq = p.v + (int64_t)b * p.L * p.ldq + hk * HD;
+  const bf16_t* doseq = p.dout + (int64_t)b * p.L * p.ldo + h * HD;
+  const bf16_t* oseq = p.o + (int64_t)b * p.L * p.ldo + h * HD;
+
+  bf16x8_t qf[8], dof[8];
+  float dl = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    qf[ks] = *reinterpret_cast<const bf16x8_t*>(qseq + (int64_t)qrow_c * p.ldq + ks * 16 + hh * 8);
+    dof[ks] = *reinterpret_cast<const bf16x8_t*>(doseq + (int64_t)qrow_c * p.ldo + ks * 16 + hh * 8);
+    const bf16x8_t of = *reinterpret_cast<const bf16x8_t*>(oseq + (int64_t)qrow_c * p.ldo + ks * 16 + hh * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dl += bf2f((bf16_t)of[e]) * bf2f((bf16_t)dof[ks][e]);
+  }
+  dl += __shfl_xor(dl, 32, 64);                           // the two lanes of a row hold 64 of its 128 dims each
+  if (hh == 0 && qrow < p.L) const_cast<float*>(p.delta)[((int64_t)b * p.H + h) * p.L + qrow] = dl;
+  const float lse = p.lse[((int64_t)b * p.H + h) * p.L + qrow_c];
+  const float c1 = p.scale * 1.4426950408889634f, lse2 = lse * 1.4426950408889634f, dls = dl * p.scale;
+  f32x16_t dqt[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dqt[d][r] = 0.f;
+  const uint64_t* wrow = p.bits + ((int64_t)b * p.L + qrow_c) * p.nW;
+  const int q64_0 = qt * (ROWS / 64), q64_w = q64_0 + (wave >> 1);
+  uint64_t vis, minem;
+  {
+    bool v = false, m = false;
+    if (lane < p.nW) {
+#pragma unroll
+      for (int i = 0; i < ROWS / 64; ++i)
+        if (q64_0 + i < p.nW) v = v || p.tileany[((int64_t)b * p.nW + q64_0 + i) * p.nW + lane];
+      if (q64_w < p.nW) m = p.tileany[((int64_t)b * p.nW + q64_w) * p.nW + lane];
+    }
+    vis = __ballot(v);
+    minem = __ballot(m);
+  }
+  auto next_visible = [&](int t) {
+    const uint64_t rest = t < 64 ? vis >> t : 0ull;
+    return rest ? t + __builtin_ctzll(rest) : p.nW;
+  };
+  auto stage = [&](int t, int slot) {
+    char* base = ring + slot * 2 * T32_BYTES;
+#pragma unroll
+    for (int i = 0; i < 16 / NW; ++i) {
+      const int inst = i * NW + wave;
+      const int row = inst * 4 + (lane >> 4);
+      const int chunk = (lane & 15) ^ swz16(row);
+      const int64_t goff = (int64_t)min(t * 64 + row, p.L - 1) * p.ldq + chunk * 8;
+      __builtin_amdgcn_global_load_lds((a_gptr_t)(kseq + goff), (a_lptr_t)(base + inst * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((a_gptr_t)(vseq + goff), (a_lptr_t)(base + T32_BYTES + inst * 1024), 16, 0, 0);
+    }
+  };
+  int koff[8], voff[4][2];
+  {
+    const int sw = swz16(n);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) koff[ks] = n * 256 + (((ks * 2 + hh) ^ sw) << 4);
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int key = 4 * hh + (i16 >> 2) + 8 * e;
+        const int chunk = d * 4 + grp * 2 + ((i16 & 3) >> 1);
+        voff[d][e] = key * 256 + ((chunk ^ swz16(key)) << 4) + (i16 & 1) * 8;
+      }
+  }
+
+  int t = next_visible(0);
+  if (t < p.nW) stage(t, 0);
+  uint64_t wcur = t < p.nW ? wrow[t] : 0ull;
+  for (int it = 0; t < p.nW; ++it) {
+    const int tn = next_visible(t + 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    if (tn < p.nW) stage(tn, (it + 1) & 1);
+    const uint64_t wnext = tn < p.nW ? wrow[tn] : 0ull;
+    if ((minem >> t) & 1ull) {
+      const char* Ks = ring + (it & 1) * 2 * T32_BYTES;
+      const char* Vs = Ks + T32_BYTES;
+      const uint64_t w2 = wcur >> (hh * 4);
+      bf16x8_t sf[2][2];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        f32x16_t sc, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          const bf16x8_t ka = *reinterpret_cast<const bf16x8_t*>(Ks + kb * 8192 + koff[ks]);
+          const bf16x8_t va = *reinterpret_cast<const bf16x8_t*>(Vs + kb * 8192 + koff[ks]);
+          sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(hwbf16x8_t, ka), __builtin_bit_cast(hwbf16x8_t, qf[ks]), sc, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(hwbf16x8_t, va), __builtin_bit_cast(hwbf16x8_t, dof[ks]), dp, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const bool on = (w2 >> (kb * 32 + (r >> 2) * 8 + (r & 3))) & 1ull;
+          const float pr = on ? __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], c1, -lse2)) : 0.f;
+          sc[r] = pr * __builtin_fmaf(dp[r], p.scale, -dls);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          uint4 u;
+          u.x = pack_bf2(sc[j * 8 + 0], sc[j * 8 + 1]); u.y = pack_bf2(sc[j * 8 + 2], sc[j * 8 + 3]);
+          u.z = pack_bf2(sc[j * 8 + 4], sc[j * 8 + 5]); u.w = pack_bf2(sc[j * 8 + 6], sc[j * 8 + 7]);
+          sf[kb][j] = __builtin_bit_cast(bf16x8_t, u);
+        }
+      }
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            const char* kb_ = Ks + kb * 8192 + j * 4096;
+            const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(kb_ + voff[d][0]));
+            const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(kb_ + voff[d][1]));
+            const bf16x8_t a = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            dqt[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(hwbf16x8_t, a), __builtin_bit_cast(hwbf16x8_t, sf[kb][j]),
+                                                             dqt[d], 0, 0, 0);
+          }
+    }
+    t = tn;
+    wcur = wnext;
+  }
+  if (qrow < p.L) {
+    bf16_t* drow = p.dq + ((int64_t)b * p.L + qrow) * p.ldg + h * HD;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        uint2 w;
+        w.x = pack_bf2(dqt[d][q * 4 + 0], dqt[d][q * 4 + 1]);
+        w.y = pack_bf2(dqt[d][q * 4 + 2], dqt[d][q * 4 + 3]);
+        *reinterpret_cast<uint2*>(drow + d * 32 + q * 8 + hh * 4) = w;
+      }
+  }
+}
+
 // ================================================================== backward: dK, dV
 // grid (nKVtiles, HKV, B); each wave owns 16 keys (a lane owns key column kv = lane&15), walks the
 // H/HKV query heads of its group and all query tiles; dK^T/dV^T accumulate in registers, no atomics.
@@ -877,7 +1036,11 @@ extern "C" int ug_attn_bwd(const void* q, const void* k, const void* v, int64_t 
   a.bits = bits; a.tileany = tileany;
   a.ldq = ldq; a.ldo = ldo; a.ldg = ldg; a.B = (int)B; a.L = (int)L; a.Lp = (int)Lp; a.nW = (int)((L + 63) / 64);
   a.H = H; a.HKV = HKV; a.scale = scale;
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(wg_grid(a.nW, H, HKV, B)), dim3(256), 0, st, a);
+  static const int use32 = [] { const char* e = getenv("UNIGEN_ATTN_DQ32"); return e ? atoi(e) : 1; }();
+  if (use32 && L >= 256 && L <= 4096 && (int64_t)((L + 127) / 128) * H * B >= 512)
+    hipLaunchKernelGGL(attn_bwd_dq32_kernel<4>, dim3(wg_grid((L + 127) / 128, H, HKV, B)), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(wg_grid(a.nW, H, HKV, B)), dim3(256), 0, st, a);
   UG_CHECK_LAUNCH("ug_attn_bwd(dq)");
   if (dkv_ws) {
     hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, dim3(wg_grid(a.nW, H, HKV, B)), dim3(256), 0, st, a);
