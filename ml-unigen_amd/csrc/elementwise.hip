@@ -425,12 +425,10 @@ extern "C" int ug_rmsnorm_bwd(const void* dy, const float* x, const float* rstd,
   const int rpb = 16;          // 771 workgroups for 12 336 rows: three per CU (32 left a third of the CUs with one)
   dim3 grid((unsigned)((rows + rpb - 1) / rpb)), block(256);
   UG_REQUIRE(((uintptr_t)dres_bf16 & 7) == 0, "ug_rmsnorm_bwd: dres_bf16 must be 8-byte aligned");
-  if (cols <= 256 * 6)
-    hipLaunchKernelGGL(rmsnorm_bwd_kernel<6>, grid, block, 0, st, (const bf16_t*)dy, x, rstd, w, dres, dw, (bf16_t*)dres_bf16,
-                       (int)rows, (int)cols, rpb);
-  else
-    hipLaunchKernelGGL(rmsnorm_bwd_kernel<RN_MAXV>, grid, block, 0, st, (const bf16_t*)dy, x, rstd, w, dres, dw, (bf16_t*)dres_bf16,
-                       (int)rows, (int)cols, rpb);
+  // (a 6-slot instantiation for 1536 columns -- 148 instead of 182 registers, three waves per SIMD instead of two -- measured
+  // SLOWER inside the step: 86 vs 78 us per launch, profiles/r03b vs r03a; the generic form stays)
+  hipLaunchKernelGGL(rmsnorm_bwd_kernel<RN_MAXV>, grid, block, 0, st, (const bf16_t*)dy, x, rstd, w, dres, dw, (bf16_t*)dres_bf16,
+                     (int)rows, (int)cols, rpb);
   UG_CHECK_LAUNCH("ug_rmsnorm_bwd");
   return UG_OK;
 }
