@@ -917,6 +917,162 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnArgs p) {
   }
 }
 
+// ------------------------------------------------------------------ dK / dV, split heads, LDS-DMA ring (round 3)
+// Same arithmetic and the same 16-key waves as attn_bwd_dkv_kernel<true>; what changes is how a query tile arrives: Q and dO
+// rows by LDS-DMA into a two-slot ring one visible tile ahead (swizzled [64 rows][16 chunks] image, chunk ^= swz16b(row): conflict-
+// free for the 16-row ds_read_b128 fragments of the 16x16x32 MFMA and for the transposing half-waves), the per-row lse / delta /
+// mask words requested one tile ahead into registers of wave 0 and parked in a two-slot LDS record, ONE barrier per tile.  The
+// 16-row kernel above stages through registers between two barriers and fetches the row records inside that window.
+__device__ __forceinline__ int swz16b(int row) {
+  const int m = (row >> 2) & 3;
+  return ((row & 3) << 2) | ((0x78 >> (m * 2)) & 3);        // low bits g2[m] = {0, 2, 3, 1}
+}
+__device__ __forceinline__ bf16x8_t frag16(const char* tile, int rb, int ks, int lane) {
+  const int row = rb * 16 + (lane & 15);
+  return *reinterpret_cast<const bf16x8_t*>(tile + row * 256 + (((ks * 4 + (lane >> 4)) ^ swz16b(row)) << 4));
+}
+__device__ __forceinline__ bf16x8_t frag16_tr(const char* tile, int rb, int jp, int lane) {
+  const int i16 = lane & 15, g = lane >> 4;
+  const int row = jp * 32 + g * 4 + (i16 >> 2);
+  const char* p0 = tile + row * 256 + (((rb * 2 + ((i16 & 3) >> 1)) ^ swz16b(row)) << 4) + (i16 & 1) * 8;
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p0);
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p0 + 16 * 256));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_dma_kernel(AttnArgs p) {
+  __shared__ __attribute__((aligned(16))) char ring[2 * 2 * T32_BYTES];       // [slot][Q | dO]; reused as the epilogue's fp32 scratch
+  __shared__ __attribute__((aligned(16))) float lse_s[2][64], dl_s[2][64];
+  __shared__ __attribute__((aligned(16))) uint64_t word_s[2][64];
+  const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = p.H / p.HKV;
+  const WgCoord wc = wg_coord((int)blockIdx.x, p.nW, p.H, p.HKV, p.B);
+  if (!wc.ok) return;
+  const int t = wc.tile, b = wc.b, h = wc.h, hk = wc.h / grp;
+  const int krow = t * 64 + wave * 16 + (lane & 15);
+  const int krow_c = min(krow, p.L - 1);
+  const bf16_t* kseq = p.k + (int64_t)b * p.L * p.ldq + hk * HD;
+  const bf16_t* vseq = p.v + (int64_t)b * p.L * p.ldq + hk * HD;
+  const bf16_t* qseq = p.q + (int64_t)b * p.L * p.ldq + h * HD;
+  const bf16_t* doseq = p.dout + (int64_t)b * p.L * p.ldo + h * HD;
+  bf16x8_t kf[4], vf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    kf[ks] = *reinterpret_cast<const bf16x8_t*>(kseq + (int64_t)krow_c * p.ldq + ks * 32 + g * 8);
+    vf[ks] = *reinterpret_cast<const bf16x8_t*>(vseq + (int64_t)krow_c * p.ldq + ks * 32 + g * 8);
+  }
+  f32x4_t dkt[8], dvt[8];
+#pragma unroll
+  for (int d = 0; d < 8; ++d) { dkt[d] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dvt[d] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+  const int kbit = wave * 16 + (lane & 15);
+  const float c1 = p.scale * 1.4426950408889634f;
+  // visible query tiles of this key tile (nW <= 64), fetched once
+  uint64_t vis;
+  {
+    bool v = false;
+    if (lane < p.nW) v = p.tileany[((int64_t)b * p.nW + lane) * p.nW + t];
+    vis = __ballot(v);
+  }
+  auto next_visible = [&](int q) {
+    const uint64_t rest = q < 64 ? vis >> q : 0ull;
+    return rest ? q + __builtin_ctzll(rest) : p.nW;
+  };
+  auto stage = [&](int qt, int slot) {
+    char* base = ring + slot * 2 * T32_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int inst = i * 4 + wave;
+      const int row = inst * 4 + (lane >> 4);
+      const int chunk = (lane & 15) ^ swz16b(row);
+      const int gr = min(qt * 64 + row, p.L - 1);                           // rows past L repeat the last row: their mask words are 0
+      __builtin_amdgcn_global_load_lds((a_gptr_t)(qseq + (int64_t)gr * p.ldq + chunk * 8), (a_lptr_t)(base + inst * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((a_gptr_t)(doseq + (int64_t)gr * p.ldo + chunk * 8), (a_lptr_t)(base + T32_BYTES + inst * 1024), 16, 0, 0);
+    }
+  };
+  // row record of a query tile (wave 0, one lane per row): requested a tile ahead, parked in LDS before the tile's barrier
+  float r_lse = 0.f, r_dl = 0.f;
+  uint64_t r_word = 0ull;
+  auto fetch_rows = [&](int qt) {
+    const int qr = qt * 64 + lane;
+    const int qc = min(qr, p.L - 1);
+    r_lse = p.lse[((int64_t)b * p.H + h) * p.L + qc] * 1.4426950408889634f;      // exp2 domain
+    r_dl = p.delta[((int64_t)b * p.H + h) * p.L + qc] * p.scale;                  // delta scale
+    r_word = qr < p.L ? p.bits[((int64_t)b * p.L + qc) * p.nW + t] : 0ull;         // rows past L contribute nothing
+  };
+
+  int qt = next_visible(0);
+  if (qt < p.nW) { stage(qt, 0); if (wave == 0) fetch_rows(qt); }
+  for (int it = 0; qt < p.nW; ++it) {
+    const int qn = next_visible(qt + 1);
+    const int slot = it & 1;
+    if (wave == 0) { lse_s[slot][lane] = r_lse; dl_s[slot][lane] = r_dl; word_s[slot][lane] = r_word; }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
+    if (qn < p.nW) { stage(qn, slot ^ 1); if (wave == 0) fetch_rows(qn); }
+    const char* Qs = ring + slot * 2 * T32_BYTES;
+    const char* Ds = Qs + T32_BYTES;
+    f32x4_t pr[4], ds[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {       // query block j: rows j*16 + g*4 + r, column = this lane's key
+      f32x4_t sc = f32x4_t{0.f, 0.f, 0.f, 0.f}, dp = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag16(Qs, j, ks, lane), kf[ks], sc, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag16(Ds, j, ks, lane), vf[ks], dp, 0, 0, 0);
+      }
+      const f32x4_t ls = *reinterpret_cast<const f32x4_t*>(&lse_s[slot][j * 16 + g * 4]);
+      const f32x4_t dl4 = *reinterpret_cast<const f32x4_t*>(&dl_s[slot][j * 16 + g * 4]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ql = j * 16 + g * 4 + r;
+        const bool on = (word_s[slot][ql] >> kbit) & 1ull;
+        const float e = on ? __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], c1, -ls[r])) : 0.f;
+        pr[j][r] = e;
+        ds[j][r] = e * __builtin_fmaf(dp[r], p.scale, -dl4[r]);
+      }
+    }
+    const bf16x8_t pf0 = pack_p(pr[0], pr[1]), pf1 = pack_p(pr[2], pr[3]);
+    const bf16x8_t sf0 = pack_p(ds[0], ds[1]), sf1 = pack_p(ds[2], ds[3]);
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      dvt[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag16_tr(Ds, d, 0, lane), pf0, dvt[d], 0, 0, 0);
+      dkt[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag16_tr(Qs, d, 0, lane), sf0, dkt[d], 0, 0, 0);
+    }
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      dvt[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag16_tr(Ds, d, 1, lane), pf1, dvt[d], 0, 0, 0);
+      dkt[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag16_tr(Qs, d, 1, lane), sf1, dkt[d], 0, 0, 0);
+    }
+    qt = qn;
+  }
+  // wave-private transpose through LDS (the ring is dead once every wave is past its last tile): [16 keys][128 d] fp32 per
+  // tensor, then every atomic instruction covers 64 consecutive floats of one key row
+  __syncthreads();
+  float* tw = reinterpret_cast<float*>(ring) + wave * (16 * 132);
+  const int ldws = 2 * p.HKV * HD;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+    for (int d = 0; d < 8; ++d)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tw[(lane & 15) * 132 + d * 16 + g * 4 + r] = pass == 0 ? dkt[d][r] : dvt[d][r];
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int kr = t * 64 + wave * 16 + i;
+      if (kr < p.L) {
+        float* dst = p.dkv_ws + ((int64_t)b * p.L + kr) * ldws + (pass * p.HKV + hk) * HD;
+        atomicAdd(dst + lane, tw[i * 132 + lane]);
+        atomicAdd(dst + 64 + lane, tw[i * 132 + 64 + lane]);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
 // workspace -> bf16 dK | dV (row stride ldg) and re-zero the workspace for the next layer
 __global__ __launch_bounds__(256) void dkv_finish_kernel(float* __restrict__ ws, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv,
                                                          int64_t ldg, int64_t tokens, int kvw) {
@@ -1043,7 +1199,9 @@ extern "C" int ug_attn_bwd(const void* q, const void* k, const void* v, int64_t 
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(wg_grid(a.nW, H, HKV, B)), dim3(256), 0, st, a);
   UG_CHECK_LAUNCH("ug_attn_bwd(dq)");
   if (dkv_ws) {
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, dim3(wg_grid(a.nW, H, HKV, B)), dim3(256), 0, st, a);
+    static const int dma = [] { const char* e = getenv("UNIGEN_ATTN_DKV_DMA"); return e ? atoi(e) : 1; }();
+    if (dma && L <= 4096) hipLaunchKernelGGL(attn_bwd_dkv_dma_kernel, dim3(wg_grid(a.nW, H, HKV, B)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, dim3(wg_grid(a.nW, H, HKV, B)), dim3(256), 0, st, a);
     UG_CHECK_LAUNCH("ug_attn_bwd(dkv split)");
     const int64_t total = B * L * (2 * HKV * HD / 4);
     int64_t gsz = (total + 255) / 256; if (gsz > 4096) gsz = 4096;
