@@ -334,7 +334,8 @@ int ug_conv_split_weights(const float* w_packed, uint16_t* w_split, int taps, in
 int ug_amax_f32(const float* x, int64_t rows, int64_t cols, int64_t ld, float* out_amax, hipStream_t stream);
 int ug_conv2d_split(const float* x, const float* x_amax, const uint16_t* w_split, const float* bias, const float* residual,
                     float* y, int64_t B, int Hin, int Win, int Cin, int Cout, int cout_pad, int ksize, int stride,
-                    int pad_top, int pad_left, int Hout, int Wout, int upsample2x, hipStream_t stream);
+                    int pad_top, int pad_left, int Hout, int Wout, int upsample2x, double* out_stats, int out_groups,
+                    hipStream_t stream);   /* out_stats: as ug_conv3x3_split (needs Hout * Wout % 128 == 0), or null */
 /* 3x3 / stride 1 / pad 1 convolution (every conv1/conv2 of ResnetBlock, conv_in/conv_out of the middle stacks:
  * common_modules.py:301-360, magvitv2.py:90-178) with the split operands of ug_conv2d_split and the 10 x 18 input
  * patch of an 8 x 16 output block resident in LDS for all nine taps.  With gn_mu_rstd (from ug_groupnorm_stats on
@@ -343,7 +344,16 @@ int ug_conv2d_split(const float* x, const float* x_amax, const uint16_t* w_split
  * as in the reference.  x_amax then bounds the NORMALISED tensor. */
 int ug_conv3x3_split(const float* x, const float* x_amax, const uint16_t* w_split, const float* bias, const float* residual,
                      float* y, int64_t B, int H, int W, int Cin, int Cout, int cout_pad, const float* gn_mu_rstd,
-                     const float* gn_gamma, const float* gn_beta, int gn_groups, int gn_swish, hipStream_t stream);
+                     const float* gn_gamma, const float* gn_beta, int gn_groups, int gn_swish, double* out_stats, int out_groups,
+                     hipStream_t stream);
+/* out_stats (or null): [B][out_groups][2] fp64 + one more 8-byte slot, ZEROED BY THE CALLER -- the sum and the sum of squares of
+ * the stored y per (image, group), gathered in the convolution's epilogue with the arithmetic of ug_groupnorm_stats, for the
+ * GroupNorm that consumes y (ResnetBlock.forward, common_modules.py:308-335: norm2 reads conv1's output, the next block's norm1
+ * reads conv2's output + shortcut); ug_groupnorm_finalize turns them into (mean, rstd) without another pass over y.  The
+ * trailing slot receives max|y| as an fp32 in its first four bytes (what ug_amax_f32 computes): the x_amax of a following split
+ * convolution that has no GroupNorm on its load path (Downsample, nin_shortcut: common_modules.py:86-93,321-334). */
+int ug_groupnorm_finalize(const double* stats, float* mu_rstd, int64_t B, int64_t HW, int C, int groups, float eps,
+                          hipStream_t stream);
 /* GroupNorm statistics only: stats_ws [B][groups][2] fp64 scratch, mu_rstd [B][groups][2] fp32 = (mean, rstd),
  * rounded as ug_groupnorm_swish rounds them (common_modules.py:19-27). */
 int ug_groupnorm_stats(const float* x, double* stats_ws, float* mu_rstd, int64_t B, int64_t HW, int C, int groups,

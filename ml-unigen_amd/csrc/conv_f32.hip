@@ -565,6 +565,17 @@ extern "C" int ug_groupnorm_stats(const float* x, double* stats_ws, float* mu_rs
   return UG_OK;
 }
 
+extern "C" int ug_groupnorm_finalize(const double* stats, float* mu_rstd, int64_t B, int64_t HW, int C, int groups, float eps,
+                                     hipStream_t st) {
+  UG_REQUIRE(B > 0 && HW > 0 && groups > 0 && C % groups == 0 && stats && mu_rstd && ((uintptr_t)mu_rstd & 7) == 0,
+             "ug_groupnorm_finalize: bad args (C=%d groups=%d)", C, groups);
+  const int n_stats = (int)(B * groups);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)((n_stats + 255) / 256)), dim3(256), 0, st, stats,
+                     reinterpret_cast<float2*>(mu_rstd), n_stats, (double)HW * (C / groups), eps);
+  UG_CHECK_LAUNCH("ug_groupnorm_finalize");
+  return UG_OK;
+}
+
 extern "C" int ug_softmax_rows_f32(float* x, int64_t rows, int64_t cols, int64_t ld, float scale, hipStream_t st) {
   UG_REQUIRE(rows > 0 && cols > 0 && ld >= cols, "ug_softmax_rows_f32: bad shape");
   hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, (int)rows, (int)cols, ld, scale);

@@ -44,6 +44,9 @@ struct SplitArgs {
   int kslabs;              // ceil(Cin / 32): a ragged last slab reads zeros (weights are packed zero-padded)
   int64_t ldx, ldy, ldres; // row strides of x (per input pixel), y and residual (per output pixel), elements
   int act;                 // 1: gelu_pytorch_tanh before the residual add
+  double* stats_out;       // [B][Cout / out_cpg][2] sums of y for the GroupNorm that reads it (see QuadStats), or null;
+  int out_cpg;             // needs Hout * Wout % 128 == 0 (a pixel tile inside one image)
+  float* amax_out;         // max |y| (with stats_out)
 };
 
 // LDS image of one plane: row r (64 B), 16-byte chunk c (8 k) stored at chunk c ^ ((-(r >> 2)) & 3).  A ds_read_b128 is
@@ -66,7 +69,7 @@ __device__ __forceinline__ void store_split_quad(bf16_t* planes, int plane_strid
 }
 
 // result block epilogue: four consecutive output channels of one pixel.  y = act(acc * 2^-(ex+ew) + bias) + residual
-__device__ __forceinline__ void store_out_quad(f32x4_t a, float unscale, const float* bias, const float* res, float* y, int act) {
+__device__ __forceinline__ f32x4_t store_out_quad(f32x4_t a, float unscale, const float* bias, const float* res, float* y, int act) {
   float v[4] = {a[0] * unscale, a[1] * unscale, a[2] * unscale, a[3] * unscale};
   if (bias) {
     const float4 b = *reinterpret_cast<const float4*>(bias);
@@ -84,6 +87,58 @@ __device__ __forceinline__ void store_out_quad(f32x4_t a, float unscale, const f
     v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
   }
   *reinterpret_cast<float4*>(y) = make_float4(v[0], v[1], v[2], v[3]);
+  return f32x4_t{v[0], v[1], v[2], v[3]};
+}
+
+// Statistics of the NEXT GroupNorm gathered while the output is stored (the consumer of almost every 3x3 convolution of a
+// ResnetBlock is a GroupNorm: common_modules.py:308-335): fp64 sum and sum of squares of the stored fp32 values, exactly the
+// arithmetic of gn_stats_kernel (conv_f32.hip) -- a lane's channel quad lies inside one group (channels per group >= 4) --
+// reduced over the 16 pixel lanes, then over the workgroup through 2 x 32 LDS slots (one per quad of its 128 channels), then
+// ONE fp64 atomic per quad and statistic into stats[b][group][2].  Saves the separate pass over the tensor (537 MB at 256^2).
+struct QuadStats {
+  double s1, s2;
+  __device__ __forceinline__ void add(f32x4_t v) {
+    s1 += ((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3]);
+    s2 += ((double)v[0] * v[0] + (double)v[1] * v[1]) + ((double)v[2] * v[2] + (double)v[3] * v[3]);
+  }
+};
+__device__ __forceinline__ float quad_absmax(f32x4_t v) {
+  return fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+}
+__device__ __forceinline__ double shfl_xor_f64(double v, int m) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __shfl_xor(lo, m, 64); hi = __shfl_xor(hi, m, 64);
+  return __hiloint2double(hi, lo);
+}
+// qs[i]: this lane's sums for output block i (quad index within the workgroup's channel range: qbase + i * 4 + g)
+// mx: max |y| over this lane's stored values -> *amax_out (order-preserving unsigned max of the float bits, as amax_kernel):
+// the scale bound a following split convolution WITHOUT a GroupNorm on its load path (Downsample, nin_shortcut) needs of its
+// input, without the pass over the tensor.
+template <int NI>
+__device__ __forceinline__ void flush_quad_stats(QuadStats (&qs)[NI], float mx, double* sred, int qbase, int g, int l16, int tid,
+                                                 int n0, int Cout, int out_cpg, double* stats_b, float* amax_out) {
+  if (tid < 64) sred[tid] = 0.0;
+  unsigned int* mred = reinterpret_cast<unsigned int*>(sred + 64);
+  if (tid == 0) *mred = 0u;
+  __syncthreads();
+  mx = wave_max(mx);
+  if ((tid & 63) == 0) atomicMax(mred, __float_as_uint(mx));
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    double a = qs[i].s1, b = qs[i].s2;
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) { a += shfl_xor_f64(a, m); b += shfl_xor_f64(b, m); }
+    if (l16 == 0) {
+      atomicAdd(&sred[2 * (qbase + i * 4 + g)], a);
+      atomicAdd(&sred[2 * (qbase + i * 4 + g) + 1], b);
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const int n = n0 + (tid >> 1) * 4;                    // first channel of quad tid / 2
+    if (n < Cout) atomicAdd(stats_b + (n / out_cpg) * 2 + (tid & 1), sred[tid]);
+  }
+  if (tid == 64 && *mred) atomicMax(reinterpret_cast<unsigned int*>(amax_out), *mred);
 }
 
 // GroupNorm (+ swish) of a channel quad: gn_apply_kernel's arithmetic (conv_f32.hip) with the sigmoid on the hardware
@@ -229,6 +284,10 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitArgs p) {
   }
 
   // epilogue: block (i, j): lane holds channels n..n+3 (n = 16 i + 4 g) of pixel 16 j + l16
+  QuadStats qs[NI];
+  float mx = 0.f;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) qs[i] = QuadStats{0.0, 0.0};
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int m = m0 + wm * 64 + j * 16 + l16;
@@ -237,9 +296,16 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitArgs p) {
     for (int i = 0; i < NI; ++i) {
       const int n = nblk * SBN + nhalf * 64 + wn * (NI * 16) + i * 16 + g * 4;
       if (n >= p.Cout) continue;
-      store_out_quad(acc[i][j], unscale, p.bias ? p.bias + n : nullptr, p.res ? p.res + (int64_t)m * p.ldres + n : nullptr,
-                     p.y + (int64_t)m * p.ldy + n, p.act);
+      const f32x4_t v = store_out_quad(acc[i][j], unscale, p.bias ? p.bias + n : nullptr,
+                                       p.res ? p.res + (int64_t)m * p.ldres + n : nullptr, p.y + (int64_t)m * p.ldy + n, p.act);
+      qs[i].add(v);
+      mx = fmaxf(mx, quad_absmax(v));
     }
+  }
+  if (p.stats_out) {
+    __syncthreads();
+    flush_quad_stats<NI>(qs, mx, reinterpret_cast<double*>(Ws), wn * NI * 4, g, l16, tid, nblk * SBN + nhalf * 64, p.Cout, p.out_cpg,
+                         p.stats_out + (int64_t)(m0 / hw) * (p.Cout / p.out_cpg) * 2, p.amax_out);
   }
 }
 
@@ -260,6 +326,9 @@ struct PatchArgs {
   const float2* mu_rstd;   // [B][G] mean / rstd of the input's GroupNorm, or null: x is used as is
   const float* gamma; const float* beta;
   int cpg, G, swish;
+  double* stats_out;       // [B][Cout / out_cpg][2] fp64 sum / sum of squares of y (zeroed by the caller), or null
+  int out_cpg;
+  float* amax_out;         // max |y| (with stats_out)
 };
 
 // NI: 16-channel output blocks per wave.  4 = 128 output channels per workgroup; 2 = 64 (half of a weight tile's rows),
@@ -366,6 +435,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(PatchArgs p) {
 
   // epilogue: block (i, j): channels n..n+3 of output pixel (y0 + 4 wm + j, x0 + l16)
   const int ox = x0 + l16;
+  QuadStats qs[NI];
+  float mx = 0.f;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) qs[i] = QuadStats{0.0, 0.0};
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int oy = y0 + wm * 4 + j;
@@ -375,9 +448,16 @@ __global__ __launch_bounds__(256, 2) void conv3x3_patch_kernel(PatchArgs p) {
     for (int i = 0; i < NI; ++i) {
       const int n = nblk * SBN + nhalf * 64 + wn * (NI * 16) + i * 16 + g * 4;
       if (n >= p.Cout) continue;
-      store_out_quad(acc[i][j], unscale, p.bias ? p.bias + n : nullptr, p.res ? p.res + m * p.Cout + n : nullptr,
-                     p.y + m * p.Cout + n, 0);
+      const f32x4_t v = store_out_quad(acc[i][j], unscale, p.bias ? p.bias + n : nullptr, p.res ? p.res + m * p.Cout + n : nullptr,
+                                       p.y + m * p.Cout + n, 0);
+      qs[i].add(v);
+      mx = fmaxf(mx, quad_absmax(v));
     }
+  }
+  if (p.stats_out) {
+    __syncthreads();                                         // the weight tile's LDS is free now
+    flush_quad_stats<NI>(qs, mx, reinterpret_cast<double*>(Ws), wn * NI * 4, g, l16, tid, nblk * SBN + nhalf * 64, p.Cout, p.out_cpg,
+                         p.stats_out + (int64_t)b * (p.Cout / p.out_cpg) * 2, p.amax_out);
   }
 }
 
@@ -547,6 +627,10 @@ __global__ __launch_bounds__(512) void conv3x3_patch16_kernel(PatchArgs p) {
   }
 
   const int ox = x0 + l16;
+  QuadStats qs[4];
+  float mx = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) qs[i] = QuadStats{0.0, 0.0};
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int oy = y0 + wm * 4 + j;
@@ -556,9 +640,16 @@ __global__ __launch_bounds__(512) void conv3x3_patch16_kernel(PatchArgs p) {
     for (int i = 0; i < 4; ++i) {
       const int n = nblk * SBN + wn * 64 + i * 16 + g * 4;
       if (n >= p.Cout) continue;
-      store_out_quad(acc[i][j], unscale, p.bias ? p.bias + n : nullptr, p.res ? p.res + m * p.Cout + n : nullptr,
-                     p.y + m * p.Cout + n, 0);
+      const f32x4_t v = store_out_quad(acc[i][j], unscale, p.bias ? p.bias + n : nullptr, p.res ? p.res + m * p.Cout + n : nullptr,
+                                       p.y + m * p.Cout + n, 0);
+      qs[i].add(v);
+      mx = fmaxf(mx, quad_absmax(v));
     }
+  }
+  if (p.stats_out) {
+    __syncthreads();                                         // every DMA has landed (vmcnt(0) at the last tap) and been read
+    flush_quad_stats<4>(qs, mx, reinterpret_cast<double*>(W0), wn * 16, g, l16, tid, nblk * SBN, p.Cout, p.out_cpg,
+                        p.stats_out + (int64_t)b * (p.Cout / p.out_cpg) * 2, p.amax_out);
   }
 }
 
@@ -670,8 +761,13 @@ extern "C" int ug_conv_split_weights(const float* w_packed, uint16_t* w_split, i
 
 extern "C" int ug_conv2d_split(const float* x, const float* x_amax, const uint16_t* w_split, const float* bias, const float* residual,
                                float* y, int64_t B, int Hin, int Win, int Cin, int Cout, int cout_pad, int ksize, int stride,
-                               int pad_top, int pad_left, int Hout, int Wout, int upsample2x, hipStream_t st) {
+                               int pad_top, int pad_left, int Hout, int Wout, int upsample2x, double* out_stats, int out_groups,
+                               hipStream_t st) {
   UG_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && ksize >= 1 && ksize <= 16, "ug_conv2d_split: bad shape");
+  UG_REQUIRE(!out_stats || (out_groups > 0 && Cout % out_groups == 0 && (Cout / out_groups) % 4 == 0 && (Hout * Wout) % SBM == 0 &&
+                            ((uintptr_t)out_stats & 7) == 0),
+             "ug_conv2d_split: output statistics need channels-per-group %% 4 == 0 and Hout * Wout %% 128 == 0 (Cout=%d groups=%d)",
+             Cout, out_groups);
   UG_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0 && cout_pad % SBN == 0 && cout_pad >= Cout,
              "ug_conv2d_split: needs Cin %% 4 == 0, Cout %% 4 == 0, cout_pad %% 128 == 0 (Cin=%d Cout=%d cout_pad=%d)", Cin,
              Cout, cout_pad);
@@ -687,6 +783,10 @@ extern "C" int ug_conv2d_split(const float* x, const float* x_amax, const uint16
   a.KH = ksize; a.KW = ksize; a.stride = stride; a.pad_t = pad_top; a.pad_l = pad_left; a.ups = upsample2x;
   a.nblks = cout_pad / SBN; a.M = (int)M; a.kslabs = (Cin + SBK - 1) / SBK;
   a.ldx = Cin; a.ldy = Cout; a.ldres = Cout;
+  if (out_stats) {
+    a.stats_out = out_stats; a.out_cpg = Cout / out_groups;
+    a.amax_out = reinterpret_cast<float*>(out_stats + 2 * B * out_groups);
+  }
   launch_split(a, M, Cout, st);
   UG_CHECK_LAUNCH("ug_conv2d_split");
   return UG_OK;
@@ -717,8 +817,11 @@ extern "C" int ug_linear_split(const float* x, int64_t ldx, const float* x_amax,
 
 extern "C" int ug_conv3x3_split(const float* x, const float* x_amax, const uint16_t* w_split, const float* bias, const float* residual,
                                 float* y, int64_t B, int H, int W, int Cin, int Cout, int cout_pad, const float* gn_mu_rstd,
-                                const float* gn_gamma, const float* gn_beta, int gn_groups, int gn_swish, hipStream_t st) {
+                                const float* gn_gamma, const float* gn_beta, int gn_groups, int gn_swish, double* out_stats,
+                                int out_groups, hipStream_t st) {
   UG_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "ug_conv3x3_split: bad shape");
+  UG_REQUIRE(!out_stats || (out_groups > 0 && Cout % out_groups == 0 && (Cout / out_groups) % 4 == 0 && ((uintptr_t)out_stats & 7) == 0),
+             "ug_conv3x3_split: output statistics need channels-per-group %% 4 == 0 (Cout=%d groups=%d)", Cout, out_groups);
   UG_REQUIRE(Cin % SBK == 0 && Cout % 4 == 0 && cout_pad % SBN == 0 && cout_pad >= Cout,
              "ug_conv3x3_split: needs Cin %% 32 == 0, Cout %% 4 == 0, cout_pad %% 128 == 0 (Cin=%d Cout=%d cout_pad=%d)", Cin,
              Cout, cout_pad);
@@ -729,6 +832,10 @@ extern "C" int ug_conv3x3_split(const float* x, const float* x_amax, const uint1
   a.x = x; a.w = (const bf16_t*)w_split; a.bias = bias; a.res = residual; a.y = y;
   a.x_amax = x_amax; a.w_amax = reinterpret_cast<const float*>(w_split + split_tile_elems(9, Cin, cout_pad));
   a.B = (int)B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.nblks = cout_pad / SBN; a.kslabs = Cin / SBK;
+  if (out_stats) {
+    a.stats_out = out_stats; a.out_cpg = Cout / out_groups;
+    a.amax_out = reinterpret_cast<float*>(out_stats + 2 * B * out_groups);
+  }
   // 16-row tiles (eight waves, DMA-fed weights) when they still give every CU two workgroups' worth of work
   const int nb_n = (Cout + SBN - 1) / SBN;
   const int64_t big_tiles = B * ((W + PT_W - 1) / PT_W) * ((H + QT_H - 1) / QT_H);

@@ -148,6 +148,8 @@ class MAGVITv2(ModelMixin, ConfigMixin):
         # True: every conv on the exact fp32 MFMA chain (ug_conv2d_f32) and stand-alone GroupNorm passes;
         # False (default): wide convs on the split-f16 contraction.  Flip it on an instance to compare the two.
         self.exact_fp32_convs = not _SPLIT_CONV
+        # GroupNorm sums gathered in the producing convolution's epilogue (UNIGEN_GN_FUSE_STATS=0: a separate pass per norm)
+        self.fuse_gn_stats = os.environ.get("UNIGEN_GN_FUSE_STATS", "1") != "0"
 
     # ------------------------------------------------------------------ plumbing
     def _apply(self, fn, *a, **k):
@@ -159,7 +161,7 @@ class MAGVITv2(ModelMixin, ConfigMixin):
         return super().load_state_dict(*a, **k)
 
     def _pk(self, conv, pad_cin_to=None):
-        key = (id(conv), self.exact_fp32_convs)
+        key = (id(conv), self.exact_fp32_convs, pad_cin_to)
         ver = conv.weight._version
         hit = self._packed.get(key)
         if hit is not None and hit[0] == ver:
@@ -179,20 +181,47 @@ class MAGVITv2(ModelMixin, ConfigMixin):
         self._packed[key] = (ver, p)
         return p
 
-    def _conv(self, x, conv, residual=None, upsample=False, asym=False, pad_cin_to=None, norm=None, swish=True):
+    def _conv(self, x, conv, residual=None, upsample=False, asym=False, pad_cin_to=None, norm=None, swish=True, stats=False):
         """conv(x), or conv(swish?(norm(x))) when `norm` (a GroupNorm) is given.  Wide 3x3 stride-1 convs take the
-        LDS-resident-patch kernel, which applies the normalisation on its load path."""
+        LDS-resident-patch kernel, which applies the normalisation on its load path and -- `stats=True`: the output feeds a
+        GroupNorm(32) -- gathers that norm's sums while it stores (the result carries them as `_ug_gn_stats`)."""
         p = self._pk(conv, pad_cin_to)
         if p.ws is not None and p.k == 3 and not upsample and not asym:
             gn, bound = None, None
+            st_in = getattr(x, "_ug_gn_stats", None)
             if norm is not None:
-                gn = (ops.groupnorm_stats(x, groups=32, eps=norm.eps), norm.weight.detach(), norm.bias.detach(), 32, swish)
+                mr = (ops.groupnorm_finalize(st_in, x.shape[0], x.shape[1] * x.shape[2], x.shape[3], groups=32, eps=norm.eps)
+                      if st_in is not None else ops.groupnorm_stats(x, groups=32, eps=norm.eps))
+                gn = (mr, norm.weight.detach(), norm.bias.detach(), 32, swish)
                 bound = self._gn_bound(norm, (x.shape[3] // 32) * x.shape[1] * x.shape[2])
-            return ops.conv3x3_nhwc(x, p.ws, p.cpad, p.bias, p.cout, residual=residual, gn=gn, gn_bound=bound)
+            st = self._stats_slot(x) if stats and p.cout % 128 == 0 else None
+            y = ops.conv3x3_nhwc(x, p.ws, p.cpad, p.bias, p.cout, residual=residual, gn=gn, gn_bound=bound, out_stats=st,
+                                 x_amax=ops.stats_amax(st_in) if norm is None and st_in is not None else None)
+            if st is not None:
+                y._ug_gn_stats = st
+            return y
         if norm is not None:
             x = self._norm(x, norm, swish)
-        return ops.conv2d_nhwc(x, p.w, p.cpad, p.bias, p.cout, p.k, stride=2 if asym else 1, asym_pad=asym,
-                               upsample=upsample, residual=residual, w_split=p.ws)
+        st_in = getattr(x, "_ug_gn_stats", None) if p.ws is not None else None       # (a normalised x is a new tensor: no attribute)
+        st = None
+        if stats and p.ws is not None and p.cout % 128 == 0:
+            Ho, Wo = (x.shape[1] // 2, x.shape[2] // 2) if asym else (x.shape[1] * 2, x.shape[2] * 2) if upsample else x.shape[1:3]
+            st = self._stats_slot(x) if (Ho * Wo) % 128 == 0 else None
+        y = ops.conv2d_nhwc(x, p.w, p.cpad, p.bias, p.cout, p.k, stride=2 if asym else 1, asym_pad=asym, upsample=upsample,
+                            residual=residual, w_split=p.ws, out_stats=st, x_amax=ops.stats_amax(st_in) if st_in is not None else None)
+        if st is not None:
+            y._ug_gn_stats = st
+        return y
+
+    def _stats_slot(self, x):
+        """a zeroed statistics buffer for a convolution whose output feeds a GroupNorm(32) (one pooled allocation per pass)"""
+        if not self.fuse_gn_stats:
+            return None
+        pool = self.__dict__.get("_stats_pool")
+        if not pool or pool[0] != x.shape[0] or not pool[1]:
+            pool = (x.shape[0], ops.gn_stats_slots(64, x.shape[0], x.device))
+            self.__dict__["_stats_pool"] = pool
+        return pool[1].pop()
 
     def _gn_bound(self, norm, group_elems):
         """scale bound of swish?(norm(x)) for the split convolution that applies `norm` on its load path, from the layer's own
@@ -210,9 +239,9 @@ class MAGVITv2(ModelMixin, ConfigMixin):
         return ops.groupnorm_swish(x, gn.weight.detach(), gn.bias.detach(), groups=32, eps=gn.eps, swish=swish)
 
     def _res(self, x, blk):
-        h = self._conv(x, blk.conv1, norm=blk.norm1)
+        h = self._conv(x, blk.conv1, norm=blk.norm1, stats=True)                 # read by norm2
         skip = self._conv(x, blk.nin_shortcut) if hasattr(blk, "nin_shortcut") else x
-        return self._conv(h, blk.conv2, residual=skip, norm=blk.norm2)
+        return self._conv(h, blk.conv2, residual=skip, norm=blk.norm2, stats=True)   # read by the next block's norm1 / norm_out
 
     def _attn(self, x, a):
         B, H, W, C = x.shape
@@ -232,13 +261,17 @@ class MAGVITv2(ModelMixin, ConfigMixin):
     def _encode_z(self, pixel_values):
         """NCHW fp32 image -> pre-quantisation latents, NHWC [B, 16, 16, 13]."""
         e = self.encoder
-        x = ops.nchw_to_nhwc(pixel_values.float().contiguous(), 4)        # pad RGB to 4 channels (16-byte pixels)
-        h = self._conv(x, e.conv_in, pad_cin_to=4)
+        # RGB padded with zero channels: to one 32-channel slab of the LDS-resident-patch kernel (a quarter of a 128 -> 128 layer's
+        # time, and the first GroupNorm's sums come with it; the exact fp32 im2col kernel on 4-channel pixels wrote its 537 MB
+        # output at 0.9 TB/s: 0.62 ms + a 0.15 ms statistics pass), or to 4 channels (16-byte pixels) on the exact-fp32 path
+        cpad_in = 4 if self.exact_fp32_convs or not self.fuse_gn_stats else 32
+        x = ops.nchw_to_nhwc(pixel_values.float().contiguous(), cpad_in)
+        h = self._conv(x, e.conv_in, pad_cin_to=cpad_in, stats=True)
         for lvl, level in enumerate(e.down):
             for blk in level.block:
                 h = self._res(h, blk)
             if hasattr(level, "downsample"):
-                h = self._conv(h, level.downsample.conv, asym=True)
+                h = self._conv(h, level.downsample.conv, asym=True, stats=True)
         h = self._mid(h, e.mid)
         h = self._conv(h, e.conv_out, norm=e.norm_out)
         return self._conv(h, e.quant_conv)
@@ -253,7 +286,7 @@ class MAGVITv2(ModelMixin, ConfigMixin):
             for blk in level.block:
                 h = self._res(h, blk)
             if hasattr(level, "upsample"):
-                h = self._conv(h, level.upsample.conv, upsample=True)
+                h = self._conv(h, level.upsample.conv, upsample=True, stats=True)
         return self._conv(h, d.conv_out, norm=d.norm_out)
 
     # ------------------------------------------------------------------ reference API

@@ -680,11 +680,12 @@ def amax(x2d):
 
 
 def conv2d_nhwc(x, wp, cout_pad, bias, cout, ksize, *, stride=1, pad=None, residual=None, upsample=False,
-                asym_pad=False, w_split=None, x_amax=None):
+                asym_pad=False, w_split=None, x_amax=None, out_stats=None, out_groups=32):
     """x [B,H,W,Cin] fp32 NHWC -> [B,Ho,Wo,Cout].  asym_pad: the reference Downsample's pad (0,1,0,1) +
     stride-2 valid conv (common_modules.py:86-93).  With `w_split` (from `split_conv_weight`) the contraction runs as
     three f16 MFMA terms of the scaled two-way split operands instead of on the fp32 MFMA; `x_amax` (device scalar, an
-    upper bound of max|x|) sets the activation scale, measured here when not given."""
+    upper bound of max|x|) sets the activation scale, measured here when not given.  out_stats (split path, output
+    pixels per image % 128 == 0): as `conv3x3_nhwc`."""
     B, H, W, Cin = x.shape
     He, We = (2 * H, 2 * W) if upsample else (H, W)
     if asym_pad:
@@ -697,9 +698,14 @@ def conv2d_nhwc(x, wp, cout_pad, bias, cout, ksize, *, stride=1, pad=None, resid
     if w_split is not None:
         if x_amax is None:
             x_amax = amax(x.view(-1, Cin))
+        if out_stats is not None and (out_stats.dtype != torch.float64 or out_stats.numel() != B * out_groups * 2 + 1):
+            raise _l.UniGenHipError("conv2d_nhwc: out_stats must be a zeroed fp64 buffer of B * groups * 2 + 1 elements (gn_stats_slots)")
         _l.check(_l.load().ug_conv2d_split(_p(x), _p(x_amax), _p(w_split), _p(bias), _p(residual), _p(y), B, H, W, Cin, cout,
-                                           cout_pad, ksize, stride, pt, pl, Ho, Wo, int(upsample), _stream()), "ug_conv2d_split")
+                                           cout_pad, ksize, stride, pt, pl, Ho, Wo, int(upsample), _p(out_stats),
+                                           int(out_groups) if out_stats is not None else 0, _stream()), "ug_conv2d_split")
         return y
+    if out_stats is not None:
+        raise _l.UniGenHipError("conv2d_nhwc: out_stats needs the split path (w_split)")
     _l.check(_l.load().ug_conv2d_f32(_p(x), _p(wp), _p(bias), _p(residual), _p(y), B, H, W, Cin, cout, cout_pad, ksize,
                                      stride, pt, pl, Ho, Wo, int(upsample), _stream()), "ug_conv2d_f32")
     return y
@@ -755,9 +761,36 @@ def gn_out_bound(gamma_absmax, beta_absmax, group_elems):
     return 2.0 ** math.ceil(math.log2(max(b, 1e-30)))
 
 
-def conv3x3_nhwc(x, w_split, cout_pad, bias, cout, *, residual=None, gn=None, x_amax=None, gn_bound=None):
+def gn_stats_slots(n, B, device, groups=32):
+    """n zeroed buffers for `conv3x3_nhwc / conv2d_nhwc(..., out_stats=)` out of ONE allocation (one clear for a whole encoder
+    pass): flat fp64 [B * groups * 2 + 1] each -- the sums per (image, group) and the trailing max|y| slot."""
+    per = B * groups * 2 + 1
+    pool = torch.zeros(n * per, dtype=torch.float64, device=device)
+    return [pool[i * per:(i + 1) * per] for i in range(n)]
+
+
+def stats_amax(stats):
+    """the fp32 max|y| a convolution left in the trailing slot of its `out_stats` buffer (a 1-element device tensor)"""
+    return stats[-1:].view(torch.float32)[:1]
+
+
+def groupnorm_finalize(stats, B, HW, C, *, groups=32, eps=1e-6):
+    """(mean, rstd) [B, groups, 2] fp32 from the fp64 sums a convolution gathered while storing its output
+    (`conv3x3_nhwc(..., out_stats=)`): `groupnorm_stats` without the pass over the tensor."""
+    if stats.numel() != B * groups * 2 + 1:
+        raise _l.UniGenHipError("groupnorm_finalize: stats buffer does not match B x groups")
+    mr = torch.empty((B, groups, 2), dtype=torch.float32, device=stats.device)
+    _l.check(_l.load().ug_groupnorm_finalize(_p(stats), _p(mr), B, HW, C, groups, eps, _stream()), "ug_groupnorm_finalize")
+    return mr
+
+
+def conv3x3_nhwc(x, w_split, cout_pad, bias, cout, *, residual=None, gn=None, x_amax=None, gn_bound=None, out_stats=None,
+                 out_groups=32):
     """3x3 / stride 1 / pad 1 convolution of NHWC fp32 x with split weights (`split_conv_weight`), input patch resident
-    in LDS.  gn = (mu_rstd, gamma, beta, groups, swish): apply swish?(GroupNorm(x)) on the load path; the scale bound of the
+    in LDS.  out_stats (a ZEROED buffer from `gn_stats_slots`): the epilogue also gathers the fp64 (sum, sum of squares) of the
+    output per (image, group) and max|y| into it -- input of `groupnorm_finalize` for the GroupNorm that reads y, and of
+    `stats_amax` for a split convolution that reads y directly.
+    gn = (mu_rstd, gamma, beta, groups, swish): apply swish?(GroupNorm(x)) on the load path; the scale bound of the
     normalised tensor, `gn_bound`, is then known without a pass over it: `gn_out_bound` of the layer's gamma / beta (required
     with gn -- a fixed constant would silently saturate activations of a checkpoint with larger affine parameters).  Without
     gn the bound is measured unless `x_amax` is given."""
@@ -768,8 +801,11 @@ def conv3x3_nhwc(x, w_split, cout_pad, bias, cout, *, residual=None, gn=None, x_
         if gn is not None and gn_bound is None:
             raise _l.UniGenHipError("conv3x3_nhwc: GroupNorm on the load path needs gn_bound (ops.gn_out_bound of the layer's gamma / beta)")
         x_amax = amax_const(gn_bound, x.device) if gn is not None else amax(x.view(-1, Cin))
+    if out_stats is not None and (out_stats.dtype != torch.float64 or out_stats.numel() != B * out_groups * 2 + 1):
+        raise _l.UniGenHipError("conv3x3_nhwc: out_stats must be a zeroed fp64 buffer of B * groups * 2 + 1 elements (gn_stats_slots)")
     _l.check(_l.load().ug_conv3x3_split(_p(x), _p(x_amax), _p(w_split), _p(bias), _p(residual), _p(y), B, H, W, Cin, cout,
-                                        cout_pad, _p(mr), _p(ga), _p(be), groups, int(swish), _stream()), "ug_conv3x3_split")
+                                        cout_pad, _p(mr), _p(ga), _p(be), groups, int(swish), _p(out_stats),
+                                        int(out_groups) if out_stats is not None else 0, _stream()), "ug_conv3x3_split")
     return y
 
 

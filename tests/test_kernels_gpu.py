@@ -560,6 +560,43 @@ def test_conv3x3_patch_matches_fp64(dev, cin, cout, H, W, gn):
     assert _maxabs(got, unfused) < 3e-5
 
 
+@pytest.mark.parametrize("cin,cout,H,W", [(128, 128, 16, 32), (64, 256, 11, 21), (512, 512, 6, 6), (128, 128, 250, 263), (64, 256, 128, 128)])
+def test_conv3x3_epilogue_groupnorm_sums(dev, cin, cout, H, W):
+    """The sums of the consuming GroupNorm gathered in the convolution's epilogue (three kernel variants: 64- / 128-channel
+    8-row workgroups, 16-row eight-wave workgroups; ragged tiles; a residual) give the (mean, rstd) of the separate pass over
+    the stored output, and the fp64 statistics of that output."""
+    ops = _ops()
+    gen = torch.Generator().manual_seed(cin + 3 * cout + W)
+    B = 3 if H * W < 4096 else 2
+    x = (torch.randn(B, cin, H, W, generator=gen) * 2.0 + 0.3).permute(0, 2, 3, 1).contiguous().to(dev)
+    w = torch.randn(cout, cin, 3, 3, generator=gen) / math.sqrt(cin * 9)
+    bias = (torch.randn(cout, generator=gen) * 3.0).to(dev)
+    res = (torch.randn(B, H, W, cout, generator=gen) + 1.5).to(dev)
+    wp, cpad = ops.pack_conv_weight(w.to(dev))
+    ws = ops.split_conv_weight(wp)
+    plain = ops.conv3x3_nhwc(x, ws, cpad, bias, cout, residual=res)
+    st, st2 = ops.gn_stats_slots(2, B, dev)
+    y = ops.conv3x3_nhwc(x, ws, cpad, bias, cout, residual=res, out_stats=st)
+    assert torch.equal(y, plain)
+    assert torch.equal(ops.stats_amax(st), ops.amax(y.view(-1, cout)).view(1))
+    if (H * W) % 128 == 0:                                   # the im2col form of the same convolution gathers the same sums
+        y2 = ops.conv2d_nhwc(x, wp, cpad, bias, cout, 3, residual=res, w_split=ws, out_stats=st2)
+        mr2 = ops.groupnorm_finalize(st2, B, H * W, cout, groups=32, eps=1e-6)
+        assert (mr2 - ops.groupnorm_stats(y2, groups=32, eps=1e-6)).abs().max().item() == 0.0
+        assert torch.equal(ops.stats_amax(st2), ops.amax(y2.view(-1, cout)).view(1))
+    mr = ops.groupnorm_finalize(st, B, H * W, cout, groups=32, eps=1e-6)
+    mr_pass = ops.groupnorm_stats(y, groups=32, eps=1e-6)
+    y64 = y.double().view(B, H * W, 32, cout // 32)
+    mean = y64.mean(dim=(1, 3))
+    rstd = 1.0 / torch.sqrt(y64.var(dim=(1, 3), unbiased=False) + 1e-6)
+    e_mean = (mr[..., 0].double() - mean).abs().max().item()
+    e_rstd = ((mr[..., 1].double() - rstd).abs() / rstd).max().item()
+    d = (mr - mr_pass).abs().max().item()
+    print(f"    epilogue GroupNorm sums {cin}->{cout} {H}x{W}: mean err {e_mean:.1e}, rstd rel err {e_rstd:.1e}, vs the separate pass {d:.1e}")
+    assert e_mean < 2e-7 * max(1.0, mean.abs().max().item()) and e_rstd < 2e-7
+    assert d <= 2.4e-7 * max(1.0, mr_pass.abs().max().item())          # both are fp64 sums rounded to fp32 once
+
+
 def test_conv3x3_groupnorm_on_load_with_large_affine_parameters(dev):
     """the GroupNorm-on-load convolution took a FIXED bound (|gamma| <= 1, |beta| <= 12) for the scale of the
     normalised tensor, so a checkpoint with larger affine parameters would have saturated silently.  The bound now comes

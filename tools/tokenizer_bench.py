@@ -31,6 +31,8 @@ def timed(fn, reps=10):
 
 
 print(f"get_code(16 x 256^2) alone: {timed(lambda: vq.get_code(images)):.2f} ms", flush=True)
+if os.environ.get("ONLY_GET_CODE") == "1":       # kernel-trace runs: rocprofv3 --kernel-trace --stats -- python3 tools/tokenizer_bench.py
+    sys.exit(0)
 from unigen_hip import ops
 n = 1_543_000_000
 p, gr, m, v = (torch.zeros(n, device=dev) for _ in range(4))
