@@ -445,6 +445,33 @@ def main():
     ms = dt / args.steps * 1e3
     value = B * world / (dt / args.steps)
 
+    # north_star's stated target is a fraction of the bf16 MFMA roofline "on the 1.5B fwd/bwd at 1 GPU": time the backbone's
+    # forward + backward alone (same batch, tokens and mask prepared once; no tokenizer, no optimizer, no exchange), wall clock
+    fwd_bwd = None
+    if rank == 0 and world == 1 and not args.no_roofline:
+        with torch.no_grad():
+            codes = vq.get_code(images) + TEXT_VOCAB
+            ids, labels, mask = t2i_rows(ops, text, torch.full_like(codes, MASK_ID), codes)
+        opt.synchronize()
+
+        def fb():
+            _, l, _, _ = model(input_ids=ids, attention_mask=mask, labels=labels, batch_size_t2i=B,
+                               max_seq_length=args.text_len + 1, num_vq_tokens=NVQ)
+            l.backward()
+            opt.zero_grad(set_to_none=True)
+        fb()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            fb()
+        torch.cuda.synchronize()
+        t_fb = (time.perf_counter() - t0) / 5
+        fwd_bwd = {"ms": round(t_fb * 1e3, 2), "tflop": round(3 * B * FLOP_LLM_FWD / 1e12, 2),
+                   "achieved": round(3 * B * FLOP_LLM_FWD / t_fb / 1e12, 1), "unit": "TFLOP/s",
+                   "frac": round(3 * B * FLOP_LLM_FWD / t_fb / PEAK_BF16, 4),
+                   "what": "UniGen forward + backward of the 28-layer backbone, head and loss on the bench batch (5 iterations, "
+                           "wall clock); no tokenizer, optimizer or exchange"}
+
     roof = None
     if not args.no_roofline:
         # one more step with HIP events around every GEMM launch (on the launch stream): EVERY rank runs it -- the step
@@ -494,6 +521,7 @@ def main():
                 e.update(achieved=round(w / (t_ms * 1e-3) / 1e12, 2), unit="TFLOP/s" if bound != "hbm" else "TB/s", frac=round(w / (t_ms * 1e-3) / peak, 4))
             by_family[k] = e
         roof["by_family"] = by_family
+        roof["fwd_bwd_1p5b"] = fwd_bwd
     ar = None
     if rank == 0 and world == 1 and not args.no_ar:
         ar = ar_decode_bench(model, dev)

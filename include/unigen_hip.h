@@ -147,7 +147,11 @@ int ug_attn_bwd(const void* q, const void* k, const void* v, int64_t ldq,
                 const void* o, const void* dout, int64_t ldo, const float* lse,
                 float* delta, void* dq, void* dk, void* dv, int64_t ldg, const uint64_t* bits,
                 const uint8_t* tileany, int64_t B, int64_t L, int64_t Lp, int H, int HKV, int head_dim,
-                float scale, float* dkv_ws, hipStream_t stream);
+                float scale, float* dkv_ws, const float* rope_cos, const float* rope_sin, float* dbias_qkv, hipStream_t stream);
+/* rope_cos / rope_sin ([L][64] fp32, or null): dq and dk leave as the gradient w.r.t. the PRE-RoPE projections -- the transposed
+ * rotation of apply_rotary_pos_emb (modeling_qwen2.py:131-135) applied where the gradients are stored, same arithmetic as
+ * ug_rope(backward = 1) on the stored tensor.  dbias_qkv ([(H + 2 HKV) * 128] fp32, or null): += the column sums of the stored
+ * dq | dk | dv (the bias gradient of the fused q / k / v projection, what ug_colsum_bf16 over the three tensors adds). */
 
 /* ---- autoregressive decode (static KV cache, graph-capturable) -------------------------------- */
 /* replaces: transformers DynamicCache.update + SDPA on one new token per row inside

@@ -220,7 +220,34 @@ struct AttnArgs {
   int64_t ldq, ldo, ldg;
   int B, L, Lp, nW, H, HKV;
   float scale;
+  // backward only: RoPE transposed on dq / dk before they are stored, and the q | k | v bias gradient (column sums of the stored
+  // bf16 values) added into dbias[(H + 2 HKV) * 128] -- what the rope and colsum passes over dqkv did (or null: plain stores)
+  const float* rope_cos; const float* rope_sin; float* dbias;
 };
+
+// RoPE backward of one rotary pair, the arithmetic of rope_kernel<true> (elementwise.hip): the gradient is rounded to bf16
+// first (it arrives as a bf16 tensor in the reference), products and sums round separately
+__device__ __forceinline__ void rope_bwd_pair(float& g1, float& g2, float c, float s) {
+#pragma clang fp contract(off)
+  const float x1 = bf2f(f2bf(g1)), x2 = bf2f(f2bf(g2));
+  const float a1 = x1 * c, a2 = x2 * c;
+  const float b1 = x2 * s, b2 = x1 * s;
+  g1 = a1 + b1; g2 = a2 - b2;
+}
+// sum of x[v] over the 32 lanes n = lane & 31 (same lane half) by recursive halving: 62 exchanges instead of 320; lane n ends up
+// with the sums of v = 2 n and 2 n + 1 in x[0], x[1]
+template <int N>
+__device__ __forceinline__ void halve_sum(float (&x)[64], int lane, int m) {
+  const bool up = (lane & m) != 0;
+#pragma unroll
+  for (int i = 0; i < N / 2; ++i) {
+    const float lo = x[i], hi = x[i + N / 2];
+    x[i] = (up ? hi : lo) + __shfl_xor(up ? lo : hi, m, 64);
+  }
+}
+__device__ __forceinline__ void lanes32_colsum(float (&x)[64], int lane) {
+  halve_sum<64>(x, lane, 16); halve_sum<32>(x, lane, 8); halve_sum<16>(x, lane, 4); halve_sum<8>(x, lane, 2); halve_sum<4>(x, lane, 1);
+}
 
 // Workgroup -> (tile, head, batch).  Consecutive workgroup ids of a launch go round-robin over the 8 XCDs, each with a private
 // 4 MB L2; with a (tile, head, batch) grid every XCD meets every (batch, kv head) and re-fetches ALL K / V rows (12.6 MB at
@@ -773,6 +800,25 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq32_kernel(AttnArgs p) {
     t = tn;
     wcur = wnext;
   }
+  // register r of block d is column d * 32 + (r >> 2) * 8 + hh * 4 + (r & 3) of this lane's row: the rotary partner (column + 64)
+  // is register r of block d + 2 in the same lane
+  if (p.rope_cos) {
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int col = d * 32 + q * 8 + hh * 4;
+        const float4 c = *reinterpret_cast<const float4*>(p.rope_cos + (int64_t)qrow_c * (HD / 2) + col);
+        const float4 sn = *reinterpret_cast<const float4*>(p.rope_sin + (int64_t)qrow_c * (HD / 2) + col);
+        const float cc[4] = {c.x, c.y, c.z, c.w}, ss[4] = {sn.x, sn.y, sn.z, sn.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float g1 = dqt[d][q * 4 + e], g2 = dqt[d + 2][q * 4 + e];
+          rope_bwd_pair(g1, g2, cc[e], ss[e]);
+          dqt[d][q * 4 + e] = g1; dqt[d + 2][q * 4 + e] = g2;
+        }
+      }
+  }
   if (qrow < p.L) {
     bf16_t* drow = p.dq + ((int64_t)b * p.L + qrow) * p.ldg + h * HD;
 #pragma unroll
@@ -784,6 +830,30 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq32_kernel(AttnArgs p) {
         w.y = pack_bf2(dqt[d][q * 4 + 2], dqt[d][q * 4 + 3]);
         *reinterpret_cast<uint2*>(drow + d * 32 + q * 8 + hh * 4) = w;
       }
+  }
+  if (p.dbias) {
+    // bias gradient of the q projection: column sums of the stored (bf16) values over this workgroup's rows
+    float x[64];
+    const bool live = qrow < p.L;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) x[d * 16 + r] = live ? bf2f(f2bf(dqt[d][r])) : 0.f;
+    lanes32_colsum(x, lane);
+    __syncthreads();                                             // every wave is done with the K / V ring
+    float* red = reinterpret_cast<float*>(ring);                 // [NW][128]
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int v = 2 * n + e, d = v >> 4, r = v & 15;
+      red[wave * HD + d * 32 + (r >> 2) * 8 + hh * 4 + (r & 3)] = x[e];
+    }
+    __syncthreads();
+    if (tid < HD) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) t += red[w * HD + tid];
+      atomicAdd(p.dbias + h * HD + tid, t);
+    }
   }
 }
 
@@ -1073,6 +1143,84 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_dma_kernel(AttnArgs p) {
   }
 }
 
+// workspace -> bf16 dK | dV with RoPE transposed on dK and the k | v bias gradient (column sums of the stored values); re-zeroes
+// the workspace.  Thread = (row slot, kv head, 4-column group c4 of the first half): it owns columns c4*4.. and their rotary
+// partners (+64) of dK and dV for every row of its stripe, so the column sums stay in registers until the end.
+__global__ __launch_bounds__(256) void dkv_finish_rope_kernel(float* __restrict__ ws, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv,
+                                                              int64_t ldg, int64_t tokens, int L, int HKV,
+                                                              const float* __restrict__ cs, const float* __restrict__ sn,
+                                                              float* __restrict__ dbias_k, float* __restrict__ dbias_v,
+                                                              int rows_per_block) {
+  __shared__ float red[256 * 16];
+  const int per_row = HKV * 16;                              // threads per row (HKV * 16 <= 256, a power of two)
+  const int slot = threadIdx.x / per_row, nslots = 256 / per_row;
+  const int hk = (threadIdx.x % per_row) >> 4, c4 = threadIdx.x & 15;
+  const int kvw = HKV * HD;
+  float sum[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) sum[i] = 0.f;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(tokens, r0 + rows_per_block);
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  // two rows per thread in flight (the pass is latency-bound at the ~128 workgroups the atomics at its end allow)
+  for (int64_t rowa = r0 + slot; rowa < r1; rowa += 2 * nslots) {
+    float4 k1[2], k2[2], v1[2], v2[2];
+    bool ok[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int64_t row = rowa + u * nslots;
+      ok[u] = row < r1;
+      float* wk = ws + (ok[u] ? row : rowa) * 2 * kvw + hk * HD + c4 * 4;
+      float* wv = wk + kvw;
+      k1[u] = *reinterpret_cast<float4*>(wk); k2[u] = *reinterpret_cast<float4*>(wk + HD / 2);
+      v1[u] = *reinterpret_cast<float4*>(wv); v2[u] = *reinterpret_cast<float4*>(wv + HD / 2);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (!ok[u]) continue;
+      const int64_t row = rowa + u * nslots;
+      float* wk = ws + row * 2 * kvw + hk * HD + c4 * 4;
+      float* wv = wk + kvw;
+      *reinterpret_cast<float4*>(wk) = z; *reinterpret_cast<float4*>(wk + HD / 2) = z;
+      *reinterpret_cast<float4*>(wv) = z; *reinterpret_cast<float4*>(wv + HD / 2) = z;
+      if (cs) {
+        const int pos = (int)(row % L);
+        const float4 c = *reinterpret_cast<const float4*>(cs + (int64_t)pos * (HD / 2) + c4 * 4);
+        const float4 s = *reinterpret_cast<const float4*>(sn + (int64_t)pos * (HD / 2) + c4 * 4);
+        rope_bwd_pair(k1[u].x, k2[u].x, c.x, s.x); rope_bwd_pair(k1[u].y, k2[u].y, c.y, s.y);
+        rope_bwd_pair(k1[u].z, k2[u].z, c.z, s.z); rope_bwd_pair(k1[u].w, k2[u].w, c.w, s.w);
+      }
+      uint2 a, bq, cq, dq;
+      a.x = pack_bf2(k1[u].x, k1[u].y); a.y = pack_bf2(k1[u].z, k1[u].w);
+      bq.x = pack_bf2(k2[u].x, k2[u].y); bq.y = pack_bf2(k2[u].z, k2[u].w);
+      cq.x = pack_bf2(v1[u].x, v1[u].y); cq.y = pack_bf2(v1[u].z, v1[u].w);
+      dq.x = pack_bf2(v2[u].x, v2[u].y); dq.y = pack_bf2(v2[u].z, v2[u].w);
+      bf16_t* okp = dk + row * ldg + hk * HD + c4 * 4;
+      bf16_t* ovp = dv + row * ldg + hk * HD + c4 * 4;
+      *reinterpret_cast<uint2*>(okp) = a; *reinterpret_cast<uint2*>(okp + HD / 2) = bq;
+      *reinterpret_cast<uint2*>(ovp) = cq; *reinterpret_cast<uint2*>(ovp + HD / 2) = dq;
+      const uint32_t pk[8] = {a.x, a.y, bq.x, bq.y, cq.x, cq.y, dq.x, dq.y};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        sum[2 * i] += bf2f((bf16_t)(pk[i] & 0xffffu));
+        sum[2 * i + 1] += bf2f((bf16_t)(pk[i] >> 16));
+      }
+    }
+  }
+  if (!dbias_k) return;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) red[i * 256 + threadIdx.x] = sum[i];
+  __syncthreads();
+  // 16 values x per_row column owners, summed over the row slots: value i of owner o -> column (i: 0-3 k lo, 4-7 k hi, 8-11 v lo, 12-15 v hi)
+  for (int e = threadIdx.x; e < 16 * per_row; e += 256) {
+    const int i = e / per_row, o = e % per_row;
+    float t = 0.f;
+    for (int sl = 0; sl < nslots; ++sl) t += red[i * 256 + sl * per_row + o];
+    const int ohk = o >> 4, oc4 = o & 15;
+    const int col = ohk * HD + ((i >> 2) & 1) * (HD / 2) + oc4 * 4 + (i & 3);
+    atomicAdd((i < 8 ? dbias_k : dbias_v) + col, t);
+  }
+}
+
 // workspace -> bf16 dK | dV (row stride ldg) and re-zero the workspace for the next layer
 __global__ __launch_bounds__(256) void dkv_finish_kernel(float* __restrict__ ws, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv,
                                                          int64_t ldg, int64_t tokens, int kvw) {
@@ -1179,8 +1327,10 @@ extern "C" int ug_attn_bwd(const void* q, const void* k, const void* v, int64_t 
                            const void* o, const void* dout, int64_t ldo, const float* lse,
                            float* delta, void* dq, void* dk, void* dv, int64_t ldg, const uint64_t* bits,
                            const uint8_t* tileany, int64_t B, int64_t L, int64_t Lp, int H, int HKV, int head_dim,
-                           float scale, float* dkv_ws, hipStream_t st) {
+                           float scale, float* dkv_ws, const float* rope_cos, const float* rope_sin, float* dbias, hipStream_t st) {
   if (int rc = check_common("ug_attn_bwd", B, L, Lp, H, HKV, head_dim, ldq)) return rc;
+  UG_REQUIRE((rope_cos == nullptr) == (rope_sin == nullptr) && (!rope_cos || (ug_aligned16(rope_cos) && ug_aligned16(rope_sin))),
+             "ug_attn_bwd: rope_cos / rope_sin come together, 16-byte aligned");
   UG_REQUIRE(ug_aligned16(dkv_ws), "ug_attn_bwd: workspace alignment");
   UG_REQUIRE(ug_aligned16(q) && ug_aligned16(k) && ug_aligned16(v) && ug_aligned16(dout) && ldo % 8 == 0 && ldg % 4 == 0,
              "ug_attn_bwd: alignment");
@@ -1193,16 +1343,40 @@ extern "C" int ug_attn_bwd(const void* q, const void* k, const void* v, int64_t 
   a.ldq = ldq; a.ldo = ldo; a.ldg = ldg; a.B = (int)B; a.L = (int)L; a.Lp = (int)Lp; a.nW = (int)((L + 63) / 64);
   a.H = H; a.HKV = HKV; a.scale = scale;
   static const int use32 = [] { const char* e = getenv("UNIGEN_ATTN_DQ32"); return e ? atoi(e) : 1; }();
-  if (use32 && L >= 256 && L <= 4096 && (int64_t)((L + 127) / 128) * H * B >= 512)
+  static const int fuse = [] { const char* e = getenv("UNIGEN_ATTN_BWD_FUSE_ROPE"); return e ? atoi(e) : 1; }();
+  const int64_t tokens = B * L;
+  // what the fused stores do not cover is done by the stand-alone passes (same arithmetic): ug_rope / ug_colsum_bf16
+  auto rope_pass = [&](void* x, int nheads) -> int { return rope_cos ? ug_rope(x, rope_cos, rope_sin, tokens, L, ldg, nheads, HD, 1, st) : UG_OK; };
+  auto colsum_pass = [&](const void* x, float* out, int cols) -> int { return dbias ? ug_colsum_bf16(x, ldg, out, tokens, cols, st) : UG_OK; };
+  if (use32 && L >= 256 && L <= 4096 && (int64_t)((L + 127) / 128) * H * B >= 512) {
+    if (fuse) { a.rope_cos = rope_cos; a.rope_sin = rope_sin; a.dbias = dbias; }
     hipLaunchKernelGGL(attn_bwd_dq32_kernel<4>, dim3(wg_grid((L + 127) / 128, H, HKV, B)), dim3(256), 0, st, a);
-  else
+    UG_CHECK_LAUNCH("ug_attn_bwd(dq)");
+    if (!fuse) { if (int rc = rope_pass(dq, H)) return rc; if (int rc = colsum_pass(dq, dbias, H * HD)) return rc; }
+  } else {
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(wg_grid(a.nW, H, HKV, B)), dim3(256), 0, st, a);
-  UG_CHECK_LAUNCH("ug_attn_bwd(dq)");
+    UG_CHECK_LAUNCH("ug_attn_bwd(dq)");
+    if (int rc = rope_pass(dq, H)) return rc;
+    if (int rc = colsum_pass(dq, dbias, H * HD)) return rc;
+  }
+  a.rope_cos = a.rope_sin = nullptr; a.dbias = nullptr;
+  float* dbias_k = dbias ? dbias + H * HD : nullptr;
+  float* dbias_v = dbias ? dbias + (H + HKV) * HD : nullptr;
   if (dkv_ws) {
     static const int dma = [] { const char* e = getenv("UNIGEN_ATTN_DKV_DMA"); return e ? atoi(e) : 1; }();
     if (dma && L <= 4096) hipLaunchKernelGGL(attn_bwd_dkv_dma_kernel, dim3(wg_grid(a.nW, H, HKV, B)), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, dim3(wg_grid(a.nW, H, HKV, B)), dim3(256), 0, st, a);
     UG_CHECK_LAUNCH("ug_attn_bwd(dkv split)");
+    if (fuse && (rope_cos || dbias) && HKV <= 16 && (HKV & (HKV - 1)) == 0) {
+      // ~128 workgroups: every workgroup ends with one atomic per bias column (512 addresses), and 1 000 same-address atomics
+      // in a burst cost more (53 us measured) than the whole streaming pass (9 us)
+      static const int fin_wgs = [] { const char* e = getenv("UNIGEN_ATTN_FINISH_WGS"); return e ? atoi(e) : 128; }();
+      const int rpb = (int)((tokens + fin_wgs - 1) / fin_wgs < 8 ? 8 : (tokens + fin_wgs - 1) / fin_wgs);
+      hipLaunchKernelGGL(dkv_finish_rope_kernel, dim3((unsigned)((tokens + rpb - 1) / rpb)), dim3(256), 0, st, dkv_ws, a.dk, a.dv, ldg,
+                         tokens, (int)L, HKV, rope_cos, rope_sin, dbias_k, dbias_v, rpb);
+      UG_CHECK_LAUNCH("ug_attn_bwd(dkv finish + rope)");
+      return UG_OK;
+    }
     const int64_t total = B * L * (2 * HKV * HD / 4);
     int64_t gsz = (total + 255) / 256; if (gsz > 4096) gsz = 4096;
     hipLaunchKernelGGL(dkv_finish_kernel, dim3((unsigned)gsz), dim3(256), 0, st, dkv_ws, a.dk, a.dv, ldg, B * L, HKV * HD);
@@ -1211,5 +1385,8 @@ extern "C" int ug_attn_bwd(const void* q, const void* k, const void* v, int64_t 
     hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, dim3(wg_grid(a.nW, HKV, HKV, B)), dim3(256), 0, st, a);
     UG_CHECK_LAUNCH("ug_attn_bwd(dkv)");
   }
+  if (int rc = rope_pass(dk, HKV)) return rc;
+  if (int rc = colsum_pass(dk, dbias_k, HKV * HD)) return rc;
+  if (int rc = colsum_pass(dv, dbias_v, HKV * HD)) return rc;
   return UG_OK;
 }

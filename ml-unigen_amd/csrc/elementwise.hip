@@ -11,6 +11,30 @@
 
 namespace {
 
+// Streaming accesses.  NT bit 0 = non-temporal stores, bit 1 = non-temporal loads; UNIGEN_EW_NT = four hex digits, AdamW |
+// rmsnorm_bwd | swiglu_bwd | swiglu_fwd.  Default 0x3032, measured inside the step (tools/probes/run_r3p.sh): the SwiGLU backward
+// reads gate | up and d(act) for the last time and nothing reads d(gate | up) before the two GEMMs that follow evict it anyway
+// (203 -> ~185 us per launch); the forward's gate | up is next read in the backward, its output at once by the down projection
+// (so only its loads); the optimizer touches every byte once per step.  Together 132.8 -> 131.7 ms per step; the RMSNorm
+// backward did not move (0x0232 vs 0x0032 within noise).
+typedef unsigned int ntu4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int ntu2_t __attribute__((ext_vector_type(2)));
+template <int NT, typename T>
+__device__ __forceinline__ T ld_stream(const T* p) {
+  static_assert(sizeof(T) == 16 || sizeof(T) == 8, "ld_stream: 8- or 16-byte accesses");
+  if constexpr ((NT & 2) && sizeof(T) == 16) return __builtin_bit_cast(T, __builtin_nontemporal_load(reinterpret_cast<const ntu4_t*>(p)));
+  else if constexpr ((NT & 2) && sizeof(T) == 8) return __builtin_bit_cast(T, __builtin_nontemporal_load(reinterpret_cast<const ntu2_t*>(p)));
+  else return *p;
+}
+template <int NT, typename T>
+__device__ __forceinline__ void st_stream(T* p, T v) {
+  static_assert(sizeof(T) == 16 || sizeof(T) == 8, "st_stream: 8- or 16-byte accesses");
+  if constexpr ((NT & 1) && sizeof(T) == 16) __builtin_nontemporal_store(__builtin_bit_cast(ntu4_t, v), reinterpret_cast<ntu4_t*>(p));
+  else if constexpr ((NT & 1) && sizeof(T) == 8) __builtin_nontemporal_store(__builtin_bit_cast(ntu2_t, v), reinterpret_cast<ntu2_t*>(p));
+  else *p = v;
+}
+static int ew_nt() { static const int v = [] { const char* e = getenv("UNIGEN_EW_NT"); return e ? (int)strtol(e, nullptr, 16) : 0x3032; }(); return v; }
+
 // =========================================================================== RMSNorm
 // y = bf16( w * (x * rsqrt(mean(x^2) + eps)) )      (transformers Qwen2RMSNorm.forward,
 // modeling_qwen2.py:246-252 followed by the autocast bf16 cast of the next Linear's input)
@@ -50,7 +74,7 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restric
 constexpr int RN_MAXV = 8;   // supports cols <= 2048
 // NV = float4 slots per lane actually needed (cols <= 256 NV): the 1.5B model's 1536 columns take 6 of the 8 -- 30 fewer live
 // registers per lane than the generic form, i.e. more resident waves and more rows in flight for an HBM-latency-bound row walk
-template <int NV>
+template <int NV, int NT>
 __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ dy, const float* __restrict__ x,
                                                           const float* __restrict__ rstd, const float* __restrict__ w,
                                                           float* __restrict__ dres, float* __restrict__ dw,
@@ -81,7 +105,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
     for (int k = 0; k < NV; ++k) {
       const int i = lane + k * 64;
       if (i < nv) {
-        const float4 v = xr[i], ww = wr[i]; const uint2 d = dyr[i];
+        const float4 v = ld_stream<NT>(xr + i), ww = wr[i]; const uint2 d = ld_stream<NT>(dyr + i);   // last use of x and dy
         const float d0 = bf2f(d.x & 0xffff), d1 = bf2f(d.x >> 16), d2 = bf2f(d.y & 0xffff), d3 = bf2f(d.y >> 16);
         xh[k] = make_float4(v.x * r, v.y * r, v.z * r, v.w * r);
         g[k] = make_float4(d0 * ww.x, d1 * ww.y, d2 * ww.z, d3 * ww.w);
@@ -97,7 +121,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
         float4 o = acc[k];
         o.x += r * (g[k].x - xh[k].x * dot); o.y += r * (g[k].y - xh[k].y * dot);
         o.z += r * (g[k].z - xh[k].z * dot); o.w += r * (g[k].w - xh[k].w * dot);
-        dr[i] = o;
+        st_stream<NT>(dr + i, o);
         if (dres_bf16) {          // the next GEMM's bf16 operand, written here instead of by a cast pass over dres
           uint2 ob; ob.x = pack_bf2(o.x, o.y); ob.y = pack_bf2(o.z, o.w);
           reinterpret_cast<uint2*>(dres_bf16 + (int64_t)row * cols)[i] = ob;
@@ -165,34 +189,36 @@ __global__ __launch_bounds__(256) void rope_kernel(bf16_t* __restrict__ qkv, con
 // silu and the product are separate bf16-rounded ops).  gu = [tokens, 2*I] = [gate | up].
 __device__ __forceinline__ float silu_f(float g) { return g / (1.f + __expf(-g)); }
 
+template <int NT>
 __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict__ act,
                                                          int64_t tokens, int I) {
   const int per_row = I >> 3;
   const int64_t total = tokens * per_row;
   for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     const int64_t t = idx / per_row; const int c = (int)(idx % per_row) * 8;
-    const bf16x8_t g = *reinterpret_cast<const bf16x8_t*>(gu + t * 2 * I + c);
-    const bf16x8_t u = *reinterpret_cast<const bf16x8_t*>(gu + t * 2 * I + I + c);
+    const bf16x8_t g = ld_stream<NT>(reinterpret_cast<const bf16x8_t*>(gu + t * 2 * I + c));
+    const bf16x8_t u = ld_stream<NT>(reinterpret_cast<const bf16x8_t*>(gu + t * 2 * I + I + c));
     bf16x8_t o;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const float s = bf2f(f2bf(silu_f(bf2f((bf16_t)g[k]))));
       o[k] = (short)f2bf(s * bf2f((bf16_t)u[k]));
     }
-    *reinterpret_cast<bf16x8_t*>(act + t * I + c) = o;
+    st_stream<NT>(reinterpret_cast<bf16x8_t*>(act + t * I + c), o);
   }
 }
 
 // dgate = dact * up * silu'(gate),  dup = dact * silu(gate);   dgu = [dgate | dup]
+template <int NT>
 __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restrict__ gu, const bf16_t* __restrict__ dact,
                                                          bf16_t* __restrict__ dgu, int64_t tokens, int I) {
   const int per_row = I >> 3;
   const int64_t total = tokens * per_row;
   for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
     const int64_t t = idx / per_row; const int c = (int)(idx % per_row) * 8;
-    const bf16x8_t g = *reinterpret_cast<const bf16x8_t*>(gu + t * 2 * I + c);
-    const bf16x8_t u = *reinterpret_cast<const bf16x8_t*>(gu + t * 2 * I + I + c);
-    const bf16x8_t d = *reinterpret_cast<const bf16x8_t*>(dact + t * I + c);
+    const bf16x8_t g = ld_stream<NT>(reinterpret_cast<const bf16x8_t*>(gu + t * 2 * I + c));        // last use of gate | up
+    const bf16x8_t u = ld_stream<NT>(reinterpret_cast<const bf16x8_t*>(gu + t * 2 * I + I + c));
+    const bf16x8_t d = ld_stream<NT>(reinterpret_cast<const bf16x8_t*>(dact + t * I + c));
     bf16x8_t og, ou;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -203,8 +229,8 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restric
       ou[k] = (short)f2bf(df * s);
       og[k] = (short)f2bf(dsilu * (sg * (1.f + gf * (1.f - sg))));
     }
-    *reinterpret_cast<bf16x8_t*>(dgu + t * 2 * I + c) = og;
-    *reinterpret_cast<bf16x8_t*>(dgu + t * 2 * I + I + c) = ou;
+    st_stream<NT>(reinterpret_cast<bf16x8_t*>(dgu + t * 2 * I + c), og);
+    st_stream<NT>(reinterpret_cast<bf16x8_t*>(dgu + t * 2 * I + I + c), ou);
   }
 }
 
@@ -270,6 +296,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
 // Same update order as torch.optim.AdamW's single-tensor path (reference optimizer,
 // training/train.py:324-330): decay, lerp first moment, second moment, bias-corrected step.
 // Also refreshes the bf16 compute copy of the weights in the same pass.
+template <int NT>
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v,
                                                     bf16_t* __restrict__ p_bf16, int64_t n, float lr, float beta1,
@@ -279,10 +306,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   const float step_size = lr / bc1;
   const float decay = 1.f - lr * wd;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-    float4 pp = reinterpret_cast<float4*>(p)[i];
-    float4 gg = reinterpret_cast<const float4*>(g)[i];
-    float4 mm = reinterpret_cast<float4*>(m)[i];
-    float4 vv = reinterpret_cast<float4*>(v)[i];
+    float4 pp = ld_stream<NT>(reinterpret_cast<const float4*>(p) + i);
+    float4 gg = ld_stream<NT>(reinterpret_cast<const float4*>(g) + i);
+    float4 mm = ld_stream<NT>(reinterpret_cast<const float4*>(m) + i);
+    float4 vv = ld_stream<NT>(reinterpret_cast<const float4*>(v) + i);
     float* pa = &pp.x; float* ga = &gg.x; float* ma = &mm.x; float* va = &vv.x;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -294,10 +321,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
       pk = pk - step_size * (mk / denom);
       pa[k] = pk; ma[k] = mk; va[k] = vk;
     }
-    reinterpret_cast<float4*>(p)[i] = pp;
-    reinterpret_cast<float4*>(m)[i] = mm;
-    reinterpret_cast<float4*>(v)[i] = vv;
-    if (p_bf16) { uint2 o; o.x = pack_bf2(pp.x, pp.y); o.y = pack_bf2(pp.z, pp.w); reinterpret_cast<uint2*>(p_bf16)[i] = o; }
+    st_stream<NT>(reinterpret_cast<float4*>(p) + i, pp);
+    st_stream<NT>(reinterpret_cast<float4*>(m) + i, mm);
+    st_stream<NT>(reinterpret_cast<float4*>(v) + i, vv);
+    if (p_bf16) { uint2 o; o.x = pack_bf2(pp.x, pp.y); o.y = pack_bf2(pp.z, pp.w); st_stream<NT>(reinterpret_cast<uint2*>(p_bf16) + i, o); }
   }
   // tail (n % 4)
   const int64_t tail0 = n4 << 2;
@@ -396,6 +423,8 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const bf16_t* __restri
 }
 
 inline int grid_for(int64_t work_items, int block = 256, int cap = 256 * 8) {
+  static const int cap_env = [] { const char* e = getenv("UNIGEN_EW_GRID_CAP"); return e ? atoi(e) : 0; }();
+  if (cap_env > 0) cap = cap_env;
   int64_t g = (work_items + block - 1) / block;
   if (g < 1) g = 1;
   if (g > cap) g = cap;
@@ -427,8 +456,15 @@ extern "C" int ug_rmsnorm_bwd(const void* dy, const float* x, const float* rstd,
   UG_REQUIRE(((uintptr_t)dres_bf16 & 7) == 0, "ug_rmsnorm_bwd: dres_bf16 must be 8-byte aligned");
   // (a 6-slot instantiation for 1536 columns -- 148 instead of 182 registers, three waves per SIMD instead of two -- measured
   // SLOWER inside the step: 86 vs 78 us per launch, profiles/r03b vs r03a; the generic form stays)
-  hipLaunchKernelGGL(rmsnorm_bwd_kernel<RN_MAXV>, grid, block, 0, st, (const bf16_t*)dy, x, rstd, w, dres, dw, (bf16_t*)dres_bf16,
-                     (int)rows, (int)cols, rpb);
+#define UG_RNB(NTV) hipLaunchKernelGGL((rmsnorm_bwd_kernel<RN_MAXV, NTV>), grid, block, 0, st, (const bf16_t*)dy, x, rstd, w, dres, dw, \
+                                      (bf16_t*)dres_bf16, (int)rows, (int)cols, rpb)
+  switch ((ew_nt() >> 8) & 0xf) {          // third hex digit
+    case 1: UG_RNB(1); break;
+    case 2: UG_RNB(2); break;
+    case 3: UG_RNB(3); break;
+    default: UG_RNB(0);
+  }
+#undef UG_RNB
   UG_CHECK_LAUNCH("ug_rmsnorm_bwd");
   return UG_OK;
 }
@@ -450,7 +486,12 @@ extern "C" int ug_swiglu_fwd(const void* gate_up, void* act, int64_t tokens, int
   UG_REQUIRE(tokens > 0 && I % 8 == 0, "ug_swiglu_fwd: I=%ld must be a multiple of 8", (long)I);
   UG_REQUIRE(ug_aligned16(gate_up) && ug_aligned16(act), "ug_swiglu_fwd: alignment");
   dim3 grid(grid_for(tokens * (I / 8))), block(256);
-  hipLaunchKernelGGL(swiglu_fwd_kernel, grid, block, 0, st, (const bf16_t*)gate_up, (bf16_t*)act, tokens, (int)I);
+  switch (ew_nt() & 0xf) {
+    case 1: hipLaunchKernelGGL(swiglu_fwd_kernel<1>, grid, block, 0, st, (const bf16_t*)gate_up, (bf16_t*)act, tokens, (int)I); break;
+    case 2: hipLaunchKernelGGL(swiglu_fwd_kernel<2>, grid, block, 0, st, (const bf16_t*)gate_up, (bf16_t*)act, tokens, (int)I); break;
+    case 3: hipLaunchKernelGGL(swiglu_fwd_kernel<3>, grid, block, 0, st, (const bf16_t*)gate_up, (bf16_t*)act, tokens, (int)I); break;
+    default: hipLaunchKernelGGL(swiglu_fwd_kernel<0>, grid, block, 0, st, (const bf16_t*)gate_up, (bf16_t*)act, tokens, (int)I);
+  }
   UG_CHECK_LAUNCH("ug_swiglu_fwd");
   return UG_OK;
 }
@@ -460,7 +501,14 @@ extern "C" int ug_swiglu_bwd(const void* gate_up, const void* dact, void* dgate_
   UG_REQUIRE(tokens > 0 && I % 8 == 0, "ug_swiglu_bwd: I=%ld must be a multiple of 8", (long)I);
   UG_REQUIRE(ug_aligned16(gate_up) && ug_aligned16(dact) && ug_aligned16(dgate_up), "ug_swiglu_bwd: alignment");
   dim3 grid(grid_for(tokens * (I / 8))), block(256);
-  hipLaunchKernelGGL(swiglu_bwd_kernel, grid, block, 0, st, (const bf16_t*)gate_up, (const bf16_t*)dact, (bf16_t*)dgate_up, tokens, (int)I);
+#define UG_SWB(NTV) hipLaunchKernelGGL(swiglu_bwd_kernel<NTV>, grid, block, 0, st, (const bf16_t*)gate_up, (const bf16_t*)dact, (bf16_t*)dgate_up, tokens, (int)I)
+  switch ((ew_nt() >> 4) & 0xf) {          // second hex digit: the backward
+    case 1: UG_SWB(1); break;
+    case 2: UG_SWB(2); break;
+    case 3: UG_SWB(3); break;
+    default: UG_SWB(0);
+  }
+#undef UG_SWB
   UG_CHECK_LAUNCH("ug_swiglu_bwd");
   return UG_OK;
 }
@@ -511,8 +559,15 @@ extern "C" int ug_adamw_flat(float* p, const float* g, float* m, float* v, void*
   // max_blocks > 0: a deliberately small grid (one 4-wave, ~32-register workgroup per CU) for an update that runs on a
   // side stream beside MFMA-bound kernels -- it leaves the register file and LDS to them and lives off spare HBM bandwidth
   dim3 grid(max_blocks > 0 ? grid_for(n / 4 + 1, 256, max_blocks) : grid_for(n / 4 + 1)), block(256);
-  hipLaunchKernelGGL(adamw_kernel, grid, block, 0, st, p, g, m, v, (bf16_t*)p_bf16, n, lr, beta1, beta2, eps,
-                     weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale);
+#define UG_ADW(NTV) hipLaunchKernelGGL(adamw_kernel<NTV>, grid, block, 0, st, p, g, m, v, (bf16_t*)p_bf16, n, lr, beta1, beta2, eps, \
+                     weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale)
+  switch ((ew_nt() >> 12) & 0xf) {         // fourth hex digit
+    case 1: UG_ADW(1); break;
+    case 2: UG_ADW(2); break;
+    case 3: UG_ADW(3); break;
+    default: UG_ADW(0);
+  }
+#undef UG_ADW
   UG_CHECK_LAUNCH("ug_adamw_flat");
   return UG_OK;
 }

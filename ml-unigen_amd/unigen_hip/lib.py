@@ -39,7 +39,7 @@ SIGNATURES = {
     "ug_attn_mask_compress": [P, I32, I64, I64, P, P, I64, I64, P, P],
     "ug_attn_mask_causal": [P, P, P, I64, I64, P],
     "ug_attn_fwd": [P, P, P, I64, P, I64, P, P, P, I64, I64, I64, I32, I32, I32, F32, P],
-    "ug_attn_bwd": [P, P, P, I64, P, P, I64, P, P, P, P, P, I64, P, P, I64, I64, I64, I32, I32, I32, F32, P, P],
+    "ug_attn_bwd": [P, P, P, I64, P, P, I64, P, P, P, P, P, I64, P, P, I64, I64, I64, I32, I32, I32, F32, P, P, P, P, P],
     "ug_kv_store": [P, I64, I64, I64, P, P, I64, I64, I32, I32, I64, P, I32, P],
     "ug_rope_at": [P, P, P, I64, I64, I32, I32, P, I64, P],
     "ug_attn_decode": [P, I64, P, P, P, P, I64, I64, I32, I32, I32, I64, P, F32, P],

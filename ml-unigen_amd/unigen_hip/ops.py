@@ -427,8 +427,10 @@ def _dkv_workspace(tokens, width, device):
     return _DKV_WS[key]
 
 
-def attn_bwd(qkv, o, lse, dout, mb, H, HKV, hd, scale=None, split_heads=True):
-    """-> dqkv bf16 [B*L, (H+2*HKV)*hd] (gradient w.r.t. the post-RoPE q/k and v)."""
+def attn_bwd(qkv, o, lse, dout, mb, H, HKV, hd, scale=None, split_heads=True, rope=None, dbias=None):
+    """-> dqkv bf16 [B*L, (H+2*HKV)*hd]: the gradient w.r.t. the post-RoPE q / k and v, or -- rope = (cos, sin) tables [L, hd/2] --
+    w.r.t. the projection's own output (RoPE transposed where dq / dk are stored).  dbias (fp32 [(H+2*HKV)*hd]): += the column
+    sums of dqkv, the bias gradient of the fused projection."""
     B, L, Lp = mb.B, mb.L, mb.Lp
     scale = 1.0 / math.sqrt(hd) if scale is None else scale
     q = qkv[:, : H * hd]
@@ -442,7 +444,8 @@ def attn_bwd(qkv, o, lse, dout, mb, H, HKV, hd, scale=None, split_heads=True):
     ws = _dkv_workspace(B * L, 2 * HKV * hd, qkv.device) if split_heads and H > HKV else None
     _l.check(_l.load().ug_attn_bwd(_p(q), _p(k), _p(v), qkv.stride(0), _p(o), _p(dout), o.stride(0),
                                    _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), dqkv.stride(0), _p(mb.bits),
-                                   _p(mb.tileany), B, L, Lp, H, HKV, hd, scale, _p(ws), _stream()), "ug_attn_bwd")
+                                   _p(mb.tileany), B, L, Lp, H, HKV, hd, scale, _p(ws), _p(rope[0] if rope else None),
+                                   _p(rope[1] if rope else None), _p(dbias), _stream()), "ug_attn_bwd")
     return dqkv
 
 

@@ -301,9 +301,8 @@ class Qwen2Engine:
         # ---- attention
         w_o = wg(f"l{i}.wo", dyo, s.o)
         do = ops.gemm(dyo, fp.w(f"l{i}.wo"), b_kmajor=True)
-        dqkv = ops.attn_bwd(s.qkv, s.o, s.lse, do, mb, Hq, Hk, hd)
-        ops.rope_(dqkv, cos, sin, L, Hq + Hk, hd, backward=True)
-        ops.colsum_(dqkv, fp.g(f"l{i}.bqkv"))
+        # RoPE transposed and the bias gradient (column sums) where the attention backward stores dq / dk / dv
+        dqkv = ops.attn_bwd(s.qkv, s.o, s.lse, do, mb, Hq, Hk, hd, rope=(cos, sin), dbias=fp.g(f"l{i}.bqkv"))
         w_qkv = wg(f"l{i}.wqkv", dqkv, s.xn1)
         dxn1 = ops.gemm(dqkv, fp.w(f"l{i}.wqkv"), b_kmajor=True)
         dnext = ops.rmsnorm_bwd(dxn1, s.h, s.rstd1, fp.p(f"l{i}.ln1"), dh, fp.g(f"l{i}.ln1"), want_bf16=True)

@@ -445,6 +445,48 @@ def test_attention_fwd_bwd(dev, kind, B, L, H, HKV):
     assert _rel(dv, vf.grad) < 2e-2, f"dv rel {_rel(dv, vf.grad)}"
 
 
+@pytest.mark.parametrize("B,L,H,HKV,split", [(8, 333, 24, 4, True), (6, 400, 12, 2, True), (2, 129, 6, 2, True), (1, 200, 12, 2, False),
+                                             (16, 771, 12, 2, True)])
+def test_attention_bwd_fused_rope_and_bias_sums(dev, B, L, H, HKV, split):
+    """RoPE transposed and the q | k | v bias gradient applied where the attention backward stores dq / dk / dv (32-row dQ kernel,
+    dK / dV finishing pass) against the stand-alone passes over the stored tensor (ug_rope backward, ug_colsum_bf16): the
+    gradients bit for bit (same arithmetic on the same bf16 values; dK / dV carry the fp32 atomics' run-to-run order, so those are
+    compared through the deterministic kernel when the shape has one), the bias gradient to fp32 summation order.  Small / odd
+    shapes take the library's fall-back (the stand-alone passes, issued by the library itself)."""
+    ops = _ops()
+    hd = 128
+    gen = torch.Generator().manual_seed(L * 7 + H)
+    qkv = torch.randn(B * L, (H + 2 * HKV) * hd, generator=gen).to(torch.bfloat16).to(dev)
+    mask_add, _ = _ref_masks(B, L, "t2i", gen)
+    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    mb = ops.mask_compress(mask_add.to(dev), err)
+    o, lse = ops.attn_fwd(qkv, mb, H, HKV, hd)
+    dout = torch.randn(B * L, H * hd, generator=gen).to(torch.bfloat16).to(dev)
+    inv = 1.0 / (1e6 ** (torch.arange(0, hd, 2, dtype=torch.float32) / hd))
+    ang = torch.arange(L, dtype=torch.float32)[:, None] * inv[None, :]
+    cos, sin = ang.cos().contiguous().to(dev), ang.sin().contiguous().to(dev)
+    plain = ops.attn_bwd(qkv, o, lse, dout, mb, H, HKV, hd, split_heads=split)
+    want = plain.clone()
+    ops.rope_(want, cos, sin, L, H + HKV, hd, backward=True)
+    want_b = torch.zeros((H + 2 * HKV) * hd, device=dev)
+    ops.colsum_(want, want_b)
+    got_b = torch.full(((H + 2 * HKV) * hd,), 0.25, device=dev)                 # accumulates into what is there
+    got = ops.attn_bwd(qkv, o, lse, dout, mb, H, HKV, hd, split_heads=split, rope=(cos, sin), dbias=got_b)
+    nq = H * hd
+    assert torch.equal(got[:, :nq], want[:, :nq])                                # dq: deterministic kernels
+    if split:
+        assert _rel(got[:, nq:].float(), want[:, nq:].float()) < 4e-3           # fp32 atomics order before the bf16 rounding
+        ref_b = torch.zeros_like(want_b)
+        ops.colsum_(got, ref_b)                                                  # the sums of what THIS run stored
+    else:
+        assert torch.equal(got[:, nq:], want[:, nq:])
+        ref_b = want_b
+    eb = (got_b - 0.25 - ref_b).abs().max().item()
+    print(f"    fused RoPE / bias sums B={B} L={L} H={H}/{HKV} split={split}: bias-gradient max diff {eb:.2e} at max {ref_b.abs().max().item():.1f}")
+    assert eb < 2e-4 * max(1.0, ref_b.abs().max().item())
+    assert float(ops._dkv_workspace(B * L, 2 * HKV * hd, dev).abs().max()) == 0.0
+
+
 def test_mask_rejects_soft_values(dev):
     ops = _ops()
     m = torch.zeros(1, 1, 64, 64, device=dev); m[0, 0, 3, 5] = -1.5

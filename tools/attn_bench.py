@@ -32,6 +32,21 @@ for name, mb in masks.items():
     frac = 0.5 if name == "causal" else 1.0
     o, lse = ops.attn_fwd(qkv, mb, H, HKV, hd)
     t_f = timed(lambda: ops.attn_fwd(qkv, mb, H, HKV, hd))
+    if os.environ.get("ROPE") == "2":       # kernel-trace runs: the fused backward only
+        cos, sin = ops.rope_tables(L, hd, 1e6, dev)
+        db = torch.zeros((H + 2 * HKV) * hd, device=dev)
+        print(f"{name}: fused bwd {timed(lambda: ops.attn_bwd(qkv, o, lse, dout, mb, H, HKV, hd, rope=(cos, sin), dbias=db)):7.1f} us")
+        continue
     t_b = timed(lambda: ops.attn_bwd(qkv, o, lse, dout, mb, H, HKV, hd))
+    if os.environ.get("ROPE") == "1":       # + RoPE transposed and the bias-gradient sums: fused into the stores, or as the separate passes
+        cos, sin = ops.rope_tables(L, hd, 1e6, dev)
+        db = torch.zeros((H + 2 * HKV) * hd, device=dev)
+        t_fused = timed(lambda: ops.attn_bwd(qkv, o, lse, dout, mb, H, HKV, hd, rope=(cos, sin), dbias=db))
+
+        def sep():
+            d = ops.attn_bwd(qkv, o, lse, dout, mb, H, HKV, hd)
+            ops.rope_(d, cos, sin, L, H + HKV, hd, backward=True)
+            ops.colsum_(d, db)
+        print(f"       bwd + rope + bias sums: in the stores {t_fused:7.1f} us, separate passes {timed(sep):7.1f} us (plain bwd {t_b:7.1f})")
     fl = 4.0 * B * H * L * L * hd * frac
     print(f"{name:6s} B={B} L={L}: fwd {t_f:7.1f} us ({fl / t_f / 1e6:6.1f} TF/s)   bwd {t_b:7.1f} us ({2.5 * fl / t_b / 1e6:6.1f} TF/s, 5-matmul count)", flush=True)

@@ -11,8 +11,20 @@ dev = torch.device("cuda:0")
 T, H, I = 12336, 1536, 8960
 
 
+COLD = os.environ.get("COLD") == "1"        # evict L2 / Infinity Cache between calls (what a kernel inside the step sees)
+_junk = torch.empty(1 << 28, device=dev) if COLD else None          # 1 GiB
+
+
 def timed(fn, reps=20):
     fn(); torch.cuda.synchronize()
+    if COLD:
+        tot = 0.0
+        for _ in range(reps):
+            _junk.add_(1.0)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+            tot += e0.elapsed_time(e1)
+        return tot / reps * 1e3
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
