@@ -139,7 +139,8 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
     __syncthreads();
     const int c = threadIdx.x;           // 256 threads <-> 256 columns of this chunk
     const int col = k * 256 + c;
-    if (col < cols) atomicAdd(dw + col, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+    if constexpr (!(NT & 4))          // (NT bit 2: timing probe without the dw atomics -- wrong gradients, never a default)
+      if (col < cols) atomicAdd(dw + col, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
   }
 }
 
@@ -462,6 +463,7 @@ extern "C" int ug_rmsnorm_bwd(const void* dy, const float* x, const float* rstd,
     case 1: UG_RNB(1); break;
     case 2: UG_RNB(2); break;
     case 3: UG_RNB(3); break;
+    case 4: UG_RNB(4); break;
     default: UG_RNB(0);
   }
 #undef UG_RNB

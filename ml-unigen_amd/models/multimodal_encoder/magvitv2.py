@@ -264,9 +264,8 @@ class MAGVITv2(ModelMixin, ConfigMixin):
         # RGB padded with zero channels: to one 32-channel slab of the LDS-resident-patch kernel (a quarter of a 128 -> 128 layer's
         # time, and the first GroupNorm's sums come with it; the exact fp32 im2col kernel on 4-channel pixels wrote its 537 MB
         # output at 0.9 TB/s: 0.62 ms + a 0.15 ms statistics pass), or to 4 channels (16-byte pixels) on the exact-fp32 path
-        cpad_in = 4 if self.exact_fp32_convs or not self.fuse_gn_stats else 32
-        x = ops.nchw_to_nhwc(pixel_values.float().contiguous(), cpad_in)
-        h = self._conv(x, e.conv_in, pad_cin_to=cpad_in, stats=True)
+        x = ops.nchw_to_nhwc(pixel_values.float().contiguous(), 4)         # 16-byte pixels; the kernel reads the other 28 as zero
+        h = self._conv(x, e.conv_in, pad_cin_to=4 if self.exact_fp32_convs or not self.fuse_gn_stats else 32, stats=True)
         for lvl, level in enumerate(e.down):
             for blk in level.block:
                 h = self._res(h, blk)

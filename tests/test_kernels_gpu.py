@@ -602,6 +602,33 @@ def test_conv3x3_patch_matches_fp64(dev, cin, cout, H, W, gn):
     assert _maxabs(got, unfused) < 3e-5
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 37, 50), (3, 256, 256)])
+def test_conv3x3_patch_four_channel_input(dev, B, H, W):
+    """conv_in (3 -> 128 on RGB padded to 16-byte pixels, magvitv2.py:152-156) on the LDS-resident-patch kernel: x has 4 channels,
+    the weights are packed for one 32-channel slab and the kernel reads the other 28 channels as zero.  Against fp64 and the exact
+    fp32 im2col kernel, with the epilogue statistics."""
+    ops = _ops()
+    gen = torch.Generator().manual_seed(H + W)
+    x = torch.rand(B, 3, H, W, generator=gen) * 2 - 1
+    w = torch.randn(128, 3, 3, 3, generator=gen) / math.sqrt(27)
+    bias = torch.randn(128, generator=gen)
+    ref = F.conv2d(x.double(), w.double(), bias.double(), padding=1)
+    xd = ops.nchw_to_nhwc(x.to(dev), 4)
+    w4 = torch.cat([w, w.new_zeros(128, 1, 3, 3)], 1).to(dev)
+    w32 = torch.cat([w, w.new_zeros(128, 29, 3, 3)], 1).to(dev)
+    wp4, cpad = ops.pack_conv_weight(w4)
+    exact = ops.conv2d_nhwc(xd, wp4, cpad, bias.to(dev), 128, 3)
+    wp32, cpad32 = ops.pack_conv_weight(w32)
+    st = ops.gn_stats_slots(1, B, dev)[0]
+    got = ops.conv3x3_nhwc(xd, ops.split_conv_weight(wp32), cpad32, bias.to(dev), 128, out_stats=st)
+    e_split = (got.permute(0, 3, 1, 2).cpu().double() - ref).abs().max().item()
+    e_exact = (exact.permute(0, 3, 1, 2).cpu().double() - ref).abs().max().item()
+    print(f"    conv_in {B}x{H}x{W}: split patch kernel max err vs fp64 {e_split:.2e}, exact fp32 kernel {e_exact:.2e}")
+    assert e_split < 3e-6 and e_split <= 3.0 * e_exact + 1e-6
+    mr = ops.groupnorm_finalize(st, B, H * W, 128)
+    assert (mr - ops.groupnorm_stats(got)).abs().max().item() == 0.0
+
+
 @pytest.mark.parametrize("cin,cout,H,W", [(128, 128, 16, 32), (64, 256, 11, 21), (512, 512, 6, 6), (128, 128, 250, 263), (64, 256, 128, 128)])
 def test_conv3x3_epilogue_groupnorm_sums(dev, cin, cout, H, W):
     """The sums of the consuming GroupNorm gathered in the convolution's epilogue (three kernel variants: 64- / 128-channel
