@@ -296,6 +296,51 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
 // =========================================================================== AdamW (flat, fused)
 // Same update order as torch.optim.AdamW's single-tensor path (reference optimizer,
 // training/train.py:324-330): decay, lerp first moment, second moment, bias-corrected step.
+// The overlapped form of the update (side stream, beside the tokenizer's convolutions): TWO elements per lane and iteration.
+// The four-element kernel needs 50-53 registers; the eight-wave convolution workgroups hold 2 x 232 of a SIMD's 512, so one more
+// wave fits beside them only up to 48 -- above that the update's workgroups wait for whole CUs and then hold them (a grid-stride
+// workgroup lives for the whole update), and the convolutions run on what is left.  Same arithmetic, element by element.
+template <int NT>
+__global__ __launch_bounds__(256) void adamw_lean_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                         float* __restrict__ v, bf16_t* __restrict__ p_bf16, int64_t n, float lr,
+                                                         float beta1, float beta2, float eps, float wd, float bc1, float bc2_sqrt,
+                                                         float grad_scale) {
+  const int64_t n2 = n >> 1;
+  const float step_size = lr / bc1;
+  const float decay = 1.f - lr * wd;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n2; i += (int64_t)gridDim.x * blockDim.x) {
+    float2 pp = ld_stream<NT>(reinterpret_cast<const float2*>(p) + i);
+    const float2 gg = ld_stream<NT>(reinterpret_cast<const float2*>(g) + i);
+    float2 mm = ld_stream<NT>(reinterpret_cast<const float2*>(m) + i);
+    float2 vv = ld_stream<NT>(reinterpret_cast<const float2*>(v) + i);
+    float* pa = &pp.x; const float* ga = &gg.x; float* ma = &mm.x; float* va = &vv.x;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const float gr = ga[k] * grad_scale;
+      float pk = pa[k] * decay;
+      const float mk = ma[k] + (gr - ma[k]) * (1.f - beta1);
+      const float vk = va[k] * beta2 + (1.f - beta2) * gr * gr;
+      const float denom = sqrtf(vk) / bc2_sqrt + eps;
+      pk = pk - step_size * (mk / denom);
+      pa[k] = pk; ma[k] = mk; va[k] = vk;
+    }
+    st_stream<NT>(reinterpret_cast<float2*>(p) + i, pp);
+    st_stream<NT>(reinterpret_cast<float2*>(m) + i, mm);
+    st_stream<NT>(reinterpret_cast<float2*>(v) + i, vv);
+    if (p_bf16) reinterpret_cast<uint32_t*>(p_bf16)[i] = pack_bf2(pp.x, pp.y);
+  }
+  const int64_t ti = (n2 << 1) + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (ti < n) {
+    const float gr = g[ti] * grad_scale;
+    float pk = p[ti] * decay;
+    const float mk = m[ti] + (gr - m[ti]) * (1.f - beta1);
+    const float vk = v[ti] * beta2 + (1.f - beta2) * gr * gr;
+    pk = pk - step_size * (mk / (sqrtf(vk) / bc2_sqrt + eps));
+    p[ti] = pk; m[ti] = mk; v[ti] = vk;
+    if (p_bf16) p_bf16[ti] = f2bf(pk);
+  }
+}
+
 // Also refreshes the bf16 compute copy of the weights in the same pass.
 template <int NT>
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
@@ -558,9 +603,22 @@ extern "C" int ug_adamw_flat(float* p, const float* g, float* m, float* v, void*
              "ug_adamw_flat: buffers must be 16B aligned");
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
   const double bc2 = 1.0 - pow((double)beta2, (double)step);
-  // max_blocks > 0: a deliberately small grid (one 4-wave, ~32-register workgroup per CU) for an update that runs on a
+  // max_blocks > 0: a deliberately small grid (one 4-wave workgroup per CU; the lean kernel above) for an update that runs on a
   // side stream beside MFMA-bound kernels -- it leaves the register file and LDS to them and lives off spare HBM bandwidth
   dim3 grid(max_blocks > 0 ? grid_for(n / 4 + 1, 256, max_blocks) : grid_for(n / 4 + 1)), block(256);
+  static const int lean = [] { const char* e = getenv("UNIGEN_ADAMW_LEAN"); return e ? atoi(e) : 1; }();
+  if (max_blocks > 0 && lean) {
+    const int wgs = lean > 1 ? lean : max_blocks;
+    dim3 lgrid(grid_for(n / 2 + 1, 256, wgs));
+    if ((ew_nt() >> 12) & 0xf)
+      hipLaunchKernelGGL(adamw_lean_kernel<3>, lgrid, block, 0, st, p, g, m, v, (bf16_t*)p_bf16, n, lr, beta1, beta2, eps, weight_decay,
+                         (float)bc1, (float)sqrt(bc2), grad_scale);
+    else
+      hipLaunchKernelGGL(adamw_lean_kernel<0>, lgrid, block, 0, st, p, g, m, v, (bf16_t*)p_bf16, n, lr, beta1, beta2, eps, weight_decay,
+                         (float)bc1, (float)sqrt(bc2), grad_scale);
+    UG_CHECK_LAUNCH("ug_adamw_flat(lean)");
+    return UG_OK;
+  }
 #define UG_ADW(NTV) hipLaunchKernelGGL(adamw_kernel<NTV>, grid, block, 0, st, p, g, m, v, (bf16_t*)p_bf16, n, lr, beta1, beta2, eps, \
                      weight_decay, (float)bc1, (float)sqrt(bc2), grad_scale)
   switch ((ew_nt() >> 12) & 0xf) {         // fourth hex digit
