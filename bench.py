@@ -479,13 +479,19 @@ def main():
         from unigen_hip import lib as ug_lib
         if rank == 0:
             ops.GEMM_PROFILE = []
+        step()
+        torch.cuda.synchronize()
+        # ... and one with events around EVERY library launch, filed by family (a separate step: nested inside the GEMM events
+        # above, the second pair of event records per launch cost the GEMM figure 2-3 ms per step)
+        rec_gemm = ops.GEMM_PROFILE
+        ops.GEMM_PROFILE = None
+        if rank == 0:
             ug_lib.PROFILE = {}
         step()
         torch.cuda.synchronize()
         fam_rec, ug_lib.PROFILE = ug_lib.PROFILE, None
     if rank == 0 and not args.no_roofline:
-        rec = ops.GEMM_PROFILE
-        ops.GEMM_PROFILE = None
+        rec = rec_gemm
         tot_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in rec)
         tot_fl = sum(f for _, _, f in rec)
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
