@@ -223,6 +223,7 @@ struct AttnArgs {
   // backward only: RoPE transposed on dq / dk before they are stored, and the q | k | v bias gradient (column sums of the stored
   // bf16 values) added into dbias[(H + 2 HKV) * 128] -- what the rope and colsum passes over dqkv did (or null: plain stores)
   const float* rope_cos; const float* rope_sin; float* dbias;
+  int ablate;               // probe builds of the timing tools only (UNIGEN_ATTN_ABLATE): 1 = no K / V staging after the first tile
 };
 
 // RoPE backward of one rotary pair, the arithmetic of rope_kernel<true> (elementwise.hip): the gradient is rounded to bf16
@@ -468,7 +469,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd32_kernel(AttnArgs p) {
     const int tn = next_visible(t + 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of tile t has landed
     asm volatile("s_barrier" ::: "memory");               // ... everyone's has; everyone is past its reads of the other slot
-    if (tn < p.nW) stage(tn, (it + 1) & 1);
+    if (tn < p.nW && !p.ablate) stage(tn, (it + 1) & 1);
     const uint64_t wnext = tn < p.nW ? wrow[tn] : 0ull;
     const bool mine = (minem >> t) & 1ull;
     if (mine) {
@@ -1311,6 +1312,7 @@ extern "C" int ug_attn_fwd(const void* q, const void* k, const void* v, int64_t 
   a.o = (bf16_t*)o; a.lse = lse; a.bits = bits; a.tileany = tileany;
   a.ldq = ldq; a.ldo = ldo; a.B = (int)B; a.L = (int)L; a.Lp = (int)Lp; a.nW = (int)((L + 63) / 64);
   a.H = H; a.HKV = HKV; a.scale = scale;
+  { static const int abl = [] { const char* e = getenv("UNIGEN_ATTN_ABLATE"); return e ? atoi(e) : 0; }(); a.ablate = abl; }
   // 128-row query tiles (eight waves share each staged K / V tile) once there are enough of them to fill the chip
   static const int use32 = [] { const char* e = getenv("UNIGEN_ATTN_FWD32"); return e ? atoi(e) : 1; }();
   if (use32 && L >= 256 && L <= 4096 && (int64_t)((L + 127) / 128) * H * B >= 512)
@@ -1342,6 +1344,7 @@ extern "C" int ug_attn_bwd(const void* q, const void* k, const void* v, int64_t 
   a.bits = bits; a.tileany = tileany;
   a.ldq = ldq; a.ldo = ldo; a.ldg = ldg; a.B = (int)B; a.L = (int)L; a.Lp = (int)Lp; a.nW = (int)((L + 63) / 64);
   a.H = H; a.HKV = HKV; a.scale = scale;
+  { static const int abl = [] { const char* e = getenv("UNIGEN_ATTN_ABLATE"); return e ? atoi(e) : 0; }(); a.ablate = abl; }
   static const int use32 = [] { const char* e = getenv("UNIGEN_ATTN_DQ32"); return e ? atoi(e) : 1; }();
   static const int fuse = [] { const char* e = getenv("UNIGEN_ATTN_BWD_FUSE_ROPE"); return e ? atoi(e) : 1; }();
   const int64_t tokens = B * L;
