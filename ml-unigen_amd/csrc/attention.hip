@@ -256,7 +256,9 @@ __device__ __forceinline__ void lanes32_colsum(float (&x)[64], int lane) {
 // workgroup that reads the K / V rows of one (batch, kv head) pair -- its G query heads x nT tiles -- runs on ONE XCD (4 pairs
 // of 395 KB per XCD at the training shape).  1-D grid of 8 * ceil(pairs / 8) * nT * G workgroups; surplus ones exit.
 struct WgCoord { int tile, h, b; bool ok; };
-__device__ __forceinline__ WgCoord wg_coord(int wid, int nT, int H, int HKV, int B) {
+// heavy_last: the tiles' cost grows with their index (query tiles under a causal mask) -> hand them out in descending order,
+// so that the launch ends with its cheapest workgroups
+__device__ __forceinline__ WgCoord wg_coord(int wid, int nT, int H, int HKV, int B, bool heavy_last = false) {
   const int G = H / HKV, per_pair = nT * G, P = B * HKV;
   const int xcd = wid & 7, idx = wid >> 3;
   const int pair = (idx / per_pair) * 8 + xcd, rem = idx % per_pair;
@@ -264,7 +266,7 @@ __device__ __forceinline__ WgCoord wg_coord(int wid, int nT, int H, int HKV, int
   c.ok = pair < P;
   c.b = pair / HKV;
   c.h = (pair % HKV) * G + rem / nT;
-  c.tile = rem % nT;
+  c.tile = heavy_last ? nT - 1 - rem % nT : rem % nT;
   return c;
 }
 static inline unsigned wg_grid(int64_t nT, int H, int HKV, int64_t B) {
@@ -383,6 +385,17 @@ typedef const __attribute__((address_space(1))) void* a_gptr_t;
 typedef __attribute__((address_space(3))) void* a_lptr_t;
 __device__ __forceinline__ int swz16(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 constexpr int T32_BYTES = 64 * 256;
+// Query tiles of the 32-row kernels are aligned to the END of the sequence: tile qt holds rows off + qt * ROWS ... with
+// off = L - nT * ROWS <= 0, so the ragged tile is the FIRST one.  Every BASELINE length is 128 k + 3 or 128 k + 67 (max_seq + 256 + 3):
+// aligned to the start, the last tile held 3 image rows that see every key tile and cost a full workgroup (16 x 771: forward
+// 78.7 us against 71.6 at L = 768); at the front the same 3 rows are causal text rows that see one key tile.
+// Tile flags (`tileany`, per 64 x 64 block) of a row range that is no longer 64-aligned: the OR over the blocks it touches.
+__device__ __forceinline__ bool rows_see_tile(const uint8_t* tileany, int b, int nW, int lo, int hi, int L, int kt) {
+  lo = max(lo, 0); hi = min(hi, L - 1);
+  bool v = false;
+  for (int q64 = lo >> 6; lo <= hi && q64 <= (hi >> 6); ++q64) v = v || tileany[((int64_t)b * nW + q64) * nW + kt];
+  return v;
+}
 
 template <int NW>
 __global__ __launch_bounds__(64 * NW, 2) void attn_fwd32_kernel(AttnArgs p) {
@@ -391,12 +404,14 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd32_kernel(AttnArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 31, hh = lane >> 5, i16 = lane & 15, grp = (lane >> 4) & 1;
   constexpr int ROWS = 32 * NW;
-  const WgCoord wc = wg_coord((int)blockIdx.x, (p.L + ROWS - 1) / ROWS, p.H, p.HKV, p.B);
+  const WgCoord wc = wg_coord((int)blockIdx.x, (p.L + ROWS - 1) / ROWS, p.H, p.HKV, p.B, true);
   if (!wc.ok) return;
   const int qt = wc.tile, h = wc.h, b = wc.b;
   const int hk = h / (p.H / p.HKV);
-  const int qrow = qt * ROWS + wave * 32 + n;
-  const int qrow_c = min(qrow, p.L - 1);
+  const int row0 = p.L - ((p.L + ROWS - 1) / ROWS) * ROWS + qt * ROWS;       // end-aligned tiles: < 0 in the first one
+  const int qrow = row0 + wave * 32 + n;
+  const bool qlive = qrow >= 0;                                              // (always < L)
+  const int qrow_c = max(qrow, 0);
   const bf16_t* qseq = p.q + (int64_t)b * p.L * p.ldq + h * HD;
   const bf16_t* kseq = p.k + (int64_t)b * p.L * p.ldq + hk * HD;
   const bf16_t* vseq = p.v + (int64_t)b * p.L * p.ldq + hk * HD;
@@ -416,15 +431,12 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd32_kernel(AttnArgs p) {
   // 64-row tile flags (nW <= 64 tiles), fetched ONCE: bit t of `vis` = some row of the workgroup sees key tile t (uniform),
   // bit t of `minem` = this wave's 32 rows do.  (A flag byte fetched per tile right before its use was a dependent global
   // load on every iteration's critical path.)
-  const int q64_0 = qt * (ROWS / 64), q64_w = q64_0 + (wave >> 1);
   uint64_t vis, minem;
   {
     bool v = false, m = false;
     if (lane < p.nW) {
-#pragma unroll
-      for (int i = 0; i < ROWS / 64; ++i)
-        if (q64_0 + i < p.nW) v = v || p.tileany[((int64_t)b * p.nW + q64_0 + i) * p.nW + lane];
-      if (q64_w < p.nW) m = p.tileany[((int64_t)b * p.nW + q64_w) * p.nW + lane];
+      v = rows_see_tile(p.tileany, b, p.nW, row0, row0 + ROWS - 1, p.L, lane);
+      m = rows_see_tile(p.tileany, b, p.nW, row0 + wave * 32, row0 + wave * 32 + 31, p.L, lane);
     }
     vis = __ballot(v);
     minem = __ballot(m);
@@ -551,7 +563,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd32_kernel(AttnArgs p) {
     t = tn;
     wcur = wnext;
   }
-  if (qrow < p.L) {
+  if (qlive) {
     const float inv = (l_i > 0.f) ? 1.f / l_i : 0.f;
     bf16_t* orow = p.o + ((int64_t)b * p.L + qrow) * p.ldo + h * HD;
 #pragma unroll
@@ -668,12 +680,14 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq32_kernel(AttnArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 31, hh = lane >> 5, i16 = lane & 15, grp = (lane >> 4) & 1;
   constexpr int ROWS = 32 * NW;
-  const WgCoord wc = wg_coord((int)blockIdx.x, (p.L + ROWS - 1) / ROWS, p.H, p.HKV, p.B);
+  const WgCoord wc = wg_coord((int)blockIdx.x, (p.L + ROWS - 1) / ROWS, p.H, p.HKV, p.B, true);
   if (!wc.ok) return;
   const int qt = wc.tile, h = wc.h, b = wc.b;
   const int hk = h / (p.H / p.HKV);
-  const int qrow = qt * ROWS + wave * 32 + n;
-  const int qrow_c = min(qrow, p.L - 1);
+  const int row0 = p.L - ((p.L + ROWS - 1) / ROWS) * ROWS + qt * ROWS;       // end-aligned tiles: < 0 in the first one
+  const int qrow = row0 + wave * 32 + n;
+  const bool qlive = qrow >= 0;                                              // (always < L)
+  const int qrow_c = max(qrow, 0);
   const bf16_t* qseq = p.q + (int64_t)b * p.L * p.ldq + h * HD;
   const bf16_t* kseq = p.k + (int64_t)b * p.L * p.ldq + hk * HD;
   const bf16_t* vseq = p.v + (int64_t)b * p.L * p.ldq + hk * HD;
@@ -691,7 +705,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq32_kernel(AttnArgs p) {
     for (int e = 0; e < 8; ++e) dl += bf2f((bf16_t)of[e]) * bf2f((bf16_t)dof[ks][e]);
   }
   dl += __shfl_xor(dl, 32, 64);                           // the two lanes of a row hold 64 of its 128 dims each
-  if (hh == 0 && qrow < p.L) const_cast<float*>(p.delta)[((int64_t)b * p.H + h) * p.L + qrow] = dl;
+  if (hh == 0 && qlive) const_cast<float*>(p.delta)[((int64_t)b * p.H + h) * p.L + qrow] = dl;
   const float lse = p.lse[((int64_t)b * p.H + h) * p.L + qrow_c];
   const float c1 = p.scale * 1.4426950408889634f, lse2 = lse * 1.4426950408889634f, dls = dl * p.scale;
   f32x16_t dqt[4];
@@ -700,15 +714,12 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq32_kernel(AttnArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) dqt[d][r] = 0.f;
   const uint64_t* wrow = p.bits + ((int64_t)b * p.L + qrow_c) * p.nW;
-  const int q64_0 = qt * (ROWS / 64), q64_w = q64_0 + (wave >> 1);
   uint64_t vis, minem;
   {
     bool v = false, m = false;
     if (lane < p.nW) {
-#pragma unroll
-      for (int i = 0; i < ROWS / 64; ++i)
-        if (q64_0 + i < p.nW) v = v || p.tileany[((int64_t)b * p.nW + q64_0 + i) * p.nW + lane];
-      if (q64_w < p.nW) m = p.tileany[((int64_t)b * p.nW + q64_w) * p.nW + lane];
+      v = rows_see_tile(p.tileany, b, p.nW, row0, row0 + ROWS - 1, p.L, lane);
+      m = rows_see_tile(p.tileany, b, p.nW, row0 + wave * 32, row0 + wave * 32 + 31, p.L, lane);
     }
     vis = __ballot(v);
     minem = __ballot(m);
@@ -820,7 +831,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq32_kernel(AttnArgs p) {
         }
       }
   }
-  if (qrow < p.L) {
+  if (qlive) {
     bf16_t* drow = p.dq + ((int64_t)b * p.L + qrow) * p.ldg + h * HD;
 #pragma unroll
     for (int d = 0; d < 4; ++d)
@@ -835,7 +846,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq32_kernel(AttnArgs p) {
   if (p.dbias) {
     // bias gradient of the q projection: column sums of the stored (bf16) values over this workgroup's rows
     float x[64];
-    const bool live = qrow < p.L;
+    const bool live = qlive;
 #pragma unroll
     for (int d = 0; d < 4; ++d)
 #pragma unroll
