@@ -174,7 +174,9 @@ int ug_gemv_bf16(const void* x, int64_t ldx, int64_t R, const void* W, int64_t l
  * row-major fp32 accumulator acc[r*ldacc + n] a decode GEMV filled and leaves it zeroed for the next step:
  *   x += bf16round(acc);  xn = bf16(rmsnorm(x) * w) */
 int ug_decode_finish_resid_norm(float* acc, int64_t ldacc, float* x, const float* w, void* xn, int64_t rows, int64_t cols,
-                                float eps, hipStream_t stream);
+                                float eps, int* pos_inc, int* len_inc, hipStream_t stream);
+/* pos_inc / len_inc (both or neither): the cache's device-side write position and visible length, incremented by one here -- every
+ * kernel of the step that reads them has run by then (the `cache_position += 1` of the reference's loop, models/unigen.py:517). */
 /* Five-launch decode layer (what UniGen.t2i_generate_ar's per-token forward, models/unigen.py:496-502, runs).  A decode
  * step is bound by the ~4 us floor of every launch, so all finishing work moves to the CONSUMER of each accumulator
  * and kernel boundaries are the only synchronisation:

@@ -190,25 +190,27 @@ __global__ __launch_bounds__(64 * ADF_WAVES) void attn_decode_fused_kernel(
   __shared__ float ml[ADF_WAVES][2];
   const int r = blockIdx.y, h = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int hk = h / (H / HKV);
-  const int pos0 = *pos_dev;
-  const int len = min(pos0, Tmax);                         // cache keys visible to the new token
   const bf16_t* kb = ck + ((int64_t)r * HKV + hk) * Tmax * DHD;
   const bf16_t* vb = cv + ((int64_t)r * HKV + hk) * Tmax * DHD;
   const int kq = lane >> 4, dc = lane & 15;
   // the first key chunk's K row / V pieces do not depend on the new token: request them before the prologue's own
-  // round trip (accumulator, bias, RoPE table) so the two latencies overlap
+  // round trip (accumulator, bias, RoPE table) so the two latencies overlap.  (Requesting them before the position word
+  // as well -- clamped to the cache instead of the visible length, masked afterwards -- measured SLOWER, 5 730 vs 5 885
+  // tokens/s: every wave then loads a chunk at every step, visible or not.)
   bf16x8_t kf[DHD / 8], vf[16];
-  auto load_chunk = [&](int t0) {
-    const bf16_t* kr = kb + (int64_t)min(t0 + lane, len - 1) * DHD;
+  auto load_chunk = [&](int t0, int last) {
+    const bf16_t* kr = kb + (int64_t)min(t0 + lane, last) * DHD;
 #pragma unroll
     for (int c = 0; c < DHD / 8; ++c) kf[c] = *reinterpret_cast<const bf16x8_t*>(kr + c * 8);
 #pragma unroll
     for (int jj = 0; jj < 16; ++jj) {
-      const int tt = min(t0 + jj * 4 + kq, len - 1);
+      const int tt = min(t0 + jj * 4 + kq, last);
       vf[jj] = *reinterpret_cast<const bf16x8_t*>(vb + (int64_t)tt * DHD + dc * 8);
     }
   };
-  if (wave * 64 < len) load_chunk(wave * 64);
+  const int pos0 = *pos_dev;
+  const int len = min(pos0, Tmax);                         // cache keys visible to the new token
+  if (wave * 64 < len) load_chunk(wave * 64, len - 1);
   const float rs = rsqrtf(ss[r] / (float)norm_cols + eps);
   const float* arow = acc_qkv + (int64_t)r * lda;
   if (wave < 3) {
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(64 * ADF_WAVES) void attn_decode_fused_kernel(
   for (int t0 = wave * 64; t0 < len; t0 += 64 * ADF_WAVES) {
     const int t = t0 + lane;
     float s = -INFINITY;
-    if (t0 != wave * 64) load_chunk(t0);                 // later chunks (contexts beyond 256 keys)
+    if (t0 != wave * 64) load_chunk(t0, len - 1);        // later chunks (contexts beyond 512 keys)
     if (t < len && (!key_valid || key_valid[(int64_t)r * Tmax + t])) {
       float d = 0.f;
       asm volatile("" ::: "memory");           // keep the q reads below inside the chunk loop
@@ -454,8 +456,11 @@ __device__ __forceinline__ void finish_resid_norm_row(float* __restrict__ acc, i
 template <int MAXV>
 __global__ __launch_bounds__(64) void finish_resid_norm_kernel(float* __restrict__ acc, int64_t lda, float* __restrict__ x,
                                                                const float* __restrict__ w, bf16_t* __restrict__ xn, int cols,
-                                                               float eps) {
+                                                               float eps, int* __restrict__ pos_inc, int* __restrict__ len_inc) {
   finish_resid_norm_row<MAXV>(acc, lda, x, w, xn, cols, eps, blockIdx.x, threadIdx.x);
+  // the step's last launch that comes after every reader of the write position: advance it here (was two one-element torch
+  // kernels per decode step)
+  if (pos_inc && blockIdx.x == 0 && threadIdx.x == 0) { ++*pos_inc; ++*len_inc; }
 }
 
 // gate/up projection:  act = bf16( bf16(silu(bf16 gate)) * bf16 up )  (swiglu_fwd_kernel's arithmetic).
@@ -861,17 +866,18 @@ extern "C" int ug_decode_gemv_swiglu(const float* gate_up_acc, int64_t ld_gu, co
 }
 
 extern "C" int ug_decode_finish_resid_norm(float* acc, int64_t ldacc, float* x, const float* w, void* xn, int64_t rows,
-                                           int64_t cols, float eps, hipStream_t st) {
+                                           int64_t cols, float eps, int* pos_inc, int* len_inc, hipStream_t st) {
+  UG_REQUIRE((pos_inc == nullptr) == (len_inc == nullptr), "ug_decode_finish_resid_norm: pos_inc / len_inc come together");
   UG_REQUIRE(rows > 0 && cols > 0 && cols % 4 == 0 && cols <= 4096 && ldacc % 4 == 0 && acc && x && w && xn,
              "ug_decode_finish_resid_norm: bad args (cols=%ld, multiple of 4 and <= 4096)", (long)cols);
   UG_REQUIRE(ug_aligned16(x) && ug_aligned16(w) && ug_aligned16(acc) && ((uintptr_t)xn & 7) == 0,
              "ug_decode_finish_resid_norm: alignment");
   if (cols <= 2048)
     hipLaunchKernelGGL(finish_resid_norm_kernel<8>, dim3((unsigned)rows), dim3(64), 0, st, acc, ldacc, x, w, (bf16_t*)xn,
-                       (int)cols, eps);
+                       (int)cols, eps, pos_inc, len_inc);
   else
     hipLaunchKernelGGL(finish_resid_norm_kernel<16>, dim3((unsigned)rows), dim3(64), 0, st, acc, ldacc, x, w, (bf16_t*)xn,
-                       (int)cols, eps);
+                       (int)cols, eps, pos_inc, len_inc);
   UG_CHECK_LAUNCH("ug_decode_finish_resid_norm");
   return UG_OK;
 }

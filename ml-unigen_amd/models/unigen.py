@@ -632,8 +632,7 @@ class UniGen(ModelMixin, ConfigMixin):
             out_tokens[:, 0] = tok[:, 0]
 
         def step():
-            hn = eng.decode_step(st, x)
-            st.advance()
+            hn = eng.decode_step(st, x)            # (also advances the cache position)
             sample(hn)
 
         graph = None
@@ -715,8 +714,7 @@ class UniGen(ModelMixin, ConfigMixin):
                     break
             if i + 1 < max_new_tokens:
                 x.copy_(embed(nxt)[:, 0])
-                hn = eng.decode_step(st, x)
-                st.advance()
+                hn = eng.decode_step(st, x)            # (also advances the cache position)
         out = out[:, :n_out]
         if input_embeddings is None:
             return torch.cat([input_ids.to(dev), out], dim=1)
@@ -769,8 +767,7 @@ class UniGen(ModelMixin, ConfigMixin):
                 break
             if i + 1 < max_new_tokens:
                 x.copy_(embed(idx_next)[:, 0])
-                hn = eng.decode_step(st, x)
-                st.advance()
+                hn = eng.decode_step(st, x)            # (also advances the cache position)
         return result
 
     @torch.no_grad()
@@ -816,8 +813,7 @@ class UniGen(ModelMixin, ConfigMixin):
                     break
             if i + 1 < max_new_tokens:
                 x.copy_(embed(idx_next)[:, 0])
-                hn = eng.decode_step(st, x)
-                st.advance()
+                hn = eng.decode_step(st, x)            # (also advances the cache position)
         tokens, lengths = tokens.cpu(), lengths.cpu()
         return [list(tokens[r, :int(lengths[r])]) for r in range(R)]
 

@@ -48,7 +48,7 @@ SIGNATURES = {
     "ug_decode_gemv_resid_norm": [P, P, I64, P, P, P, I64, P, I64, P, I64, I64, I64, P, I64, P, I64, P, P],
     "ug_decode_gemv_swiglu": [P, I64, P, F32, I64, I64, P, I64, P, I64, I64, I64, P, I64, P, I64, P, P],
     "ug_attn_decode_fused": [P, I64, P, F32, I64, P, P, P, P, P, P, P, P, I64, I64, I32, I32, I32, I64, I64, F32, P],
-    "ug_decode_finish_resid_norm": [P, I64, P, P, P, I64, I64, F32, P],
+    "ug_decode_finish_resid_norm": [P, I64, P, P, P, I64, I64, F32, P, P, P],
     "ug_t2i_assemble": [P, P, P, I64, P, I64, P, P, I64, I64, I64, I64, I64, I64, I64, P, P, P, P],
     "ug_attn_mask_from_ids": [P, I64, I64, I64, I64, I64, I32, P, P, P, P, P],
     "ug_maskgit_train_mask": [P, P, P, I64, I64, I64, I64, P, P, P],

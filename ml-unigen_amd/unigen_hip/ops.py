@@ -494,9 +494,11 @@ def gemv_acc_(x, w, acc):
     return acc
 
 
-def decode_finish_resid_norm_(acc, x, w, xn, eps):
+def decode_finish_resid_norm_(acc, x, w, xn, eps, advance=None):
+    """advance = (pos, len) device int32 scalars of the decode state: incremented by this launch (the step's last reader is done)"""
+    pos, ln = advance if advance is not None else (None, None)
     _l.check(_l.load().ug_decode_finish_resid_norm(_p(acc), acc.stride(0), _p(x), _p(w), _p(xn), x.shape[0], x.shape[1], eps,
-                                                   _stream()), "ug_decode_finish_resid_norm")
+                                                   _p(pos), _p(ln), _stream()), "ug_decode_finish_resid_norm")
     return xn
 
 

@@ -398,7 +398,7 @@ def _decode_methods(cls):
 
     def decode_step(self, st, x):
         """x fp32 [rows, H] = embedding of the newest token (updated in place as the residual stream);
-        appends its K/V at st.pos and returns the final-norm hidden bf16 [rows, H].  No host sync, no
+        appends its K/V at st.pos, ADVANCES st.pos / st.len by one and returns the final-norm hidden bf16 [rows, H].  No host sync, no
         shape depends on the step: capturable.  Five launches per layer (see include/unigen_hip.h): each
         projection leaves its raw fp32 accumulator behind and the NEXT kernel applies bias / RoPE / residual add /
         RMSNorm / SiLU-mul while it builds its own operand, so kernel boundaries are the only synchronisation."""
@@ -423,7 +423,7 @@ def _decode_methods(cls):
             ops.decode_gemv_swiglu_(st.acc_gu, st.ss_mlp, eps, H, fp.w(f"l{i}.wdown"), st.acc_down, zero0=st.acc_o)
         # pending down_proj of the last layer + final RMSNorm (also clears acc_down for the next step)
         hn = torch.empty((R, H), dtype=torch.bfloat16, device=x.device)
-        ops.decode_finish_resid_norm_(st.acc_down, x, fp.p("norm"), hn, eps)
+        ops.decode_finish_resid_norm_(st.acc_down, x, fp.p("norm"), hn, eps, advance=(st.pos, st.len))
         return hn
 
     def _decode_step_wide(self, st, x):
@@ -443,6 +443,7 @@ def _decode_methods(cls):
             act = ops.swiglu_fwd(gu)
             ops.skinny_linear(act, fp.w(f"l{i}.wdown"), resid=x)
         hn, _ = ops.rmsnorm_fwd(x, fp.p("norm"), d.rms_norm_eps, want_rstd=False)
+        st.advance()
         return hn
 
     def head_slice(self, hn, v0, v1):
