@@ -776,7 +776,7 @@ def test_conv_split_weights_reconstruct(dev):
     ew = 14 - math.floor(math.log2(float(amax)))
     ws = buf[:n].view(taps, cin // 32, cpad // 128, 2, 128, 4, 8).double()
     r = torch.arange(128, device=dev)
-    stored = torch.arange(4, device=dev)[None, :] ^ ((0 - (r[:, None] >> 2)) & 3)    # logical chunk -> stored position
+    stored = torch.arange(4, device=dev)[None, :] ^ (((r[:, None] >> 2) & 1) << 1)   # logical chunk -> stored position (swz_q, conv_split.hip)
     idx = stored[None, None, None, None, :, :, None].expand(taps, cin // 32, cpad // 128, 2, 128, 4, 8)
     logical = torch.gather(ws, 5, idx)                                               # [.., n, chunk, 8]
     assert float(logical[:, :, :, 0].abs().max()) < 2.0 ** 15 and float(logical[:, :, :, 0].abs().max()) >= 2.0 ** 14
