@@ -497,7 +497,8 @@ extern "C" int ug_rmsnorm_bwd(const void* dy, const float* x, const float* rstd,
              "ug_rmsnorm_bwd: cols=%ld unsupported (multiple of 4, <= %d)", (long)cols, 64 * 4 * RN_MAXV);
   UG_REQUIRE(ug_aligned16(x) && ug_aligned16(w) && ug_aligned16(dres) && ((uintptr_t)dy & 7) == 0,
              "ug_rmsnorm_bwd: pointers must be aligned");
-  const int rpb = 16;          // 771 workgroups for 12 336 rows: three per CU (32 left a third of the CUs with one)
+  static const int rpb_env = [] { const char* e = getenv("UNIGEN_RN_RPB"); return e ? atoi(e) : 0; }();
+  const int rpb = rpb_env > 0 ? rpb_env : 16;          // 771 workgroups for 12 336 rows: three per CU (32 left a third of the CUs with one)
   dim3 grid((unsigned)((rows + rpb - 1) / rpb)), block(256);
   UG_REQUIRE(((uintptr_t)dres_bf16 & 7) == 0, "ug_rmsnorm_bwd: dres_bf16 must be 8-byte aligned");
   // (a 6-slot instantiation for 1536 columns -- 148 instead of 182 registers, three waves per SIMD instead of two -- measured
