@@ -845,12 +845,15 @@ extern "C" int ug_conv3x3_split(const float* x, const float* x_amax, const uint1
     a.stats_out = out_stats; a.out_cpg = Cout / out_groups;
     a.amax_out = reinterpret_cast<float*>(out_stats + 2 * B * out_groups);
   }
-  // 16-row tiles (eight waves, DMA-fed weights) when they still give every CU two workgroups' worth of work
+  // 16-row tiles (eight waves, DMA-fed weights) when they still give every CU a workgroup
   const int nb_n = (Cout + SBN - 1) / SBN;
   const int64_t big_tiles = B * ((W + PT_W - 1) / PT_W) * ((H + QT_H - 1) / QT_H);
   // (a one-slab layer -- conv_in, nine taps per workgroup, write-bound: 537 MB at 256^2 -- measures the same on either variant:
   // 303 us on this one, 322 us on the four-wave one)
-  const bool big = big_tiles * nb_n >= 512;
+  // (>= one workgroup per CU: the 512 -> 512 layers at 32^2 -- 256 such workgroups for 16 images -- run 227 -> ~150 us on it;
+  // measured per threshold, get_code on 16 images: 512: 18.41 ms, 256: 18.07, 128: 18.06, 64: 18.49)
+  static const int big_min = [] { const char* e = getenv("UNIGEN_CONV_BIG_MIN"); return e ? atoi(e) : 256; }();
+  const bool big = big_tiles * nb_n >= big_min;
   a.tiles_x = (W + PT_W - 1) / PT_W; a.tiles_y = big ? (H + QT_H - 1) / QT_H : (H + PT_H - 1) / PT_H;
   const int64_t ntiles = B * a.tiles_x * a.tiles_y;
   UG_REQUIRE(ntiles < (1LL << 30) && B * H * W < (1LL << 31), "ug_conv3x3_split: too many output pixels");
