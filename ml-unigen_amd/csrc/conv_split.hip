@@ -660,6 +660,165 @@ __global__ __launch_bounds__(512) void conv3x3_patch16_kernel(PatchArgs p) {
   }
 }
 
+// The 8-row variant with the 16-row kernel's weight path: tiles by LDS-DMA into a three-slot ring two taps ahead (separate arrays,
+// taps unrolled: see above), fragments of a tap read BEFORE the tap's barrier, ONE barrier per tap -- the MFMAs of tap t run while
+// the slower waves still read tap t + 1.  The register-staged form above waits out an L2 round trip per tap (fetch -> stash ->
+// barrier -> read): 0.9 us per tap on the 512-channel layers at 16^2 / 32^2, where a workgroup runs 144 taps of 24-48 MFMAs.
+template <bool GN, int NI>
+__global__ __launch_bounds__(256, 2) void conv3x3_patch_dma_kernel(PatchArgs p) {
+  __shared__ __attribute__((aligned(1024))) bf16_t W0[TILE];
+  __shared__ __attribute__((aligned(1024))) bf16_t W1[TILE];
+  __shared__ __attribute__((aligned(1024))) bf16_t W2[TILE];
+  __shared__ __attribute__((aligned(16))) bf16_t Xp[NPL * XPATCH];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave & 1, wm = wave >> 1;
+  const int g = lane >> 4, l16 = lane & 15;
+  const int ex = scale_exp(p.x_amax);
+  const float unscale = __builtin_ldexpf(1.f, -(ex + scale_exp(p.w_amax)));
+  const int per_xcd = gridDim.x >> 3;
+  const int tile = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  if (tile >= p.ntiles) return;
+  const int nblk = NI == 4 ? blockIdx.y : blockIdx.y >> 1, nhalf = NI == 4 ? 0 : blockIdx.y & 1;
+  const int tx = tile % p.tiles_x, ty = (tile / p.tiles_x) % p.tiles_y, b = tile / (p.tiles_x * p.tiles_y);
+  const int y0 = ty * PT_H, x0 = tx * PT_W;
+
+  const int q = tid & 7;
+  const float* ppix[6];
+  bool pok[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int prow = (tid >> 3) + 32 * i;
+    const int iy = y0 + prow / PP_W - 1, ix = x0 + prow % PP_W - 1;
+    pok[i] = prow < PP_ROWS && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W && q * 4 < p.Cin;
+    ppix[i] = pok[i] ? p.x + (((int64_t)b * p.H + iy) * p.W + ix) * p.Cin + q * 4 : p.x;
+  }
+
+  f32x4_t acc[NI][4];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  f32x4_t rx[6];
+  // weight tile of a tap: NI == 4 the whole 16 KB image (4 one-KiB pieces per wave); NI == 2 this workgroup's 64 rows of each
+  // plane (2 x 4 KB, one piece per wave and plane), parked at rows 0..63 of the plane's LDS image
+  constexpr int WPIECES = NI == 4 ? 4 : 2;
+  constexpr int WSTEP_B = NI == 4 ? 4096 : PLANE * 2;             // bytes between a wave's pieces (global and LDS alike)
+  const char* wsrc = reinterpret_cast<const char*>(p.w) + (int64_t)nblk * (TILE * 2) + nhalf * 4096 + tid * 16;
+  auto dma_w = [&](int slab, int tap, bf16_t* slot) __attribute__((always_inline)) {
+    const char* src = wsrc + ((int64_t)tap * p.kslabs + slab) * p.nblks * (TILE * 2);
+    char* dst = reinterpret_cast<char*>(slot) + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < WPIECES; ++i) __builtin_amdgcn_global_load_lds((gptr_t)(src + i * WSTEP_B), (lptr_t)(dst + i * WSTEP_B), 16, 0, 0);
+  };
+  auto fetch_x = [&](int slab) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) rx[i] = *reinterpret_cast<const f32x4_t*>(pok[i] ? ppix[i] + slab * SBK : p.x);
+  };
+  auto stash_x = [&](int slab) __attribute__((always_inline)) {
+    float mu = 0.f, rstd = 1.f;
+    f32x4_t ga = {1.f, 1.f, 1.f, 1.f}, be = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (GN) {
+      const int c = slab * SBK + q * 4;
+      const float2 mr = p.mu_rstd[b * p.G + c / p.cpg];
+      mu = mr.x; rstd = mr.y;
+      ga = *reinterpret_cast<const f32x4_t*>(p.gamma + c);
+      be = *reinterpret_cast<const f32x4_t*>(p.beta + c);
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int prow = (tid >> 3) + 32 * i;
+      if (prow >= PP_ROWS) continue;
+      f32x4_t v = rx[i];
+      if constexpr (GN) v = gn_swish_quad(v, mu, rstd, ga, be, p.swish);
+      if (!pok[i]) v = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      store_split_quad(Xp, XPATCH, prow, q, v, ex);
+    }
+  };
+
+  const int nkt = p.kslabs * 9;
+  fetch_x(0);
+  dma_w(0, 0, W0);
+  dma_w(0, 1, W1);
+  stash_x(0);
+  // tap 0's tile has landed (tap 1's pieces may still be in flight)
+  if constexpr (WPIECES == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  RAW_BARRIER();
+  const int wrow = swz(wn * (NI * 16) + l16, g);
+  for (int slab = 0; slab < p.kslabs; ++slab) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      bf16_t* cur = tap % 3 == 0 ? W0 : tap % 3 == 1 ? W1 : W2;
+      bf16_t* two_ahead = (tap + 2) % 3 == 0 ? W0 : (tap + 2) % 3 == 1 ? W1 : W2;   // last read one tap ago, before that tap's barrier
+      const bool has2 = slab * 9 + tap + 2 < nkt;
+      const bool next_slab = tap == 8 && slab + 1 < p.kslabs;
+      const int dy = tap / 3, dx = tap % 3;
+      h16x8_t w1[NI], w2[NI], x1[4], x2[4];
+      const bf16_t* wl = cur + wrow;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        w1[i] = *reinterpret_cast<const h16x8_t*>(wl + i * 16 * SBK);
+        w2[i] = *reinterpret_cast<const h16x8_t*>(wl + PLANE + i * 16 * SBK);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bf16_t* xr = Xp + swz((wm * 4 + j + dy) * PP_W + l16 + dx, g);
+        x1[j] = *reinterpret_cast<const h16x8_t*>(xr);
+        x2[j] = *reinterpret_cast<const h16x8_t*>(xr + XPATCH);
+      }
+      if (has2) dma_w(slab + (tap + 2 >= 9 ? 1 : 0), (tap + 2) % 9, two_ahead);
+      if (next_slab) fetch_x(slab + 1);                         // six register loads behind the DMA
+      // the NEXT tap's tile (issued one tap ago) has landed; the pieces issued just now (and the patch loads) may stay in flight
+      if (next_slab) { if constexpr (WPIECES == 4) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+      else if (has2) { if constexpr (WPIECES == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      RAW_BARRIER();                                            // everyone's fragments of this tap are in registers, the next tile is complete
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[i], x2[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w2[i], x1[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[i], x1[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    if (slab + 1 < p.kslabs) {
+      stash_x(slab + 1);                                        // (every wave's reads of this slab's patch came before the last barrier)
+      RAW_BARRIER();
+    }
+  }
+
+  const int ox = x0 + l16;
+  QuadStats qs[NI];
+  float mx = 0.f;
+#pragma unroll
+  for (int i = 0; i < NI; ++i) qs[i] = QuadStats{0.0, 0.0};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int oy = y0 + wm * 4 + j;
+    if (oy >= p.H || ox >= p.W) continue;
+    const int64_t m = ((int64_t)b * p.H + oy) * p.W + ox;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int n = nblk * SBN + nhalf * 64 + wn * (NI * 16) + i * 16 + g * 4;
+      if (n >= p.Cout) continue;
+      const f32x4_t v = store_out_quad(acc[i][j], unscale, p.bias ? p.bias + n : nullptr, p.res ? p.res + m * p.Cout + n : nullptr,
+                                       p.y + m * p.Cout + n, 0);
+      qs[i].add(v);
+      mx = fmaxf(mx, quad_absmax(v));
+    }
+  }
+  if (p.stats_out) {
+    __syncthreads();
+    flush_quad_stats<NI>(qs, mx, reinterpret_cast<double*>(W0), wn * NI * 4, g, l16, tid, nblk * SBN + nhalf * 64, p.Cout, p.out_cpg,
+                         p.stats_out + (int64_t)b * (p.Cout / p.out_cpg) * 2, p.amax_out);
+  }
+}
+
 // packed fp32 weights [taps][Cin][cout_pad] -> per (tap, slab, cout block) tile: 2 planes x [128 cout][32 cin] fp16 of
 // the weights scaled by 2^ew (ew from *amax, the tensor's max|w| computed just before), in the swizzled LDS image.
 // One thread per 16-byte chunk of the output.
@@ -862,6 +1021,7 @@ extern "C" int ug_conv3x3_split(const float* x, const float* x_amax, const uint1
   const bool half = !big && ntiles * nb_n < 512;
   dim3 grid((unsigned)((ntiles + 7) / 8 * 8), (unsigned)(half ? (Cout + 63) / 64 : nb_n));
   const dim3 block(big ? 512 : 256);
+  static const int dma8 = [] { const char* e = getenv("UNIGEN_CONV_DMA8"); return e ? atoi(e) : 1; }();
   if (gn_mu_rstd) {
     UG_REQUIRE(gn_gamma && gn_beta && gn_groups > 0 && Cin % gn_groups == 0 && (Cin / gn_groups) % 4 == 0 &&
                    ug_aligned16(gn_gamma) && ug_aligned16(gn_beta) && ((uintptr_t)gn_mu_rstd & 7) == 0,
@@ -870,11 +1030,15 @@ extern "C" int ug_conv3x3_split(const float* x, const float* x_amax, const uint1
     a.mu_rstd = reinterpret_cast<const float2*>(gn_mu_rstd); a.gamma = gn_gamma; a.beta = gn_beta;
     a.G = gn_groups; a.cpg = Cin / gn_groups; a.swish = gn_swish;
     if (big) hipLaunchKernelGGL(conv3x3_patch16_kernel<true>, grid, block, 0, st, a);
+    else if (half && dma8) hipLaunchKernelGGL((conv3x3_patch_dma_kernel<true, 2>), grid, block, 0, st, a);
     else if (half) hipLaunchKernelGGL((conv3x3_patch_kernel<true, 2>), grid, block, 0, st, a);
+    else if (dma8) hipLaunchKernelGGL((conv3x3_patch_dma_kernel<true, 4>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((conv3x3_patch_kernel<true, 4>), grid, block, 0, st, a);
   } else {
     if (big) hipLaunchKernelGGL(conv3x3_patch16_kernel<false>, grid, block, 0, st, a);
+    else if (half && dma8) hipLaunchKernelGGL((conv3x3_patch_dma_kernel<false, 2>), grid, block, 0, st, a);
     else if (half) hipLaunchKernelGGL((conv3x3_patch_kernel<false, 2>), grid, block, 0, st, a);
+    else if (dma8) hipLaunchKernelGGL((conv3x3_patch_dma_kernel<false, 4>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((conv3x3_patch_kernel<false, 4>), grid, block, 0, st, a);
   }
   UG_CHECK_LAUNCH("ug_conv3x3_split");
