@@ -69,6 +69,50 @@ __global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* __restric
   }
 }
 
+// The same for rows of at most 64 * 4 * NV columns with the row kept in registers between the two passes (one read of x instead
+// of an HBM read + an L2 re-read), several rows per wave; identical arithmetic and summation order.
+template <bool OUT_F32, int NV>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_reg_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              void* __restrict__ y, float* __restrict__ rstd,
+                                                              int rows, int cols, float eps, int rows_per_wave) {
+  const int lane = threadIdx.x & 63;
+  const int nv = cols >> 2;
+  const float4* wr = reinterpret_cast<const float4*>(w);
+  const int r0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * rows_per_wave;
+  for (int row = r0; row < min(rows, r0 + rows_per_wave); ++row) {
+    const float4* xr = reinterpret_cast<const float4*>(x + (int64_t)row * cols);
+    float4 v[NV];
+    float ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int i = lane + k * 64;
+      if (i < nv) { v[k] = xr[i]; }
+    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int i = lane + k * 64;
+      if (i < nv) ss += v[k].x * v[k].x + v[k].y * v[k].y + v[k].z * v[k].z + v[k].w * v[k].w;
+    }
+    ss = wave_sum(ss);
+    const float r = rsqrtf(ss / (float)cols + eps);
+    if (lane == 0 && rstd) rstd[row] = r;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      const int i = lane + k * 64;
+      if (i < nv) {
+        const float4 g = wr[i];
+        const float o0 = g.x * (v[k].x * r), o1 = g.y * (v[k].y * r), o2 = g.z * (v[k].z * r), o3 = g.w * (v[k].w * r);
+        if constexpr (OUT_F32) {
+          reinterpret_cast<float4*>(reinterpret_cast<float*>(y) + (int64_t)row * cols)[i] = make_float4(o0, o1, o2, o3);
+        } else {
+          uint2 o; o.x = pack_bf2(o0, o1); o.y = pack_bf2(o2, o3);
+          reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(y) + (int64_t)row * cols)[i] = o;
+        }
+      }
+    }
+  }
+}
+
 // dres += rstd * (g - xhat * mean(g * xhat)),  g = dy * w,  xhat = x * rstd;   dw += sum_rows dy * xhat
 // Each wave walks ROWS_PER_WAVE rows keeping its dw partials in registers (cols <= 64*4*MAXV).
 constexpr int RN_MAXV = 8;   // supports cols <= 2048
@@ -95,9 +139,17 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
     float4* dr = reinterpret_cast<float4*>(dres + (int64_t)row * cols);
     const float r = rstd[row];
     float4 g[NV], xh[NV], acc[NV];
+    uint2 dyv[NV];
     float dot = 0.f;
+    // every load of the row goes out before anything is consumed (x / dy first: the dot product needs them; then the residual
+    // gradient this row adds to)
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {                      // the residual gradient this row adds to: in flight with x / dy
+    for (int k = 0; k < NV; ++k) {
+      const int i = lane + k * 64;
+      if (i < nv) { xh[k] = ld_stream<NT>(xr + i); dyv[k] = ld_stream<NT>(dyr + i); }   // last use of x and dy
+    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
       const int i = lane + k * 64;
       if (i < nv) acc[k] = dr[i];
     }
@@ -105,7 +157,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
     for (int k = 0; k < NV; ++k) {
       const int i = lane + k * 64;
       if (i < nv) {
-        const float4 v = ld_stream<NT>(xr + i), ww = wr[i]; const uint2 d = ld_stream<NT>(dyr + i);   // last use of x and dy
+        const float4 v = xh[k], ww = wr[i]; const uint2 d = dyv[k];
         const float d0 = bf2f(d.x & 0xffff), d1 = bf2f(d.x >> 16), d2 = bf2f(d.y & 0xffff), d3 = bf2f(d.y >> 16);
         xh[k] = make_float4(v.x * r, v.y * r, v.z * r, v.w * r);
         g[k] = make_float4(d0 * ww.x, d1 * ww.y, d2 * ww.z, d3 * ww.w);
@@ -485,7 +537,13 @@ extern "C" int ug_rmsnorm_fwd(const float* x, const float* w, void* y, float* rs
   UG_REQUIRE(rows > 0 && cols > 0 && cols % 4 == 0, "ug_rmsnorm_fwd: cols=%ld must be a positive multiple of 4", (long)cols);
   UG_REQUIRE(ug_aligned16(x) && ug_aligned16(w) && ug_aligned16(y), "ug_rmsnorm_fwd: pointers must be 16B aligned");
   dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-  if (out_f32) hipLaunchKernelGGL(rmsnorm_fwd_kernel<true>, grid, block, 0, st, x, w, y, rstd, (int)rows, (int)cols, eps);
+  // rows per wave of the register form (0: the two-pass kernel).  In the step (tools/probes/run_r3v.sh): 27.7 us two-pass, 21.0 at one
+  // row per wave, 22.2 at two, 25.4 at four
+  static const int reg = [] { const char* e = getenv("UNIGEN_RN_FWD_REG"); return e ? atoi(e) : 1; }();
+  if (reg > 0 && cols <= 2048 && !out_f32) {
+    dim3 g2((unsigned)((rows + 4 * reg - 1) / (4 * reg)));
+    hipLaunchKernelGGL((rmsnorm_fwd_reg_kernel<false, 8>), g2, block, 0, st, x, w, y, rstd, (int)rows, (int)cols, eps, reg);
+  } else if (out_f32) hipLaunchKernelGGL(rmsnorm_fwd_kernel<true>, grid, block, 0, st, x, w, y, rstd, (int)rows, (int)cols, eps);
   else hipLaunchKernelGGL(rmsnorm_fwd_kernel<false>, grid, block, 0, st, x, w, y, rstd, (int)rows, (int)cols, eps);
   UG_CHECK_LAUNCH("ug_rmsnorm_fwd");
   return UG_OK;
