@@ -11,6 +11,8 @@ Nothing is skipped, cached across steps or run at reduced size.
 
     python bench.py --gpus 1 --steps 5 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...      (no launcher: bench.py starts torch.distributed.run itself as a CHILD process before
+                                       anything touches the GPU and relays its output and exit code)
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the bf16 MFMA GEMM): algorithmic
 flops per launch / average launch duration, measured with HIP events on the launch stream during
@@ -351,6 +353,31 @@ def extra_cases(model, vq, opt, dev, args, steps=2):
     return out
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): start the N ranks through torch.distributed.run as a
+    child process and relay its stdout / exit code.  This parent never initialises the GPU (it only counts devices, which does not)
+    and never replaces itself (no exec): on this pool an exec from a GPU-initialised process takes the machine down."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n and os.environ.get("UNIGEN_BENCH_ONE_DEVICE") != "1":
+        raise SystemExit(f"--gpus {n} but this node exposes {have} GPU(s); a weak-scaling number needs one GPU per rank "
+                         "(UNIGEN_DIST_BACKEND=gloo UNIGEN_BENCH_ONE_DEVICE=1 rehearses the path on one device)")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)      # stderr is inherited
+    for line in proc.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -364,11 +391,13 @@ def main():
     ap.add_argument("--no-ar", action="store_true", help="skip the AR image-token generation measurement (second half of the metric)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node must equal --gpus")
     # UNIGEN_DIST_BACKEND=gloo + UNIGEN_BENCH_ONE_DEVICE=1: rehearse the N > 1 path with every rank on cuda:0 (RCCL refuses
     # two ranks on one device); the default is RCCL ("nccl") with one GPU per rank
     backend = os.environ.get("UNIGEN_DIST_BACKEND", "nccl")
@@ -433,15 +462,27 @@ def main():
         step()
     model.llm.engine.check_errors()
     barrier()
+    sync = model.llm.engine.grad_sync               # the flat-gradient exchange the engine installed (None at N = 1)
+    wire0 = (sync.bytes_on_wire, sync.lookup_bytes_on_wire) if sync is not None else (0, 0)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     dt = time.perf_counter() - t0
+    exchange = None
     if world > 1:
         t = torch.tensor([dt], device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
+        # proof that the exchange's communicator spans N ranks: a SUM of ones on the process group the buckets move through
+        if sync is None:
+            raise SystemExit("world > 1 but the engine installed no gradient exchange: the timed steps were not data-parallel")
+        exchange = dict(sync.describe(), ranks_seen=sync.ranks_seen(),
+                        bytes_on_wire_per_step=int((sync.bytes_on_wire - wire0[0]) / args.steps),
+                        lookup_bytes_on_wire_per_step=int((sync.lookup_bytes_on_wire - wire0[1]) / args.steps),
+                        early_embed_handovers=sync.early_embed_handovers)
+        if exchange["ranks_seen"] != world:
+            raise SystemExit(f"the exchange's communicator saw {exchange['ranks_seen']} ranks, expected {world}")
     ms = dt / args.steps * 1e3
     value = B * world / (dt / args.steps)
 
@@ -543,6 +584,7 @@ def main():
                                       "fwd+bwd+grad all-reduce+AdamW, random-init weights",
                           "global_batch": B * world, "seq_len": L, "parallelism": f"dp{world}"},
                "loss_first_last": [round(losses[0].item(), 4), round(losses[-1].item(), 4)],
+               "ranks_seen": exchange["ranks_seen"] if exchange else 1, "exchange": exchange,
                "roofline": roof, "cpu_baseline": cpu, "ar_decode": ar, "extra_cases": extra}
         print(json.dumps(out))
     if world > 1:

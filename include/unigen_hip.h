@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define UG_ABI_VERSION 3
+#define UG_ABI_VERSION 4
 
 /* ---- library ---------------------------------------------------------------------------- */
 const char* ug_last_error(void);
@@ -114,6 +114,11 @@ int ug_embed_fwd(const int64_t* ids, const float* W, float* out, int64_t tokens,
                  int* err_flag, hipStream_t stream);
 int ug_embed_bwd(const int64_t* ids, const float* dout, float* dW, int64_t tokens, int64_t H, int64_t V,
                  hipStream_t stream);
+/* the same scatter-add, deterministic, for the (id, row) pairs gathered from every data-parallel rank: `ids_sorted` ascending
+ * (stable sort: equal ids in rank, then position order; ids outside [0, V) are padding and skipped), `order[p]` = row of `rows`
+ * that sorted position p came from; dW[id] += scale * (sum of the run's rows in that order), one writer per table row */
+int ug_embed_bwd_sorted(const int64_t* ids_sorted, const int64_t* order, const float* rows, float* dW, int64_t n,
+                        int64_t H, int64_t V, float scale, hipStream_t stream);
 /* gather (scatter=0): out[i,:] = in[idx[i],:] ; scatter (1): out[idx[i],:] = in[i,:]   (bf16 rows)
  * replaces the logits[..., -(n+1):-1] / [:, :-1] position slicing of models/unigen.py:310-338 */
 int ug_gather_rows_bf16(const void* in, int64_t ld_in, const int64_t* idx, void* out, int64_t ld_out,
@@ -303,6 +308,12 @@ int ug_grad_sum_shards_bf16(const void* shards_bf16, int world, int64_t stride, 
  *                             UG_COMM_FP32          ncclAllReduce(fp32, AVG): DDP's arithmetic, 4 bytes per element on the links
  *                             UG_COMM_BF16_FP32ACC  bf16 on the links, fp32 sum in rank order, one final bf16 rounding
  *                             UG_COMM_BF16          bf16(g / world) summed by ncclAllReduce in bf16 (least accurate)
+ *                             UG_COMM_FP32_RSAG     fp32 as ncclReduceScatter(AVG) + ncclAllGather in place (+ a short all-reduce
+ *                                                   for the tail that does not divide by the world size)
+ *   ug_comm_allgather       recv[r * bytes_per_rank ...] = rank r's `send` bytes, on the communicator's side stream, ordered
+ *                           after `producer` like a bucket (the per-token embedding-lookup gradient rows and their ids: the
+ *                           dense head gradient of the tied table is exchanged right after the head's backward, the lookups'
+ *                           few rows at the end, training/train.py:602-609 are the lookups)
  *   ug_comm_wait            `consumer` waits for every bucket issued so far (end of backward, before clipping / the optimizer)
  *   ug_comm_bytes_on_wire   payload handed to the collectives since init (reporting)
  * No call synchronises the host.  Buckets must be 16-byte aligned. */
@@ -311,9 +322,11 @@ typedef struct ug_comm ug_comm;
 #define UG_COMM_FP32 0
 #define UG_COMM_BF16_FP32ACC 1
 #define UG_COMM_BF16 2
+#define UG_COMM_FP32_RSAG 3
 int ug_comm_unique_id(void* id128);
 int ug_comm_init(ug_comm** out, int world, int rank, const void* id128, int64_t max_bucket_elems);
 int ug_comm_allreduce_bucket(ug_comm* comm, float* grad, int64_t n, int mode, hipStream_t producer);
+int ug_comm_allgather(ug_comm* comm, const void* send, void* recv, int64_t bytes_per_rank, hipStream_t producer);
 int ug_comm_wait(ug_comm* comm, hipStream_t consumer);
 int ug_comm_destroy(ug_comm* comm);
 int64_t ug_comm_bytes_on_wire(const ug_comm* comm);

@@ -17,13 +17,29 @@
 //                         ncclSend / ncclRecv); rank-ordered fp32 sum of the world copies of this rank's slice, x 1 / world,
 //                         one bf16 rounding (ug_grad_sum_shards_bf16); ncclAllGather; unpack
 //   UG_COMM_BF16          pack bf16(g / world); ncclAllReduce(bf16, SUM); unpack  (world - 1 extra roundings on a ring)
+//   UG_COMM_FP32_RSAG     fp32 like UG_COMM_FP32 but as ncclReduceScatter(AVG) + ncclAllGather in place on the bucket (every rank
+//                         owns one slice of the sum; both halves are single collectives RCCL can spread over all seven xGMI links
+//                         of a rank at once), a short ncclAllReduce for the tail that does not divide by the world size
+// ug_comm_allgather moves opaque bytes (the per-token embedding-lookup gradient rows + their ids, unigen_hip/ddp.py).
 #include "common.h"
 #include "unigen_hip.h"
 #include <dlfcn.h>
 #include <stdlib.h>
 #include <string.h>
 #include <new>
-#include <rccl/rccl.h>           // types and enumerators only: every function is called through dlsym
+
+// The handful of RCCL types and enumerators this file needs, declared here with the values of rccl.h (NCCL's stable ABI) so that the
+// library builds on hosts without RCCL headers; every function is resolved with dlsym at ug_comm_init time.
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef int ncclResult_t;
+typedef int ncclDataType_t;
+typedef int ncclRedOp_t;
+}
+enum : int { ncclSuccess = 0 };
+enum : int { ncclUint8 = 1, ncclFloat32 = 7, ncclBfloat16 = 9 };
+enum : int { ncclSum = 0, ncclAvg = 4 };
 
 namespace {
 
@@ -34,6 +50,7 @@ struct RcclApi {
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
@@ -63,6 +80,7 @@ int load_rccl() {
   UG_SYM(CommDestroy, "ncclCommDestroy")
   UG_SYM(AllReduce, "ncclAllReduce")
   UG_SYM(AllGather, "ncclAllGather")
+  UG_SYM(ReduceScatter, "ncclReduceScatter")
   UG_SYM(Send, "ncclSend")
   UG_SYM(Recv, "ncclRecv")
   UG_SYM(GroupStart, "ncclGroupStart")
@@ -149,10 +167,11 @@ extern "C" int ug_comm_destroy(ug_comm* c) {
 
 extern "C" int ug_comm_allreduce_bucket(ug_comm* c, float* grad, int64_t n, int mode, hipStream_t producer) {
   UG_REQUIRE(c && grad && n > 0 && ug_aligned16(grad), "ug_comm_allreduce_bucket: need a communicator and a 16-byte aligned bucket");
-  UG_REQUIRE(mode == UG_COMM_FP32 || mode == UG_COMM_BF16_FP32ACC || mode == UG_COMM_BF16, "ug_comm_allreduce_bucket: unknown mode %d", mode);
+  UG_REQUIRE(mode == UG_COMM_FP32 || mode == UG_COMM_BF16_FP32ACC || mode == UG_COMM_BF16 || mode == UG_COMM_FP32_RSAG,
+             "ug_comm_allreduce_bucket: unknown mode %d", mode);
   const int W = c->world;
   const int64_t chunk = ((n + 8 * W - 1) / (8 * W)) * 8, n_pad = chunk * W;
-  UG_REQUIRE(mode == UG_COMM_FP32 || n_pad <= c->cap, "ug_comm_allreduce_bucket: bucket of %ld elements exceeds the %ld the communicator was "
+  UG_REQUIRE(mode == UG_COMM_FP32 || mode == UG_COMM_FP32_RSAG || n_pad <= c->cap, "ug_comm_allreduce_bucket: bucket of %ld elements exceeds the %ld the communicator was "
              "created for", (long)n, (long)c->cap);
   // the side stream starts when the producer stream has retired what is queued on it now (the kernels that wrote the bucket)
   UG_HIP(hipEventRecord(c->ready, producer));
@@ -160,6 +179,18 @@ extern "C" int ug_comm_allreduce_bucket(ug_comm* c, float* grad, int64_t n, int 
   hipStream_t s = c->stream;
   if (mode == UG_COMM_FP32) {
     UG_NCCL(g_rccl.AllReduce(grad, grad, (size_t)n, ncclFloat32, ncclAvg, c->comm, s));
+    c->bytes_on_wire += n * 4;
+    return UG_OK;
+  }
+  if (mode == UG_COMM_FP32_RSAG) {
+    // in place: rank r's slice of the mean lands at grad + r * part (NCCL's in-place reduce-scatter convention), then every
+    // rank's slice is gathered back around it; part is a multiple of 4 elements so slices stay 16-byte aligned
+    const int64_t part = (n / ((int64_t)W * 4)) * 4, body = part * W;
+    if (part > 0) {
+      UG_NCCL(g_rccl.ReduceScatter(grad, grad + (int64_t)c->rank * part, (size_t)part, ncclFloat32, ncclAvg, c->comm, s));
+      UG_NCCL(g_rccl.AllGather(grad + (int64_t)c->rank * part, grad, (size_t)part, ncclFloat32, c->comm, s));
+    }
+    if (n > body) UG_NCCL(g_rccl.AllReduce(grad + body, grad + body, (size_t)(n - body), ncclFloat32, ncclAvg, c->comm, s));
     c->bytes_on_wire += n * 4;
     return UG_OK;
   }
@@ -174,16 +205,36 @@ extern "C" int ug_comm_allreduce_bucket(ug_comm* c, float* grad, int64_t n, int 
   if (n_pad > n) UG_HIP(hipMemsetAsync(send + n, 0, (size_t)(n_pad - n) * sizeof(bf16_t), s));
   if (int rc = ug_grad_pack_bf16(grad, send, n, 1.0f, s)) return rc;
   UG_NCCL(g_rccl.GroupStart());                          // all-to-all: recv[j] = rank j's copy of this rank's slice
-  for (int j = 0; j < W; ++j) {
-    UG_NCCL(g_rccl.Send(send + (int64_t)j * chunk, (size_t)chunk, ncclBfloat16, j, c->comm, s));
-    UG_NCCL(g_rccl.Recv(recv + (int64_t)j * chunk, (size_t)chunk, ncclBfloat16, j, c->comm, s));
+  ncclResult_t first = ncclSuccess;                      // (an error inside the bracket must not leave the group open: every
+  const char* what = "";                                 //  later collective of this thread would queue into it and hang)
+  for (int j = 0; j < W && first == ncclSuccess; ++j) {
+    first = g_rccl.Send(send + (int64_t)j * chunk, (size_t)chunk, ncclBfloat16, j, c->comm, s);
+    what = "ncclSend";
+    if (first == ncclSuccess) {
+      first = g_rccl.Recv(recv + (int64_t)j * chunk, (size_t)chunk, ncclBfloat16, j, c->comm, s);
+      what = "ncclRecv";
+    }
   }
-  UG_NCCL(g_rccl.GroupEnd());
+  const ncclResult_t closed = g_rccl.GroupEnd();
+  if (first != ncclSuccess || closed != ncclSuccess) {
+    ug_set_error("ug_comm all-to-all: %s failed: %s", first != ncclSuccess ? what : "ncclGroupEnd",
+                 g_rccl.GetErrorString(first != ncclSuccess ? first : closed));
+    return UG_ERR_LAUNCH;
+  }
   bf16_t* mine = send + (int64_t)c->rank * chunk;        // (this rank's own packed slice has been sent: reuse it)
   if (int rc = ug_grad_sum_shards_bf16(recv, W, chunk, mine, chunk, 1.0f / (float)W, s)) return rc;
   UG_NCCL(g_rccl.AllGather(mine, recv, (size_t)chunk, ncclBfloat16, c->comm, s));
   c->bytes_on_wire += 2 * n_pad * 2;
   return ug_grad_unpack_bf16(recv, grad, n, s);
+}
+
+extern "C" int ug_comm_allgather(ug_comm* c, const void* send, void* recv, int64_t bytes_per_rank, hipStream_t producer) {
+  UG_REQUIRE(c && send && recv && bytes_per_rank > 0, "ug_comm_allgather: need a communicator, both buffers and a positive size");
+  UG_HIP(hipEventRecord(c->ready, producer));
+  UG_HIP(hipStreamWaitEvent(c->stream, c->ready, 0));
+  UG_NCCL(g_rccl.AllGather(send, recv, (size_t)bytes_per_rank, ncclUint8, c->comm, c->stream));
+  c->bytes_on_wire += bytes_per_rank * c->world;
+  return UG_OK;
 }
 
 extern "C" int ug_comm_wait(ug_comm* c, hipStream_t consumer) {

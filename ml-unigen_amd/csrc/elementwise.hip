@@ -330,6 +330,31 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restric
   }
 }
 
+// Deterministic form for the data-parallel exchange (unigen_hip/ddp.py): the (id, gradient row) pairs of EVERY rank, sorted by id
+// with a stable sort (so equal ids keep rank order, then position order).  One workgroup per sorted position; only the first
+// position of a run of equal ids works: it sums the run's rows in that fixed order and adds scale * sum to dW[id] -- one writer
+// per table row, no atomics, the same bits on every rank.
+__global__ __launch_bounds__(256) void embed_bwd_sorted_kernel(const int64_t* __restrict__ ids_sorted, const int64_t* __restrict__ order,
+                                                               const float* __restrict__ rows, float* __restrict__ dW,
+                                                               int64_t n, int H, int64_t V, float scale) {
+  const int64_t p = blockIdx.x;
+  const int64_t id = ids_sorted[p];
+  if (id < 0 || id >= V) return;
+  if (p > 0 && ids_sorted[p - 1] == id) return;
+  const int per_row = H >> 2;
+  for (int c = threadIdx.x; c < per_row; c += blockDim.x) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t j = p; j < n && ids_sorted[j] == id; ++j) {
+      const float4 v = reinterpret_cast<const float4*>(rows + order[j] * H)[c];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    float4* d = reinterpret_cast<float4*>(dW + id * H) + c;
+    float4 o = *d;
+    o.x += scale * acc.x; o.y += scale * acc.y; o.z += scale * acc.z; o.w += scale * acc.w;
+    *d = o;
+  }
+}
+
 // =========================================================================== column sums (bias grad)
 // out[c] += sum_r in[r, c]   (bf16 in, fp32 out); block = 64 columns x 4 row-lanes
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ in, int64_t ld, float* __restrict__ out,
@@ -642,6 +667,15 @@ extern "C" int ug_embed_bwd(const int64_t* ids, const float* dout, float* dW, in
   dim3 grid(grid_for(tokens * H)), block(256);
   hipLaunchKernelGGL(embed_bwd_kernel, grid, block, 0, st, ids, dout, dW, tokens, (int)H, V);
   UG_CHECK_LAUNCH("ug_embed_bwd");
+  return UG_OK;
+}
+
+extern "C" int ug_embed_bwd_sorted(const int64_t* ids_sorted, const int64_t* order, const float* rows, float* dW, int64_t n,
+                                   int64_t H, int64_t V, float scale, hipStream_t st) {
+  UG_REQUIRE(ids_sorted && order && rows && dW && n > 0 && H > 0 && H % 4 == 0 && n < (1ll << 31) && ug_aligned16(rows) && ug_aligned16(dW),
+             "ug_embed_bwd_sorted: need sorted ids, their permutation, 16B-aligned rows / table and H %% 4 == 0");
+  hipLaunchKernelGGL(embed_bwd_sorted_kernel, dim3((unsigned)n), dim3(256), 0, st, ids_sorted, order, rows, dW, n, (int)H, V, scale);
+  UG_CHECK_LAUNCH("ug_embed_bwd_sorted");
   return UG_OK;
 }
 

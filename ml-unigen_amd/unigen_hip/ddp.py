@@ -10,6 +10,8 @@ gradient buffer, issued bucket by bucket on a side HIP stream while backward is 
 
 * reduce = "fp32" (default): the bucket itself is all-reduced (AVG on RCCL, SUM and a scale on gloo) -- bit-for-bit
   what DDP's reducer computes; 6.2 GB per step on the links for the 1.5B model.
+* reduce = "fp32_rsag" (`UNIGEN_DDP_REDUCE=fp32_rsag`): the same fp32 mean as ONE reduce-scatter + ONE all-gather in place on
+  the bucket (every rank owns a slice of the sum; a short all-reduce covers the tail that does not divide by the world size).
 * reduce = "bf16_fp32acc" (`UNIGEN_DDP_REDUCE=bf16_fp32acc`): bf16 on the wire, fp32 arithmetic.  Each rank packs
   bf16(g), an all-to-all hands rank r every rank's copy of slice r, the slice is summed in fp32 in rank order and scaled
   (`ug_grad_sum_shards_bf16`), rounded to bf16 ONCE and all-gathered: two bf16 roundings per element whatever the world
@@ -21,6 +23,18 @@ gradient buffer, issued bucket by bucket on a side HIP stream while backward is 
 Transport: `torch.distributed` collectives by default (backend "nccl" IS RCCL on ROCm); `UNIGEN_DDP_TRANSPORT=ug_comm` moves
 the buckets through the library's own RCCL entry points instead (include/unigen_hip.h: ug_comm_*; csrc/comm.hip) -- the same
 wire formats on the communicator's own side stream, torch.distributed only carries the 128-byte rendezvous id.
+
+The tied embedding table (983 MB of fp32 for the 1.5B model, a sixth of the payload) has two kinds of writers: the head's DENSE
+weight gradient, final right after the head's backward -- the very first thing a backward pass computes -- and the per-token
+scatter-adds of the embedding lookups, which come last.  The dense part is handed over as soon as the last recorded head has run
+(tag 'head', before 'norm') and travels under the whole decoder-stack backward; the lookups never touch the table before the
+exchange: their (token id, gradient row) pairs -- 12 336 rows of 6 KB per rank for the benchmark batch, 76 MB -- are kept aside,
+all-gathered at the end (padded to the largest per-rank count, agreed by a one-element MAX collective issued at the START of the
+backward pass on the side stream, so the host never waits for the device), sorted by id with a stable sort and added by a
+one-writer-per-row kernel (`ug_embed_bwd_sorted`): mean(head) + (1 / W) sum of every rank's lookup rows, the same bits on every
+rank.  Any other order of writers stays correct: a dense writer that arrives after the hand-over waits for the exchange in
+flight and marks the table for a second exchange at the end (the mean of identical values).  `UNIGEN_DDP_SPARSE_EMBED=0`
+restores the single end-of-backward exchange of the whole table.
 
 After `finish()` every gradient holds the MEAN over ranks, exactly what DDP leaves in `.grad`: the caller's unchanged
 `accelerator.clip_grad_norm_` and any stock torch optimizer see the same values as in the reference (no grad_scale
@@ -50,9 +64,9 @@ class FlatGradSync:
         self.cuda = engine.fp.grad.is_cuda
         if reduce is None:
             reduce = os.environ.get("UNIGEN_DDP_REDUCE", "fp32")
-        if reduce not in ("bf16", "bf16_fp32acc", "fp32"):
-            raise ValueError(f"FlatGradSync: reduce must be 'fp32', 'bf16_fp32acc' or 'bf16' (got {reduce!r})")
-        if reduce != "fp32" and not self.cuda:
+        if reduce not in ("bf16", "bf16_fp32acc", "fp32", "fp32_rsag"):
+            raise ValueError(f"FlatGradSync: reduce must be 'fp32', 'fp32_rsag', 'bf16_fp32acc' or 'bf16' (got {reduce!r})")
+        if reduce.startswith("bf16") and not self.cuda:
             raise ValueError("FlatGradSync: the bf16 exchanges pack with a HIP kernel; CPU tensors use reduce='fp32'")
         self.reduce = reduce
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
@@ -75,8 +89,18 @@ class FlatGradSync:
         self._starts = {i: fp.off[f"l{i}.wqkv"][0] for i in range(n)}
         self._numel = fp.grad.numel()
         self._stage = None              # bf16 staging buffer, sized for the largest bucket on first use
-        self._gather = None
         self.bytes_on_wire = 0          # payload handed to the collective since construction (tests / bench reporting)
+        self.early_embed_handovers = 0  # passes in which the tied table's dense part left right after the head's backward
+        self.lookup_bytes_on_wire = 0   # ... of which the all-gathered embedding-lookup rows and ids (counted separately)
+        # tied embedding table: dense head gradient handed over early, lookups exchanged as (id, row) pairs at the end
+        emb = fp.off.get("embed")
+        self.sparse_embed = (os.environ.get("UNIGEN_DDP_SPARSE_EMBED", "1") == "1" and emb is not None and len(emb[1]) == 2
+                             and emb[0] == 0 and emb[1][1] % 4 == 0)
+        self._embed_end = self._starts[0] if emb is not None and emb[0] == 0 else 0
+        self._embed_done = False        # the table's dense part has been handed over in this pass
+        self._lookups = []              # (ids int64 [n], rows fp32 [n, H]) kept aside in this pass
+        self._cap = None                # agreed per-rank row capacity of this pass: int, or (event, pinned tensor) until read
+        self._pin = None
         engine.grad_ready_hook = self.on_ready
         if self.transport == "ug_comm":
             if not self.cuda:
@@ -99,7 +123,7 @@ class FlatGradSync:
         _l.check(L.ug_comm_init(ctypes.byref(handle), self.world, self.rank, ctypes.create_string_buffer(box[0], 128), int(cap)), "ug_comm_init")
         self._comm, self._lib = handle, L
         self.backend = "ug_comm(rccl)"
-        self._mode = {"fp32": 0, "bf16_fp32acc": 1, "bf16": 2}[self.reduce]
+        self._mode = {"fp32": 0, "bf16_fp32acc": 1, "bf16": 2, "fp32_rsag": 3}[self.reduce]
 
     def _comm_bucket(self, buf, mode=None):
         from . import lib as _l
@@ -123,6 +147,17 @@ class FlatGradSync:
             self._stage = torch.empty(2 * cap, dtype=torch.bfloat16, device=self.engine.fp.grad.device)
         return self._stage
 
+    def _coll(self, fn, out, inp, **kw):
+        """One tensor-API collective (reduce_scatter_tensor / all_gather_into_tensor / all_to_all_single) on the exchange's
+        process group.  RCCL takes device tensors; a rehearsal transport (gloo) is handed host copies, so the slice arithmetic
+        around the call is the one an RCCL run executes (the rank-dependent paths must run with world > 1)."""
+        if self.backend == "nccl" or not out.is_cuda:
+            fn(out, inp, group=self.pg, **kw)
+        else:
+            o, i = out.cpu(), inp.cpu()
+            fn(o, i, group=self.pg, **kw)
+            out.copy_(o)
+
     def _allreduce_mean_(self, buf):
         """in-place mean over ranks of an fp32 tensor on the current stream / host"""
         if self.backend == "nccl":
@@ -130,6 +165,23 @@ class FlatGradSync:
         else:
             dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg)
             buf.mul_(1.0 / self.world)
+
+    def _reduce_scatter_all_gather_mean_(self, buf):
+        """fp32 mean as reduce-scatter + all-gather in place (reduce = 'fp32_rsag'); the tail that does not divide by the world
+        size goes through a short all-reduce"""
+        W = self.world
+        part = buf.numel() // (W * 4) * 4
+        body = part * W
+        if part:
+            mine = buf[self.rank * part:(self.rank + 1) * part]
+            if self.backend == "nccl":
+                dist.reduce_scatter_tensor(mine, buf[:body], op=dist.ReduceOp.AVG, group=self.pg)
+            else:
+                self._coll(dist.reduce_scatter_tensor, mine, buf[:body], op=dist.ReduceOp.SUM)
+                mine.mul_(1.0 / W)
+            self._coll(dist.all_gather_into_tensor, buf[:body], mine)
+        if buf.numel() > body:
+            self._allreduce_mean_(buf[body:])
 
     def _exchange_bf16_fp32acc(self, buf):
         """bf16 on the wire, fp32 arithmetic (see the module docstring); runs on the current (side) stream"""
@@ -142,21 +194,10 @@ class FlatGradSync:
         if n_pad > n:
             send[n:].zero_()
         ops.grad_pack_bf16(buf, send[:n], 1.0)
-        if self.backend != "nccl":
-            # rehearsal transports (gloo moves device tensors through the host and has no all-to-all for them): every rank
-            # gathers every packed bucket and sums all of it -- W times the bytes, the same arithmetic in the same order
-            if self._gather is None or self._gather.numel() < W * n_pad:
-                self._gather = torch.empty(W * n_pad, dtype=torch.bfloat16, device=buf.device)
-            parts = list(self._gather[:W * n_pad].view(W, n_pad).unbind(0))
-            dist.all_gather(parts, send, group=self.pg)
-            ops.grad_sum_shards_bf16(self._gather, W, n_pad, recv, 1.0 / W)
-            ops.grad_unpack_bf16(recv[:n], buf)
-            self.bytes_on_wire += W * n_pad * 2
-            return
-        dist.all_to_all_single(recv, send, group=self.pg)                  # recv[j] = rank j's copy of my slice
+        self._coll(dist.all_to_all_single, recv, send)                    # recv[j] = rank j's copy of my slice
         mine = send[self.rank * chunk:(self.rank + 1) * chunk]            # (my own packed slice is no longer needed)
         ops.grad_sum_shards_bf16(recv, W, chunk, mine, 1.0 / W)
-        dist.all_gather_into_tensor(recv, mine, group=self.pg)
+        self._coll(dist.all_gather_into_tensor, recv, mine)
         ops.grad_unpack_bf16(recv[:n], buf)
         self.bytes_on_wire += 2 * n_pad * 2
 
@@ -170,6 +211,9 @@ class FlatGradSync:
         buf = self.engine.fp.grad[lo:hi]
         if not self.cuda:
             self.bytes_on_wire += buf.numel() * 4
+            if self.reduce == "fp32_rsag":
+                self._reduce_scatter_all_gather_mean_(buf)
+                return
             self._pending.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True), buf))
             return
         if self._comm is not None:
@@ -188,17 +232,146 @@ class FlatGradSync:
                 self.bytes_on_wire += stage.numel() * 2
             elif self.reduce == "bf16_fp32acc":
                 self._exchange_bf16_fp32acc(buf)
+            elif self.reduce == "fp32_rsag":
+                self._reduce_scatter_all_gather_mean_(buf)
+                self.bytes_on_wire += buf.numel() * 4
             else:
                 self._allreduce_mean_(buf)
                 self.bytes_on_wire += buf.numel() * 4
 
+    # ------------------------------------------------------------------ embedding lookups kept aside
+    def wants_lookups(self):
+        """True while a backward pass that exchanges gradients keeps embedding-lookup gradients aside as (id, row) pairs."""
+        return self.active and self.enabled and self.sparse_embed
+
+    def _agree_capacity(self, rows_live):
+        """Start of a backward pass: every rank's count of lookup rows recorded on its autograd graphs (known on the HOST since
+        the forward) -> the MAX over ranks = the padded length of the end-of-backward all-gather.  On a GPU transport the
+        collective and the copy back to pinned memory run on the side stream, which is idle now: the result is on the host long
+        before finish() asks for it."""
+        n = int(rows_live)
+        if self.world == 1:
+            self._cap = n
+        elif not self.cuda or self.backend not in ("nccl", "ug_comm(rccl)"):
+            t = torch.tensor([n], dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.pg)
+            self._cap = int(t.item())
+        else:
+            dev = self.engine.fp.grad.device
+            if self._pin is None:
+                self._pin = (torch.zeros(1, dtype=torch.int64).pin_memory(), torch.zeros(self.world, dtype=torch.int64).pin_memory(),
+                             torch.zeros(1, dtype=torch.int64, device=dev), torch.zeros(self.world, dtype=torch.int64, device=dev))
+            src, dst, d_src, d_all = self._pin
+            src[0] = n
+            with torch.cuda.stream(self.stream):
+                d_src.copy_(src, non_blocking=True)
+                if self._comm is not None:
+                    from . import lib as _l
+                    side = torch.cuda.current_stream().cuda_stream
+                    _l.check(self._lib.ug_comm_allgather(self._comm, d_src.data_ptr(), d_all.data_ptr(), 8, side), "ug_comm_allgather")
+                    _l.check(self._lib.ug_comm_wait(self._comm, side), "ug_comm_wait")
+                else:
+                    dist.all_gather_into_tensor(d_all, d_src, group=self.pg)
+                dst.copy_(d_all, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+            self._cap = (ev, dst)
+
+    def _capacity(self):
+        if isinstance(self._cap, tuple):
+            ev, dst = self._cap
+            ev.synchronize()
+            self._cap = int(dst.max().item())
+        return self._cap or 0
+
+    def add_lookup(self, ids, rows):
+        """An embedding lookup's backward: ids int64 [n], rows fp32 [n, H] (kept, not copied)."""
+        self._lookups.append((ids.reshape(-1), rows))
+
+    def before_dense_embed_write(self):
+        """A dense writer of the tied table (a head's weight gradient, a lookup that could not be kept aside) is about to run.
+        If the table has already been handed over in this pass, wait for that exchange and schedule another one at the end
+        (what is there is the mean over ranks already: averaging identical values again changes nothing)."""
+        if not self._embed_done:
+            return
+        if self.cuda:
+            if self._comm is not None:
+                from . import lib as _l
+                _l.check(self._lib.ug_comm_wait(self._comm, torch.cuda.current_stream().cuda_stream), "ug_comm_wait")
+            else:
+                torch.cuda.current_stream().wait_stream(self.stream)
+        else:
+            self._drain_pending()
+        self._embed_done = False
+
+    def _drain_pending(self):
+        for w, buf in self._pending:
+            w.wait()
+            buf.mul_(1.0 / self.world)
+        self._pending = []
+
+    def _all_gather_flat(self, recv, send):
+        """recv [W * n] <- every rank's send [n] (on the current stream / host)"""
+        if self._comm is not None:
+            from . import lib as _l
+            side = torch.cuda.current_stream().cuda_stream
+            _l.check(self._lib.ug_comm_allgather(self._comm, send.data_ptr(), recv.data_ptr(), send.numel() * send.element_size(), side),
+                     "ug_comm_allgather")
+            _l.check(self._lib.ug_comm_wait(self._comm, side), "ug_comm_wait")
+        else:
+            self._coll(dist.all_gather_into_tensor, recv, send)
+
+    def _exchange_lookups(self):
+        """End of backward, on the side stream (the host, on CPU): all-gather the padded (id, row) pairs of every rank and add
+        (1 / W) x their sum to the table, deterministically (stable sort by id, one writer per table row)."""
+        cap = self._capacity()
+        lookups, self._lookups = self._lookups, []
+        if cap == 0:
+            return
+        fp = self.engine.fp
+        (o, (V, H)) = fp.off["embed"]
+        table = fp.grad[o:o + V * H].view(V, H)
+        n = sum(i.numel() for i, _ in lookups)
+        dev = fp.grad.device
+        ids = torch.full((cap,), -1, dtype=torch.int64, device=dev)
+        rows = torch.empty((cap, H), dtype=torch.float32, device=dev)
+        a = 0
+        for i, r in lookups:
+            ids[a:a + i.numel()] = i
+            rows[a:a + i.numel()] = r.reshape(-1, H)
+            a += i.numel()
+        if n < cap:
+            rows[n:].zero_()
+        W = self.world
+        if W > 1:
+            ids_all = torch.empty(W * cap, dtype=torch.int64, device=dev)
+            rows_all = torch.empty((W * cap, H), dtype=torch.float32, device=dev)
+            self._all_gather_flat(ids_all, ids)
+            self._all_gather_flat(rows_all.view(-1), rows.view(-1))
+            self.lookup_bytes_on_wire += W * cap * (8 + 4 * H)
+        else:
+            ids_all, rows_all = ids, rows
+        if self.cuda:
+            from . import ops
+            ids_sorted, order = torch.sort(ids_all, stable=True)
+            ops.embed_bwd_sorted(ids_sorted, order, rows_all, table, 1.0 / W)
+        else:
+            keep = ids_all >= 0
+            table.index_add_(0, ids_all[keep], rows_all[keep], alpha=1.0 / W)       # sequential on the host: deterministic
+
     # ------------------------------------------------------------------ driven by backward
-    def begin(self, enabled=True):
+    def begin(self, enabled=True, lookup_rows=0):
         """Start of a backward pass.  enabled=False: a gradient-accumulation micro-step (DDP's no_sync): nothing is
-        exchanged, gradients keep accumulating locally."""
+        exchanged, gradients keep accumulating locally.  lookup_rows: embedding-lookup rows recorded on this rank's live
+        autograd graphs (an upper bound of what this pass will keep aside)."""
         self.enabled = bool(enabled)
         self._hi = None
         self._overlap = True
+        self._embed_done = False
+        self._lookups = []
+        self._cap = None
+        if self.wants_lookups():
+            self._agree_capacity(lookup_rows)
 
     def set_overlap(self, on):
         """Called at the start of every decoder-stack segment of a backward pass: only the LAST segment that writes the
@@ -207,10 +380,18 @@ class FlatGradSync:
         self._overlap = bool(on)
 
     def on_ready(self, tag):
-        """tag: 'norm' (first), layer index N-1 .. 0, then 'embed' (any number of times, last).
+        """tag: 'head' (the tied table's dense part is final), 'norm', layer index N-1 .. 0, then 'embed' (any number of times, last).
         The embedding table is NEVER handed over from here: a forward may look embeddings up several times (the reference's
         callers do: training/train.py:602-609,633,671 -- text, t2i and mmu parts), the tied head writes the same table, and
         only the end of backward (finish) knows that no writer is left."""
+        if tag == "head":
+            # the last recorded head has written its dense weight gradient into the tied table: nothing but lookups (kept
+            # aside) is expected to touch it any more in this pass
+            if self.enabled and self.active and self.sparse_embed and not self._embed_done and self._embed_end > 0:
+                self._flush(0, self._embed_end)
+                self._embed_done = True
+                self.early_embed_handovers += 1
+            return
         if not self.enabled or not self._overlap:
             return
         if tag == "norm":
@@ -234,9 +415,24 @@ class FlatGradSync:
             return
         if self._hi is None:
             self._hi = self._numel
-        if self._hi > 0:
-            self._flush(0, self._hi)
+        lo = self._embed_end if self._embed_done else 0
+        if self._hi > lo:
+            self._flush(lo, self._hi)
         self._hi = None
+        if self.sparse_embed:
+            if not self.cuda:
+                self._drain_pending()
+                self._exchange_lookups()
+            else:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                with torch.cuda.stream(self.stream):
+                    self.stream.wait_event(ev)
+                    if self._comm is not None:      # the dense buckets run on the communicator's own stream
+                        from . import lib as _l
+                        _l.check(self._lib.ug_comm_wait(self._comm, self.stream.cuda_stream), "ug_comm_wait")
+                    self._exchange_lookups()
+        self._embed_done = False
         extra = [p for p in (self.extra_params() if self.extra_params is not None else []) if p.grad is not None]
         if self._comm is not None:
             from . import lib as _l
@@ -244,6 +440,7 @@ class FlatGradSync:
             if flat is not None:
                 self._comm_bucket(flat, mode=0)
             _l.check(self._lib.ug_comm_wait(self._comm, torch.cuda.current_stream().cuda_stream), "ug_comm_wait")
+            torch.cuda.current_stream().wait_stream(self.stream)        # (the lookups' sort + scatter ran there)
             o = 0
             for p in extra:
                 n = p.grad.numel()
@@ -256,10 +453,7 @@ class FlatGradSync:
                     self._average_extra(extra)
             torch.cuda.current_stream().wait_stream(self.stream)
         else:
-            for w, buf in self._pending:
-                w.wait()
-                buf.mul_(1.0 / self.world)
-            self._pending = []
+            self._drain_pending()
             if extra:
                 self._average_extra(extra)
 
@@ -272,6 +466,30 @@ class FlatGradSync:
             n = p.grad.numel()
             p.grad.copy_(flat[o:o + n].view_as(p.grad))
             o += n
+
+    # ------------------------------------------------------------------ reporting
+    def describe(self):
+        return {"transport": self.transport, "backend": self.backend, "reduce": self.reduce, "world": self.world,
+                "collective": {"fp32": "all_reduce(AVG)", "fp32_rsag": "reduce_scatter(AVG) + all_gather",
+                               "bf16_fp32acc": "all_to_all + fp32 sum + all_gather", "bf16": "all_reduce(bf16 SUM)"}[self.reduce],
+                "tied_embedding": "dense head gradient after the head's backward, lookups as (id, row) pairs at the end"
+                                  if self.sparse_embed else "one dense exchange at the end of backward",
+                "layers_per_bucket": self.layers_per_bucket}
+
+    def ranks_seen(self):
+        """Number of ranks that answer on the communicator the buckets move through: every rank marks its own slot of a
+        64-slot vector, the vector goes through the SAME exchange as a gradient bucket (mean over ranks), and the non-zero slots
+        are counted."""
+        dev = self.engine.fp.grad.device
+        v = torch.zeros(max(64, self.world), dtype=torch.float32, device=dev)
+        v[self.rank] = 1.0
+        if self._comm is not None:
+            from . import lib as _l
+            self._comm_bucket(v, mode=0)
+            _l.check(self._lib.ug_comm_wait(self._comm, torch.cuda.current_stream().cuda_stream), "ug_comm_wait")
+        elif dist.is_initialized():
+            self._allreduce_mean_(v)
+        return int((v > 0).sum().item())
 
     @property
     def grad_scale(self):

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
 LIB_PATH = os.environ.get("UNIGEN_HIP_LIB") or os.path.join(CSRC_DIR, "libunigen_hip.so")     # (probe builds: tools/probes/_build/*.so)
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 P = ctypes.c_void_p
 I64 = ctypes.c_int64
 I32 = ctypes.c_int
@@ -34,6 +34,7 @@ SIGNATURES = {
     "ug_gelu": [P, P, P, I64, P],
     "ug_embed_fwd": [P, P, P, I64, I64, I64, P, P],
     "ug_embed_bwd": [P, P, P, I64, I64, I64, P],
+    "ug_embed_bwd_sorted": [P, P, P, P, I64, I64, I64, F32, P],
     "ug_gather_rows_bf16": [P, I64, P, P, I64, I64, I64, I32, P],
     "ug_colsum_bf16": [P, I64, P, I64, I64, P],
     "ug_attn_mask_compress": [P, I32, I64, I64, P, P, I64, I64, P, P],
@@ -63,6 +64,7 @@ SIGNATURES = {
     "ug_comm_unique_id": [P],
     "ug_comm_init": [P, I32, I32, P, I64],
     "ug_comm_allreduce_bucket": [P, P, I64, I32, P],
+    "ug_comm_allgather": [P, P, P, I64, P],
     "ug_comm_wait": [P, P],
     "ug_comm_destroy": [P],
     "ug_comm_bytes_on_wire": [P],

@@ -31,14 +31,26 @@ class _EmbedFn(torch.autograd.Function):
         engine.fp.wait_pending_update()
         out = ops.embed_fwd(flat_ids, engine.fp.p("embed"), engine.err_flag)
         ctx.engine, ctx.ids = engine, flat_ids
+        if ctx.needs_input_grad[0]:
+            engine._lookup_rows_live += flat_ids.numel()     # host-side count: the data-parallel exchange sizes its all-gather from it
         return out.view(*ids.shape, engine.dims.hidden_size)
 
     @staticmethod
     def backward(ctx, dout):
         eng = ctx.engine
         eng.begin_grad_pass()
-        eng.fp.ensure_zeroed("embed")
-        ops.embed_bwd(ctx.ids, dout.reshape(-1, eng.dims.hidden_size).float().contiguous(), eng.fp.g("embed"))
+        drows = dout.reshape(-1, eng.dims.hidden_size).float().contiguous()
+        sync = eng.grad_sync
+        if sync is not None and sync.wants_lookups() and eng._lookup_rows_kept + ctx.ids.numel() <= eng._lookup_rows_cap:
+            # data parallel: the (id, row) pairs are kept aside and exchanged as such at the end of backward; the tied
+            # table's dense part (the head's weight gradient) is already travelling (unigen_hip/ddp.py)
+            eng._lookup_rows_kept += ctx.ids.numel()
+            sync.add_lookup(ctx.ids, drows)
+        else:
+            if sync is not None:
+                sync.before_dense_embed_write()
+            eng.fp.ensure_zeroed("embed")
+            ops.embed_bwd(ctx.ids, drows, eng.fp.g("embed"))
         if eng.grad_ready_hook:
             eng.grad_ready_hook("embed")
         return None, None, None
@@ -95,6 +107,8 @@ class _HeadLossFn(torch.autograd.Function):
             stats.append((lse, lc))
         ctx.engine, ctx.rows, ctx.logits, ctx.idx, ctx.labels, ctx.bounds, ctx.stats = engine, rows, logits, idx, labels, bounds, stats
         ctx.shape = (B, L, H)
+        if any(ctx.needs_input_grad):
+            engine._head_graphs_live += 1        # dense writers of the tied table waiting for their backward
         return torch.cat(outs)
 
     @staticmethod
@@ -107,7 +121,10 @@ class _HeadLossFn(torch.autograd.Function):
         for s, (r0, r1) in enumerate(ctx.bounds):
             lse, lc = ctx.stats[s]
             ops.ce_bwd_(ctx.logits[r0:r1], V, ctx.labels[r0:r1], lse, lc, dloss[s:s + 1])
+        if eng.grad_sync is not None:
+            eng.grad_sync.before_dense_embed_write()
         drows = eng.head_bwd(ctx.logits, ctx.rows)
+        eng.head_written()
         ctx.logits = None
         dhn = torch.zeros((B * L, H), dtype=torch.bfloat16, device=drows.device)
         ops.scatter_rows_(drows, ctx.idx, dhn)
@@ -127,6 +144,8 @@ class _HeadRowsFn(torch.autograd.Function):
         out = torch.empty((rows.shape[0], npad), dtype=torch.bfloat16, device=hn.device)
         ops.gemm(rows, engine.fp.w("embed")[v0:v1], out=out, N=n, K=H)
         ctx.engine, ctx.rows, ctx.idx, ctx.rng, ctx.shape = engine, rows, idx, (v0, v1), (B, L, H)
+        if any(ctx.needs_input_grad):
+            engine._head_graphs_live += 1
         return out[:, :n]
 
     @staticmethod
@@ -139,9 +158,12 @@ class _HeadRowsFn(torch.autograd.Function):
         npad = ops.round_up(n, 8)
         dl = torch.zeros((R, npad), dtype=torch.bfloat16, device=dout.device)
         dl[:, :n] = dout
+        if eng.grad_sync is not None:
+            eng.grad_sync.before_dense_embed_write()
         eng.fp.ensure_zeroed("embed")
         ops.gemm(dl, ctx.rows, out=eng.fp.g("embed")[v0:v1], M=n, N=H, K=R, a_kmajor=True, b_kmajor=True,
                  epilogue=ops.UG_EPI_F32, beta=1)
+        eng.head_written()
         drows = ops.gemm(dl, eng.fp.w("embed")[v0:v1], M=R, N=H, K=n, b_kmajor=True)
         dhn = torch.zeros((B * L, H), dtype=torch.bfloat16, device=dout.device)
         ops.scatter_rows_(drows, ctx.idx, dhn)
@@ -382,6 +404,17 @@ class TrainEngine(Qwen2Engine):
         self.extra_grad_params = None        # callable -> ordinary Parameters to average when no DDP wrapper does it
         self._in_backward = False
         self._stack_graphs_live = 0
+        self._head_graphs_live = 0           # recorded head segments (dense writers of the tied table) waiting for their backward
+        self._lookup_rows_live = 0           # embedding-lookup rows recorded on live autograd graphs (host-side count)
+        self._lookup_rows_cap = 0            # ... as announced to the exchange at the start of the running backward pass
+        self._lookup_rows_kept = 0
+
+    def head_written(self):
+        """A head segment has added its weight gradient to the tied table.  When it was the last recorded one, the table's
+        dense part is final -- only embedding lookups (kept aside by the exchange) follow -- and is handed over at once."""
+        self._head_graphs_live = max(0, self._head_graphs_live - 1)
+        if self._head_graphs_live == 0 and self.grad_ready_hook:
+            self.grad_ready_hook("head")
 
     def named_param_views(self):
         if self._params is None:
@@ -437,6 +470,8 @@ class TrainEngine(Qwen2Engine):
     def _end_of_backward(self):
         self._in_backward = False
         self._stack_graphs_live = 0          # graphs that were built and dropped without a backward do not count against the next pass
+        self._head_graphs_live = 0
+        self._lookup_rows_live = 0
         if self.grad_sync is not None:
             self.grad_sync.finish()
 
@@ -461,7 +496,8 @@ class TrainEngine(Qwen2Engine):
             sync = self._dp_sync()
             if sync is not None:
                 self._in_backward = True
-                sync.begin(enabled=self._sync_this_pass())
+                self._lookup_rows_cap, self._lookup_rows_kept = self._lookup_rows_live, 0
+                sync.begin(enabled=self._sync_this_pass(), lookup_rows=self._lookup_rows_live)
                 torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
 
     def mask_bits(self, attention_mask, B, L):

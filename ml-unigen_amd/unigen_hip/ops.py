@@ -295,6 +295,13 @@ def embed_bwd(ids, dout, dW):
     _l.check(_l.load().ug_embed_bwd(_p(ids), _p(dout), _p(dW), ids.numel(), H, V, _stream()), "ug_embed_bwd")
 
 
+def embed_bwd_sorted(ids_sorted, order, rows, dW, scale):
+    """dW[id] += scale * sum of the rows of each run of equal ids, in sorted order (deterministic; ddp.py's lookup exchange)"""
+    V, H = dW.shape
+    _l.check(_l.load().ug_embed_bwd_sorted(_p(ids_sorted), _p(order), _p(rows), _p(dW), ids_sorted.numel(), H, V, float(scale), _stream()),
+             "ug_embed_bwd_sorted")
+
+
 def gather_rows(x, idx):
     n, C = idx.numel(), x.shape[1]
     out = torch.empty((n, C), dtype=torch.bfloat16, device=x.device)

@@ -132,7 +132,9 @@ if mode == "bare" and world > 1:
 rec["weights"] = {k: params[k].detach().float().cpu().clone() for k in probe}
 eng = model.llm.engine
 rec["sync"] = None if eng.grad_sync is None else dict(reduce=eng.grad_sync.reduce, bytes=eng.grad_sync.bytes_on_wire,
-                                                      numel=eng.fp.grad.numel(), backend=eng.grad_sync.backend)
+                                                      numel=eng.fp.grad.numel(), backend=eng.grad_sync.backend,
+                                                      lookup_bytes=eng.grad_sync.lookup_bytes_on_wire,
+                                                      early=eng.grad_sync.early_embed_handovers)
 torch.cuda.synchronize()
 torch.save(rec, out)
 if world > 1:

@@ -23,14 +23,14 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, layers_per_bucket, q):
+def _worker(rank, world, port, layers_per_bucket, reduce, q):
     sys.path.insert(0, os.path.join(ROOT, "ml-unigen_amd"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from unigen_hip.ddp import FlatGradSync
-    n_layers, per_layer, embed, norm = 6, 1000, 3000, 64
-    off = {"embed": (0, (embed,))}
+    n_layers, per_layer, embed, norm = 6, 1001, 3000, 64
+    off = {"embed": (0, (50, 60))}
     pos = embed
     for i in range(n_layers):
         off[f"l{i}.wqkv"] = (pos, (per_layer,))
@@ -44,8 +44,9 @@ def _worker(rank, world, port, layers_per_bucket, q):
                                 grad_ready_hook=None)
     extra = torch.nn.Parameter(torch.zeros(7))
     extra.grad = torch.full((7,), float(rank + 1))
-    sync = FlatGradSync(eng, layers_per_bucket=layers_per_bucket, extra_params=lambda: [extra])
-    assert sync.reduce == "fp32"
+    sync = FlatGradSync(eng, layers_per_bucket=layers_per_bucket, reduce=reduce, extra_params=lambda: [extra])
+    assert sync.reduce == reduce and sync.sparse_embed and sync.ranks_seen() == world
+    assert sync.describe()["collective"].startswith("all_reduce" if reduce == "fp32" else "reduce_scatter")
     # backward order: final norm, layers N-1..0, embedding
     sync.begin()
     eng.grad_ready_hook("norm")
@@ -80,12 +81,13 @@ def _worker(rank, world, port, layers_per_bucket, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("layers_per_bucket", [1, 4])
-def test_flat_grad_sync_two_ranks(layers_per_bucket):
+@pytest.mark.parametrize("layers_per_bucket,reduce", [(1, "fp32"), (4, "fp32"), (2, "fp32_rsag")])
+def test_flat_grad_sync_two_ranks(layers_per_bucket, reduce):
+    """(per-layer size 1001: the reduce-scatter form also has to cover a tail that does not divide by 4 x world)"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, layers_per_bucket, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, layers_per_bucket, reduce, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]
@@ -156,17 +158,23 @@ def test_bf16_exchange_error_by_world_size():
     assert err[(8, "bf16 ring sum")][0] < 1e-2 and err[(8, "bf16 ring sum")][1] < 9 * 2.0 ** -8
 
 
-def _worker_multi_lookup(rank, world, port, q):
+def _worker_multi_lookup(rank, world, port, sparse, q):
     """a forward with SEVERAL embedding lookups fires the 'embed' hook several times, and a backward pass with
-    TWO decoder-stack segments writes every layer's gradient twice.  Writers are emulated on the flat buffer in the order
-    backward produces them; after finish() every rank must hold the mean of the ranks' TOTAL gradients."""
+    TWO decoder-stack segments writes every layer's gradient twice.  Round 4: the tied table's DENSE part (the head's weight
+    gradient) is handed over by the 'head' tag right after the last head's backward and the lookups travel as (id, row) pairs at
+    the end (`sparse`); writers are emulated on the flat buffer in the order backward produces them, including the orders the
+    early hand-over must survive: a lookup that arrives before the last head, a dense writer that arrives after the hand-over,
+    ranks with different numbers of lookup rows.  After finish() every rank must hold the mean of the ranks' TOTAL gradients,
+    bit-identical on both ranks."""
     sys.path.insert(0, os.path.join(ROOT, "ml-unigen_amd"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["UNIGEN_DDP_SPARSE_EMBED"] = "1" if sparse else "0"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from unigen_hip.ddp import FlatGradSync
-    n_layers, per_layer, embed, norm = 4, 500, 2000, 64
-    off = {"embed": (0, (embed,))}
+    n_layers, per_layer, V, H, norm = 4, 500, 50, 40, 64
+    embed = V * H
+    off = {"embed": (0, (V, H))}
     pos = embed
     for i in range(n_layers):
         off[f"l{i}.wqkv"] = (pos, (per_layer,))
@@ -177,14 +185,32 @@ def _worker_multi_lookup(rank, world, port, q):
     eng = types.SimpleNamespace(fp=types.SimpleNamespace(grad=grad, off=off), dims=types.SimpleNamespace(num_hidden_layers=n_layers),
                                 grad_ready_hook=None)
     sync = FlatGradSync(eng, layers_per_bucket=1)
+    assert sync.sparse_embed == sparse
     gen = torch.Generator().manual_seed(7 + rank)
     contrib = lambda n: torch.randn(n, generator=gen)
     total = torch.zeros(numel)
+    table = lambda t: t[:embed].view(V, H)
 
     def write(lo, n):
         c = contrib(n)
         grad[lo:lo + n] += c
         total[lo:lo + n] += c
+
+    def head():                                          # a head segment's dense weight gradient (what modules.py does around it)
+        sync.before_dense_embed_write()
+        write(0, embed)
+
+    def lookup(n_rows):                                  # an embedding lookup's backward
+        ids = torch.randint(0, V, (n_rows,), generator=gen)
+        ids[: n_rows // 3] = 7                           # a token that repeats (padding does)
+        rows = contrib(n_rows * H).view(n_rows, H)
+        table(total).index_add_(0, ids, rows)
+        if sync.wants_lookups():
+            sync.add_lookup(ids, rows)
+        else:
+            sync.before_dense_embed_write()
+            table(grad).index_add_(0, ids, rows)
+        eng.grad_ready_hook("embed")
 
     def stack_segment(last_writer):
         sync.set_overlap(last_writer)
@@ -195,32 +221,46 @@ def _worker_multi_lookup(rank, world, port, q):
             eng.grad_ready_hook(i)
 
     ok = True
-    for two_segments in (False, True):
+    for case in ("one segment", "two segments", "late dense writer", "no head"):
         grad.zero_()
         total.zero_()
-        sync.begin()
-        write(0, embed)                                  # tied head: first writer of the embedding table
-        if two_segments:
-            stack_segment(False)                         # e.g. the rejected half of a DPO pair: its hooks must not flush
-            write(0, embed)                              # second head segment adds to the table
+        rows_live = 3 * (11 + 2 * rank) + (5 if case == "two segments" else 0)      # ranks look up different numbers of rows
+        sync.begin(lookup_rows=rows_live)
+        if case == "two segments":
+            head()                                       # e.g. the rejected half of a DPO pair: not the last head, no hand-over
+            stack_segment(False)                         # ... and its stack hooks must not flush
+            lookup(5)                                    # its lookup arrives BEFORE the last head has written
+        if case != "no head":
+            head()
+            eng.grad_ready_hook("head")                  # last recorded head: the table's dense part travels from here on
+            assert sync._embed_done == sparse
         stack_segment(True)
-        for _ in range(3):                               # three lookups (text / t2i / mmu parts): three 'embed' hooks,
-            write(0, embed)                              # each AFTER a scatter-add into the table
-            eng.grad_ready_hook("embed")
+        if case == "late dense writer":
+            head()                                       # an unrecorded dense writer after the hand-over: must wait + re-exchange
+            assert not sync._embed_done
+        for _ in range(3):                               # three lookups (text / t2i / mmu parts): three 'embed' hooks
+            lookup(11 + 2 * rank)
         sync.finish()
         gathered = [torch.empty_like(total) for _ in range(world)]
         dist.all_gather(gathered, total)
         want = torch.stack(gathered).mean(0)
-        ok = ok and torch.allclose(grad, want, atol=1e-5)
+        got = [torch.empty_like(grad) for _ in range(world)]
+        dist.all_gather(got, grad)
+        ok = ok and torch.allclose(grad, want, atol=1e-5) and torch.equal(got[0], got[1])
+        if not ok:
+            print(f"rank {rank} case {case!r} sparse {sparse}: max err {(grad - want).abs().max().item():.3e}")
+            break
+    ok = ok and (sync.lookup_bytes_on_wire > 0) == sparse
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 
 
-def test_flat_grad_sync_multiple_lookups_and_two_stack_segments():
+@pytest.mark.parametrize("sparse", [True, False])
+def test_flat_grad_sync_multiple_lookups_and_two_stack_segments(sparse):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_multi_lookup, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker_multi_lookup, args=(r, 2, port, sparse, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]

@@ -48,9 +48,9 @@ def _rel(a, b):
     return ((a - b).norm() / (b.norm() + 1e-30)).item()
 
 
-@pytest.mark.parametrize("reduce", ["fp32", "bf16_fp32acc", "bf16"])
+@pytest.mark.parametrize("reduce", ["fp32", "fp32_rsag", "bf16_fp32acc", "bf16"])
 def test_two_ranks_on_one_gpu_match_single_process(dev, tmp_path, reduce):
-    tol = 2e-4 if reduce == "fp32" else 1e-2
+    tol = 2e-4 if reduce.startswith("fp32") else 1e-2
     for mode in ("ddp", "bare", "multi"):
         single = _run(1, "single" if mode == "ddp" else mode, tmp_path, reduce)[0]
         r0, r1 = _run(2, mode, tmp_path, reduce)
@@ -72,8 +72,10 @@ def test_two_ranks_on_one_gpu_match_single_process(dev, tmp_path, reduce):
         assert worst < tol, (mode, reduce, worst)
         assert lerr < 1e-3 and gn < tol
         per_step = r0["sync"]["numel"] * (2 if reduce == "bf16" else 4)
-        if reduce == "bf16_fp32acc":                 # (the gloo rehearsal gathers whole buckets: byte count is not the RCCL path's)
-            assert r0["sync"]["bytes"] > 0
+        # the tied table's dense part goes early, the lookups as (id, row) pairs: 2 ranks x cap rows x (8-byte id + fp32 row)
+        assert r0["sync"]["lookup_bytes"] > 0 and r0["sync"]["lookup_bytes"] % (2 * (8 + 4 * 256)) == 0
+        if reduce == "bf16_fp32acc":                 # (bucket slices are padded to 8 elements per rank: not an exact multiple)
+            assert r0["sync"]["bytes"] >= 3 * per_step
             continue
         if mode == "bare":
             # 3 steps + 1 exchanged accumulation step (+ the ordinary parameters, a few KB); the no_sync step moved nothing
@@ -121,9 +123,10 @@ from models import UniGen
 from oracle import weights
 g = golden("g2_tiny_unigen.pt"); cfg = g["cfg"]; dev = torch.device("cuda:0")
 res = {}
-for case in ("off", "fp32", "bf16_fp32acc", "bf16", "ug_comm:fp32", "ug_comm:bf16_fp32acc", "ug_comm:bf16"):
+for case in ("off", "fp32", "fp32_rsag", "bf16_fp32acc", "bf16", "ug_comm:fp32", "ug_comm:fp32_rsag", "ug_comm:bf16_fp32acc", "ug_comm:bf16", "dense:fp32"):
     reduce = case.split(":")[-1]
     os.environ["UNIGEN_DDP_TRANSPORT"] = "ug_comm" if case.startswith("ug_comm") else "torch"
+    os.environ["UNIGEN_DDP_SPARSE_EMBED"] = "0" if case.startswith("dense") else "1"
     os.environ["UNIGEN_DDP_REDUCE"] = "fp32" if reduce == "off" else reduce
     os.environ["UNIGEN_DDP_FORCE"] = "0" if reduce == "off" else "1"
     m = UniGen(w_und_encoder=False, vocab_size=cfg["vocab_size"], llm_vocab_size=312, llm_model_path=llm_config_dir(cfg), codebook_size=20,
@@ -135,7 +138,9 @@ for case in ("off", "fp32", "bf16_fp32acc", "bf16", "ug_comm:fp32", "ug_comm:bf1
     torch.cuda.synchronize()
     eng = m.llm.engine
     res[case] = dict(grad=eng.fp.grad.detach().cpu().clone(), bytes=0 if eng.grad_sync is None else eng.grad_sync.bytes_on_wire,
-                     backend=None if eng.grad_sync is None else eng.grad_sync.backend)
+                     backend=None if eng.grad_sync is None else eng.grad_sync.backend,
+                     seen=None if eng.grad_sync is None else eng.grad_sync.ranks_seen(),
+                     early=None if eng.grad_sync is None else eng.grad_sync.early_embed_handovers)
     eng.grad_sync = None
 torch.save(res, sys.argv[2])
 dist.destroy_process_group()
@@ -150,25 +155,33 @@ dist.destroy_process_group()
     # (two runs of the same backward differ in the last bits: the embedding scatter-add and the dK / dV finish use fp32 atomics)
     rel = lambda a, b: ((a - b).norm() / b.norm()).item()
     for pre, backend in (("", "nccl"), ("ug_comm:", "ug_comm(rccl)")):      # torch.distributed's RCCL | the library's own ug_comm_* entry points
-        for k in ("fp32", "bf16_fp32acc", "bf16"):
+        for k in ("fp32", "fp32_rsag", "bf16_fp32acc", "bf16"):
             r = res[pre + k]
             assert r["backend"] == backend and r["bytes"] > 0, (pre + k, r["backend"], r["bytes"])
-        assert rel(res[pre + "fp32"]["grad"], base) < 1e-5
+            assert r["seen"] == 1 and r["early"] == 1, (pre + k, r["seen"], r["early"])      # the head's dense part left early
+        assert rel(res[pre + "fp32"]["grad"], base) < 1e-5 and rel(res[pre + "fp32_rsag"]["grad"], base) < 1e-5
         for k in ("bf16_fp32acc", "bf16"):
             g = res[pre + k]["grad"]
-            assert torch.equal(g, g.to(torch.bfloat16).float()) and rel(g, base) < 2.0 ** -8, (pre + k, rel(g, base))
+            # (the tied table -- the first 333 x 256 elements -- carries the lookups' fp32 rows on top of the bf16-rounded dense part)
+            tail = g[333 * 256:]
+            assert torch.equal(tail, tail.to(torch.bfloat16).float()) and rel(g, base) < 2.0 ** -8, (pre + k, rel(g, base))
         print(f"[{backend}, world 1] bytes handed to the collectives: " + ", ".join(f"{k} {res[pre + k]['bytes']}" for k in ("fp32", "bf16_fp32acc", "bf16")))
     assert res["ug_comm:fp32"]["bytes"] == res["fp32"]["bytes"] and res["ug_comm:bf16"]["bytes"] == res["bf16"]["bytes"]
+    assert res["ug_comm:fp32_rsag"]["bytes"] == res["fp32"]["bytes"]
+    assert res["dense:fp32"]["early"] == 0 and rel(res["dense:fp32"]["grad"], base) < 1e-5
 
 
 def test_bench_runs_end_to_end_with_two_ranks(dev):
-    """bench.py exactly as the driver launches it for N > 1 (torch.distributed.run, one JSON line from rank 0), with both ranks
-    on cuda:0 over gloo (RCCL refuses two ranks on one device): every rank must run every step that contains the gradient
-    exchange -- including the instrumented roofline step -- or rank 0 waits for its peers forever."""
+    """`python bench.py --gpus 2` with NO launcher around it: bench.py starts torch.distributed.run itself as
+    a child process before anything touches the GPU -- the child line is exactly the one the driver uses for N > 1 -- and relays
+    the one JSON line of rank 0.  Both ranks on cuda:0 over gloo (RCCL refuses two ranks on one device): every rank must run every
+    step that contains the gradient exchange -- including the instrumented roofline steps -- or rank 0 waits for its peers forever.
+    The line must prove that the exchange's communicator saw both ranks."""
     import json
     env = dict(os.environ, UNIGEN_DIST_BACKEND="gloo", UNIGEN_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", _free_port(), os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"]
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, (res.stdout + res.stderr)[-3000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
@@ -176,3 +189,7 @@ def test_bench_runs_end_to_end_with_two_ranks(dev):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 32 and out["config"]["parallelism"] == "dp2"
     assert out["roofline"]["launches_per_step"] > 0 and out["cpu_baseline"] is None
+    ex = out["exchange"]
+    assert out["ranks_seen"] == 2 and ex["ranks_seen"] == 2 and ex["reduce"] == "fp32" and ex["transport"] == "torch"
+    # fp32 payload: every element of the flat gradient buffer once per step + the lookups' (id, row) pairs of both ranks
+    assert ex["bytes_on_wire_per_step"] >= 4 * 1.5e9 and ex["lookup_bytes_on_wire_per_step"] == 2 * 16 * 771 * (8 + 4 * 1536)

@@ -32,7 +32,7 @@ def test_abi_library_exports_every_declared_symbol():
     bound = set(lib.SIGNATURES) | {"ug_last_error"}
     assert set(syms) == bound, (set(syms) ^ bound)
     lib.load()
-    assert lib.load().ug_abi_version() == lib.ABI_VERSION == 3
+    assert lib.load().ug_abi_version() == lib.ABI_VERSION == 4
 
 
 def test_abi_argument_errors_are_reported_not_thrown():
@@ -149,3 +149,16 @@ def test_masking_options_match_reference_golden():
         for b in range(m.shape[0]):                       # every mask is one filled rectangle
             rows, cols = m[b].any(1).nonzero().flatten(), m[b].any(0).nonzero().flatten()
             assert int(m[b].sum()) == len(rows) * len(cols) and rows[-1] - rows[0] + 1 == len(rows) and cols[-1] - cols[0] + 1 == len(cols)
+
+
+def test_bench_self_launch_refuses_more_ranks_than_gpus():
+    """`python bench.py --gpus 2` without a launcher spawns torch.distributed.run as a child -- but only when the node has a GPU
+    per rank: here (no GPU) it must say so and exit non-zero at once, without initialising anything."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "UNIGEN_BENCH_ONE_DEVICE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert r.returncode != 0 and "one GPU per rank" in (r.stderr + r.stdout)

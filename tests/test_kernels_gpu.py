@@ -311,6 +311,38 @@ def test_embed_fwd_bwd(dev):
     assert err.item() == 1
 
 
+def test_embed_bwd_sorted_is_deterministic_and_matches_index_add(dev):
+    """`ug_embed_bwd_sorted` (the data-parallel exchange's lookup scatter): pairs of W ranks padded with id -1, sorted by a stable
+    sort; result = table + scale * index_add in that very order -- compared with a sequential fp32 host loop bit for bit, and
+    two runs must agree bit for bit (the atomics form does not)."""
+    ops = _ops()
+    torch.manual_seed(5)
+    V, H, W, cap = 333, 256, 4, 61
+    ids = torch.randint(0, V, (W * cap,))
+    ids[::3] = 11                                        # a long run (padding tokens repeat)
+    ids[cap - 5:cap] = -1                                # rank 0's padding
+    ids[-9:] = -1
+    rows = torch.randn(W * cap, H)
+    base = torch.randn(V, H)
+    srt, order = torch.sort(ids.to(dev), stable=True)
+    outs = []
+    for _ in range(2):
+        t = base.to(dev).clone()
+        ops.embed_bwd_sorted(srt, order, rows.to(dev), t, 1.0 / W)
+        outs.append(t.cpu())
+    assert torch.equal(outs[0], outs[1])
+    ref = base.clone()
+    acc = {}
+    for j in order.cpu().tolist():                       # sequential fp32 sums in sorted order, one scaled add per table row
+        i = int(ids[j])
+        if i >= 0:
+            acc[i] = rows[j].clone() if i not in acc else acc[i] + rows[j]
+    for i, a in acc.items():
+        ref[i] = ref[i] + (1.0 / W) * a
+    assert _rel(outs[0], ref) < 1e-6
+    assert (outs[0] - ref).abs().max().item() < 1e-5
+
+
 def test_colsum(dev):
     ops = _ops()
     x = torch.randn(1000, 200).to(torch.bfloat16)
