@@ -86,24 +86,33 @@ __global__ __launch_bounds__(256) void mask_causal_kernel(uint64_t* __restrict__
 // meta[b] = {last_pad, soi_pos, first_eoi_of_batch(+1, 0 = none), unused}; flags[b][t]: bit0 = pad, bit1 = inside <soi>..<eoi>
 __global__ __launch_bounds__(64) void mask_ids_meta_kernel(const int64_t* __restrict__ ids, int L, int64_t pad_id, int64_t soi_id,
                                                            int64_t eoi_id, int* __restrict__ meta, uint8_t* __restrict__ flags) {
-  const int b = blockIdx.x;
-  if (threadIdx.x != 0) return;                      // L is a few hundred tokens: one serial walk per row
+  // one wave per row, 64 tokens per trip: the delimiter / padding tests become ballots, the inclusive cumulative counts a
+  // popcount of the ballot below each lane plus the running totals of the earlier trips (round 3 walked the row on one lane: 96 us
+  // for 16 x 771 ids)
+  const int b = blockIdx.x, lane = threadIdx.x;
   const int64_t* row = ids + (int64_t)b * L;
   int starts = 0, ends = 0, last_pad = -1, soi_pos = -1, eoi_first = -1;
-  for (int t = 0; t < L; ++t) {
-    const int64_t v = row[t];
-    const bool st = v == soi_id, en = v == eoi_id, pd = v == pad_id;
-    starts += st;
-    ends += en;
-    const bool in_img = (starts > ends) || st || en;   // inclusive cumsum(start) > cumsum(end), or a delimiter itself
-    flags[(int64_t)b * L + t] = (uint8_t)((pd ? 1 : 0) | (in_img ? 2 : 0));
-    if (pd) last_pad = t;
-    if (st && soi_pos < 0) soi_pos = t;
-    if (en && eoi_first < 0) eoi_first = t;
+  const uint64_t below = lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1ull);        // lanes 0 .. lane (inclusive)
+  for (int t0 = 0; t0 < L; t0 += 64) {
+    const int t = t0 + lane;
+    const bool in = t < L;
+    const int64_t v = in ? row[t] : 0;
+    const bool st = in && v == soi_id, en = in && v == eoi_id, pd = in && v == pad_id;
+    const uint64_t ms = __ballot(st), me = __ballot(en), mp = __ballot(pd);
+    const int cs = starts + __popcll(ms & below), ce = ends + __popcll(me & below);
+    const bool in_img = (cs > ce) || st || en;          // inclusive cumsum(start) > cumsum(end), or a delimiter itself
+    if (in) flags[(int64_t)b * L + t] = (uint8_t)((pd ? 1 : 0) | (in_img ? 2 : 0));
+    starts += __popcll(ms);
+    ends += __popcll(me);
+    if (mp) last_pad = t0 + 63 - __clzll(mp);
+    if (ms && soi_pos < 0) soi_pos = t0 + __ffsll((long long)ms) - 1;
+    if (me && eoi_first < 0) eoi_first = t0 + __ffsll((long long)me) - 1;
   }
-  meta[b * 4 + 0] = last_pad;
-  meta[b * 4 + 1] = soi_pos < 0 ? 0 : soi_pos;        // argmax of an all-zero row is 0
-  meta[b * 4 + 2] = eoi_first;
+  if (lane == 0) {
+    meta[b * 4 + 0] = last_pad;
+    meta[b * 4 + 1] = soi_pos < 0 ? 0 : soi_pos;        // argmax of an all-zero row is 0
+    meta[b * 4 + 2] = eoi_first;
+  }
 }
 
 __global__ __launch_bounds__(256) void mask_ids_kernel(uint64_t* __restrict__ bits, const int* __restrict__ meta,
@@ -194,11 +203,12 @@ __device__ __forceinline__ bf16x8_t pack_p(const f32x4_t& a, const f32x4_t& b) {
 // integer-sequence RNE packing (what pack_p was before the hardware converter).  The dQ kernel keeps it: measured in one
 // session, 216.6 us with this sequence vs 255 us with v_cvt_pk_bf16_f32 (the forward and dK/dV kernels go the other way).
 __device__ __forceinline__ bf16_t f2bf_sw(float f) {
-  // branch-free: the NaN test of round 2 compiled to an exec-mask branch per element (60 scalar instructions per key tile);
-  // a quiet NaN (0x7fc00000 + 0x7fff) still rounds to a NaN
-  uint32_t u = __float_as_uint(f);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+  // branch-free: the NaN test of round 2 compiled to an exec-mask branch per element (60 scalar instructions per key tile).
+  // A NaN stays a NaN whatever its payload (a select, v_cndmask: adding the rounding constant to a NaN whose low payload bits
+  // are set would wrap it to +-0 or a denormal and hide a divergence in dQ)
+  const uint32_t u = __float_as_uint(f);
+  const uint32_t r = u + 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(((u & 0x7fffffffu) > 0x7f800000u ? (u | 0x00400000u) : r) >> 16);
 }
 __device__ __forceinline__ bf16x8_t pack_p_sw(const f32x4_t& a, const f32x4_t& b) {
   bf16x8_t r;

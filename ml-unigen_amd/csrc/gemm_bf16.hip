@@ -883,382 +883,9 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p10(GemmArgs p) {
   store_tile_lds<EPI, 10>(p, acc, lds + wave * EP_STRIP, m0 + grp * 160, n0 + wn * 64, lane);
 }
 
-#ifdef UG_GEMM_R4
-// =============================================================================================
-// PROBE BUILDS ONLY (-DUG_GEMM_R4, tools/probes/gemm_r4_ablate.py; measured and not shipped).
-// Register-blocked kernel: 256 x 256 tile, FOUR waves (one per SIMD), each wave 128 x 128 = 4 x 4 blocks of
-// v_mfma_f32_32x32x16_bf16 (256 accumulator registers).  One wave per SIMD issues that instruction back to back (32 clocks each:
-// tools/probes/mfma_peak.py measures the same 2.5 PF on zeros / 1.75 PF on random operands from one wave per SIMD as from two),
-// and there are ~8 issue slots under every MFMA, so the SAME wave issues its fragment reads and its share of the LDS-DMA operand
-// stream between its MFMAs -- no phase separation, no partner wave.  Against the 8-wave kernel above a k-tile moves 64 KB of
-// fragment reads instead of 96 KB through the LDS port (each wave reads 128 + 128 operand rows for 128 x 128 outputs).
-//   ring: 4 slots x (A 16 KB | B 16 KB), k-tiles of 32 = two MFMA k-steps; ONE workgroup barrier per k-tile:
-//     phase A(t):  16 MFMAs of k-step 0   ||  8 (16 transposing) fragment reads of tile t, k-step 1
-//                  wait: own DMA share of tile t+1 landed (two newer tiles stay in flight) ; s_barrier
-//     phase B(t):  16 MFMAs of k-step 1   ||  8 DMA instructions of tile t+4 into the slot of tile t (every wave is past its
-//                                              reads of tile t) ; 8 fragment reads of tile t+1, k-step 0
-//   k-major LDS image for this kernel: [32 k][32 chunks of 8 rows], chunk ^= (k & 3) << 2 -- the 4 k-rows x 4 chunks a
-//   32-lane half of ds_read_b64_tr_b16 touches for a 32-row block fall on 16 distinct 16-byte bank groups.
-constexpr int R_NW = 4;
-__device__ __forceinline__ int swz_krow4(int k, int chunk) { return chunk ^ ((k & 3) << 2); }
-
-template <bool KMAJOR>
-struct Stager4 {                 // 256-row x 32-k operand tile, 4 waves: 4 one-KiB DMA instructions per wave per k-tile
-  const bf16_t* src[4];
-  int64_t step[4];
-  int kofs[4];
-  __device__ __forceinline__ void init(const bf16_t* X, int64_t ld, int row0, int rows_total, int wave, int lane) {
-    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int inst = i * R_NW + wave;
-      if constexpr (!KMAJOR) {                 // [256 rows][4 chunks]: 16 rows per instruction
-        const int row = inst * 16 + (lane >> 2);
-        const int chunk = swz_rowk32(row, lane & 3);
-        const int r = min(row0 + row, rows_total - 1);
-        src[i] = X + (int64_t)r * ld + chunk * 8;
-        step[i] = PBK;
-        kofs[i] = chunk * 8;
-      } else {                                 // [32 k][32 chunks]: 2 k-rows per instruction
-        const int k = inst * 2 + (lane >> 5);
-        const int chunk = swz_krow4(k, lane & 31);
-        const int col = row0 + chunk * 8;
-        const bool ok = (col + 8 <= ld);
-        src[i] = ok ? X + (int64_t)k * ld + col : zero;
-        step[i] = ok ? (int64_t)PBK * ld : 0;
-        kofs[i] = k;
-      }
-    }
-  }
-  template <bool CHECK>
-  __device__ __forceinline__ void issue(int kt, int K, char* lds_tile, int wave) const {
-    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const bf16_t* s = src[i] + kt * step[i];
-      if constexpr (CHECK) {
-        const bool past = kt * PBK + kofs[i] >= (KMAJOR ? K : ((K + 7) & ~7));
-        s = reinterpret_cast<const bf16_t*>(past ? reinterpret_cast<uintptr_t>(zero) : reinterpret_cast<uintptr_t>(s));
-      }
-      char* dst = lds_tile + (i * R_NW + wave) * 1024;
-      __builtin_amdgcn_global_load_lds((gptr_t)s, (lptr_t)dst, 16, 0, 0);
-    }
-  }
-};
-
-typedef __attribute__((ext_vector_type(8))) __bf16 hwbf16x8_t;
-
-// byte offsets (within an operand tile) of this lane's fragment pieces: row-major: off[ks] for 32-row block 0, block i adds
-// i * 2048; k-major: off[ks * 4 + i] for the first transposing read of block i (the second one is 4 k-rows = 2048 bytes on)
-template <bool KMAJOR>
-struct FragMap {
-  int off[KMAJOR ? 8 : 2];
-  __device__ __forceinline__ void init(int r0, int lane) {
-    if constexpr (!KMAJOR) {
-      const int row = r0 + (lane & 31);
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) off[ks] = row * 64 + swz_rowk32(row, ks * 2 + (lane >> 5)) * 16;
-    } else {
-      const int i16 = lane & 15, gi = lane >> 4;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int k = ks * 16 + (gi >> 1) * 8 + (i16 >> 2);
-          const int chunk = ((r0 + i * 32 + (gi & 1) * 16) >> 3) + ((i16 & 3) >> 1);
-          off[ks * 4 + i] = k * (PBM * 2) + swz_krow4(k, chunk) * 16 + (i16 & 1) * 8;
-        }
-    }
-  }
-  __device__ __forceinline__ bf16x8_t load(const char* tile, int ks, int i) const {
-    if constexpr (!KMAJOR) {
-      return *reinterpret_cast<const bf16x8_t*>(tile + off[ks] + i * 2048);
-    } else {
-      const char* p0 = tile + off[ks * 4 + i];
-      const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p0);
-      const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p0 + 4 * PBM * 2));
-      return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    }
-  }
-};
-
-// Epilogue of the register-blocked kernel: every wave turns its 128 x 128 block through a private LDS strip 32 rows at a time
-// (lane holds C[m = lane & 31][n = q * 8 + (lane >> 5) * 4 + 0..3] of a 32 x 32 block: swapped-operand layout of the 32x32 MFMA),
-// then stores 16 bytes per lane, whole 256-byte (bf16) / 512-byte (fp32) row segments.
-constexpr int R_PITCH_BF16 = 272, R_PITCH_F32 = 528;
-constexpr int R_STRIP = 32 * R_PITCH_F32;                    // 16 896 B per wave (bf16 needs 8 704)
-
-template <int EPI>
-__device__ __forceinline__ void store_tile_r4(const GemmArgs& p, f32x16_t (&acc)[4][4], char* strip, int mbase, int nbase, int lane) {
-  float alpha = 1.f;
-  if constexpr (EPI == EPI_F32) { if (p.alpha_dev) alpha = *p.alpha_dev; }
-  const int half = lane >> 5, mrow = lane & 31;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int col = j * 32 + q * 8 + half * 4;
-        const f32x16_t& v = acc[i][j];
-        if constexpr (EPI == EPI_BF16) {
-          float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
-          if (p.bias) {
-            const uint2 b = *reinterpret_cast<const uint2*>(p.bias + nbase + col);
-            b0 = __uint_as_float(b.x << 16); b1 = __uint_as_float(b.x & 0xffff0000u);
-            b2 = __uint_as_float(b.y << 16); b3 = __uint_as_float(b.y & 0xffff0000u);
-          }
-          uint2 o;
-          o.x = pack_bf2(v[q * 4 + 0] + b0, v[q * 4 + 1] + b1);
-          o.y = pack_bf2(v[q * 4 + 2] + b2, v[q * 4 + 3] + b3);
-          *reinterpret_cast<uint2*>(strip + mrow * R_PITCH_BF16 + col * 2) = o;
-        } else {
-          *reinterpret_cast<float4*>(strip + mrow * R_PITCH_F32 + col * 4) = make_float4(v[q * 4 + 0], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3]);
-        }
-      }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // wave-private strip
-    if constexpr (EPI == EPI_BF16) {
-#pragma unroll
-      for (int s8 = 0; s8 < 8; ++s8) {
-        const int row = s8 * 4 + (lane >> 4), ch = lane & 15;
-        const int m = mbase + i * 32 + row;
-        const uint4 v = *reinterpret_cast<const uint4*>(strip + row * R_PITCH_BF16 + ch * 16);
-        if (m < p.M) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc + nbase + ch * 8) = v;
-      }
-    } else {
-#pragma unroll
-      for (int s16 = 0; s16 < 16; ++s16) {
-        const int row = s16 * 2 + (lane >> 5), ch = lane & 31;
-        const int m = mbase + i * 32 + row;
-        float4 v = *reinterpret_cast<const float4*>(strip + row * R_PITCH_F32 + ch * 16);
-        if (m < p.M) {
-          float* cptr = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + nbase + ch * 4;
-          if constexpr (EPI == EPI_F32) {
-            v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha;
-            if (p.beta) { const float4 old = *reinterpret_cast<const float4*>(cptr); v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w; }
-          } else {
-            const float4 old = *reinterpret_cast<const float4*>(p.resid + (int64_t)m * p.ldr + nbase + ch * 4);
-            v.x = old.x + bf2f(f2bf(v.x)); v.y = old.y + bf2f(f2bf(v.y)); v.z = old.z + bf2f(f2bf(v.z)); v.w = old.w + bf2f(f2bf(v.w));
-          }
-          *reinterpret_cast<float4*>(cptr) = v;
-        }
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  }
-}
-
-// ragged column panels / unaligned rows: guarded element-wise form
-template <int EPI>
-__device__ __forceinline__ void store_tile_r4_guarded(const GemmArgs& p, f32x16_t (&acc)[4][4], int mbase, int nbase, int lane) {
-  float alpha = 1.f;
-  if constexpr (EPI == EPI_F32) { if (p.alpha_dev) alpha = *p.alpha_dev; }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = mbase + i * 32 + (lane & 31);
-    if (m >= p.M) continue;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int n = nbase + j * 32 + (r >> 2) * 8 + (lane >> 5) * 4 + (r & 3);
-        if (n >= p.N) continue;
-        const float v = acc[i][j][r];
-        if constexpr (EPI == EPI_BF16) {
-          reinterpret_cast<bf16_t*>(p.C)[(int64_t)m * p.ldc + n] = f2bf(v + (p.bias ? bf2f(p.bias[n]) : 0.f));
-        } else if constexpr (EPI == EPI_F32) {
-          float* c = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + n;
-          *c = (p.beta ? *c : 0.f) + v * alpha;
-        } else {
-          reinterpret_cast<float*>(p.C)[(int64_t)m * p.ldc + n] = p.resid[(int64_t)m * p.ldr + n] + bf2f(f2bf(v));
-        }
-      }
-  }
-}
-
-#define R4_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
-
-template <int EPI, bool AK, bool BKM>
-__device__ __forceinline__ void r4_body(const GemmArgs& p, const int bid, char* lds) {
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-
-  const int nwg = p.tiles_m * p.tiles_n;
-  const bool tail = p.tail_split > 1 && bid >= p.full_tiles;
-  const int tail_j = tail ? bid - p.full_tiles : 0;
-  const int tile_lin = tail ? p.full_tiles + tail_j / p.tail_split : bid;
-  const int pid = xcd_remap(tile_lin, nwg);
-  const int per_group = P8_GROUP_M * p.tiles_n;
-  const int gid = pid / per_group, first_m = gid * P8_GROUP_M;
-  const int gsz = min(p.tiles_m - first_m, P8_GROUP_M);
-  const int tm = first_m + (pid % per_group) % gsz;
-  const int tn = (pid % per_group) / gsz;
-  const int m0 = tm * PBM, n0 = tn * PBN;
-
-  Stager4<AK> sa; Stager4<BKM> sb;
-  sa.init(p.A, p.lda, m0, p.M, wave, lane);
-  sb.init(p.B, p.ldb, n0, p.N, wave, lane);
-  FragMap<AK> ma; FragMap<BKM> mb;
-  ma.init(wm * 128, lane);
-  mb.init(wn * 128, lane);
-
-  f32x16_t acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int nk_all = (p.K + PBK - 1) / PBK;
-  const int per_split = tail ? (nk_all + p.tail_split - 1) / p.tail_split : nk_all;
-  const int kt0 = tail ? (tail_j % p.tail_split) * per_split : 0;
-  const int nk = min(nk_all, kt0 + per_split) - kt0;
-  if (nk <= 0) return;
-  const bool ragged = (p.K % PBK) != 0;
-
-  auto stage_in = [&](int lt) {                 // 8 DMA instructions per wave; the launch's last k-tile may be ragged
-    const int kt = kt0 + lt;
-    char* st = lds + (lt & (P_NST - 1)) * P_STAGE;
-    if (ragged && kt + 1 == nk_all) { sa.template issue<true>(kt, p.K, st, wave); sb.template issue<true>(kt, p.K, st + P_TILE, wave); }
-    else { sa.template issue<false>(kt, p.K, st, wave); sb.template issue<false>(kt, p.K, st + P_TILE, wave); }
-  };
-  auto stage_whole = [&](int lt) {
-    char* st = lds + (lt & (P_NST - 1)) * P_STAGE;
-    sa.template issue<false>(kt0 + lt, p.K, st, wave);
-    sb.template issue<false>(kt0 + lt, p.K, st + P_TILE, wave);
-  };
-  bf16x8_t fa[2][4], fb[2][4];
-  auto read_frags = [&](int t, int ks) {
-    const char* tA = lds + (t & (P_NST - 1)) * P_STAGE;
-    const char* tB = tA + P_TILE;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { fa[ks][i] = ma.load(tA, ks, i); fb[ks][i] = mb.load(tB, ks, i); }
-  };
-  auto mfmas = [&](int ks) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)     // swapped operands: lane gets C[m = lane & 31][4 consecutive n]
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(hwbf16x8_t, fb[ks][j]), __builtin_bit_cast(hwbf16x8_t, fa[ks][i]),
-                                                            acc[i][j], 0, 0, 0);
-  };
-  constexpr int DSR = (AK ? 8 : 4) + (BKM ? 8 : 4);           // LDS read instructions per k-step of fragments
-
-  // prologue: tiles 0..3 in flight, tile 0 landed, its k-step-0 fragments in registers
-  stage_in(0);
-  if (nk > 1) stage_in(1);
-  if (nk > 2) stage_in(2);
-  if (nk > 3) stage_in(3);
-  if (nk > 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-  else if (nk > 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-  else if (nk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  P_BARRIER();
-  read_frags(0, 0);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-
-  // one MFMA of k-step ks: block (i, j) of the wave's 4 x 4
-  auto mfma1 = [&](int ks, int i, int j) {
-    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(hwbf16x8_t, fb[ks][j]), __builtin_bit_cast(hwbf16x8_t, fa[ks][i]),
-                                                        acc[i][j], 0, 0, 0);
-  };
-  auto iteration = [&](int t, auto steady) {
-    constexpr bool ST = decltype(steady)::value;
-    const char* tA = lds + (t & (P_NST - 1)) * P_STAGE;
-    const char* tB = tA + P_TILE;
-    const char* nA = lds + ((t + 1) & (P_NST - 1)) * P_STAGE;
-    const char* nB = nA + P_TILE;
-    char* dA = lds + (t & (P_NST - 1)) * P_STAGE;            // slot of tile t+4 == slot of tile t
-    const bool have_next = ST || (t + 1 < nk);
-    const bool do_dma = ST || (t + 4 < nk);
-    const bool dma_checked = !ST && ragged && (kt0 + t + 4 + 1 == nk_all);
-    // ---------------- phase A: k-step 0 of tile t; fragments of k-step 1 arrive under it (one per MFMA gap, pinned)
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      mfma1(0, g >> 2, g & 3);
-#ifndef UG_R4_ABLATE_READS
-      if (g < 4) fa[1][g] = ma.load(tA, 1, g);
-      else if (g < 8) fb[1][g - 4] = mb.load(tB, 1, g - 4);
+#ifdef UG_GEMM_R4                                // probe builds only: the rejected register-blocked 4-wave kernel lives in tools/probes/
+#include "../../tools/probes/gemm_r4_kernel.inc"
 #endif
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // own DMA share of tile t+1 landed (the two newer tiles may stay in flight); every wave past its reads of tile t
-    if constexpr (ST) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else if (t + 3 < nk) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else if (t + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#ifndef UG_R4_ABLATE_BARRIER
-    P_BARRIER();
-#endif
-    // ---------------- phase B: k-step 1 of tile t; per MFMA gap one DMA instruction of tile t+4 (into tile t's slot) and one
-    // k-step-0 fragment of tile t+1
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      mfma1(1, g >> 2, g & 3);
-#ifndef UG_R4_ABLATE_DMA
-      if (g < 8 && do_dma) {
-        const int kt = kt0 + t + 4;
-        if (g < 4) {
-          const bf16_t* sp = sa.src[g] + kt * sa.step[g];
-          if (dma_checked && kt * PBK + sa.kofs[g] >= (AK ? p.K : ((p.K + 7) & ~7))) sp = reinterpret_cast<const bf16_t*>(g_zero_page);
-          __builtin_amdgcn_global_load_lds((gptr_t)sp, (lptr_t)(dA + (g * R_NW + wave) * 1024), 16, 0, 0);
-        } else {
-          const bf16_t* sp = sb.src[g - 4] + kt * sb.step[g - 4];
-          if (dma_checked && kt * PBK + sb.kofs[g - 4] >= (BKM ? p.K : ((p.K + 7) & ~7))) sp = reinterpret_cast<const bf16_t*>(g_zero_page);
-          __builtin_amdgcn_global_load_lds((gptr_t)sp, (lptr_t)(dA + P_TILE + ((g - 4) * R_NW + wave) * 1024), 16, 0, 0);
-        }
-      }
-#endif
-#ifndef UG_R4_ABLATE_READS
-      if (have_next) {
-        if (g < 4) fa[0][g] = ma.load(nA, 0, g);
-        else if (g < 8) fb[0][g - 4] = mb.load(nB, 0, g - 4);
-      }
-#endif
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  };
-  {
-    int t = 0;
-    for (; t + 5 < nk; ++t) iteration(t, std::true_type{});     // tile t+4 exists and is not the launch's last (ragged) one
-    for (; t < nk; ++t) iteration(t, std::false_type{});
-  }
-
-  if (tail) {
-    const int64_t slot = (int64_t)(tile_lin - p.full_tiles) * p.tail_split + tail_j % p.tail_split;      // private partials only
-    float* ws = p.tail_ws + slot * (PBM * PBN);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int ml = wm * 128 + i * 32 + (lane & 31);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float* dst = ws + ml * PBN + wn * 128 + j * 32 + q * 8 + (lane >> 5) * 4;
-          *reinterpret_cast<float4*>(dst) = make_float4(acc[i][j][q * 4], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]);
-        }
-    }
-    return;
-  }
-  const bool wide = (n0 + PBN <= p.N) &&
-                    (EPI == EPI_BF16 ? (p.ldc % 8 == 0 && (!p.bias || (reinterpret_cast<uintptr_t>(p.bias) & 7) == 0))
-                                     : (p.ldc % 4 == 0 && (EPI != EPI_RESID || p.ldr % 4 == 0)));
-  if (wide) store_tile_r4<EPI>(p, acc, lds + wave * R_STRIP, m0 + wm * 128, n0 + wn * 128, lane);
-  else store_tile_r4_guarded<EPI>(p, acc, m0 + wm * 128, n0 + wn * 128, lane);
-}
-
-template <int EPI, bool AK, bool BKM>
-__global__ __launch_bounds__(256, 1) void gemm_kernel_r4(GemmArgs p) {
-  __shared__ __attribute__((aligned(16))) char lds[P_NST * P_STAGE];
-  r4_body<EPI, AK, BKM>(p, (int)blockIdx.x, lds);
-}
-#endif  // UG_GEMM_R4
 
 // Epilogue of the k-sliced tail tiles: scratch -> C with the launch's epilogue, scratch re-zeroed.
 template <int EPI>

@@ -99,9 +99,11 @@ class UniGen(ModelMixin, ConfigMixin):
         llm_cfg = _load_llm_config(llm_model_path, ckpt_base_path)
         self.register_to_config(hidden_size=llm_cfg["hidden_size"])
         llm_cfg["vocab_size"] = vocab_size          # reference: config.vocab_size = vocab_size / resize_token_embeddings
-        if rope_theta is not None:
+        # reference :58-64: rope_theta / scaling_factor / rope_type override the config ONLY in the load_from_pretrained=True
+        # branch (random init from config); with load_from_pretrained=False (HF weights) the reference ignores all three
+        if load_from_pretrained and rope_theta is not None:
             llm_cfg["rope_theta"] = rope_theta
-        if scaling_factor != 1:                       # reference :63-64
+        if load_from_pretrained and scaling_factor != 1:
             llm_cfg["rope_scaling"] = {"factor": float(scaling_factor), "type": rope_type}
         dims = Qwen2Dims(**llm_cfg)
         seed = kwargs.get("init_seed", None)

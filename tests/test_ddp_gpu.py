@@ -171,6 +171,45 @@ dist.destroy_process_group()
     assert res["dense:fp32"]["early"] == 0 and rel(res["dense:fp32"]["grad"], base) < 1e-5
 
 
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device")
+def test_rccl_two_gpus_every_transport_and_wire_format(dev, tmp_path):
+    """the rank-dependent exchanges over REAL RCCL with world > 1 -- both transports (torch.distributed,
+    ug_comm_*), all four wire formats, with the early dense hand-over of the tied table and the lookups' all-gather -- against
+    the host emulations of tests/test_ddp_cpu.py.  Runs wherever the box has two GPUs; the pool's one-GPU boxes skip it (the
+    same branches run there over gloo with two ranks and over RCCL at world 1)."""
+    from test_ddp_cpu import emulate_bf16_fp32acc, emulate_bf16_ring
+    world, port = 2, _free_port()
+    outs = [str(tmp_path / f"rccl2_{r}.pt") for r in range(world)]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "ddp_rccl_worker.py"), str(r), str(world), port, outs[r]], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    logs = [p.communicate(timeout=600)[0] for p in procs]
+    for p, o in zip(procs, logs):
+        assert p.returncode == 0, o[-3000:]
+    res = [torch.load(o, weights_only=False) for o in outs]
+    V, H = 500, 64
+    locs = [r["local"] for r in res]
+    look = torch.zeros(V, H)
+    for r in res:
+        look.index_add_(0, r["ids"], r["rows"], alpha=1.0 / world)
+    rel = lambda a, b: ((a - b).norm() / b.norm()).item()
+    for case in res[0]["cases"]:
+        c0, c1 = res[0]["cases"][case], res[1]["cases"][case]
+        reduce = case.split(":")[1]
+        assert c0["seen"] == world and c0["early"] == 1 and c0["lookup_bytes"] == world * (37 + 5) * (8 + 4 * H), (case, c0["seen"], c0["early"])
+        assert torch.equal(c0["grad"], c1["grad"]), case                  # replicas bit-identical
+        dense = {"fp32": lambda g: torch.stack(g).mean(0), "fp32_rsag": lambda g: torch.stack(g).mean(0),
+                 "bf16_fp32acc": emulate_bf16_fp32acc, "bf16": emulate_bf16_ring}[reduce](locs)
+        want = dense.clone()
+        want[:V * H] += look.reshape(-1)
+        got = c0["grad"]
+        if reduce == "bf16_fp32acc":                                      # rank-ordered fp32 sums: the emulation bit for bit
+            assert torch.equal(got[V * H:], want[V * H:]), case
+        tol = 1e-6 if reduce.startswith("fp32") else 4e-3
+        assert rel(got, want) < tol, (case, rel(got, want))
+        print(f"[RCCL world 2, {case}] rel err vs emulation {rel(got, want):.2e}, {c0['bytes']} + {c0['lookup_bytes']} bytes, backend {c0['backend']}")
+
+
 def test_bench_runs_end_to_end_with_two_ranks(dev):
     """`python bench.py --gpus 2` with NO launcher around it: bench.py starts torch.distributed.run itself as
     a child process before anything touches the GPU -- the child line is exactly the one the driver uses for N > 1 -- and relays
