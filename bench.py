@@ -194,6 +194,17 @@ def extra_cases(model, vq, opt, dev, args, steps=2):
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / n * 1e3
 
+    def by_family(fn):
+        """one more pass of `fn` with HIP events around every library launch (on the launch stream), filed by kernel family:
+        where a secondary case's time goes; ms per step"""
+        from unigen_hip import lib as ug_lib
+        torch.cuda.synchronize()
+        ug_lib.PROFILE = {}
+        fn()
+        torch.cuda.synchronize()
+        rec, ug_lib.PROFILE = ug_lib.PROFILE, None
+        return {k: round(sum(e0.elapsed_time(e1) for e0, e1, _ in v), 2) for k, v in sorted(rec.items())}
+
     def cat_masks(*ms):
         return ops.MaskBits(torch.cat([m.bits for m in ms]), torch.cat([m.tileany for m in ms]), sum(m.B for m in ms), ms[0].L)
 
@@ -244,7 +255,8 @@ def extra_cases(model, vq, opt, dev, args, steps=2):
     # 386 shifted positions instead of 256 label rows: 3 x (1.0141 + 0.0186 + 386/256 x 0.1257) + 0.355
     fl = Bt * (3.475e12 + 0.3551e12) + Bm * (3 * (1.0141e12 + 0.0186e12 + 386 / 256 * 0.1257e12) + 0.3551e12)
     out["pt1_mixed_L387"] = {"ms_per_step": round(ms, 2), "samples_per_s": round((Bt + Bm) / ms * 1e3, 2), "rows": f"{Bt} t2i + {Bm} mmu",
-                             "seq_len": L, "step_frac_of_bf16_peak": round(fl / (ms * 1e-3) / PEAK_BF16, 4)}
+                             "seq_len": L, "step_frac_of_bf16_peak": round(fl / (ms * 1e-3) / PEAK_BF16, 4),
+                             "by_family_ms": by_family(step_pt1)}
 
     # ---- DPO: 10 pairs at L = 387 (a second, frozen copy of the model as the reference policy)
     pairs, beta = 10, 0.1
@@ -279,7 +291,7 @@ def extra_cases(model, vq, opt, dev, args, steps=2):
         dpo_loss.append(loss.detach())
     ms = timed(step_dpo)
     out["dpo_L387"] = {"ms_per_step": round(ms, 2), "pairs_per_s": round(pairs / ms * 1e3, 2), "pairs": pairs, "seq_len": L,
-                       "loss": round(float(dpo_loss[-1]), 4)}
+                       "loss": round(float(dpo_loss[-1]), 4), "by_family_ms": by_family(step_dpo)}
     del ref
     torch.cuda.empty_cache()
 
@@ -348,7 +360,8 @@ def extra_cases(model, vq, opt, dev, args, steps=2):
         sft_loss.append(torch.stack([l1.detach(), l2.detach(), l3.detach()]))
     ms = timed(step_sft)
     out["sft_L1603"] = {"ms_per_step": round(ms, 2), "samples_per_s": round((bt + bl + bm) / ms * 1e3, 2), "rows": f"{bt} t2i + {bl} lm + {bm} mmu",
-                        "seq_len": Ls, "siglip_images": bm, "losses": [round(float(x), 3) for x in sft_loss[-1]]}
+                        "seq_len": Ls, "siglip_images": bm, "losses": [round(float(x), 3) for x in sft_loss[-1]],
+                        "by_family_ms": by_family(step_sft)}
     model.llm.engine.check_errors()
     return out
 

@@ -8,6 +8,8 @@
 namespace {
 
 constexpr int DHD = 128;
+typedef const __attribute__((address_space(1))) void* gptr_t;      // LDS-DMA operands (global_load_lds)
+typedef __attribute__((address_space(3))) void* lptr_t;
 
 // qkv rows (r*L + t) -> cache[r][hk][pos0 + t][:]   (k already rotated).  One thread per 16-byte chunk.
 __global__ __launch_bounds__(256) void kv_store_kernel(const bf16_t* __restrict__ qkv, int64_t ldq, int k_col, int v_col,
@@ -156,26 +158,10 @@ __global__ __launch_bounds__(64 * AD_WAVES) void attn_decode_kernel(const bf16_t
   }
 }
 
-// The new token's q / k / v head slices straight from the raw qkv accumulator (consumer-side finishing of the qkv
-// projection): x = bf16(rstd * acc + bias), RoPE at `pos` on q and k.  Thread i of a 64-thread group owns the
-// rotary pair (i, i+64).  Same arithmetic as finish_qkv_tile / rope_at_kernel.
-__device__ __forceinline__ void new_token_pair(const float* __restrict__ arow, const bf16_t* __restrict__ bias, float rs,
-                                               int col0, int i, bool rot, const float* __restrict__ cs,
-                                               const float* __restrict__ sn, int pos, float& x1, float& x2) {
-#pragma clang fp contract(off)
-  const int c1 = col0 + i, c2 = c1 + DHD / 2;
-  float v1 = rs * arow[c1], v2 = rs * arow[c2];
-  if (bias) { v1 += bf2f(bias[c1]); v2 += bf2f(bias[c2]); }
-  x1 = bf2f(f2bf(v1)); x2 = bf2f(f2bf(v2));
-  if (rot) {
-    const float c = cs[(int64_t)pos * (DHD / 2) + i], s = sn[(int64_t)pos * (DHD / 2) + i];
-    const float p1 = x1 * c, p2 = x2 * c;
-    const float q1 = x2 * s, q2 = x1 * s;
-    x1 = bf2f(f2bf(p1 - q1)); x2 = bf2f(f2bf(p2 + q2));
-  }
-}
-
 constexpr int ADF_WAVES = 8;            // one 64-key chunk per wave up to 512 keys: no serialized second chunk
+#ifndef UG_ADF_ABLATE                   // probe builds only (tools/probes/build_variant.py): 1 no K/V loads, 2 no score / PV
+#define UG_ADF_ABLATE 0                 // arithmetic, 4 no prologue loads, 8 return at once -- timing probes, wrong results
+#endif
 // Cache attention of one decode step fed by the RAW qkv accumulator: every (row, query head) workgroup rebuilds
 // q and its kv head's new k / v row itself (no dependency between workgroups; the first query head of each kv head
 // also appends the row to the cache), attends to cache keys [0, pos) exactly like attn_decode_kernel, and merges
@@ -184,24 +170,48 @@ __global__ __launch_bounds__(64 * ADF_WAVES) void attn_decode_fused_kernel(
     const float* __restrict__ acc_qkv, int64_t lda, const float* __restrict__ ss, float eps, int norm_cols,
     const bf16_t* __restrict__ bias, const float* __restrict__ cs, const float* __restrict__ sn, const int* __restrict__ pos_dev,
     bf16_t* __restrict__ ck, bf16_t* __restrict__ cv, const uint8_t* __restrict__ key_valid, bf16_t* __restrict__ o, int64_t ldo,
-    int H, int HKV, int Tmax, int max_pos, float scale) {
+    int R, int H, int HKV, int Tmax, int max_pos, float scale) {
   __shared__ float qs[DHD], kn[DHD], vn[DHD];
   __shared__ float om[ADF_WAVES][DHD];
   __shared__ float ml[ADF_WAVES][2];
-  const int r = blockIdx.y, h = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int hk = h / (H / HKV);
+  // K rows of a wave's 64-key chunk: 16 KB, CONTIGUOUS in the cache ([row][kv head][t][128]).  Round 3 let lane j load "its" key
+  // row piece by piece (16 loads of 16 B at a 256-byte lane stride): every instruction touched 64 cache lines and the 256 KB a
+  // workgroup walks do not stay in the CU's 32 KB L1, so each line came up from L2 up to eight times -- 5.3 of the kernel's
+  // 10.7 us (ablation, profiles/r04_ar_decode.md).  Now the chunk goes HBM/L2 -> LDS by LDS-DMA, 1 KB of contiguous source per
+  // instruction, and lane j reads its row back from LDS.  LDS-DMA writes lane-linear, so the bank swizzle is applied on the
+  // SOURCE side: LDS slot s of key k holds 16-byte chunk s ^ (k & 15); the 16 lanes of a ds_read_b128 service group hold 16
+  // different k & 15, so the reads are conflict-free.
+  __shared__ __attribute__((aligned(1024))) char ktile[ADF_WAVES][64 * DHD * 2];
+  // Workgroup -> (row, query head): the H / HKV query heads that share one (row, kv head)'s K / V are placed on ONE XCD (workgroup
+  // b runs on XCD b % 8 and every XCD has its own L2): dealt out head-major they landed on six different XCDs and each XCD
+  // fetched the same K / V from HBM -- 36 MB per layer instead of 6, the part of this kernel that grew with the context
+  // (8.2 us at 171 keys, 11.2 at 363).
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int per = H / HKV, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int grp = xcd + 8 * (slot / per);                 // (row, kv head) group
+  if (grp >= R * HKV) return;
+  const int r = grp / HKV, hk = grp % HKV, h = hk * per + slot % per;
+  if constexpr (UG_ADF_ABLATE & 8) return;
   const bf16_t* kb = ck + ((int64_t)r * HKV + hk) * Tmax * DHD;
   const bf16_t* vb = cv + ((int64_t)r * HKV + hk) * Tmax * DHD;
   const int kq = lane >> 4, dc = lane & 15;
-  // the first key chunk's K row / V pieces do not depend on the new token: request them before the prologue's own
+  // the first key chunk's K rows / V pieces do not depend on the new token: request them before the prologue's own
   // round trip (accumulator, bias, RoPE table) so the two latencies overlap.  (Requesting them before the position word
   // as well -- clamped to the cache instead of the visible length, masked afterwards -- measured SLOWER, 5 730 vs 5 885
   // tokens/s: every wave then loads a chunk at every step, visible or not.)
-  bf16x8_t kf[DHD / 8], vf[16];
+  bf16x8_t vf[16];
   auto load_chunk = [&](int t0, int last) {
-    const bf16_t* kr = kb + (int64_t)min(t0 + lane, last) * DHD;
+    if constexpr (UG_ADF_ABLATE & 1) {
 #pragma unroll
-    for (int c = 0; c < DHD / 8; ++c) kf[c] = *reinterpret_cast<const bf16x8_t*>(kr + c * 8);
+      for (int c = 0; c < 16; ++c) vf[c] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int k = i * 4 + kq;                                    // key of the chunk this lane's 16 bytes belong to
+      const bf16_t* src = kb + (int64_t)min(t0 + k, last) * DHD + ((dc ^ (k & 15)) << 3);
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ktile[wave] + i * 1024), 16, 0, 0);
+    }
 #pragma unroll
     for (int jj = 0; jj < 16; ++jj) {
       const int tt = min(t0 + jj * 4 + kq, last);
@@ -210,13 +220,38 @@ __global__ __launch_bounds__(64 * ADF_WAVES) void attn_decode_fused_kernel(
   };
   const int pos0 = *pos_dev;
   const int len = min(pos0, Tmax);                         // cache keys visible to the new token
-  if (wave * 64 < len) load_chunk(wave * 64, len - 1);
-  const float rs = rsqrtf(ss[r] / (float)norm_cols + eps);
+  // The new token's q / k / v pair of this lane (waves 0-2): its loads -- the raw accumulator the projection's atomics left at
+  // the device coherence point, bias, RoPE table: one ~2 us round trip -- go out FIRST, the chunk's K / V requests behind them.
+  // Memory returns a wave's loads in order, so issued the other way round (round 3) the prologue's data sat behind 32 K / V
+  // loads per lane and its arithmetic + the workgroup barrier started only after the whole chunk had landed.
   const float* arow = acc_qkv + (int64_t)r * lda;
+  const int col0 = wave == 0 ? h * DHD : wave == 1 ? (H + hk) * DHD : (H + HKV + hk) * DHD;
+  const int rpos = min(pos0, max_pos - 1);
+  float a1 = 0.f, a2 = 0.f, b1 = 0.f, b2 = 0.f, rc = 1.f, rsn = 0.f, ssr = 1.f;
+  if (wave < 3 && !(UG_ADF_ABLATE & 4)) {
+    ssr = ss[r];
+    a1 = arow[col0 + lane]; a2 = arow[col0 + lane + DHD / 2];
+    if (bias) { b1 = bf2f(bias[col0 + lane]); b2 = bf2f(bias[col0 + lane + DHD / 2]); }
+    if (wave < 2) { rc = cs[(int64_t)rpos * (DHD / 2) + lane]; rsn = sn[(int64_t)rpos * (DHD / 2) + lane]; }
+  }
+  if (wave * 64 < len) load_chunk(wave * 64, len - 1);
   if (wave < 3) {
-    const int col0 = wave == 0 ? h * DHD : wave == 1 ? (H + hk) * DHD : (H + HKV + hk) * DHD;
     float x1, x2;
-    new_token_pair(arow, bias, rs, col0, lane, wave < 2, cs, sn, min(pos0, max_pos - 1), x1, x2);
+    {
+#pragma clang fp contract(off)
+      // consumer-side finishing of the qkv projection, same arithmetic as finish_qkv_tile / rope_at_kernel: bf16(rstd * acc + bias), rotate-half with
+      // separately rounded products
+      const float rs = rsqrtf(ssr / (float)norm_cols + eps);
+      float v1 = rs * a1, v2 = rs * a2;
+      if (bias) { v1 += b1; v2 += b2; }
+      x1 = bf2f(f2bf(v1)); x2 = bf2f(f2bf(v2));
+      if (wave < 2) {
+        const float p1 = x1 * rc, p2 = x2 * rc;
+        const float q1 = x2 * rsn, q2 = x1 * rsn;
+        x1 = bf2f(f2bf(p1 - q1)); x2 = bf2f(f2bf(p2 + q2));
+      }
+      if constexpr (UG_ADF_ABLATE & 4) { x1 = 0.01f * lane; x2 = -0.02f * lane; }
+    }
     float* dst = wave == 0 ? qs : wave == 1 ? kn : vn;
     dst[lane] = x1; dst[lane + DHD / 2] = x2;
     if (wave > 0 && h % (H / HKV) == 0 && pos0 < Tmax) {
@@ -233,17 +268,22 @@ __global__ __launch_bounds__(64 * ADF_WAVES) void attn_decode_fused_kernel(
   for (int t0 = wave * 64; t0 < len; t0 += 64 * ADF_WAVES) {
     const int t = t0 + lane;
     float s = -INFINITY;
-    if (t0 != wave * 64) load_chunk(t0, len - 1);        // later chunks (contexts beyond 512 keys)
+    if (t0 != wave * 64) {                               // later chunks (contexts beyond 512 keys): the wave's own reads of the
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); //  previous chunk have returned before the DMA overwrites the tile
+      load_chunk(t0, len - 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the chunk's K rows have landed in LDS (this wave's own DMA)
     if (t < len && (!key_valid || key_valid[(int64_t)r * Tmax + t])) {
       float d = 0.f;
-      asm volatile("" ::: "memory");           // keep the q reads below inside the chunk loop
+      const char* krow = ktile[wave] + lane * (DHD * 2);
 #pragma unroll
       for (int c = 0; c < DHD / 8; ++c) {
         // q is re-read from LDS (broadcast) where it is used: hoisting all 128 values would not fit 8 waves' registers
+        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(krow + ((c ^ (lane & 15)) << 4));
         const float4 q0 = *reinterpret_cast<const float4*>(&qs[c * 8]);
         const float4 q1 = *reinterpret_cast<const float4*>(&qs[c * 8 + 4]);
-        d += bf2f((bf16_t)kf[c][0]) * q0.x + bf2f((bf16_t)kf[c][1]) * q0.y + bf2f((bf16_t)kf[c][2]) * q0.z + bf2f((bf16_t)kf[c][3]) * q0.w;
-        d += bf2f((bf16_t)kf[c][4]) * q1.x + bf2f((bf16_t)kf[c][5]) * q1.y + bf2f((bf16_t)kf[c][6]) * q1.z + bf2f((bf16_t)kf[c][7]) * q1.w;
+        d += bf2f((bf16_t)kf[0]) * q0.x + bf2f((bf16_t)kf[1]) * q0.y + bf2f((bf16_t)kf[2]) * q0.z + bf2f((bf16_t)kf[3]) * q0.w;
+        d += bf2f((bf16_t)kf[4]) * q1.x + bf2f((bf16_t)kf[5]) * q1.y + bf2f((bf16_t)kf[6]) * q1.z + bf2f((bf16_t)kf[7]) * q1.w;
       }
       s = d * scale;
     }
@@ -372,8 +412,6 @@ __global__ __launch_bounds__(256) void gemv_kernel(const bf16_t* __restrict__ x,
 // 64 bytes per row (measured 2.8 TB/s on gate_up).  So weight tiles go HBM -> LDS with 16-byte LDS-DMA, each
 // instruction covering two rows x 512 contiguous bytes, and the fragments come back out of LDS.  LDS-DMA writes
 // lane-linear, so the bank swizzle (16-byte chunk index ^ row) is applied to the SOURCE address.
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
 
 // ------------------------------------------------------------------ fused finishers of the decode step
 // Every finisher consumes a row-major fp32 accumulator filled by the GEMV (acc[r*lda + n]) and leaves it ZEROED
@@ -921,9 +959,11 @@ extern "C" int ug_attn_decode_fused(const float* acc_qkv, int64_t ldacc, const f
                                     int H, int HKV, int head_dim, int64_t Tmax, int64_t max_pos, float scale, hipStream_t st) {
   UG_REQUIRE(rows > 0 && head_dim == DHD && H % HKV == 0 && acc_qkv && ss_in && norm_cols > 0 && pos_dev && cache_k && cache_v && o,
              "ug_attn_decode_fused: bad args");
-  hipLaunchKernelGGL(attn_decode_fused_kernel, dim3(H, (unsigned)rows), dim3(64 * ADF_WAVES), 0, st, acc_qkv, ldacc, ss_in, eps,
+  // 1-D block index (XCD-aware placement inside the kernel)
+  const unsigned nblk = 8u * (unsigned)((rows * HKV + 7) / 8) * (unsigned)(H / HKV);
+  hipLaunchKernelGGL(attn_decode_fused_kernel, dim3(nblk, 1), dim3(64 * ADF_WAVES), 0, st, acc_qkv, ldacc, ss_in, eps,
                      (int)norm_cols, (const bf16_t*)bias, cos_tab, sin_tab, pos_dev, (bf16_t*)cache_k, (bf16_t*)cache_v, key_valid,
-                     (bf16_t*)o, ldo, H, HKV, (int)Tmax, (int)max_pos, scale);
+                     (bf16_t*)o, ldo, (int)rows, H, HKV, (int)Tmax, (int)max_pos, scale);
   UG_CHECK_LAUNCH("ug_attn_decode_fused");
   return UG_OK;
 }

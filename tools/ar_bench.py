@@ -41,5 +41,8 @@ def run(n_img=8, prefix=138, n_tok=256, use_graph=True, reps=2):
 
 
 if __name__ == "__main__":
-    for ug in (False, True):
-        print(json.dumps(run(use_graph=ug)), flush=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "graph":          # profiling runs: the captured path only, one repetition after the warm-up
+        print(json.dumps(run(use_graph=True, reps=1)), flush=True)
+    else:
+        for ug in (False, True):
+            print(json.dumps(run(use_graph=ug)), flush=True)

@@ -1,0 +1,79 @@
+"""Per-launch timeline of the captured AR decode step from a rocprofv3 kernel trace:
+
+    rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_ar -- python3 tools/ar_bench.py graph
+    python3 tools/ar_timeline.py gpurun_out/prof_ar > profiles/r04_ar_timeline.md
+
+Takes the LAST generation in the trace, cuts it into decode steps at the sampling kernel, and reports for every launch position of
+a step (28 layers x launches per layer + head + sampler): the kernel, its mean body (end - start) and the mean gap to the previous
+kernel's end, averaged over the steps of the second half of the generation (longest contexts).  Then one layer of one step verbatim."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+base = sys.argv[1]
+files = glob.glob(os.path.join(base, "**", "*kernel_trace.csv"), recursive=True)
+if not files:
+    raise SystemExit(f"no kernel_trace.csv under {base}")
+rows = []
+for r in csv.DictReader(open(files[0])):
+    rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+rows.sort()
+
+
+def short(n):
+    n = n.replace("void ", "").replace("(anonymous namespace)::", "")
+    return n.split("(")[0][:58]
+
+
+# decode steps end with the sampler; take the last 128 complete steps
+idx = [i for i, r in enumerate(rows) if "ar_sample" in r[2]]
+steps = []
+for a, b in zip(idx[:-1], idx[1:]):
+    seg = rows[a + 1:b + 1]
+    steps.append(seg)
+lens = defaultdict(int)
+for s in steps:
+    lens[len(s)] += 1
+L = max(lens, key=lens.get)                       # launches per captured step
+steps = [s for s in steps if len(s) == L][-128:]
+print(f"# AR decode timeline: {files[0].split('/')[-1]}; {len(steps)} steps of {L} launches each (the last {len(steps)} of the trace)\n")
+body = [0.0] * L
+gap = [0.0] * L
+for s in steps:
+    for j, (st, en, _) in enumerate(s):
+        body[j] += (en - st) / 1e3
+        if j:
+            gap[j] += (st - s[j - 1][1]) / 1e3
+n = len(steps)
+body = [b / n for b in body]
+gap = [g / n for g in gap]
+names = [short(r[2]) for r in steps[-1]]
+step_us = sum((s[-1][1] - s[0][0]) / 1e3 for s in steps) / n
+print(f"step span (first launch start -> sampler end): {step_us:.1f} us; sum of bodies {sum(body):.1f} us, sum of gaps {sum(gap):.1f} us\n")
+# per kernel name
+agg = defaultdict(lambda: [0, 0.0, 0.0])
+for j, nm in enumerate(names):
+    a = agg[nm]
+    a[0] += 1; a[1] += body[j]; a[2] += gap[j]
+print("| kernel | launches / step | body us (mean) | gap before us (mean) | us / step (body + gap) |\n|---|---|---|---|---|")
+for nm, (c, b, g) in sorted(agg.items(), key=lambda kv: -(kv[1][1] + kv[1][2])):
+    print(f"| `{nm}` | {c} | {b / c:.2f} | {g / c:.2f} | {b + g:.1f} |")
+# one layer verbatim: find the period
+per = None
+for cand in range(2, 12):
+    if all(names[j] == names[j + cand] for j in range(0, cand * 20)):
+        per = cand
+        break
+if per:
+    j0 = per * 13
+    print(f"\nOne layer (launches {j0}..{j0 + per - 1} of the last step; layer period {per} launches), us relative to the layer's first start:\n")
+    s = steps[-1]
+    t0 = s[j0][0]
+    print("| launch | start | end | body | gap before |\n|---|---|---|---|---|")
+    for j in range(j0, j0 + per):
+        st, en, nm = s[j]
+        print(f"| `{short(nm)}` | {(st - t0) / 1e3:.2f} | {(en - t0) / 1e3:.2f} | {(en - st) / 1e3:.2f} | {(st - s[j - 1][1]) / 1e3:.2f} |")
+    print(f"\nlayer period (start to next layer's start): {(s[j0 + per][0] - t0) / 1e3:.2f} us; "
+          f"mean over the averaged steps: {sum(body[j0:j0 + per]) + sum(gap[j0:j0 + per]):.2f} us")
