@@ -783,6 +783,7 @@ __global__ __launch_bounds__(64 * NW) void gemv_ring4_kernel(int R, const bf16_t
   }
 }
 
+
 template <int RB>
 void launch_gemv(int U, dim3 grid, hipStream_t st, const bf16_t* x, int64_t ldx, int R, const bf16_t* W, int64_t ldw,
                  float* acc, int64_t sr, int64_t sn, int N, int K) {
