@@ -250,13 +250,14 @@ class FlatGradSync:
         collective and the copy back to pinned memory run on the side stream, which is idle now: the result is on the host long
         before finish() asks for it."""
         n = int(rows_live)
-        if self.world == 1:
-            self._cap = n
-        elif not self.cuda or self.backend not in ("nccl", "ug_comm(rccl)"):
+        if not self.cuda or self.backend not in ("nccl", "ug_comm(rccl)"):
+            if self.world == 1:
+                self._cap = n
+                return
             t = torch.tensor([n], dtype=torch.int64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.pg)
             self._cap = int(t.item())
-        else:
+        else:                                     # (also at world size 1 with the exchange forced on: the one-GPU boxes drive this path)
             dev = self.engine.fp.grad.device
             if self._pin is None:
                 self._pin = (torch.zeros(1, dtype=torch.int64).pin_memory(), torch.zeros(self.world, dtype=torch.int64).pin_memory(),
@@ -343,7 +344,7 @@ class FlatGradSync:
         if n < cap:
             rows[n:].zero_()
         W = self.world
-        if W > 1:
+        if W > 1 or (self.cuda and self.backend in ("nccl", "ug_comm(rccl)")):       # (world 1 on RCCL: a one-rank gather, for coverage)
             ids_all = torch.empty(W * cap, dtype=torch.int64, device=dev)
             rows_all = torch.empty((W * cap, H), dtype=torch.float32, device=dev)
             self._all_gather_flat(ids_all, ids)
