@@ -233,8 +233,7 @@ extern "C" int ug_comm_allgather(ug_comm* c, const void* send, void* recv, int64
   UG_HIP(hipEventRecord(c->ready, producer));
   UG_HIP(hipStreamWaitEvent(c->stream, c->ready, 0));
   UG_NCCL(g_rccl.AllGather(send, recv, (size_t)bytes_per_rank, ncclUint8, c->comm, c->stream));
-  c->bytes_on_wire += bytes_per_rank * c->world;
-  return UG_OK;
+  return UG_OK;                                  // (bytes_on_wire counts the gradient buckets only; the host accounts for what it gathers)
 }
 
 extern "C" int ug_comm_wait(ug_comm* c, hipStream_t consumer) {
