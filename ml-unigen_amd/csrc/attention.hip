@@ -233,6 +233,7 @@ struct AttnArgs {
   // backward only: RoPE transposed on dq / dk before they are stored, and the q | k | v bias gradient (column sums of the stored
   // bf16 values) added into dbias[(H + 2 HKV) * 128] -- what the rope and colsum passes over dqkv did (or null: plain stores)
   const float* rope_cos; const float* rope_sin; float* dbias;
+  int dkv_heads;            // query heads per workgroup of the split-head dK / dV kernel (1 or 2)
   int ablate;               // probe builds of the timing tools only (UNIGEN_ATTN_ABLATE): 1 = no K / V staging after the first tile
 };
 
@@ -1039,15 +1040,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_dma_kernel(AttnArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = p.H / p.HKV;
-  const WgCoord wc = wg_coord((int)blockIdx.x, p.nW, p.H, p.HKV, p.B);
+  // HPW query heads per workgroup (p.dkv_heads: 1 or 2, dividing the group): the workgroup walks its heads one after the other
+  // with the SAME dK / dV accumulators, so the fp32 atomics into the split-head workspace (64 KB per workgroup, 160 MB per launch
+  // at one head each) and the finishing pass's contention halve at two
+  const int HPW = p.dkv_heads;
+  const WgCoord wc = wg_coord((int)blockIdx.x, p.nW, p.H / HPW, p.HKV, p.B);
   if (!wc.ok) return;
-  const int t = wc.tile, b = wc.b, h = wc.h, hk = wc.h / grp;
+  const int t = wc.tile, b = wc.b, h0 = wc.h * HPW, hk = h0 / grp;
   const int krow = t * 64 + wave * 16 + (lane & 15);
   const int krow_c = min(krow, p.L - 1);
   const bf16_t* kseq = p.k + (int64_t)b * p.L * p.ldq + hk * HD;
   const bf16_t* vseq = p.v + (int64_t)b * p.L * p.ldq + hk * HD;
-  const bf16_t* qseq = p.q + (int64_t)b * p.L * p.ldq + h * HD;
-  const bf16_t* doseq = p.dout + (int64_t)b * p.L * p.ldo + h * HD;
+  const bf16_t* qseq = p.q + (int64_t)b * p.L * p.ldq + h0 * HD;
+  const bf16_t* doseq = p.dout + (int64_t)b * p.L * p.ldo + h0 * HD;
+  int h = h0;
   bf16x8_t kf[4], vf[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
@@ -1093,14 +1099,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_dma_kernel(AttnArgs p) {
     r_word = qr < p.L ? p.bits[((int64_t)b * p.L + qc) * p.nW + t] : 0ull;         // rows past L contribute nothing
   };
 
+  // the (head, visible query tile) sequence: head h0's tiles, then head h0 + 1's, ... -- one ring, one barrier per step
   int qt = next_visible(0);
+  int hleft = qt < p.nW ? HPW - 1 : 0;                    // heads still to come after the current one
   if (qt < p.nW) { stage(qt, 0); if (wave == 0) fetch_rows(qt); }
   for (int it = 0; qt < p.nW; ++it) {
-    const int qn = next_visible(qt + 1);
+    int qn = next_visible(qt + 1);
     const int slot = it & 1;
     if (wave == 0) { lse_s[slot][lane] = r_lse; dl_s[slot][lane] = r_dl; word_s[slot][lane] = r_word; }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
+    if (qn >= p.nW && hleft > 0) {                        // next head: its Q / dO / row records from the first visible tile on
+      --hleft; ++h;
+      qseq += HD; doseq += HD;
+      qn = next_visible(0);
+    }
     if (qn < p.nW) { stage(qn, slot ^ 1); if (wave == 0) fetch_rows(qn); }
     const char* Qs = ring + slot * 2 * T32_BYTES;
     const char* Ds = Qs + T32_BYTES;
@@ -1388,7 +1401,9 @@ extern "C" int ug_attn_bwd(const void* q, const void* k, const void* v, int64_t 
   float* dbias_v = dbias ? dbias + (H + HKV) * HD : nullptr;
   if (dkv_ws) {
     static const int dma = [] { const char* e = getenv("UNIGEN_ATTN_DKV_DMA"); return e ? atoi(e) : 1; }();
-    if (dma && L <= 4096) hipLaunchKernelGGL(attn_bwd_dkv_dma_kernel, dim3(wg_grid(a.nW, H, HKV, B)), dim3(256), 0, st, a);
+    static const int hpw_env = [] { const char* e = getenv("UNIGEN_ATTN_DKV_HEADS"); return e ? atoi(e) : 2; }();
+    a.dkv_heads = (hpw_env >= 1 && (H / HKV) % hpw_env == 0 && (int64_t)a.nW * (H / hpw_env) * B >= 1024) ? hpw_env : 1;
+    if (dma && L <= 4096) hipLaunchKernelGGL(attn_bwd_dkv_dma_kernel, dim3(wg_grid(a.nW, H / a.dkv_heads, HKV, B)), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, dim3(wg_grid(a.nW, H, HKV, B)), dim3(256), 0, st, a);
     UG_CHECK_LAUNCH("ug_attn_bwd(dkv split)");
     if (fuse && (rope_cos || dbias) && HKV <= 16 && (HKV & (HKV - 1)) == 0) {
