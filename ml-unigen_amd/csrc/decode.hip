@@ -4,6 +4,7 @@
 //   cache layout: K,V [rows][HKV][Tmax][128] bf16 (keys of one (row, kv-head) contiguous)
 #include "common.h"
 #include "unigen_hip.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -682,14 +683,27 @@ __global__ __launch_bounds__(64) void gemv_ring_kernel(const bf16_t* __restrict_
 template <int RB, int KW, int XIN, int NW>
 __global__ __launch_bounds__(64 * NW) void gemv_ring4_kernel(int R, const bf16_t* __restrict__ W, int64_t ldw,
                                                              float* __restrict__ acc, int64_t sr, int64_t sn, int N, int K,
-                                                             int nslabs, DecodeIn f) {
+                                                             int nslabs, int xcd_chunks, DecodeIn f) {
   __shared__ __attribute__((aligned(1024))) char tile[NW][2][8192];
   __shared__ __attribute__((aligned(16))) bf16x8_t frag[RB][8][64];
   constexpr int UPW = (8 + NW - 1) / NW;           // k-steps of the operand each wave converts
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, row = lane & 15;
-  const int chunk = blockIdx.x / nslabs;
+  // (chunk of weight rows, k-slab) of this workgroup.  xcd_chunks > 0 (many slabs: the down projection): the `xcd_chunks`
+  // workgroups that share a slab -- and therefore its fp32 operand, which the previous launch's atomics left at the device
+  // coherence point -- sit on ONE XCD (block b runs on XCD b % 8), so the slab comes through the slow path once per XCD instead
+  // of once per workgroup (7.7 -> 1.1 MB per launch); surplus workgroups of the padded grid only take part in the clears.
+  int chunk, slab;
+  if (xcd_chunks > 0) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    slab = xcd + 8 * (j / xcd_chunks);
+    chunk = j % xcd_chunks;
+    if (slab >= nslabs) { decode_clear(f, threadIdx.x, blockIdx.x, gridDim.x); return; }
+  } else {
+    chunk = blockIdx.x / nslabs;
+    slab = blockIdx.x % nslabs;
+  }
   const int grp0 = (chunk * NW + wave) * KW;
-  const int kbase = (blockIdx.x % nslabs) * 256;
+  const int kbase = slab * 256;
   int roff[8], kc[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -822,11 +836,19 @@ void launch_ring_auto(hipStream_t st, const bf16_t* x, int64_t ldx, int R, const
       const int64_t cost = ((blocks + 255) / 256) * cands[c].nw * cands[c].kw;
       if (cost < best_cost) { best_cost = cost; best = c; }
     }
-    const int NWc = cands[best].nw, KWc = cands[best].kw;
-    dim3 grid((unsigned)(((groups + NWc * KWc - 1) / (NWc * KWc)) * nslabs));
-#define UG_RING4(RBV, KWV, NWV) hipLaunchKernelGGL((gemv_ring4_kernel<RBV, KWV, XIN, NWV>), grid, dim3(64 * NWV), 0, st, R, W, ldw, acc, sr, sn, N, K, nslabs, f)
+    int NWc = cands[best].nw, KWc = cands[best].kw, xcd_chunks = 0;
+    // many k-slabs (down projection: 35): the workgroups of a slab on one XCD -- 8 waves x 2 tiles, chunks x ceil(slabs / 8)
+    // workgroups per XCD must fit its 32 CUs
+    static const int xcd_major = [] { const char* e = getenv("UNIGEN_DECODE_XCD_SLABS"); return e ? atoi(e) : 1; }();
+    if (xcd_major && R <= 16 && nslabs >= 16) {
+      const int64_t chunks8 = (groups + 15) / 16;
+      if (chunks8 * ((nslabs + 7) / 8) <= 32) { NWc = 8; KWc = 2; xcd_chunks = (int)chunks8; }
+    }
+    // (dealing the nslabs % 8 left-over slabs' workgroups over all XCDs for equal bytes per XCD measured no better: 10.50 vs 10.33 us)
+    dim3 grid(xcd_chunks ? (unsigned)(8 * ((nslabs + 7) / 8) * xcd_chunks) : (unsigned)(((groups + NWc * KWc - 1) / (NWc * KWc)) * nslabs));
+#define UG_RING4(RBV, KWV, NWV) hipLaunchKernelGGL((gemv_ring4_kernel<RBV, KWV, XIN, NWV>), grid, dim3(64 * NWV), 0, st, R, W, ldw, acc, sr, sn, N, K, nslabs, xcd_chunks, f)
     if (R <= 16) {
-      if (NWc == 9) UG_RING4(1, 3, 9); else if (NWc == 7) UG_RING4(1, 2, 7); else if (KWc == 2) UG_RING4(1, 2, 4); else UG_RING4(1, 1, 4);
+      if (NWc == 9) UG_RING4(1, 3, 9); else if (NWc == 8) UG_RING4(1, 2, 8); else if (NWc == 7) UG_RING4(1, 2, 7); else if (KWc == 2) UG_RING4(1, 2, 4); else UG_RING4(1, 1, 4);
     } else { if (KWc == 2) UG_RING4(2, 2, 4); else UG_RING4(2, 1, 4); }
 #undef UG_RING4
   }
