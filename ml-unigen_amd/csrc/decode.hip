@@ -274,6 +274,8 @@ __global__ __launch_bounds__(64 * ADF_WAVES) void attn_decode_fused_kernel(
       load_chunk(t0, len - 1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the chunk's K rows have landed in LDS (this wave's own DMA)
+    if constexpr (UG_ADF_ABLATE & 2) { if (t < len) s = 0.001f * lane + bf2f((bf16_t)(*reinterpret_cast<const bf16x8_t*>(ktile[wave] + lane * 256))[0]); }
+    else
     if (t < len && (!key_valid || key_valid[(int64_t)r * Tmax + t])) {
       float d = 0.f;
       const char* krow = ktile[wave] + lane * (DHD * 2);
@@ -298,6 +300,10 @@ __global__ __launch_bounds__(64 * ADF_WAVES) void attn_decode_fused_kernel(
     const float pb = bf2f(f2bf(p));
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] *= alpha;
+    if constexpr (UG_ADF_ABLATE & 2) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += pb * bf2f((bf16_t)vf[e][e]) + bf2f((bf16_t)vf[e + 8][e]);
+    } else
 #pragma unroll
     for (int jj = 0; jj < 16; ++jj) {
       const float pj = __shfl(pb, jj * 4 + kq, 64);
