@@ -82,13 +82,15 @@ int ug_gemm_bf16_swiglu(const ug_handle* h, const void* x, int64_t ldx, const vo
                         int64_t ld_gu, void* act, int64_t ld_act, int64_t M, int64_t I, int64_t K, hipStream_t stream);
 
 /* Grouped weight gradients (replaces: the autograd wgrad of the four nn.Linear of a Qwen2DecoderLayer, modeling_qwen2.py:
- * q/k/v_proj fused, o_proj, gate/up_proj fused, down_proj): dw[i][rows_i, cols_i] (= or +=, beta[i]) dy[i]^T x[i] over the same
- * K tokens, both operands token-major (dy[i]: [K][ld_dy_i], x[i]: [K][ld_x_i], bf16), fp32 outputs with row stride ld_dw[i].
- * All 256x256 tiles cost the same, so ONE launch packs the problems into ceil(sum tiles / 256) rounds of the chip (3 for a
- * 1.5B layer at 12 336 tokens; 2 + 1 rounds + two k-sliced launches when issued one by one).  Host arrays of n <= 8 entries. */
+ * q/k/v_proj fused, o_proj, gate/up_proj fused, down_proj): dw[i][rows_i, cols_i] (= or +=, beta[i]) dy[i]^T x[i] over K[i]
+ * tokens, both operands token-major (dy[i]: [K_i][ld_dy_i], x[i]: [K_i][ld_x_i], bf16), fp32 outputs with row stride ld_dw[i].
+ * Tiles of one K cost the same, so ONE launch packs the problems into ceil(sum tiles / 256) rounds of the chip (3 for a
+ * 1.5B layer at 12 336 tokens; 2 + 1 rounds + two k-sliced launches when issued one by one).  K is per problem (round 4): the
+ * host appends a slice of the tied lm_head's weight gradient (models/unigen.py:287, K = the label rows) to every layer's
+ * launch, where its short tiles fill the CUs the partial last round leaves idle.  Host arrays of n <= 8 entries. */
 int ug_gemm_bf16_wgrad_group(int n, const void* const* dy, const int64_t* ld_dy, const void* const* x, const int64_t* ld_x,
                              float* const* dw, const int64_t* ld_dw, const int64_t* rows, const int64_t* cols,
-                             const int* beta, int64_t K, hipStream_t stream);
+                             const int* beta, const int64_t* K, hipStream_t stream);
 
 /* ---- Qwen2 decoder-layer row ops ----------------------------------------------------------- */
 /* replaces: transformers Qwen2RMSNorm.forward (modeling_qwen2.py:246-252) + the autocast bf16 cast

@@ -747,15 +747,17 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p8(GemmArgs p) {
 
 // Grouped weight gradients: the four dW = dY^T X of a decoder layer (gate_up 420 tiles, down 210, qkv 48, o 36 at 12 336 tokens)
 // share the contraction length, so their 256x256 tiles cost the same and ONE launch packs them into ceil(714 / 256) = 3 rounds
+// (round 4: the contraction length is per problem -- the launch also carries a slice of the tied head's weight gradient, K = the
+// label rows, whose short tiles run on the CUs the third round leaves idle)
 // of the chip; launched one by one they take 2 + 1 rounds plus two k-sliced launches with their finishing passes.  Every
 // problem's first block index is a multiple of 8 (XCD round-robin as in the single launch); padding blocks return at once.
 constexpr int GROUP_MAX = 8;
 struct GroupProblem {
   const bf16_t* A; const bf16_t* B; float* C;
   int64_t lda, ldb, ldc;
-  int M, N, beta, tiles_m, tiles_n, start;
+  int M, N, K, beta, tiles_m, tiles_n, start;
 };
-struct GroupArgs { GroupProblem pr[GROUP_MAX]; int n, K; };
+struct GroupArgs { GroupProblem pr[GROUP_MAX]; int n; };
 
 __global__ __launch_bounds__(512, 2) void gemm_kernel_p8_wgrad_group(GroupArgs g) {
   __shared__ __attribute__((aligned(16))) char lds[P_NST * P_STAGE];
@@ -768,7 +770,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p8_wgrad_group(GroupArgs g
   if (local >= pr.tiles_m * pr.tiles_n) return;
   GemmArgs p;
   p.A = pr.A; p.B = pr.B; p.C = pr.C; p.bias = nullptr; p.resid = nullptr; p.alpha_dev = nullptr;
-  p.M = pr.M; p.N = pr.N; p.K = g.K; p.lda = pr.lda; p.ldb = pr.ldb; p.ldc = pr.ldc; p.ldr = 0; p.beta = pr.beta;
+  p.M = pr.M; p.N = pr.N; p.K = pr.K; p.lda = pr.lda; p.ldb = pr.ldb; p.ldc = pr.ldc; p.ldr = 0; p.beta = pr.beta;
   p.tiles_m = pr.tiles_m; p.tiles_n = pr.tiles_n; p.full_tiles = pr.tiles_m * pr.tiles_n; p.tail_split = 1;
   p.tail_ws = nullptr; p.tail_private = 1; p.one_barrier = 1; p.wide_epilogue = 1; p.swiglu_I = 0; p.act = nullptr; p.ld_act = 0;
   p8_body<EPI_F32, true, true, true>(p, local, lds);
@@ -1105,13 +1107,14 @@ extern "C" int ug_gemm_bf16(const ug_handle* h, const void* A, int64_t lda, int 
 
 extern "C" int ug_gemm_bf16_wgrad_group(int n, const void* const* dy, const int64_t* ld_dy, const void* const* x, const int64_t* ld_x,
                                         float* const* dw, const int64_t* ld_dw, const int64_t* rows, const int64_t* cols,
-                                        const int* beta, int64_t K, hipStream_t stream) {
-  UG_REQUIRE(n >= 1 && n <= GROUP_MAX && K > 0 && K < (1 << 30), "ug_gemm_bf16_wgrad_group: 1..%d problems and a positive K required", GROUP_MAX);
+                                        const int* beta, const int64_t* K, hipStream_t stream) {
+  UG_REQUIRE(n >= 1 && n <= GROUP_MAX && K, "ug_gemm_bf16_wgrad_group: 1..%d problems and their contraction lengths required", GROUP_MAX);
   GroupArgs g;
-  g.n = n; g.K = (int)K;
+  g.n = n;
   int start = 0;
   for (int i = 0; i < n; ++i) {
-    UG_REQUIRE(rows[i] > 0 && cols[i] > 0 && rows[i] < (1 << 30) && cols[i] < (1 << 30), "ug_gemm_bf16_wgrad_group: empty problem %d", i);
+    UG_REQUIRE(rows[i] > 0 && cols[i] > 0 && rows[i] < (1 << 30) && cols[i] < (1 << 30) && K[i] > 0 && K[i] < (1 << 30),
+               "ug_gemm_bf16_wgrad_group: empty problem %d", i);
     UG_REQUIRE(ld_dy[i] % 8 == 0 && ld_x[i] % 8 == 0 && ld_dy[i] >= rows[i] && ld_x[i] >= cols[i] && ld_dw[i] % 4 == 0 && ld_dw[i] >= cols[i],
                "ug_gemm_bf16_wgrad_group: problem %d: token-major operands need leading dimensions that are multiples of 8 and cover "
                "their rows; ld_dw a multiple of 4", i);
@@ -1119,7 +1122,7 @@ extern "C" int ug_gemm_bf16_wgrad_group(int n, const void* const* dy, const int6
     GroupProblem& pr = g.pr[i];
     pr.A = (const bf16_t*)dy[i]; pr.B = (const bf16_t*)x[i]; pr.C = dw[i];
     pr.lda = ld_dy[i]; pr.ldb = ld_x[i]; pr.ldc = ld_dw[i];
-    pr.M = (int)rows[i]; pr.N = (int)cols[i]; pr.beta = beta[i];
+    pr.M = (int)rows[i]; pr.N = (int)cols[i]; pr.K = (int)K[i]; pr.beta = beta[i];
     pr.tiles_m = (pr.M + PBM - 1) / PBM; pr.tiles_n = (pr.N + PBN - 1) / PBN;
     pr.start = start;
     start += (pr.tiles_m * pr.tiles_n + 7) & ~7;

@@ -24,6 +24,8 @@ class _LogpFn(torch.autograd.Function):
         _, lse, _, logp = ops.ce_fwd(logits, V, row_labels, want_logp=True)
         ctx.engine, ctx.rows, ctx.logits, ctx.idx, ctx.labels, ctx.lse, ctx.weights = engine, rows, logits, idx, row_labels, lse, weights
         ctx.shape, ctx.B = (Bh, L, H), B
+        if any(ctx.needs_input_grad) and hasattr(engine, "_head_graphs_live"):
+            engine._head_graphs_live += 1            # a dense writer of the tied table waiting for its backward (modules.py)
         return (logp * weights).view(B, -1).sum(-1)
 
     @staticmethod
@@ -35,6 +37,8 @@ class _LogpFn(torch.autograd.Function):
         # d logp / d logits = onehot - softmax = -(softmax - onehot)
         ops.ce_bwd_(ctx.logits, eng.dims.vocab_size, ctx.labels, ctx.lse, None, row_scale=(-per_row).reshape(-1).contiguous())
         drows = eng.head_bwd(ctx.logits, ctx.rows)
+        if hasattr(eng, "head_written"):
+            eng.head_written()
         ctx.logits = None
         dhn = torch.zeros((Bh * L, H), dtype=torch.bfloat16, device=drows.device)
         ops.scatter_rows_(drows, ctx.idx, dhn)

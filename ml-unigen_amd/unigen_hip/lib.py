@@ -59,7 +59,7 @@ SIGNATURES = {
     "ug_ce_fwd": [P, I64, I64, I64, P, I64, P, P, P, P, P],
     "ug_ce_bwd": [P, I64, I64, I64, P, I64, P, P, P, P, P],
     "ug_adamw_flat": [P, P, P, P, P, I64, F32, F32, F32, F32, F32, I64, F32, I32, P],
-    "ug_gemm_bf16_wgrad_group": [I32, P, P, P, P, P, P, P, P, P, I64, P],
+    "ug_gemm_bf16_wgrad_group": [I32, P, P, P, P, P, P, P, P, P, P, P],
     "ug_grad_pack_bf16": [P, P, I64, F32, P],
     "ug_comm_unique_id": [P],
     "ug_comm_init": [P, I32, I32, P, I64],

@@ -40,6 +40,7 @@ class _EmbedFn(torch.autograd.Function):
         eng = ctx.engine
         eng.begin_grad_pass()
         drows = dout.reshape(-1, eng.dims.hidden_size).float().contiguous()
+        eng.flush_deferred_head()                # (a head weight gradient still waiting for a layer launch overwrites: it goes first)
         sync = eng.grad_sync
         if sync is not None and sync.wants_lookups() and eng._lookup_rows_kept + ctx.ids.numel() <= eng._lookup_rows_cap:
             # data parallel: the (id, row) pairs are kept aside and exchanged as such at the end of backward; the tied
@@ -121,8 +122,6 @@ class _HeadLossFn(torch.autograd.Function):
         for s, (r0, r1) in enumerate(ctx.bounds):
             lse, lc = ctx.stats[s]
             ops.ce_bwd_(ctx.logits[r0:r1], V, ctx.labels[r0:r1], lse, lc, dloss[s:s + 1])
-        if eng.grad_sync is not None:
-            eng.grad_sync.before_dense_embed_write()
         drows = eng.head_bwd(ctx.logits, ctx.rows)
         eng.head_written()
         ctx.logits = None
@@ -158,6 +157,7 @@ class _HeadRowsFn(torch.autograd.Function):
         npad = ops.round_up(n, 8)
         dl = torch.zeros((R, npad), dtype=torch.bfloat16, device=dout.device)
         dl[:, :n] = dout
+        eng.flush_deferred_head()
         if eng.grad_sync is not None:
             eng.grad_sync.before_dense_embed_write()
         eng.fp.ensure_zeroed("embed")

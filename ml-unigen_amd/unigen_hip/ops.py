@@ -125,10 +125,9 @@ WGRAD_GROUP_MIN_TILES = 256      # below one round of 256x256 tiles the per-prob
 
 
 def gemm_wgrad_group(problems):
-    """problems: [(dy bf16 [K, rows], x bf16 [K, cols], dw fp32 [rows, cols], beta), ...] over the same K tokens:
+    """problems: [(dy bf16 [K_i, rows], x bf16 [K_i, cols], dw fp32 [rows, cols], beta), ...]:
     dw (= / +=) dy^T x for all of them in one launch (include/unigen_hip.h: ug_gemm_bf16_wgrad_group) when together they are at
-    least a round of 256x256 tiles, one by one otherwise."""
-    K = problems[0][0].shape[0]
+    least a round of 256x256 tiles, one by one otherwise.  The contraction length K_i may differ between problems."""
     tiles = sum(((dy.shape[1] + 255) // 256) * ((x.shape[1] + 255) // 256) for dy, x, _, _ in problems)
     if tiles < WGRAD_GROUP_MIN_TILES or len(problems) > 8 or GEMM_POLICY != -1:
         for dy, x, dw, beta in problems:
@@ -138,7 +137,7 @@ def gemm_wgrad_group(problems):
     PA, LA, IA = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_int * n
     for dy, x, dw, _ in problems:
         _need_cuda(dy, x, dw)
-        assert dy.shape[0] == K and x.shape[0] == K and dw.shape == (dy.shape[1], x.shape[1])
+        assert dy.shape[0] == x.shape[0] and dw.shape == (dy.shape[1], x.shape[1])
     prof = GEMM_PROFILE
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -148,11 +147,11 @@ def gemm_wgrad_group(problems):
         PA(*[_p(x) for _, x, _, _ in problems]), LA(*[x.stride(0) for _, x, _, _ in problems]),
         PA(*[_p(dw) for _, _, dw, _ in problems]), LA(*[dw.stride(0) for _, _, dw, _ in problems]),
         LA(*[dy.shape[1] for dy, _, _, _ in problems]), LA(*[x.shape[1] for _, x, _, _ in problems]),
-        IA(*[int(b) for _, _, _, b in problems]), K, _stream())
+        IA(*[int(b) for _, _, _, b in problems]), LA(*[dy.shape[0] for dy, _, _, _ in problems]), _stream())
     _l.check(rc, "ug_gemm_bf16_wgrad_group")
     if prof is not None:
         e1.record()
-        prof.append((e0, e1, sum(2.0 * dy.shape[1] * x.shape[1] * K for dy, x, _, _ in problems)))
+        prof.append((e0, e1, sum(2.0 * dy.shape[1] * x.shape[1] * dy.shape[0] for dy, x, _, _ in problems)))
 
 
 def set_gemm_tile_policy(policy):

@@ -12,6 +12,7 @@ Memory plan (sized for 288 GB HBM3E, no activation recompute):
     stream, bf16 GEMM operands, fp32 accumulation / statistics / gradients.
 """
 import math
+import os
 
 import types
 
@@ -306,7 +307,11 @@ class Qwen2Engine:
         w_qkv = wg(f"l{i}.wqkv", dqkv, s.xn1)
         dxn1 = ops.gemm(dqkv, fp.w(f"l{i}.wqkv"), b_kmajor=True)
         dnext = ops.rmsnorm_bwd(dxn1, s.h, s.rstd1, fp.p(f"l{i}.ln1"), dh, fp.g(f"l{i}.ln1"), want_bf16=True)
-        ops.gemm_wgrad_group([w_gu, w_down, w_qkv, w_o])
+        # ... plus a slice of the tied head's weight gradient when one is waiting (head_bwd): its 128-k-tile tiles run on the CUs
+        # the group's partial third round (714 tiles = 2.79 rounds) leaves idle, so most of the head's 1.7 ms weight-gradient
+        # launch disappears from the step
+        self._wgrad_tokens = dyd.shape[0]
+        ops.gemm_wgrad_group([w_gu, w_down, w_qkv, w_o] + self._head_wgrad_slice())
         return dh, dnext
 
     def stack_bwd(self, saved, h_last, rstd_last, dhn, mb, L):
@@ -320,6 +325,7 @@ class Qwen2Engine:
             saved[i] = None                       # release this layer's activations
             if self.grad_ready_hook:
                 self.grad_ready_hook(i)
+        self.flush_deferred_head()
         self.fp.flush_fresh()
         return dh
 
@@ -334,12 +340,83 @@ class Qwen2Engine:
         """dlogits bf16 [R, vocab_pad] (pad columns zero) -> dhn_rows bf16 [R,H]; embed grad accumulated."""
         d, fp = self.dims, self.fp
         R = hn_rows.shape[0]
+        sync = getattr(self, "grad_sync", None)
+        if sync is not None:
+            sync.before_dense_embed_write()       # (data parallel: a table already handed over is waited for and re-exchanged)
         # dW[V,H] += dlogits^T hn : both k-major over the R selected rows (dlogits' leading dim is vocab_pad)
-        ops.gemm(dlogits, hn_rows, out=fp.g("embed"), M=d.vocab_size, N=d.hidden_size, K=R, a_kmajor=True, b_kmajor=True,
-                 epilogue=ops.UG_EPI_F32, beta=fp.beta_for("embed"))
+        if self._may_defer_head_wgrad(R):
+            # a leaf of the backward graph: handed to the decoder layers' grouped weight-gradient launches slice by slice
+            # (layer_bwd), whatever is left is launched by flush_deferred_head before any other writer of the table runs
+            self.flush_deferred_head()
+            self._deferred_head = [dlogits, hn_rows, fp.beta_for("embed"), 0]
+            torch.autograd.Variable._execution_engine.queue_callback(self.flush_deferred_head)
+        else:
+            ops.gemm(dlogits, hn_rows, out=fp.g("embed"), M=d.vocab_size, N=d.hidden_size, K=R, a_kmajor=True, b_kmajor=True,
+                     epilogue=ops.UG_EPI_F32, beta=fp.beta_for("embed"))
         # dhn[R,H] = dlogits[R,V] W[V,H] : W read k-major; its rows >= V come from the zero page and the
         # dlogits pad columns are zero (ug_ce_bwd), so K = V needs no padding
         return ops.gemm(dlogits, fp.w("embed"), M=R, N=d.hidden_size, K=d.vocab_size, b_kmajor=True)
+
+
+def _head_deferral_methods(cls):
+    def _may_defer_head_wgrad(self, R):
+        """Only inside a backward pass (the end-of-backward callback is the safety net), on the single-GPU path (with a gradient
+        exchange the table's dense part is handed over right after the head instead, unigen_hip/ddp.py), and when the layers'
+        grouped launches exist to carry the slices (the grouped form needs a round of tiles)."""
+        if os.environ.get("UNIGEN_DEFER_HEAD_WGRAD", "1") != "1" or not torch.is_tensor(self.fp.grad) or not self.fp.grad.is_cuda:
+            return False
+        sync = getattr(self, "grad_sync", None)
+        if sync is not None and sync.active and sync.enabled:
+            return False
+        d = self.dims
+        layer_tiles = sum(-(-a // 256) * -(-b // 256) for a, b in ((2 * d.intermediate_size, d.hidden_size), (d.hidden_size, d.intermediate_size),
+                                                                   (d.qkv_out, d.hidden_size), (d.hidden_size, d.hidden_size)))
+        return layer_tiles >= ops.WGRAD_GROUP_MIN_TILES and ops.GEMM_POLICY == -1
+
+    def _head_wgrad_slice(self):
+        """the next slice of a waiting head weight gradient as a problem of ops.gemm_wgrad_group, or []"""
+        st = getattr(self, "_deferred_head", None)
+        if not st:
+            return []
+        dlogits, hn_rows, beta, v0 = st
+        V = self.dims.vocab_size
+        # Row tiles of the table per layer launch: what fits on the CUs the layer's own tiles leave idle in their last round --
+        # idle x (cost of a layer tile / cost of a head tile), costs in k-tiles of 32 plus ~60 for a tile's prologue and fp32
+        # epilogue, 80 % of it (measured at the 1.5B shape, 12 336 tokens, 4 096 label rows: 54 idle CUs -> 16 row tiles = 96
+        # tiles; 23 -- the whole table over 28 layers -- spills into a fourth round: +45 us per launch).  The rest of the table
+        # goes out as one launch at the end of the stack's backward.
+        d = self.dims
+        layer_tiles = sum(-(-a // 256) * -(-b // 256) for a, b in ((2 * d.intermediate_size, d.hidden_size), (d.hidden_size, d.intermediate_size),
+                                                                   (d.qkv_out, d.hidden_size), (d.hidden_size, d.hidden_size)))
+        idle = -layer_tiles % 256
+        cols = -(-d.hidden_size // 256)
+        fit = int(0.8 * idle * (self._wgrad_tokens / 32 + 60) / (hn_rows.shape[0] / 32 + 60) / cols)
+        per = int(os.environ.get("UNIGEN_HEAD_SLICE_TILES", "0")) or fit
+        if per <= 0:
+            return []
+        per *= 256
+        v1 = min(V, v0 + per)
+        prob = (dlogits[:, v0:v1], hn_rows, self.fp.g("embed")[v0:v1], beta)
+        if v1 >= V:
+            self._deferred_head = None
+        else:
+            st[3] = v1
+        return [prob]
+
+    def flush_deferred_head(self):
+        """what is left of a waiting head weight gradient, as one launch (before any other writer of the tied table; end of the
+        decoder stack's backward; end of the backward pass)"""
+        st = getattr(self, "_deferred_head", None)
+        if not st:
+            return
+        dlogits, hn_rows, beta, v0 = st
+        self._deferred_head = None
+        V, H = self.dims.vocab_size, self.dims.hidden_size
+        ops.gemm(dlogits[:, v0:], hn_rows, out=self.fp.g("embed")[v0:], M=V - v0, N=H, K=hn_rows.shape[0], a_kmajor=True,
+                 b_kmajor=True, epilogue=ops.UG_EPI_F32, beta=beta)
+
+    cls._may_defer_head_wgrad, cls._head_wgrad_slice, cls.flush_deferred_head = _may_defer_head_wgrad, _head_wgrad_slice, flush_deferred_head
+    return cls
 
 
 class DecodeState:
@@ -459,3 +536,4 @@ def _decode_methods(cls):
 
 
 _decode_methods(Qwen2Engine)
+_head_deferral_methods(Qwen2Engine)

@@ -71,7 +71,7 @@ call("ug_gemm_bf16", None, P(M * H * 2), H, 0, P(256 * H * 2), H, 0, P(M * 256 *
 n = 2
 PA, LA, IA = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_int * n
 dy, x, dw = PA(P(M * 256 * 2), P(M * 512 * 2)), PA(P(M * H * 2), P(M * H * 2)), PA(P(256 * H * 4), P(512 * H * 4))
-call("ug_gemm_bf16_wgrad_group", n, dy, LA(256, 512), x, LA(H, H), dw, LA(H, H), LA(256, 512), LA(H, H), IA(0, 1), M, None)
+call("ug_gemm_bf16_wgrad_group", n, dy, LA(256, 512), x, LA(H, H), dw, LA(H, H), LA(256, 512), LA(H, H), IA(0, 1), LA(M, M), None)
 B, L, Hq, Hk = 2, 128, 4, 2
 ldq = (Hq + 2 * Hk) * 128
 qkv = P(B * L * ldq * 2)

@@ -180,8 +180,9 @@ def test_gemm_wgrad_group_matches_single_launches(dev, K, shapes):
     g = torch.Generator(device=dev).manual_seed(K)
     probs, refs = [], []
     for n, (rows, cols) in enumerate(shapes):
-        dy = (torch.randn(K, ops.round_up(rows, 8) + 8, device=dev, generator=g) * 0.1).to(torch.bfloat16)[:, :rows]
-        x = (torch.randn(K, ops.round_up(cols, 8), device=dev, generator=g) * 0.5).to(torch.bfloat16)[:, :cols]
+        Kn = K if n != 1 else max(40, K // 3 // 8 * 8)        # (round 4: the contraction length is per problem)
+        dy = (torch.randn(Kn, ops.round_up(rows, 8) + 8, device=dev, generator=g) * 0.1).to(torch.bfloat16)[:, :rows]
+        x = (torch.randn(Kn, ops.round_up(cols, 8), device=dev, generator=g) * 0.5).to(torch.bfloat16)[:, :cols]
         beta = n % 2
         dw = torch.full((rows, ops.round_up(cols, 4) + 4), 0.25, dtype=torch.float32, device=dev)[:, :cols]
         probs.append((dy, x, dw, beta))

@@ -481,6 +481,53 @@ def test_gradient_accumulation_and_fresh_write_semantics(dev):
         _check("params[n].grad", params[n].grad, once[n], 2e-3)
 
 
+def test_deferred_head_weight_gradient_is_the_same_gradient(dev, monkeypatch):
+    """Round 4: the tied head's weight gradient is a leaf of the backward graph and rides, slice by slice, on the decoder layers'
+    grouped weight-gradient launches (unigen_hip/qwen2.py: head_bwd / _head_wgrad_slice / flush_deferred_head).  Forced on for the
+    tiny model (grouped launches whatever the tile count) and compared with the direct launch: first write after zero_grad
+    (beta 0), accumulation over a second backward, a poisoned gradient buffer, two forwards under one backward (a second head
+    while the first one's slices are still waiting) -- the embedding gradient includes the lookups' scatter-add, which must land
+    AFTER the head's overwrite."""
+    from unigen_hip import ops
+    g = golden("g2_tiny_unigen.pt")
+    mask = additive(g["mask_allow"]).to(dev)
+    ids, labels = g["input_ids"].to(dev), g["labels"].to(dev)
+    monkeypatch.setattr(ops, "WGRAD_GROUP_MIN_TILES", 0)
+    names = ["model.embed_tokens.weight", "model.layers.0.self_attn.q_proj.weight", "model.layers.1.mlp.down_proj.weight", "model.norm.weight"]
+    got = {}
+    for defer in ("0", "1"):
+        monkeypatch.setenv("UNIGEN_DEFER_HEAD_WGRAD", defer)
+        model, _ = _tiny_unigen(g, dev)
+        model.train()
+        eng = model.llm.engine
+        params = dict(model.llm.named_parameters())
+        seen = []
+        orig = eng._head_wgrad_slice
+        eng._head_wgrad_slice = lambda: (seen.append(1), orig())[1]          # (count the layer launches that were offered a slice)
+
+        def run(twice=False):
+            _, l1, l2, l3 = model(input_ids=ids, attention_mask=mask, labels=labels, **g["kw"])
+            loss = l1 + 0.1 * l2 + l3
+            if twice:
+                _, m1, m2, m3 = model(input_ids=ids, attention_mask=mask, labels=labels, **g["kw"])
+                loss = loss + 0.5 * (m1 + m3)
+            loss.backward()
+        run()
+        assert eng._deferred_head is None if defer == "1" else not hasattr(eng, "_deferred_head") or eng._deferred_head is None
+        first = {n: params[n].grad.clone() for n in names}
+        run()                                                   # accumulate on top
+        second = {n: params[n].grad.clone() for n in names}
+        model.zero_grad(set_to_none=True)
+        eng.fp.grad.fill_(123.0)                                # poison
+        run(twice=True)
+        third = {n: params[n].grad.clone() for n in names}
+        got[defer] = (first, second, third)
+        assert len(seen) > 0
+    for a, b in zip(got["0"], got["1"]):
+        for n in names:
+            _check(n, b[n], a[n], 1e-5 if n != "model.embed_tokens.weight" else 1e-4)
+
+
 def test_fused_adamw_overlapped_update_is_equivalent(dev):
     """FusedAdamW(overlap=True) issues the flat-buffer update on a side stream; the engine orders every later weight /
     gradient access behind it, so three steps (with unrelated work and an optimizer state_dict read in between) leave exactly
