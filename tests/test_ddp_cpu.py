@@ -81,19 +81,19 @@ def _worker(rank, world, port, layers_per_bucket, reduce, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("layers_per_bucket,reduce", [(1, "fp32"), (4, "fp32"), (2, "fp32_rsag")])
-def test_flat_grad_sync_two_ranks(layers_per_bucket, reduce):
+@pytest.mark.parametrize("layers_per_bucket,reduce,world", [(1, "fp32", 2), (4, "fp32", 2), (2, "fp32_rsag", 2), (3, "fp32_rsag", 4)])
+def test_flat_grad_sync_two_ranks(layers_per_bucket, reduce, world):
     """(per-layer size 1001: the reduce-scatter form also has to cover a tail that does not divide by 4 x world)"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, layers_per_bucket, reduce, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, layers_per_bucket, reduce, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in procs]
+    res = [q.get(timeout=180) for _ in procs]
     for p in procs:
         p.join(timeout=60)
-    assert sorted(res) == [(0, True), (1, True)]
+    assert sorted(res) == [(r, True) for r in range(world)]
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
@@ -246,7 +246,7 @@ def _worker_multi_lookup(rank, world, port, sparse, q):
         want = torch.stack(gathered).mean(0)
         got = [torch.empty_like(grad) for _ in range(world)]
         dist.all_gather(got, grad)
-        ok = ok and torch.allclose(grad, want, atol=1e-5) and torch.equal(got[0], got[1])
+        ok = ok and torch.allclose(grad, want, atol=1e-5) and all(torch.equal(got[0], g_) for g_ in got[1:])
         if not ok:
             print(f"rank {rank} case {case!r} sparse {sparse}: max err {(grad - want).abs().max().item():.3e}")
             break
@@ -255,15 +255,15 @@ def _worker_multi_lookup(rank, world, port, sparse, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("sparse", [True, False])
-def test_flat_grad_sync_multiple_lookups_and_two_stack_segments(sparse):
+@pytest.mark.parametrize("sparse,world", [(True, 2), (False, 2), (True, 4)])
+def test_flat_grad_sync_multiple_lookups_and_two_stack_segments(sparse, world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_multi_lookup, args=(r, 2, port, sparse, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker_multi_lookup, args=(r, world, port, sparse, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in procs]
+    res = [q.get(timeout=180) for _ in procs]
     for p in procs:
         p.join(timeout=60)
-    assert sorted(res) == [(0, True), (1, True)]
+    assert sorted(res) == [(r, True) for r in range(world)]
