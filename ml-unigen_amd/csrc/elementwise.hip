@@ -581,7 +581,11 @@ extern "C" int ug_rmsnorm_bwd(const void* dy, const float* x, const float* rstd,
   UG_REQUIRE(ug_aligned16(x) && ug_aligned16(w) && ug_aligned16(dres) && ((uintptr_t)dy & 7) == 0,
              "ug_rmsnorm_bwd: pointers must be aligned");
   static const int rpb_env = [] { const char* e = getenv("UNIGEN_RN_RPB"); return e ? atoi(e) : 0; }();
-  const int rpb = rpb_env > 0 ? rpb_env : 16;          // 771 workgroups for 12 336 rows: three per CU (32 left a third of the CUs with one)
+  // ONE round of workgroups: the kernel's 182 registers leave two 4-wave workgroups per CU (512 slots), and 16 rows per workgroup --
+  // round 3's choice, 771 workgroups for 12 336 rows -- is a full round plus a half-empty one.  Rows per workgroup = rows / 480 rounded
+  // up to a multiple of 4 (28 at the benchmark shape: 441 workgroups, 7 rows per wave): element-wise family 15.5 -> 14.7 ms per step
+  // (in-step sweep of 16 / 24 / 25 / 26 / 28 / 32 / 40 / 48: 15.5 / 16.1 / 14.8 / 14.8 / 14.7 / 14.6-14.8 / 15.0 / 15.6).
+  const int rpb = rpb_env > 0 ? rpb_env : (int)std::max<int64_t>(16, ((rows + 479) / 480 + 3) / 4 * 4);
   dim3 grid((unsigned)((rows + rpb - 1) / rpb)), block(256);
   UG_REQUIRE(((uintptr_t)dres_bf16 & 7) == 0, "ug_rmsnorm_bwd: dres_bf16 must be 8-byte aligned");
   // (a 6-slot instantiation for 1536 columns -- 148 instead of 182 registers, three waves per SIMD instead of two -- measured
