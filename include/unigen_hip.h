@@ -63,7 +63,7 @@ int ug_gemm_bf16(const ug_handle* h, const void* A, int64_t lda, int a_kmajor, c
  * policy: -1 = automatic kernel selection (the product path); >= 0 pins a kernel for A/B benchmarks and tests:
  * 0 = 128x128 two LDS stages, 2 = 128x128 one LDS stage, 3 = staggered 256x256, 6 = 256x256 with the k-sliced tail forced,
  * 8 = k-sliced small outputs, 10 = 320x256 tiles (A row-major, N % 256 == 0, K % 32 == 0, bf16 / residual epilogue; other
- * launches ignore it); UG_GEMM_POLICY_AUTO_BITS = automatic selection when only modifier bits are wanted;
+ * launches ignore it), 44 ... 52 except 48 = the same kernel at a tile height of 16 * (policy - 32) = 192 ... 320 rows; UG_GEMM_POLICY_AUTO_BITS = automatic selection when only modifier bits are wanted;
  * | UG_GEMM_NARROW_EPILOGUE = element-wise instead of LDS-transposed 16-byte stores in the 256x256 kernel. */
 #define UG_GEMM_NARROW_EPILOGUE 0x100
 #define UG_GEMM_ONE_BARRIER 0x200     /* force the 256x256 kernel's one-barrier-per-k-tile main loop (default: weight gradients, both operands k-major) */

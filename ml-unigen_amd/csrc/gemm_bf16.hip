@@ -17,7 +17,8 @@
 //                           for partial last rounds and small outputs
 //   gemm_kernel_p8_wgrad_group   the same loop over the tiles of up to 8 weight-gradient problems sharing K (one launch
 //                           per decoder layer)
-//   gemm_kernel_p10         320x256 tiles (A row-major): outputs whose 256-row tiling leaves a mostly empty round
+//   gemm_kernel_p10         192 ... 320 x 256 tiles (A row-major): outputs whose 256-row tiling leaves a mostly empty round; the
+//                           tile height is the smallest that keeps a one-round launch in one round
 //
 // The 128x128 kernel: BK=64, 4 waves (2x2, 64x64 per wave = 4x4 mfma_f32_16x16x32_bf16
 // fragments), operands staged HBM->LDS with 16-byte LDS-DMA (global_load_lds).  Two pipelining
@@ -245,10 +246,12 @@ __device__ __forceinline__ void store_tile_lds(const GemmArgs& p, f32x4_t (&acc)
     }
   }
 #pragma unroll
-  for (int c = 0; c < MF / 2; ++c) {                         // 32-row chunk = accumulator row blocks 2c, 2c+1
+  for (int c = 0; c < (MF + 1) / 2; ++c) {                   // 32-row chunk = accumulator row blocks 2c, 2c+1 (an odd MF ends on a half chunk)
+    const int rows_here = (2 * c + 1 < MF) ? 32 : 16;
     // ---- registers -> strip (MFMA layout: lane holds rows lane&15, 4 consecutive columns per block)
 #pragma unroll
     for (int ii = 0; ii < 2; ++ii) {
+      if (2 * c + ii >= MF) break;
       const int row = ii * 16 + (lane & 15);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -272,7 +275,7 @@ __device__ __forceinline__ void store_tile_lds(const GemmArgs& p, f32x4_t (&acc)
         const int row = q * 8 + (lane >> 3), ch = lane & 7;
         const int m = mbase + c * EP_ROWS + row;
         const uint4 v = *reinterpret_cast<const uint4*>(strip + row * EP_PITCH_BF16 + ch * 16);
-        if (m < p.M) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc + nbase + ch * 8) = v;
+        if (m < p.M && row < rows_here) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc + nbase + ch * 8) = v;
       }
     } else {
 #pragma unroll
@@ -280,7 +283,7 @@ __device__ __forceinline__ void store_tile_lds(const GemmArgs& p, f32x4_t (&acc)
         const int row = q * 4 + (lane >> 4), ch = lane & 15;
         const int m = mbase + c * EP_ROWS + row;
         float4 v = *reinterpret_cast<const float4*>(strip + row * EP_PITCH_F32 + ch * 16);
-        if (m < p.M) {
+        if (m < p.M && row < rows_here) {
           float* cptr = reinterpret_cast<float*>(p.C) + (int64_t)m * p.ldc + nbase + ch * 4;
           if constexpr (EPI == EPI_F32) {
             v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha;
@@ -791,9 +794,17 @@ constexpr int QBM = 320;
 constexpr int Q_TILE_A = QBM * PBK * 2;        // 20 KiB
 constexpr int Q_STAGE = Q_TILE_A + P_TILE;     // 36 KiB; four stages = 144 KiB
 
-template <int EPI, bool BKM>
+// Round 4: the row count of the tile is a template parameter -- group 0's waves own F0 row blocks of 16, group 1's F1 (F0 >= F1 >=
+// F0 - 1): 16 (F0 + F1) rows, 320 at (10, 10).  A one-round launch takes as long as ONE tile, so the launcher picks the smallest tile
+// height whose row tiles x column tiles still fit the 256 CUs: M = 12 336, N = 1 536 -> 304 rows (41 x 6 = 246 workgroups) instead of
+// 320 (39 x 6 = 234): the same round, 5 % less work per workgroup.  A-tile DMA: 16 (F0 + F1) / 16 instructions of 16 rows per k-tile,
+// dealt over the eight waves in order; a wave issues NA = LO or LO + 1 of them (counted waits per wave).
+template <int EPI, bool BKM, int F0, int F1>
 __global__ __launch_bounds__(512, 2) void gemm_kernel_p10(GemmArgs p) {
-  __shared__ __attribute__((aligned(16))) char lds[P_NST * Q_STAGE];
+  constexpr int BMV = 16 * (F0 + F1), NINST = BMV / 16, LO = NINST / 8, REM = NINST % 8;
+  constexpr int TILE_A = BMV * PBK * 2, STAGE = TILE_A + P_TILE;
+  static_assert(F0 >= F1 && F0 <= 10 && F1 >= 1 && LO >= 1 && LO + (REM ? 1 : 0) <= 3, "gemm_kernel_p10: unsupported tile height");
+  __shared__ __attribute__((aligned(16))) char lds[P_NST * STAGE];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2, wn = wave & 3;
@@ -804,12 +815,12 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p10(GemmArgs p) {
   const int gsz = min(p.tiles_m - first_m, P10_GROUP_M);
   const int tm = first_m + (pid % per_group) % gsz;
   const int tn = (pid % per_group) / gsz;
-  const int m0 = tm * QBM, n0 = tn * PBN;
+  const int m0 = tm * BMV, n0 = tn * PBN;
 
   const bf16_t* asrc[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    const int inst = min(i * 8 + wave, QBM / 16 - 1);          // (group 1's third slot is never issued)
+    const int inst = min(i * 8 + wave, NINST - 1);             // (slots past the tile are never issued)
     const int row = inst * 16 + (lane >> 2);
     const int r = min(m0 + row, p.M - 1);
     asrc[i] = p.A + (int64_t)r * p.lda + swz_rowk32(row, lane & 3) * 8;
@@ -817,32 +828,29 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p10(GemmArgs p) {
   Stager32<BKM> sb;
   sb.init(p.B, p.ldb, n0, p.N, wave, lane);
 
-  f32x4_t acc[10][4];
+  f32x4_t acc[F0][4];
 #pragma unroll
-  for (int i = 0; i < 10; ++i)
+  for (int i = 0; i < F0; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   const int nk = p.K / PBK;
 
-  auto run = [&](auto group0) {
+  auto run = [&](auto group0, auto na_tag) {
     constexpr bool G0 = decltype(group0)::value;
+    constexpr int NA = decltype(na_tag)::value;                // A-tile DMA instructions of this wave per k-tile
+    constexpr int FG = G0 ? F0 : F1;                           // row blocks of this wave
+    constexpr int PER = NA + 2;                                // DMA instructions per batch (+ 2 of the B tile)
     auto stage_in = [&](int lt) {
-      char* st = lds + (lt & (P_NST - 1)) * Q_STAGE;
+      char* st = lds + (lt & (P_NST - 1)) * STAGE;
 #pragma unroll
-      for (int i = 0; i < (G0 ? 3 : 2); ++i)
+      for (int i = 0; i < NA; ++i)
         __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + (int64_t)lt * PBK), (lptr_t)(st + (i * 8 + wave) * 1024), 16, 0, 0);
-      sb.template issue<false>(lt, p.K, st + Q_TILE_A, wave);
+      sb.template issue<false>(lt, p.K, st + TILE_A, wave);
     };
     auto landed = [&](int in_flight) {            // batches of this wave's DMA that may stay in flight
-      if constexpr (G0) {
-        if (in_flight >= 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        else if (in_flight == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      } else {
-        if (in_flight >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (in_flight == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
+      if (in_flight >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+      else if (in_flight == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
     stage_in(0);
     if (nk > 1) stage_in(1);
@@ -851,11 +859,11 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p10(GemmArgs p) {
     P_BARRIER();
     if (!G0) P_BARRIER();                         // stagger: group 1 runs one phase behind group 0
     auto iteration = [&](int t, auto steady) {
-      const char* tA = lds + (t & (P_NST - 1)) * Q_STAGE;
-      const char* tB = tA + Q_TILE_A;
-      bf16x8_t fa[10], fb[4];
+      const char* tA = lds + (t & (P_NST - 1)) * STAGE;
+      const char* tB = tA + TILE_A;
+      bf16x8_t fa[FG], fb[4];
 #pragma unroll
-      for (int i = 0; i < 10; ++i) fa[i] = load_frag32<false>(tA, grp * 160 + i * 16, lane);
+      for (int i = 0; i < FG; ++i) fa[i] = load_frag32<false>(tA, (G0 ? 0 : 16 * F0) + i * 16, lane);
 #pragma unroll
       for (int j = 0; j < 4; ++j) fb[j] = load_frag32<BKM>(tB, wn * 64 + j * 16, lane);
       if constexpr (decltype(steady)::value) {
@@ -869,7 +877,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p10(GemmArgs p) {
       P_BARRIER();
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int i = 0; i < 10; ++i)
+      for (int i = 0; i < FG; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
@@ -880,9 +888,11 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p10(GemmArgs p) {
     for (; t + 4 < nk; ++t) iteration(t, std::true_type{});
     for (; t < nk; ++t) iteration(t, std::false_type{});
     if (G0) P_BARRIER();
+    store_tile_lds<EPI, FG>(p, reinterpret_cast<f32x4_t (&)[FG][4]>(acc[0]), lds + wave * EP_STRIP, m0 + (G0 ? 0 : 16 * F0), n0 + wn * 64, lane);
   };
-  if (grp == 0) run(std::true_type{}); else run(std::false_type{});
-  store_tile_lds<EPI, 10>(p, acc, lds + wave * EP_STRIP, m0 + grp * 160, n0 + wn * 64, lane);
+  const bool more = REM != 0 && wave < REM;       // this wave issues LO + 1 A-tile instructions
+  if (grp == 0) { if (more) run(std::true_type{}, std::integral_constant<int, LO + (REM ? 1 : 0)>{}); else run(std::true_type{}, std::integral_constant<int, LO>{}); }
+  else { if (more) run(std::false_type{}, std::integral_constant<int, LO + (REM ? 1 : 0)>{}); else run(std::false_type{}, std::integral_constant<int, LO>{}); }
 }
 
 #ifdef UG_GEMM_R4                                // probe builds only: the rejected register-blocked 4-wave kernel lives in tools/probes/
@@ -970,9 +980,35 @@ int launch(GemmArgs a, const ug_handle* h, int policy, hipStream_t st) {
     // many rounds: a 320-row tile costs 1.25 x a 256-row one and runs ~7 % more efficiently (fewer LDS and DMA bytes per MFMA);
     // taken when whole rounds come out at least 3 % cheaper (gate_up forward: 14 rounds -> 11 x 1.16 = 12.8: 1240 -> 1322 TF/s)
     const bool fewer_rounds = tiles_p8 >= 1024 && 1.1625f * (float)((tiles_q + 255) / 256) < 0.97f * (float)((tiles_p8 + 255) / 256);
-    if (aligned && (g_tile_policy == 10 || (g_tile_policy < 0 && ((tiles_p8 > 256 && tiles_q <= 256 && tiles_q >= 200) || fewer_rounds)))) {
-      a.tiles_m = (a.M + QBM - 1) / QBM; a.tiles_n = a.N / PBN;
-      hipLaunchKernelGGL((gemm_kernel_p10<EPI, BKM>), dim3(a.tiles_m * a.tiles_n), dim3(512), 0, st, a);
+    // One-round launches (round 4): a round takes as long as one tile, so the SMALLEST tile height whose row tiles x column tiles
+    // still fit the 256 CUs wins -- 12 336 x 1 536 outputs: 304 rows (246 workgroups) instead of 320 (234); 9 288 rows: 224.
+    int hb = 0;
+    static const bool heights_on = !(getenv("UNIGEN_GEMM_HEIGHTS") && atoi(getenv("UNIGEN_GEMM_HEIGHTS")) == 0);   // A/B switch
+    if (aligned && g_tile_policy < 0 && a.N / PBN >= 1 && a.N / PBN <= 64) {
+      static const int heights[] = {192, 208, 224, 240, 256, 272, 288, 304, 320};
+      for (int h_ : heights) {
+        if (!heights_on && h_ != QBM) continue;                  // (round 3's choice: 320 rows or nothing)
+        const int64_t wgs = (int64_t)((a.M + h_ - 1) / h_) * (a.N / PBN);
+        if (wgs <= 256) { if (wgs >= 200) hb = h_; break; }
+      }
+      if (hb == 256 && p8_fits) hb = 0;                          // (the 256 x 256 kernel's own one-round case)
+    }
+    if (aligned && g_tile_policy >= 44 && g_tile_policy <= 52 && g_tile_policy != 48) hb = 16 * (g_tile_policy - 32);   // forced height (tests, A/B)
+    if (hb == 0 && aligned && (g_tile_policy == 10 || (g_tile_policy < 0 && fewer_rounds))) hb = QBM;
+    if (hb != 0) {
+      a.tiles_m = (a.M + hb - 1) / hb; a.tiles_n = a.N / PBN;
+      const dim3 grid(a.tiles_m * a.tiles_n), block(512);
+      switch (hb) {
+        case 320: hipLaunchKernelGGL((gemm_kernel_p10<EPI, BKM, 10, 10>), grid, block, 0, st, a); break;
+        case 304: hipLaunchKernelGGL((gemm_kernel_p10<EPI, BKM, 10, 9>), grid, block, 0, st, a); break;
+        case 288: hipLaunchKernelGGL((gemm_kernel_p10<EPI, BKM, 9, 9>), grid, block, 0, st, a); break;
+        case 272: hipLaunchKernelGGL((gemm_kernel_p10<EPI, BKM, 9, 8>), grid, block, 0, st, a); break;
+        case 256: hipLaunchKernelGGL((gemm_kernel_p10<EPI, BKM, 8, 8>), grid, block, 0, st, a); break;
+        case 240: hipLaunchKernelGGL((gemm_kernel_p10<EPI, BKM, 8, 7>), grid, block, 0, st, a); break;
+        case 224: hipLaunchKernelGGL((gemm_kernel_p10<EPI, BKM, 7, 7>), grid, block, 0, st, a); break;
+        case 208: hipLaunchKernelGGL((gemm_kernel_p10<EPI, BKM, 7, 6>), grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL((gemm_kernel_p10<EPI, BKM, 6, 6>), grid, block, 0, st, a); break;
+      }
       UG_CHECK_LAUNCH("ug_gemm_bf16(p10)");
       return UG_OK;
     }

@@ -156,7 +156,7 @@ def gemm_wgrad_group(problems):
 
 def set_gemm_tile_policy(policy):
     """Kernel selection passed with every following GEMM call (include/unigen_hip.h: ug_gemm_bf16 `policy`): -1 auto, 0 / 2 =
-    128x128 tiles with two / one LDS stages, 3 = staggered 256x256, 10 = 320x256 tiles (where eligible), 6 / 8 = k-sliced forms forced; 100 / 101 switch the 256x256
+    128x128 tiles with two / one LDS stages, 3 = staggered 256x256, 10 = 320x256 tiles (where eligible), 32 + h / 16 = the same kernel h = 192 ... 320 rows high, 6 / 8 = k-sliced forms forced; 100 / 101 switch the 256x256
     kernel's LDS-transposed wide epilogue off / on while leaving the selection automatic; 102 / 104 force its one- / two-barrier
     main loop with automatic selection, 103 / 105 with the 256x256 kernel forced (A/B benchmarking and tests)."""
     global GEMM_POLICY

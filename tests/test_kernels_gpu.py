@@ -50,6 +50,50 @@ def tile_policy(request):
     ops.set_gemm_tile_policy(-1)
 
 
+@pytest.mark.parametrize("height", [192, 208, 224, 240, 272, 288, 304, 320])
+@pytest.mark.parametrize("mode", ["nt", "dgrad"])
+def test_gemm_bf16_tile_heights(dev, height, mode):
+    """Round 4: the 192 ... 320 x 256 tile family (`gemm_kernel_p10<EPI, BKM, F0, F1>`; policy 32 + height / 16 forces one): bf16 (+ bias)
+    and fp32-residual epilogues, B row-major and k-major, M ragged against every height (row tiles that end inside group 0,
+    inside group 1, on an odd 16-row block).  And the automatic choice: the smallest height that keeps a one-round launch in one
+    round gives the same values as the forced one."""
+    ops = _ops()
+    M, N, K = 2 * height + 16 * 7 + 5, 512, 256
+    bk = mode == "dgrad"
+    g = torch.Generator().manual_seed(height + (7 if bk else 0))
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    b = torch.randn(N, K, generator=g).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g).to(torch.bfloat16)
+    ref = a.float() @ b.float().t()
+    A = a.to(dev)
+    B = (b.t().contiguous() if bk else b).to(dev)
+    try:
+        ops.set_gemm_tile_policy(32 + height // 16)
+        out = torch.zeros(M, N, dtype=torch.bfloat16, device=dev)
+        ops.gemm(A, B, out=out, M=M, N=N, K=K, b_kmajor=bk, bias=bias.to(dev))
+        assert _rel(out, ref + bias.float()) < 4e-3
+        if not bk:
+            res = torch.randn(M, N, generator=g)
+            r32 = torch.empty(M, N, dtype=torch.float32, device=dev)
+            ops.gemm(A, B, out=r32, M=M, N=N, K=K, epilogue=ops.UG_EPI_RESID, resid=res.to(dev))
+            want = res + ref.to(torch.bfloat16).float()
+            assert ((r32.cpu() - want).abs() <= ref.abs() * 2.0 ** -7 + 1e-3).all()
+    finally:
+        ops.set_gemm_tile_policy(-1)
+    # automatic: 12 336 x 1 536 is a one-round launch at 304 rows; same bits as the forced height (same tiles, same k order)
+    if height == 304 and not bk:
+        M2, N2, K2 = 12336, 1536, 256
+        a2 = torch.randn(M2, K2, generator=g).to(torch.bfloat16).to(dev)
+        b2 = torch.randn(N2, K2, generator=g).to(torch.bfloat16).to(dev)
+        auto = ops.gemm(a2, b2)
+        ops.set_gemm_tile_policy(32 + 304 // 16)
+        try:
+            forced = ops.gemm(a2, b2)
+        finally:
+            ops.set_gemm_tile_policy(-1)
+        assert torch.equal(auto, forced) and _rel(auto, a2.float() @ b2.float().t()) < 4e-3
+
+
 @pytest.mark.parametrize("mode", ["nt", "dgrad", "wgrad"])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (300, 200, 192), (771, 1536, 1536), (64, 336, 256),
                                    (130, 72, 100), (1536, 512, 771)])
