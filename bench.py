@@ -203,6 +203,17 @@ def extra_cases(model, vq, opt, dev, args, steps=2):
         fn()
         torch.cuda.synchronize()
         rec, ug_lib.PROFILE = ug_lib.PROFILE, None
+        if os.environ.get("UNIGEN_BENCH_BY_LAUNCH"):           # the same events per entry point (GEMMs per shape), for tools/ and DESIGN
+            per = {}
+            for v in rec.values():
+                for e0, e1, tag in v:
+                    c = per.setdefault(tag, [0, 0.0])
+                    c[0] += 1
+                    c[1] += e0.elapsed_time(e1)
+            os.makedirs("gpurun_out", exist_ok=True)
+            with open(os.path.join("gpurun_out", "by_launch_%s.txt" % fn.__name__), "w") as f:
+                for tag, (n, ms_) in sorted(per.items(), key=lambda kv: -kv[1][1]):
+                    f.write("%9.3f ms %5d x %8.1f us  %s\n" % (ms_, n, ms_ / n * 1e3, tag))
         return {k: round(sum(e0.elapsed_time(e1) for e0, e1, _ in v), 2) for k, v in sorted(rec.items())}
 
     def cat_masks(*ms):

@@ -371,6 +371,26 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
 }
 
 // =========================================================================== AdamW (flat, fused)
+// One element of the update, shared by every form of the kernel (vector loops, scalar tails, the pipelined small-grid form) with
+// floating-point contraction OFF: the forms are bit-identical to one another by construction -- hipcc otherwise fuses
+// multiply-adds differently in differently shaped code (a 1-ulp second moment in a scalar tail against the vector loop, found by
+// `test_adamw_small_grid_form_is_the_same_update`).  Operation order = torch's single-tensor AdamW: mul_, lerp_, mul_ + addcmul_,
+// sqrt / bias_correction2_sqrt + eps, addcdiv_.
+struct AdamConsts { float grad_scale, decay, w1, beta2, w2, bc2_sqrt, eps, step_size; };
+__device__ __forceinline__ void adamw_element(float& p, float g, float& m, float& v, const AdamConsts& c) {
+#pragma clang fp contract(off)
+  const float gr = g * c.grad_scale;
+  const float pk = p * c.decay;
+  const float mk = m + (gr - m) * c.w1;
+  const float vk = v * c.beta2 + (c.w2 * gr) * gr;
+  const float denom = sqrtf(vk) / c.bc2_sqrt + c.eps;
+  p = pk - c.step_size * (mk / denom);
+  m = mk; v = vk;
+}
+__device__ __forceinline__ AdamConsts adam_consts(float lr, float beta1, float beta2, float eps, float wd, float bc1, float bc2_sqrt, float grad_scale) {
+#pragma clang fp contract(off)
+  return AdamConsts{grad_scale, 1.f - lr * wd, 1.f - beta1, beta2, 1.f - beta2, bc2_sqrt, eps, lr / bc1};
+}
 // Same update order as torch.optim.AdamW's single-tensor path (reference optimizer,
 // training/train.py:324-330): decay, lerp first moment, second moment, bias-corrected step.
 // The overlapped form of the update (side stream, beside the tokenizer's convolutions): TWO elements per lane and iteration.
@@ -383,36 +403,107 @@ __global__ __launch_bounds__(256) void adamw_lean_kernel(float* __restrict__ p, 
                                                          float beta1, float beta2, float eps, float wd, float bc1, float bc2_sqrt,
                                                          float grad_scale) {
   const int64_t n2 = n >> 1;
-  const float step_size = lr / bc1;
-  const float decay = 1.f - lr * wd;
+  const AdamConsts c = adam_consts(lr, beta1, beta2, eps, wd, bc1, bc2_sqrt, grad_scale);
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n2; i += (int64_t)gridDim.x * blockDim.x) {
+#if defined(UG_ADAMW_ABLATE) && UG_ADAMW_ABLATE == 2      // probe build: the arithmetic without the memory streams (wrong results)
+    const float seed = (float)(i & 1023) * 1e-3f;
+    float2 pp = make_float2(seed, seed + 1.f), mm = make_float2(seed * .5f, seed), vv = make_float2(seed * seed, seed);
+    const float2 gg = make_float2(seed - .5f, seed + .25f);
+#else
     float2 pp = ld_stream<NT>(reinterpret_cast<const float2*>(p) + i);
     const float2 gg = ld_stream<NT>(reinterpret_cast<const float2*>(g) + i);
     float2 mm = ld_stream<NT>(reinterpret_cast<const float2*>(m) + i);
     float2 vv = ld_stream<NT>(reinterpret_cast<const float2*>(v) + i);
+#endif
     float* pa = &pp.x; const float* ga = &gg.x; float* ma = &mm.x; float* va = &vv.x;
+#if defined(UG_ADAMW_ABLATE) && UG_ADAMW_ABLATE == 1      // probe build: the memory streams without the arithmetic (wrong results)
+    pa[0] += ga[0]; pa[1] += ga[1];
+#else
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      const float gr = ga[k] * grad_scale;
-      float pk = pa[k] * decay;
-      const float mk = ma[k] + (gr - ma[k]) * (1.f - beta1);
-      const float vk = va[k] * beta2 + (1.f - beta2) * gr * gr;
-      const float denom = sqrtf(vk) / bc2_sqrt + eps;
-      pk = pk - step_size * (mk / denom);
-      pa[k] = pk; ma[k] = mk; va[k] = vk;
+      adamw_element(pa[k], ga[k], ma[k], va[k], c);
     }
+#endif
+#if defined(UG_ADAMW_ABLATE) && UG_ADAMW_ABLATE == 2
+    if (pp.x == 1234.5f && mm.y == 5432.1f && vv.x == -1.f)       // never: keeps the arithmetic alive
+#endif
+    {
     st_stream<NT>(reinterpret_cast<float2*>(p) + i, pp);
     st_stream<NT>(reinterpret_cast<float2*>(m) + i, mm);
     st_stream<NT>(reinterpret_cast<float2*>(v) + i, vv);
     if (p_bf16) reinterpret_cast<uint32_t*>(p_bf16)[i] = pack_bf2(pp.x, pp.y);
+    }
   }
   const int64_t ti = (n2 << 1) + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (ti < n) {
-    const float gr = g[ti] * grad_scale;
-    float pk = p[ti] * decay;
-    const float mk = m[ti] + (gr - m[ti]) * (1.f - beta1);
-    const float vk = v[ti] * beta2 + (1.f - beta2) * gr * gr;
-    pk = pk - step_size * (mk / (sqrtf(vk) / bc2_sqrt + eps));
+    float pk = p[ti], mk = m[ti], vk = v[ti];
+    adamw_element(pk, g[ti], mk, vk, c);
+    p[ti] = pk; m[ti] = mk; v[ti] = vk;
+    if (p_bf16) p_bf16[ti] = f2bf(pk);
+  }
+}
+
+// The lean kernel as a three-stage software pipeline (round 4): the loads of element pairs k+1 and k+2 are in flight while pair k is
+// computed and stored.  One wave per SIMD is all that fits beside the convolutions, and with loads -> wait -> ~80 VALU operations ->
+// stores in sequence that wave kept ONE request batch in flight: 11.2 ms alone against 7.05 for its memory streams without the
+// arithmetic and 2.5 for the arithmetic without the streams (tools/probes/run_adamw_ablate.sh), 22.1 ms beside the tokenizer.
+// The loads are inline assembly with hand-counted waits: hipcc's wait-count pass treats loads and stores in flight together as
+// unordered on gfx9 (one counter) and drains vmcnt(0) before the first use of any load issued ahead of a store.  vmcnt(8) is safe
+// whatever the stores do: loads return in order among themselves, so at most eight operations outstanding means at most the eight
+// younger loads (stages k+1, k+2) outstanding.  Stages are separate variables and the loop is unrolled by three: no register of
+// a load in flight is ever copied.  Same arithmetic, element by element; 32-bit indices (n < 2^29), <= 48 registers.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+struct AdamStage { f32x2_t p, g, m, v; };
+template <int NT>
+__global__ __launch_bounds__(256) void adamw_lean2_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                          float* __restrict__ v, bf16_t* __restrict__ p_bf16, uint32_t n, float lr,
+                                                          float beta1, float beta2, float eps, float wd, float bc1, float bc2_sqrt,
+                                                          float grad_scale) {
+  const uint32_t n2 = n >> 1;
+  const AdamConsts c = adam_consts(lr, beta1, beta2, eps, wd, bc1, bc2_sqrt, grad_scale);
+  const uint32_t stride = gridDim.x * blockDim.x;
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t trips = (n2 + stride - 1) / stride;             // uniform over the grid: waits and loads are never behind a divergent branch
+  auto load = [&](AdamStage& s, uint32_t idx) {                   // clamped: lanes past the end re-read the last pair and drop it
+    const uint32_t off = min(idx, n2 - 1) * 8u;
+    asm volatile("global_load_dwordx2 %0, %1, %2 nt" : "=&v"(s.p) : "v"(off), "s"(p) : "memory");
+    asm volatile("global_load_dwordx2 %0, %1, %2 nt" : "=&v"(s.g) : "v"(off), "s"(g) : "memory");
+    asm volatile("global_load_dwordx2 %0, %1, %2 nt" : "=&v"(s.m) : "v"(off), "s"(m) : "memory");
+    asm volatile("global_load_dwordx2 %0, %1, %2 nt" : "=&v"(s.v) : "v"(off), "s"(v) : "memory");
+  };
+  auto update = [&](AdamStage& s, uint32_t idx) {
+    asm volatile("s_waitcnt vmcnt(8)" : "+v"(s.p), "+v"(s.g), "+v"(s.m), "+v"(s.v) : : "memory");   // ties the uses below to the wait
+    if (idx < n2) {
+      float2 pp, mm, vv;
+      float* pa = &pp.x; float* ma = &mm.x; float* va = &vv.x;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        pa[k] = s.p[k]; ma[k] = s.m[k]; va[k] = s.v[k];
+        adamw_element(pa[k], s.g[k], ma[k], va[k], c);
+      }
+      st_stream<NT>(reinterpret_cast<float2*>(p) + idx, pp);
+      st_stream<NT>(reinterpret_cast<float2*>(m) + idx, mm);
+      st_stream<NT>(reinterpret_cast<float2*>(v) + idx, vv);
+      if (p_bf16) reinterpret_cast<uint32_t*>(p_bf16)[idx] = pack_bf2(pp.x, pp.y);
+    }
+  };
+  if (n2 > 0) {
+    AdamStage A, B, C;
+    uint32_t i = tid;
+    load(A, i);
+    load(B, i + stride);
+    for (uint32_t t = 0; t < trips; t += 3) {
+      load(C, i + 2 * stride); update(A, i);
+      load(A, i + 3 * stride); update(B, i + stride);
+      load(B, i + 4 * stride); update(C, i + 2 * stride);
+      i += 3 * stride;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  const uint32_t ti = (n2 << 1) + tid;
+  if (ti < n) {
+    float pk = p[ti], mk = m[ti], vk = v[ti];
+    adamw_element(pk, g[ti], mk, vk, c);
     p[ti] = pk; m[ti] = mk; v[ti] = vk;
     if (p_bf16) p_bf16[ti] = f2bf(pk);
   }
@@ -426,8 +517,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
                                                     float beta2, float eps, float wd, float bc1, float bc2_sqrt,
                                                     float grad_scale) {
   const int64_t n4 = n >> 2;
-  const float step_size = lr / bc1;
-  const float decay = 1.f - lr * wd;
+  const AdamConsts c = adam_consts(lr, beta1, beta2, eps, wd, bc1, bc2_sqrt, grad_scale);
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
     float4 pp = ld_stream<NT>(reinterpret_cast<const float4*>(p) + i);
     float4 gg = ld_stream<NT>(reinterpret_cast<const float4*>(g) + i);
@@ -436,13 +526,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     float* pa = &pp.x; float* ga = &gg.x; float* ma = &mm.x; float* va = &vv.x;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float gr = ga[k] * grad_scale;
-      float pk = pa[k] * decay;
-      const float mk = ma[k] + (gr - ma[k]) * (1.f - beta1);
-      const float vk = va[k] * beta2 + (1.f - beta2) * gr * gr;
-      const float denom = sqrtf(vk) / bc2_sqrt + eps;
-      pk = pk - step_size * (mk / denom);
-      pa[k] = pk; ma[k] = mk; va[k] = vk;
+      adamw_element(pa[k], ga[k], ma[k], va[k], c);
     }
     st_stream<NT>(reinterpret_cast<float4*>(p) + i, pp);
     st_stream<NT>(reinterpret_cast<float4*>(m) + i, mm);
@@ -453,11 +537,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   const int64_t tail0 = n4 << 2;
   const int64_t ti = tail0 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (ti < n) {
-    const float gr = g[ti] * grad_scale;
-    float pk = p[ti] * decay;
-    const float mk = m[ti] + (gr - m[ti]) * (1.f - beta1);
-    const float vk = v[ti] * beta2 + (1.f - beta2) * gr * gr;
-    pk = pk - step_size * (mk / (sqrtf(vk) / bc2_sqrt + eps));
+    float pk = p[ti], mk = m[ti], vk = v[ti];
+    adamw_element(pk, g[ti], mk, vk, c);
     p[ti] = pk; m[ti] = mk; v[ti] = vk;
     if (p_bf16) p_bf16[ti] = f2bf(pk);
   }
@@ -709,7 +790,11 @@ extern "C" int ug_adamw_flat(float* p, const float* g, float* m, float* v, void*
   if (max_blocks > 0 && lean) {
     const int wgs = lean > 1 ? lean : max_blocks;
     dim3 lgrid(grid_for(n / 2 + 1, 256, wgs));
-    if ((ew_nt() >> 12) & 0xf)
+    static const int piped = [] { const char* e = getenv("UNIGEN_ADAMW_PIPED"); return e ? atoi(e) : 1; }();
+    if (piped && n < (1LL << 29))
+      hipLaunchKernelGGL(adamw_lean2_kernel<3>, lgrid, block, 0, st, p, g, m, v, (bf16_t*)p_bf16, (uint32_t)n, lr, beta1, beta2, eps, weight_decay,
+                         (float)bc1, (float)sqrt(bc2), grad_scale);
+    else if ((ew_nt() >> 12) & 0xf)
       hipLaunchKernelGGL(adamw_lean_kernel<3>, lgrid, block, 0, st, p, g, m, v, (bf16_t*)p_bf16, n, lr, beta1, beta2, eps, weight_decay,
                          (float)bc1, (float)sqrt(bc2), grad_scale);
     else

@@ -636,9 +636,10 @@ def find_bf16_mirror(ptr, numel):
 
 
 # ------------------------------------------------------------------------------------ optimizer
-def adamw_flat_(p, g, m, v, p_bf16, lr, beta1, beta2, eps, wd, step, grad_scale=1.0):
+def adamw_flat_(p, g, m, v, p_bf16, lr, beta1, beta2, eps, wd, step, grad_scale=1.0, max_blocks=0):
+    """max_blocks > 0: the small-grid, register-lean form used beside MFMA-bound kernels (include/unigen_hip.h: ug_adamw_flat)."""
     _l.check(_l.load().ug_adamw_flat(_p(p), _p(g), _p(m), _p(v), _p(p_bf16), p.numel(), lr, beta1, beta2, eps, wd,
-                                     step, grad_scale, 0, _stream()), "ug_adamw_flat")
+                                     step, grad_scale, max_blocks, _stream()), "ug_adamw_flat")
 
 
 # ------------------------------------------------------------------------------------ tokenizer (fp32 NHWC)

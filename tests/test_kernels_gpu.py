@@ -427,6 +427,28 @@ def test_adamw_matches_torch(dev):
     assert torch.equal(pb.cpu(), p.cpu().to(torch.bfloat16))
 
 
+@pytest.mark.parametrize("n", [1, 2, 3, 515, 4099, 3 * 2 * 512 * 5 + 7, 1 << 20])
+def test_adamw_small_grid_form_is_the_same_update(dev, n):
+    """The update as it runs beside the tokenizer (max_blocks > 0: `adamw_lean2_kernel`, a three-stage software pipeline with
+    hand-counted waits, grid-stride over few workgroups) against the full-grid kernel: bit-identical p / m / v / bf16 copy over
+    three steps, with trip counts 0, 1, 2, a multiple of the unroll and not (max_blocks = 2: 512 lanes)."""
+    ops = _ops()
+    g0 = torch.Generator().manual_seed(n)
+    p0 = torch.randn(n, generator=g0)
+    state = []
+    for mb in (0, 2, 256):
+        p = p0.clone().to(dev); m = torch.zeros(n, device=dev); v = torch.zeros(n, device=dev)
+        pb = torch.zeros(n, dtype=torch.bfloat16, device=dev)
+        gg = torch.Generator().manual_seed(n + 1)
+        for step in range(1, 4):
+            g = torch.randn(n, generator=gg).to(dev)
+            ops.adamw_flat_(p, g, m, v, pb, 1e-3, 0.9, 0.999, 1e-8, 0.01, step, grad_scale=0.5, max_blocks=mb)
+        state.append((p.cpu(), m.cpu(), v.cpu(), pb.cpu()))
+    for other in state[1:]:
+        for a, b in zip(state[0], other):
+            assert torch.equal(a, b)
+
+
 # ------------------------------------------------------------------ cross entropy
 def test_ce_fwd_bwd(dev):
     ops = _ops()
