@@ -985,15 +985,15 @@ int launch(GemmArgs a, const ug_handle* h, int policy, hipStream_t st) {
     int hb = 0;
     static const bool heights_on = !(getenv("UNIGEN_GEMM_HEIGHTS") && atoi(getenv("UNIGEN_GEMM_HEIGHTS")) == 0);   // A/B switch
     if (aligned && g_tile_policy < 0 && a.N / PBN >= 1 && a.N / PBN <= 64) {
-      static const int heights[] = {192, 208, 224, 240, 256, 272, 288, 304, 320};
+      static const int heights[] = {128, 144, 160, 176, 192, 208, 224, 240, 256, 272, 288, 304, 320};
       for (int h_ : heights) {
         if (!heights_on && h_ != QBM) continue;                  // (round 3's choice: 320 rows or nothing)
         const int64_t wgs = (int64_t)((a.M + h_ - 1) / h_) * (a.N / PBN);
-        if (wgs <= 256) { if (wgs >= 200) hb = h_; break; }
+        if (wgs <= 256) { if (wgs >= 64) hb = h_; break; }        // (measured down to 78 workgroups: tools/gemm_shape_sweep.py at M = 1 542)
       }
       if (hb == 256 && p8_fits) hb = 0;                          // (the 256 x 256 kernel's own one-round case)
     }
-    if (aligned && g_tile_policy >= 44 && g_tile_policy <= 52 && g_tile_policy != 48) hb = 16 * (g_tile_policy - 32);   // forced height (tests, A/B)
+    if (aligned && g_tile_policy >= 40 && g_tile_policy <= 52 && g_tile_policy != 48) hb = 16 * (g_tile_policy - 32);   // forced height (tests, A/B)
     if (hb == 0 && aligned && (g_tile_policy == 10 || (g_tile_policy < 0 && fewer_rounds))) hb = QBM;
     if (hb != 0) {
       a.tiles_m = (a.M + hb - 1) / hb; a.tiles_n = a.N / PBN;
@@ -1007,7 +1007,11 @@ int launch(GemmArgs a, const ug_handle* h, int policy, hipStream_t st) {
         case 240: hipLaunchKernelGGL((gemm_kernel_p10<EPI, BKM, 8, 7>), grid, block, 0, st, a); break;
         case 224: hipLaunchKernelGGL((gemm_kernel_p10<EPI, BKM, 7, 7>), grid, block, 0, st, a); break;
         case 208: hipLaunchKernelGGL((gemm_kernel_p10<EPI, BKM, 7, 6>), grid, block, 0, st, a); break;
-        default: hipLaunchKernelGGL((gemm_kernel_p10<EPI, BKM, 6, 6>), grid, block, 0, st, a); break;
+        case 192: hipLaunchKernelGGL((gemm_kernel_p10<EPI, BKM, 6, 6>), grid, block, 0, st, a); break;
+        case 176: hipLaunchKernelGGL((gemm_kernel_p10<EPI, BKM, 6, 5>), grid, block, 0, st, a); break;
+        case 160: hipLaunchKernelGGL((gemm_kernel_p10<EPI, BKM, 5, 5>), grid, block, 0, st, a); break;
+        case 144: hipLaunchKernelGGL((gemm_kernel_p10<EPI, BKM, 5, 4>), grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL((gemm_kernel_p10<EPI, BKM, 4, 4>), grid, block, 0, st, a); break;
       }
       UG_CHECK_LAUNCH("ug_gemm_bf16(p10)");
       return UG_OK;
@@ -1034,10 +1038,11 @@ int launch(GemmArgs a, const ug_handle* h, int policy, hipStream_t st) {
     if (EPI == EPI_F32 && tiles_p8 >= 24 && tiles_p8 <= 128 && a.M >= 512 && a.N >= 512) {
       sp = 256 / tiles_p8;                               // one round
       while (sp > 1 && nk32 / sp < 32) --sp;
-    } else if (tiles_p8 >= 24 && tiles_p8 <= 128 && nk32 >= 2048) {
+    } else if (tiles_p8 >= 24 && tiles_p8 < 200 && nk32 >= 2048) {
       // few output tiles, very long contraction (lm-head dgrad: 96 tiles, K = 159 867): up to three rounds of slices,
-      // the count that fills whole rounds best (632 -> 1094 TF/s)
-      float best = 0.f;
+      // the count that fills whole rounds best (632 -> 1094 TF/s); up to 199 tiles since round 4 (the pt1 mixed batch's
+      // 7 184 head rows = 174 tiles ran 2.7 rounds of 128 x 128 tiles at 817 TF/s)
+      float best = (tiles_p8 > 128) ? (float)tiles_p8 / 256.f : 0.f;      // (must beat the unsliced single round)
       for (int c = 2; c <= 8 && tiles_p8 * c <= WS_PRIVATE_SLOTS; ++c) {
         const int items = tiles_p8 * c, r = (items + 255) / 256;
         const float eff = (float)items / (float)(r * 256);

@@ -50,10 +50,10 @@ def tile_policy(request):
     ops.set_gemm_tile_policy(-1)
 
 
-@pytest.mark.parametrize("height", [192, 208, 224, 240, 272, 288, 304, 320])
+@pytest.mark.parametrize("height", [128, 144, 160, 176, 192, 208, 224, 240, 272, 288, 304, 320])
 @pytest.mark.parametrize("mode", ["nt", "dgrad"])
 def test_gemm_bf16_tile_heights(dev, height, mode):
-    """Round 4: the 192 ... 320 x 256 tile family (`gemm_kernel_p10<EPI, BKM, F0, F1>`; policy 32 + height / 16 forces one): bf16 (+ bias)
+    """Round 4: the 128 ... 320 x 256 tile family (`gemm_kernel_p10<EPI, BKM, F0, F1>`; policy 32 + height / 16 forces one): bf16 (+ bias)
     and fp32-residual epilogues, B row-major and k-major, M ragged against every height (row tiles that end inside group 0,
     inside group 1, on an odd 16-row block).  And the automatic choice: the smallest height that keeps a one-round launch in one
     round gives the same values as the forced one."""
@@ -135,6 +135,30 @@ def test_gemm_bf16_layouts(dev, tile_policy, mode, M, N, K):
         want = res[:, :N] + ref.to(torch.bfloat16).float()
         # one bf16 ulp of slack on the rounded projection
         assert ((r32[:, :N].cpu() - want).abs() <= ref.abs() * 2.0 ** -7 + 1e-3).all()
+
+
+def test_gemm_bf16_long_contraction_slices_up_to_199_tiles(dev):
+    """132 output tiles of 256 x 256 with a 65 528-long contraction (the pt1 mixed batch's lm-head dgrad has 174 with K = 159 867):
+    the automatic selection cuts every tile along K into private fp32 partials (round 4: up to 199 tiles, was 128) -- against
+    sampled rows in fp64 on the host and against the 128 x 128 kernel (policy 0) on the whole output."""
+    ops = _ops()
+    M, N, K = 2900, 2816, 65528            # (K % 32 != 0: not eligible for the 128 ... 320-row one-round kernel, which would win)
+    g = torch.Generator().manual_seed(5)
+    a = (torch.randn(M, K, generator=g) * 0.25).to(torch.bfloat16)
+    b = (torch.randn(K, N, generator=g) * 0.25).to(torch.bfloat16)          # k-major B: the dgrad layout
+    A, B = a.to(dev), b.to(dev)
+    out = ops.gemm(A, B, b_kmajor=True)
+    rows = torch.tensor([0, 1, 255, 256, 1337, 2559, 2560, 2899])
+    want = a[rows].double() @ b.double()
+    assert _rel(out[rows.to(dev)].double().cpu(), want) < 4e-3
+    ops.set_gemm_tile_policy(0)
+    try:
+        ref = ops.gemm(A, B, b_kmajor=True)
+    finally:
+        ops.set_gemm_tile_policy(-1)
+    assert _rel(out.float().cpu(), ref.float().cpu()) < 4e-3
+    again = ops.gemm(A, B, b_kmajor=True)                                    # the scratch is left clean: same bits again
+    assert torch.equal(out, again)
 
 
 @pytest.mark.parametrize("mode", ["nt", "dgrad", "wgrad"])
