@@ -980,6 +980,11 @@ int launch(GemmArgs a, const ug_handle* h, int policy, hipStream_t st) {
     // many rounds: a 320-row tile costs 1.25 x a 256-row one and runs ~7 % more efficiently (fewer LDS and DMA bytes per MFMA);
     // taken when whole rounds come out at least 3 % cheaper (gate_up forward: 14 rounds -> 11 x 1.16 = 12.8: 1240 -> 1322 TF/s)
     const bool fewer_rounds = tiles_p8 >= 1024 && 1.1625f * (float)((tiles_q + 255) / 256) < 0.97f * (float)((tiles_p8 + 255) / 256);
+    // Round 4: the same comparison over every tile height -- rounds(h) x t(h), t(h) = 0.35 + 0.00254 h in units of a 256-row tile
+    // (from the two measured points t(256) = 1, t(320) = 1.1625).  down dgrad (12 336 x 8 960): 288 rows = 6 rounds x 1.08 against 7
+    // rounds of 256 (286 -> 255 us); 9 288 rows: 272; gate_up forward keeps 320 at 12 336 rows and takes 304 at 9 288
+    // (tools/gemm_shape_sweep.py agrees with the model's ranking on every shape it changes).
+    int hb_multi = 0;
     // One-round launches (round 4): a round takes as long as one tile, so the SMALLEST tile height whose row tiles x column tiles
     // still fit the 256 CUs wins -- 12 336 x 1 536 outputs: 304 rows (246 workgroups) instead of 320 (234); 9 288 rows: 224.
     int hb = 0;
@@ -993,8 +998,18 @@ int launch(GemmArgs a, const ug_handle* h, int policy, hipStream_t st) {
       }
       if (hb == 256 && p8_fits) hb = 0;                          // (the 256 x 256 kernel's own one-round case)
     }
+    if (aligned && g_tile_policy < 0 && heights_on && hb == 0 && tiles_p8 >= 768) {
+      static const int mheights[] = {176, 192, 208, 224, 240, 272, 288, 304, 320};
+      float best = 0.97f * (float)((tiles_p8 + 255) / 256);
+      for (int h_ : mheights) {
+        const int64_t wgs = (int64_t)((a.M + h_ - 1) / h_) * (a.N / PBN);
+        const float cost = (float)((wgs + 255) / 256) * (0.35f + 0.00254f * (float)h_);
+        if (cost < best) { best = cost; hb_multi = h_; }
+      }
+    }
     if (aligned && g_tile_policy >= 40 && g_tile_policy <= 52 && g_tile_policy != 48) hb = 16 * (g_tile_policy - 32);   // forced height (tests, A/B)
-    if (hb == 0 && aligned && (g_tile_policy == 10 || (g_tile_policy < 0 && fewer_rounds))) hb = QBM;
+    if (hb == 0 && hb_multi != 0) hb = hb_multi;
+    if (hb == 0 && aligned && (g_tile_policy == 10 || (g_tile_policy < 0 && !heights_on && fewer_rounds))) hb = QBM;
     if (hb != 0) {
       a.tiles_m = (a.M + hb - 1) / hb; a.tiles_n = a.N / PBN;
       const dim3 grid(a.tiles_m * a.tiles_n), block(512);
