@@ -517,6 +517,37 @@ __device__ __forceinline__ bf16x8_t load_frag32(const char* tile, int r0, int la
 
 #define P_BARRIER() asm volatile("s_barrier" ::: "memory")
 
+// The MFMA block of one k-tile: acc[i][j] += A block i x B block j.  Issue order (probe builds, -DUG_MFMA_ORDER=n): 0 = row block
+// outer (the A fragment stays on the operand port for four instructions), 1 = column block outer (the B fragment stays for NI),
+// 2 = serpentine (row block outer, columns alternately up and down: one operand unchanged between ANY two consecutive instructions).
+// Shipped: 2 -- measured at the power cap (tools/probes/run_mfma_order.sh, two passes, TF/s): gate_up forward 1 275 / 1 268 -> 1 283 / 1 282,
+// gate_up dgrad 1 394 / 1 392 -> 1 408 / 1 408, down dgrad 1 340 / 1 343 -> 1 354 / 1 366; in the step (three A/B pairs) GEMM launches
+// -0.7 ... -0.9 ms.  Fewer operand-port toggles per instruction is fewer joules per flop, and joules are what the step is bound by.
+#ifndef UG_MFMA_ORDER
+#define UG_MFMA_ORDER 2
+#endif
+#if UG_MFMA_ORDER == 1
+#define UG_MFMA_BLOCK(NI)                                                                                                  \
+  _Pragma("unroll") for (int j = 0; j < 4; ++j) _Pragma("unroll") for (int i = 0; i < (NI); ++i) {                          \
+    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);                                  \
+    __builtin_amdgcn_sched_barrier(0); }
+#elif UG_MFMA_ORDER == 2
+#define UG_MFMA_BLOCK(NI)                                                                                                  \
+  _Pragma("unroll") for (int i = 0; i < (NI); ++i) _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                       \
+    const int j = (i & 1) ? 3 - jj : jj;                                                                                   \
+    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);                                  \
+    __builtin_amdgcn_sched_barrier(0); }
+#elif UG_MFMA_ORDER == 3                         /* order 0 with the order pinned (control for the sched_barrier itself) */
+#define UG_MFMA_BLOCK(NI)                                                                                                  \
+  _Pragma("unroll") for (int i = 0; i < (NI); ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) {                          \
+    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);                                  \
+    __builtin_amdgcn_sched_barrier(0); }
+#else
+#define UG_MFMA_BLOCK(NI)                                                                                                  \
+  _Pragma("unroll") for (int i = 0; i < (NI); ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j)                            \
+    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+#endif
+
 // Phase timeline of workgroup 0 (probe builds only, -DUG_GEMM_TRACE; tools/probes/gemm_trace.py): s_memtime stamps of
 // waves 0 and 4 at the four boundaries of every k-tile iteration.
 #ifdef UG_GEMM_TRACE
@@ -610,11 +641,7 @@ __device__ __forceinline__ void p8_body(const GemmArgs& p, const int bid, char* 
   auto mfmas = [&](int prio) {
     __builtin_amdgcn_sched_barrier(0);
     if (prio == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+    UG_MFMA_BLOCK(8)
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -876,11 +903,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p10(GemmArgs p) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       P_BARRIER();
       __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int i = 0; i < FG; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+      UG_MFMA_BLOCK(FG)
       __builtin_amdgcn_s_setprio(0);
       P_BARRIER();
     };

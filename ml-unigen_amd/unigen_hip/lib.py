@@ -137,6 +137,8 @@ def _profiled(name, fn):
         tag = name
         if name == "ug_gemm_bf16":                     # (handle, A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, M, N, K, epilogue, ...)
             tag = "ug_gemm_bf16[M=%d N=%d K=%d ak=%d bk=%d epi=%d]" % (args[9], args[10], args[11], args[3], args[6], args[12])
+        elif name == "ug_conv3x3_split":               # (x, x_amax, w_split, bias, residual, y, B, H, W, Cin, Cout, ...)
+            tag = "ug_conv3x3_split[B=%d %dx%d %d->%d gn=%d]" % (args[6], args[7], args[8], args[9], args[10], 1 if args[12] else 0)
         elif name == "ug_gemm_bf16_wgrad_group":       # (n, dy, ld_dy, x, ld_x, dw, ld_dw, rows, cols, beta, K, stream)
             tag = "ug_gemm_bf16_wgrad_group[%s]" % " ".join("%dx%dx%d" % (args[7][i], args[8][i], args[10][i]) for i in range(args[0]))
         prof.setdefault(fam, []).append((e0, e1, tag))
