@@ -444,6 +444,14 @@ constexpr int PBM = 256, PBN = 256, PBK = 32;
 constexpr int P_TILE = PBM * PBK * 2;          // 16 KiB per operand per stage
 constexpr int P_STAGE = 2 * P_TILE;            // 32 KiB
 constexpr int P_NST = 4;
+// Cache policy of the operand streams' LDS-DMA (probe builds: -DUG_CPOL_STAGER=n / -DUG_CPOL_P10A=n; 1 = sc0, 2 = nt, 16 = sc1): measured
+// round 4 (tools/probes/run_cpol.sh), see DESIGN 4.1.
+#ifndef UG_CPOL_STAGER
+#define UG_CPOL_STAGER 0
+#endif
+#ifndef UG_CPOL_P10A
+#define UG_CPOL_P10A 0
+#endif
 
 __device__ __forceinline__ int swz_rowk32(int row, int chunk) { return chunk ^ ((0 - (row >> 2)) & 3); }
 
@@ -492,7 +500,7 @@ struct Stager32 {                // 256-row x 32-k operand tile, 8 waves: 2 one-
         s = reinterpret_cast<const bf16_t*>(past ? reinterpret_cast<uintptr_t>(zero) : reinterpret_cast<uintptr_t>(s));
       }
       char* dst = lds_tile + (i * 8 + wave) * 1024;
-      __builtin_amdgcn_global_load_lds((gptr_t)s, (lptr_t)dst, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)s, (lptr_t)dst, 16, 0, UG_CPOL_STAGER);
     }
   }
 };
@@ -871,7 +879,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p10(GemmArgs p) {
       char* st = lds + (lt & (P_NST - 1)) * STAGE;
 #pragma unroll
       for (int i = 0; i < NA; ++i)
-        __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + (int64_t)lt * PBK), (lptr_t)(st + (i * 8 + wave) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + (int64_t)lt * PBK), (lptr_t)(st + (i * 8 + wave) * 1024), 16, 0, UG_CPOL_P10A);
       sb.template issue<false>(lt, p.K, st + TILE_A, wave);
     };
     auto landed = [&](int in_flight) {            // batches of this wave's DMA that may stay in flight
