@@ -402,6 +402,64 @@ def self_launch(n):
     return proc.wait()
 
 
+class PowerSampler:
+    """Package power and shader clock of the busy GPU(s) while the timed steps run: a child process reads the hwmon files of every
+    card every 20 ms (read-only sysfs; never touches the GPU); `report(t0, t1)` averages the cards that were busy in that window.
+    profiles/r04_power.md: the step runs at the 1400 W cap with the clock pulled down -- the line says whether THIS box did too.
+    Any failure (no hwmon, no permission) gives None; the benchmark never depends on it."""
+    SRC = ("import sys, time, glob, os\n"
+           "hw = [h for h in sorted(glob.glob('/sys/class/drm/card*/device/hwmon/hwmon*')) if os.path.exists(h + '/power1_input')]\n"
+           "f = open(sys.argv[1], 'w')\n"
+           "while True:\n"
+           "    row = []\n"
+           "    for h in hw:\n"
+           "        try:\n"
+           "            row += [open(h + '/power1_input').read().strip(), open(h + '/freq1_input').read().strip()]\n"
+           "        except (OSError, ValueError):\n"
+           "            row += ['0', '0']\n"
+           "    f.write('%.4f %s\\n' % (time.time(), ' '.join(row))); f.flush()\n"
+           "    time.sleep(0.02)\n")
+
+    def __init__(self):
+        self.proc, self.path, self.cap = None, None, None
+        try:
+            import glob
+            import subprocess
+            import tempfile
+            caps = glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_cap")
+            if not caps:
+                return
+            self.cap = int(open(caps[0]).read()) / 1e6
+            self.path = os.path.join(tempfile.gettempdir(), f"unigen_bench_power_{os.getpid()}.txt")
+            self.proc = subprocess.Popen([sys.executable, "-c", self.SRC, self.path], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        except Exception:
+            self.proc = None
+
+    def report(self, w0, w1):
+        if self.proc is None:
+            return None
+        try:
+            self.proc.terminate()
+            self.proc.wait(timeout=5)
+            cards = {}
+            for line in open(self.path):
+                f = line.split()
+                if len(f) < 3 or not (w0 <= float(f[0]) <= w1):
+                    continue
+                for c in range((len(f) - 1) // 2):
+                    cards.setdefault(c, []).append((int(f[1 + 2 * c]) / 1e6, int(f[2 + 2 * c]) / 1e6))
+            os.remove(self.path)
+            busy = [v for v in cards.values() if v and sum(s[0] for s in v) / len(v) > 500.0]      # cards that ran the steps
+            if not busy:
+                return None
+            smp = [s for v in busy for s in v]
+            return {"mean_w": round(sum(s[0] for s in smp) / len(smp), 1), "cap_w": self.cap,
+                    "mean_sclk_mhz": round(sum(s[1] for s in smp) / len(smp), 1), "nominal_sclk_mhz": 2400, "gpus_sampled": len(busy),
+                    "samples": len(smp), "source": "hwmon power1_input / freq1_input every 20 ms over the timed steps"}
+        except Exception:
+            return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -482,17 +540,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    sampler = PowerSampler() if rank == 0 else None     # (started before the warm-up: it is sampling by the time the clock starts)
     for _ in range(args.warmup):
         step()
     model.llm.engine.check_errors()
     barrier()
     sync = model.llm.engine.grad_sync               # the flat-gradient exchange the engine installed (None at N = 1)
     wire0 = (sync.bytes_on_wire, sync.lookup_bytes_on_wire) if sync is not None else (0, 0)
+    w0 = time.time()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     dt = time.perf_counter() - t0
+    power = sampler.report(w0, time.time()) if sampler is not None else None
     exchange = None
     if world > 1:
         t = torch.tensor([dt], device=dev)
@@ -609,7 +670,7 @@ def main():
                           "global_batch": B * world, "seq_len": L, "parallelism": f"dp{world}"},
                "loss_first_last": [round(losses[0].item(), 4), round(losses[-1].item(), 4)],
                "ranks_seen": exchange["ranks_seen"] if exchange else 1, "exchange": exchange,
-               "roofline": roof, "cpu_baseline": cpu, "ar_decode": ar, "extra_cases": extra}
+               "power": power, "roofline": roof, "cpu_baseline": cpu, "ar_decode": ar, "extra_cases": extra}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -1424,7 +1424,8 @@ extern "C" int ug_attn_bwd(const void* q, const void* k, const void* v, int64_t 
     static const int dma = [] { const char* e = getenv("UNIGEN_ATTN_DKV_DMA"); return e ? atoi(e) : 1; }();
     a.order = (ord >> 2) & 1;
     static const int hpw_env = [] { const char* e = getenv("UNIGEN_ATTN_DKV_HEADS"); return e ? atoi(e) : 2; }();
-    a.dkv_heads = (hpw_env >= 1 && (H / HKV) % hpw_env == 0 && (int64_t)a.nW * (H / hpw_env) * B >= 1024) ? hpw_env : 1;
+    static const int hpw_min_wgs = [] { const char* e = getenv("UNIGEN_ATTN_DKV_MIN_WGS"); return e ? atoi(e) : 1024; }();
+    a.dkv_heads = (hpw_env >= 1 && (H / HKV) % hpw_env == 0 && (int64_t)a.nW * (H / hpw_env) * B >= hpw_min_wgs) ? hpw_env : 1;
     if (dma && L <= 4096) hipLaunchKernelGGL(attn_bwd_dkv_dma_kernel, dim3(wg_grid(a.nW, H / a.dkv_heads, HKV, B)), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, dim3(wg_grid(a.nW, H, HKV, B)), dim3(256), 0, st, a);
     UG_CHECK_LAUNCH("ug_attn_bwd(dkv split)");
