@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define UG_ABI_VERSION 4
+#define UG_ABI_VERSION 5
 
 /* ---- library ---------------------------------------------------------------------------- */
 const char* ug_last_error(void);
@@ -72,6 +72,14 @@ int ug_gemm_bf16(const ug_handle* h, const void* A, int64_t lda, int a_kmajor, c
 
 int ug_cast_f32_bf16(const float* in, void* out, int64_t n, hipStream_t stream);
 
+/* The fused q/k/v projection of a decoder layer (transformers modeling_qwen2.py:200-215 q_proj / k_proj / v_proj + apply_rotary_pos_emb
+ * :131-135; reference call site models/unigen.py:274-285): qkv[M, N] = bf16(x[M, K] W[N, K]^T + bias) with rotate-half RoPE (tables
+ * [L, head_dim / 2] fp32, row m at position m % L) applied in the GEMM's epilogue to the first rope_cols columns (the q and k heads) --
+ * bit-identical to ug_gemm_bf16 followed by ug_rope.  Fused for head_dim 128, N / rope_cols / K multiples of 256 / 256 / 32; any other
+ * shape runs as those two launches.  ABI v5. */
+int ug_gemm_bf16_qkv_rope(const ug_handle* h, const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias, void* qkv,
+                          int64_t ldq, int64_t M, int64_t N, int64_t K, const float* cos_tab, const float* sin_tab, int64_t L,
+                          int64_t rope_cols, int head_dim, hipStream_t stream);
 /* replaces: down_proj's input act_fn(gate_proj(x)) * up_proj(x) in Qwen2MLP.forward (modeling_qwen2.py:46-48) as ONE launch:
  * the gate_up projection of x [M, K] with the fused weight w_gate_up [2I, K] (gate rows, then up rows) whose epilogue also
  * writes act [M, I] = bf16(bf16(silu(gate)) * up).  gu [M, 2I] = [gate | up] is still written (the backward reads it).  A tile

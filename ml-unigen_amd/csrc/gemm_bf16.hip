@@ -56,7 +56,7 @@ constexpr int P8_GROUP_M = UG_P8_GROUP_M;    // row panels per column sweep of t
                                              // K = 1536 launch stay in an XCD's 4 MB L2 while its 32 workgroups walk the columns
                                              // (8: 8192^3 1325 -> 1385, gate_up forward / weight gradients +1..2 %; probe builds override it)
 
-enum Epi { EPI_BF16 = 0, EPI_F32 = 1, EPI_RESID = 2 };
+enum Epi { EPI_BF16 = 0, EPI_F32 = 1, EPI_RESID = 2, EPI_ROPE = 3 };    // EPI_ROPE: EPI_BF16 + rotate-half RoPE on the first rope_cols columns (128...320-row kernel only)
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -72,6 +72,7 @@ struct GemmArgs {
   int M, N, K;
   int64_t lda, ldb, ldc, ldr;
   int beta;                // EPI_F32: 1 => C += acc
+  const float* rope_cos; const float* rope_sin; int rope_L, rope_cols;     // EPI_ROPE: tables [rope_L, 64] fp32, row m sits at position m % rope_L
   int tiles_m, tiles_n;
   // staggered kernel, partial last round: the first `full_tiles` tiles run whole, every remaining tile is cut into
   // `tail_split` k-slices that add into the fp32 scratch tail_ws[tile - full_tiles][256][256] (finished by tail_finish)
@@ -231,16 +232,32 @@ constexpr int EP_ROWS = 32;
 constexpr int EP_PITCH_BF16 = 144, EP_PITCH_F32 = 272;
 constexpr int EP_STRIP = EP_ROWS * EP_PITCH_F32;            // 8704 B per wave (the bf16 strip needs 4608)
 
+// One rotate-half pair exactly as rope_kernel (elementwise.hip) computes it: products and sums round separately, contraction off.
+__device__ __forceinline__ void rope_pair(float x1, float x2, float c, float s, float& o1, float& o2) {
+#pragma clang fp contract(off)
+  const float a1 = x1 * c, a2 = x2 * c;
+  const float b1 = x2 * s, b2 = x1 * s;
+  o1 = a1 - b1; o2 = a2 + b2;
+}
+
+// EPI_ROPE (fused q/k/v projection, round 4): the wave's 64 columns are TWO 32-column pieces of one 128-wide head, 64 apart
+// (nbase .. nbase + 31 and nbase + 64 .. nbase + 95; accumulator column blocks 0, 1 | 2, 3), so the partner x[j + 64] of a
+// rotate-half pair is the same lane's element of block j + 2: RoPE is register arithmetic between the bf16 rounding of
+// (acc + bias) and the bf16 rounding of the result -- the same two roundings as ug_gemm_bf16 followed by ug_rope, bit for bit.
+// rope_p0 = column of the wave's first piece inside the head's first half (0 or 32); roped = this tile's columns are q / k heads.
 template <int EPI, int MF = 8>                              // MF = 16-row accumulator blocks of the wave (8, or 10 for 320-row tiles)
-__device__ __forceinline__ void store_tile_lds(const GemmArgs& p, f32x4_t (&acc)[MF][4], char* strip, int mbase, int nbase, int lane) {
+__device__ __forceinline__ void store_tile_lds(const GemmArgs& p, f32x4_t (&acc)[MF][4], char* strip, int mbase, int nbase, int lane,
+                                               int rope_p0 = 0, bool roped = false) {
+  constexpr bool BF = EPI == EPI_BF16 || EPI == EPI_ROPE;
   float alpha = 1.f;
   if constexpr (EPI == EPI_F32) { if (p.alpha_dev) alpha = *p.alpha_dev; }
   float bias4[4][4];
-  if constexpr (EPI == EPI_BF16) {
+  if constexpr (BF) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       uint2 b = make_uint2(0u, 0u);                          // 4 bf16 of this lane's columns (8-byte aligned: the flat
-      if (p.bias) b = *reinterpret_cast<const uint2*>(p.bias + nbase + j * 16 + (lane >> 4) * 4);    // buffers are 64-element aligned)
+      const int cj = EPI == EPI_ROPE ? (j & 1) * 16 + (j >> 1) * 64 : j * 16;
+      if (p.bias) b = *reinterpret_cast<const uint2*>(p.bias + nbase + cj + (lane >> 4) * 4);    // buffers are 64-element aligned)
       bias4[j][0] = __uint_as_float(b.x << 16); bias4[j][1] = __uint_as_float(b.x & 0xffff0000u);
       bias4[j][2] = __uint_as_float(b.y << 16); bias4[j][3] = __uint_as_float(b.y & 0xffff0000u);
     }
@@ -253,11 +270,37 @@ __device__ __forceinline__ void store_tile_lds(const GemmArgs& p, f32x4_t (&acc)
     for (int ii = 0; ii < 2; ++ii) {
       if (2 * c + ii >= MF) break;
       const int row = ii * 16 + (lane & 15);
+      if constexpr (EPI == EPI_ROPE) {
+        if (roped) {
+          const int pos = min(mbase + c * EP_ROWS + row, p.M - 1) % p.rope_L;
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int pc = rope_p0 + j * 16 + (lane >> 4) * 4;
+            const float4 cs = *reinterpret_cast<const float4*>(p.rope_cos + (int64_t)pos * 64 + pc);
+            const float4 sn = *reinterpret_cast<const float4*>(p.rope_sin + (int64_t)pos * 64 + pc);
+            const float cc[4] = {cs.x, cs.y, cs.z, cs.w}, ss[4] = {sn.x, sn.y, sn.z, sn.w};
+            f32x4_t& lo = acc[2 * c + ii][j];
+            f32x4_t& hi = acc[2 * c + ii][j + 2];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const float x1 = bf2f(f2bf(lo[k] + bias4[j][k])), x2 = bf2f(f2bf(hi[k] + bias4[j + 2][k]));
+              float o1, o2;
+              rope_pair(x1, x2, cc[k], ss[k], o1, o2);
+              lo[k] = o1; hi[k] = o2;                              // (the bias is already inside x1 / x2)
+            }
+          }
+        }
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int col = j * 16 + (lane >> 4) * 4;
         const f32x4_t v = acc[2 * c + ii][j];
-        if constexpr (EPI == EPI_BF16) {
+        if constexpr (EPI == EPI_ROPE) {
+          uint2 o;
+          if (roped) { o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]); }
+          else { o.x = pack_bf2(v[0] + bias4[j][0], v[1] + bias4[j][1]); o.y = pack_bf2(v[2] + bias4[j][2], v[3] + bias4[j][3]); }
+          *reinterpret_cast<uint2*>(strip + row * EP_PITCH_BF16 + col * 2) = o;
+        } else if constexpr (EPI == EPI_BF16) {
           uint2 o;
           o.x = pack_bf2(v[0] + bias4[j][0], v[1] + bias4[j][1]);
           o.y = pack_bf2(v[2] + bias4[j][2], v[3] + bias4[j][3]);
@@ -269,13 +312,14 @@ __device__ __forceinline__ void store_tile_lds(const GemmArgs& p, f32x4_t (&acc)
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the strip is wave-private: no barrier, only this wave's writes
     // ---- strip -> global, 16 bytes per lane, whole row segments
-    if constexpr (EPI == EPI_BF16) {
+    if constexpr (BF) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int row = q * 8 + (lane >> 3), ch = lane & 7;
         const int m = mbase + c * EP_ROWS + row;
         const uint4 v = *reinterpret_cast<const uint4*>(strip + row * EP_PITCH_BF16 + ch * 16);
-        if (m < p.M && row < rows_here) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc + nbase + ch * 8) = v;
+        const int gc = EPI == EPI_ROPE ? (ch & 3) * 8 + (ch >> 2) * 64 : ch * 8;        // (two 64-byte pieces per row with EPI_ROPE)
+        if (m < p.M && row < rows_here) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc + nbase + gc) = v;
       }
     } else {
 #pragma unroll
@@ -900,7 +944,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p10(GemmArgs p) {
 #pragma unroll
       for (int i = 0; i < FG; ++i) fa[i] = load_frag32<false>(tA, (G0 ? 0 : 16 * F0) + i * 16, lane);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = load_frag32<BKM>(tB, wn * 64 + j * 16, lane);
+      for (int j = 0; j < 4; ++j)
+        fb[j] = load_frag32<BKM>(tB, EPI == EPI_ROPE ? (wn >> 1) * 128 + (wn & 1) * 32 + (j & 1) * 16 + (j >> 1) * 64 : wn * 64 + j * 16, lane);
       if constexpr (decltype(steady)::value) {
         stage_in(t + 3);
         landed(2);
@@ -919,7 +964,11 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p10(GemmArgs p) {
     for (; t + 4 < nk; ++t) iteration(t, std::true_type{});
     for (; t < nk; ++t) iteration(t, std::false_type{});
     if (G0) P_BARRIER();
-    store_tile_lds<EPI, FG>(p, reinterpret_cast<f32x4_t (&)[FG][4]>(acc[0]), lds + wave * EP_STRIP, m0 + (G0 ? 0 : 16 * F0), n0 + wn * 64, lane);
+    if constexpr (EPI == EPI_ROPE)
+      store_tile_lds<EPI, FG>(p, reinterpret_cast<f32x4_t (&)[FG][4]>(acc[0]), lds + wave * EP_STRIP, m0 + (G0 ? 0 : 16 * F0),
+                              n0 + (wn >> 1) * 128 + (wn & 1) * 32, lane, (wn & 1) * 32, n0 < p.rope_cols);
+    else
+      store_tile_lds<EPI, FG>(p, reinterpret_cast<f32x4_t (&)[FG][4]>(acc[0]), lds + wave * EP_STRIP, m0 + (G0 ? 0 : 16 * F0), n0 + wn * 64, lane);
   };
   const bool more = REM != 0 && wave < REM;       // this wave issues LO + 1 A-tile instructions
   if (grp == 0) { if (more) run(std::true_type{}, std::integral_constant<int, LO + (REM ? 1 : 0)>{}); else run(std::true_type{}, std::integral_constant<int, LO>{}); }
@@ -1246,5 +1295,57 @@ extern "C" int ug_gemm_bf16_swiglu(const ug_handle* h, const void* x, int64_t ld
   a.swiglu_I = (int)I; a.act = (bf16_t*)act; a.ld_act = ld_act;
   hipLaunchKernelGGL((gemm_kernel_p8<EPI_BF16, false, false>), dim3(a.full_tiles), dim3(512), 0, stream, a);
   UG_CHECK_LAUNCH("ug_gemm_bf16_swiglu");
+  return UG_OK;
+}
+
+// The fused q/k/v projection: qkv = bf16(x W^T + b) with rotate-half RoPE applied to the first rope_cols columns (the q and k heads)
+// in the epilogue (EPI_ROPE above) -- the values of ug_gemm_bf16 followed by ug_rope, bit for bit, without the in-place pass over
+// the q / k columns (88 MB read + write per layer at the benchmark shape, 16.8 us).  transformers modeling_qwen2.py:131-135, 200-215.
+extern "C" int ug_rope(void* qkv, const float* cos_tab, const float* sin_tab, int64_t tokens, int64_t L, int64_t ldq,
+                       int nheads, int head_dim, int backward, hipStream_t st);
+
+extern "C" int ug_gemm_bf16_qkv_rope(const ug_handle* h, const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias, void* qkv,
+                                     int64_t ldq, int64_t M, int64_t N, int64_t K, const float* cos_tab, const float* sin_tab, int64_t L,
+                                     int64_t rope_cols, int head_dim, hipStream_t stream) {
+  UG_REQUIRE(M > 0 && N > 0 && K > 0 && L > 0 && M % L == 0 && head_dim > 0 && rope_cols >= 0 && rope_cols <= N && rope_cols % head_dim == 0,
+             "ug_gemm_bf16_qkv_rope: bad problem M=%ld N=%ld K=%ld L=%ld rope_cols=%ld head_dim=%d", (long)M, (long)N, (long)K, (long)L,
+             (long)rope_cols, head_dim);
+  UG_REQUIRE(cos_tab && sin_tab && ug_aligned16(cos_tab) && ug_aligned16(sin_tab), "ug_gemm_bf16_qkv_rope: cos / sin tables [L, head_dim / 2] fp32, 16-byte aligned");
+  UG_REQUIRE(M < (1 << 30) && N < (1 << 30) && K < (1 << 30), "ug_gemm_bf16_qkv_rope: dims too large");
+  const bool fused = head_dim == 128 && N % PBN == 0 && rope_cols % PBN == 0 && K % PBK == 0 && ldq % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0 &&
+                     ldx >= K && ldw >= K && ldq >= N && ug_aligned16(x) && ug_aligned16(w) && ug_aligned16(qkv) &&
+                     (!bias || (reinterpret_cast<uintptr_t>(bias) & 7) == 0) && N / PBN <= 64;
+  static const bool fused_on = !(getenv("UNIGEN_FUSED_ROPE") && atoi(getenv("UNIGEN_FUSED_ROPE")) == 0);      // A/B switch
+  if (!fused || !fused_on) {                    // any other shape: the projection and the rotation as two launches (identical values)
+    if (int rc = ug_gemm_bf16(h, x, ldx, 0, w, ldw, 0, qkv, ldq, M, N, K, EPI_BF16, bias, nullptr, 0, 0, nullptr, -1, stream)) return rc;
+    if (rope_cols == 0) return UG_OK;
+    return ug_rope(qkv, cos_tab, sin_tab, M, L, ldq, (int)(rope_cols / head_dim), head_dim, 0, stream);
+  }
+  GemmArgs a{};
+  a.A = (const bf16_t*)x; a.B = (const bf16_t*)w; a.C = qkv; a.bias = (const bf16_t*)bias;
+  a.M = (int)M; a.N = (int)N; a.K = (int)K; a.lda = ldx; a.ldb = ldw; a.ldc = ldq;
+  a.rope_cos = cos_tab; a.rope_sin = sin_tab; a.rope_L = (int)L; a.rope_cols = (int)rope_cols;
+  a.tail_split = 1; a.tail_private = 1; a.wide_epilogue = 1;
+  // tile height: rounds(h) x t(h), the rule of launch() (one round: the smallest height that fits)
+  static const int heights[] = {128, 160, 192, 208, 224, 256, 288, 320};
+  int hb = 320; float best = 1e30f;
+  for (int h_ : heights) {
+    const int64_t wgs = ((M + h_ - 1) / h_) * (N / PBN);
+    const float cost = (float)((wgs + 255) / 256) * (0.35f + 0.00254f * (float)h_);
+    if (cost < best) { best = cost; hb = h_; }
+  }
+  a.tiles_m = (int)((M + hb - 1) / hb); a.tiles_n = (int)(N / PBN);
+  const dim3 grid(a.tiles_m * a.tiles_n), block(512);
+  switch (hb) {
+    case 320: hipLaunchKernelGGL((gemm_kernel_p10<EPI_ROPE, false, 10, 10>), grid, block, 0, stream, a); break;
+    case 288: hipLaunchKernelGGL((gemm_kernel_p10<EPI_ROPE, false, 9, 9>), grid, block, 0, stream, a); break;
+    case 256: hipLaunchKernelGGL((gemm_kernel_p10<EPI_ROPE, false, 8, 8>), grid, block, 0, stream, a); break;
+    case 224: hipLaunchKernelGGL((gemm_kernel_p10<EPI_ROPE, false, 7, 7>), grid, block, 0, stream, a); break;
+    case 208: hipLaunchKernelGGL((gemm_kernel_p10<EPI_ROPE, false, 7, 6>), grid, block, 0, stream, a); break;
+    case 192: hipLaunchKernelGGL((gemm_kernel_p10<EPI_ROPE, false, 6, 6>), grid, block, 0, stream, a); break;
+    case 160: hipLaunchKernelGGL((gemm_kernel_p10<EPI_ROPE, false, 5, 5>), grid, block, 0, stream, a); break;
+    default: hipLaunchKernelGGL((gemm_kernel_p10<EPI_ROPE, false, 4, 4>), grid, block, 0, stream, a); break;
+  }
+  UG_CHECK_LAUNCH("ug_gemm_bf16_qkv_rope");
   return UG_OK;
 }

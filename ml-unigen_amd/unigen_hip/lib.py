@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
 LIB_PATH = os.environ.get("UNIGEN_HIP_LIB") or os.path.join(CSRC_DIR, "libunigen_hip.so")     # (probe builds: tools/probes/_build/*.so)
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 P = ctypes.c_void_p
 I64 = ctypes.c_int64
 I32 = ctypes.c_int
@@ -24,6 +24,7 @@ SIGNATURES = {
     "ug_create": [P],
     "ug_destroy": [P],
     "ug_gemm_bf16": [P, P, I64, I32, P, I64, I32, P, I64, I64, I64, I64, I32, P, P, I64, I32, P, I32, P],
+    "ug_gemm_bf16_qkv_rope": [P, P, I64, P, I64, P, P, I64, I64, I64, I64, P, P, I64, I64, I32, P],
     "ug_gemm_bf16_swiglu": [P, P, I64, P, I64, P, I64, P, I64, I64, I64, I64, P],
     "ug_cast_f32_bf16": [P, P, I64, P],
     "ug_rmsnorm_fwd": [P, P, P, P, I64, I64, F32, I32, P],

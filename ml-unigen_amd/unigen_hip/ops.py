@@ -267,6 +267,30 @@ def rope_(qkv, cos, sin, L, nheads, head_dim, backward=False):
     return qkv
 
 
+def gemm_qkv_rope(x, w, bias, cos, sin, L, nheads, head_dim):
+    """x bf16 [M, K], fused q/k/v weight bf16 [N, K] (+ bias bf16 [N]) -> qkv bf16 [M, N] with rotate-half RoPE applied to the first
+    nheads * head_dim columns (q and k heads; row m at position m % L): the projection with the rotation in its epilogue
+    (include/unigen_hip.h: ug_gemm_bf16_qkv_rope) -- the values of gemm_nt + rope_, bit for bit.  With a pinned tile policy (tests,
+    A/B runs) the two launches are used so that the policy applies."""
+    _need_cuda(x, w)
+    M, K = x.shape
+    N = w.shape[0]
+    if GEMM_POLICY != -1:
+        qkv = gemm(x, w, bias=bias)
+        return rope_(qkv, cos, sin, L, nheads, head_dim)
+    qkv = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
+    prof = GEMM_PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _l.check(_l.load().ug_gemm_bf16_qkv_rope(_handle(), _p(x), x.stride(0), _p(w), w.stride(0), _p(bias), _p(qkv), qkv.stride(0), M, N, K,
+                                              _p(cos), _p(sin), L, nheads * head_dim, head_dim, _stream()), "ug_gemm_bf16_qkv_rope")
+    if prof is not None:
+        e1.record()
+        prof.append((e0, e1, 2.0 * M * N * K))
+    return qkv
+
+
 def swiglu_fwd(gu):
     tokens, two_i = gu.shape
     act = torch.empty((tokens, two_i // 2), dtype=torch.bfloat16, device=gu.device)

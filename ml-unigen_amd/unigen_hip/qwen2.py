@@ -212,8 +212,7 @@ class Qwen2Engine:
         Hq, Hk, hd = d.num_attention_heads, d.num_key_value_heads, d.head_dim
         cos, sin = self.rope(L)
         xn1, rstd1 = ops.rmsnorm_fwd(h, fp.p(f"l{i}.ln1"), d.rms_norm_eps)
-        qkv = ops.gemm_nt(xn1, fp.w(f"l{i}.wqkv"), bias=fp.w(f"l{i}.bqkv"))
-        ops.rope_(qkv, cos, sin, L, Hq + Hk, hd)
+        qkv = ops.gemm_qkv_rope(xn1, fp.w(f"l{i}.wqkv"), fp.w(f"l{i}.bqkv"), cos, sin, L, Hq + Hk, hd)     # projection + RoPE, one launch
         o, lse = ops.attn_fwd(qkv, mb, Hq, Hk, hd)
         h_mid = ops.gemm_nt(o, fp.w(f"l{i}.wo"), epilogue=ops.UG_EPI_RESID, resid=h)
         xn2, rstd2 = ops.rmsnorm_fwd(h_mid, fp.p(f"l{i}.ln2"), d.rms_norm_eps)
@@ -266,8 +265,7 @@ class Qwen2Engine:
         h = seg
         for i in range(d.num_hidden_layers):
             xn1, _ = ops.rmsnorm_fwd(h, fp.p(f"l{i}.ln1"), d.rms_norm_eps, want_rstd=False)
-            qkv_s = ops.gemm_nt(xn1, fp.w(f"l{i}.wqkv"), bias=fp.w(f"l{i}.bqkv"))
-            ops.rope_(qkv_s, sess.cos, sess.sin, sess.S, Hq + Hk, hd)          # row r sits at position seg_start + r % S
+            qkv_s = ops.gemm_qkv_rope(xn1, fp.w(f"l{i}.wqkv"), fp.w(f"l{i}.bqkv"), sess.cos, sess.sin, sess.S, Hq + Hk, hd)   # row r sits at position seg_start + r % S
             ops.scatter_rows_(qkv_s, sess.rows, sess.qkv[i])
             o, _ = ops.attn_fwd(sess.qkv[i], sess.mb, Hq, Hk, hd)
             o_s = ops.gather_rows(o, sess.rows)

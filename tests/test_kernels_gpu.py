@@ -137,6 +137,30 @@ def test_gemm_bf16_layouts(dev, tile_policy, mode, M, N, K):
         assert ((r32[:, :N].cpu() - want).abs() <= ref.abs() * 2.0 ** -7 + 1e-3).all()
 
 
+@pytest.mark.parametrize("M,L,N,rope_heads,K", [(3 * 257, 257, 2048, 14, 1536), (2 * 771, 771, 2048, 14, 256), (5 * 40, 40, 768, 4, 64),
+                                                 (4 * 333, 333, 512, 2, 96), (2 * 100, 100, 2048, 14, 1536), (771 * 16, 771, 2048, 14, 128),
+                                                 (64, 64, 384, 2, 64), (120, 60, 2048, 14, 72)])
+def test_gemm_qkv_rope_is_gemm_then_rope(dev, M, L, N, rope_heads, K):
+    """The fused q/k/v projection (`ug_gemm_bf16_qkv_rope`: RoPE in the GEMM's epilogue, round 4) against `ug_gemm_bf16` followed by
+    `ug_rope`: the same bits -- every tile height the launcher can pick (M from 64 to 12 336 rows), ragged last row tiles, positions
+    that wrap inside a tile (L = 40), roped and un-roped column tiles, and shapes that take the two-launch fallback (N % 256 != 0,
+    K % 32 != 0)."""
+    ops = _ops()
+    hd = 128
+    g = torch.Generator().manual_seed(M + N + K)
+    x = (torch.randn(M, K, generator=g)).to(torch.bfloat16).to(dev)
+    w = (torch.randn(N, K, generator=g) * 0.2).to(torch.bfloat16).to(dev)
+    b = torch.randn(N, generator=g).to(torch.bfloat16).to(dev)
+    cos, sin = ops.rope_tables(L, hd, 1e6, dev)
+    want = ops.rope_(ops.gemm(x, w, bias=b), cos, sin, L, rope_heads, hd)
+    got = ops.gemm_qkv_rope(x, w, b, cos, sin, L, rope_heads, hd)
+    assert torch.equal(got, want)
+    ref = x.float().cpu() @ w.float().cpu().t() + b.float().cpu()                   # and the un-roped columns against the host
+    assert _rel(got[:, rope_heads * hd:].float().cpu(), ref[:, rope_heads * hd:]) < 4e-3 or rope_heads * hd == N
+    nob = ops.gemm_qkv_rope(x, w, None, cos, sin, L, rope_heads, hd)                 # no bias
+    assert torch.equal(nob, ops.rope_(ops.gemm(x, w), cos, sin, L, rope_heads, hd))
+
+
 def test_gemm_bf16_long_contraction_slices_up_to_199_tiles(dev):
     """132 output tiles of 256 x 256 with a 65 528-long contraction (the pt1 mixed batch's lm-head dgrad has 174 with K = 159 867):
     the automatic selection cuts every tile along K into private fp32 partials (round 4: up to 199 tiles, was 128) -- against
