@@ -73,6 +73,21 @@ __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
 }
 __device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, f) & 0xffffu); }
 
+// ---------------------------------------------------------------- SiLU of the training forward (one definition for every kernel)
+// silu(g) = g / (1 + exp(-g)) with the quotient as rcp + one residual correction (6 VALU operations; the IEEE division sequence
+// -- div_scale x 2, rcp, five fma, div_fmas, div_fixup -- was 34 of the fused gate_up epilogue's 60 extra us per launch).  The
+// divisor is in [1, inf): no scaling needed; exp(-g) = inf (g < -88.7) gives the signed zero the exact quotient rounds to.
+// swiglu_fwd_kernel and the GEMM epilogues share it, so the fused and the two-launch forms stay bit-identical to each other;
+// against the fp32 reference the quotient is within 1 ulp before the bf16 rounding that follows it everywhere.
+__device__ __forceinline__ float silu_train(float g) {
+  const float d = 1.f + __expf(-g);
+  const float y = __builtin_amdgcn_rcpf(d);
+  const float q = g * y;
+  const float r = __builtin_fmaf(-d, q, g);
+  const float v = __builtin_fmaf(r, y, q);
+  return (d > 3.0e38f) ? g * 0.f : v;
+}
+
 // ---------------------------------------------------------------- wave reductions (64 lanes)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void rope_kernel(bf16_t* __restrict__ qkv, con
 // =========================================================================== SwiGLU
 // act = bf16( bf16(silu(gate)) * up )     (Qwen2MLP.forward, modeling_qwen2.py:46-48, bf16 autocast:
 // silu and the product are separate bf16-rounded ops).  gu = [tokens, 2*I] = [gate | up].
-__device__ __forceinline__ float silu_f(float g) { return g / (1.f + __expf(-g)); }
+__device__ __forceinline__ float silu_f(float g) { return silu_train(g); }       // (common.h: shared with the GEMM epilogues)
 
 template <int NT>
 __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict__ act,

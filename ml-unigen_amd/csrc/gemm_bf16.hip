@@ -56,7 +56,7 @@ constexpr int P8_GROUP_M = UG_P8_GROUP_M;    // row panels per column sweep of t
                                              // K = 1536 launch stay in an XCD's 4 MB L2 while its 32 workgroups walk the columns
                                              // (8: 8192^3 1325 -> 1385, gate_up forward / weight gradients +1..2 %; probe builds override it)
 
-enum Epi { EPI_BF16 = 0, EPI_F32 = 1, EPI_RESID = 2, EPI_ROPE = 3 };    // EPI_ROPE: EPI_BF16 + rotate-half RoPE on the first rope_cols columns (128...320-row kernel only)
+enum Epi { EPI_BF16 = 0, EPI_F32 = 1, EPI_RESID = 2, EPI_ROPE = 3, EPI_SWIGLU = 4 };    // EPI_ROPE: EPI_BF16 + rotate-half RoPE on the first rope_cols columns (128...320-row kernel only)
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -344,55 +344,68 @@ __device__ __forceinline__ void store_tile_lds(const GemmArgs& p, f32x4_t (&acc)
   }
 }
 
-// Fused SwiGLU epilogue of the gate_up projection (Qwen2MLP.forward, modeling_qwen2.py:46-48; numerics of swiglu_fwd_kernel:
-// act = bf16(bf16(silu(gate)) * up) on the bf16-ROUNDED gate / up, i.e. bit-identical to the separate kernel).  Waves with
-// wn = 0,1 hold 128 x 64 gate values, the waves wn + 2 of the same row group the up values of the same hidden units.  Per
-// 32-row chunk every wave writes its bf16 strip and stores its own gu piece with 16-byte row-segment stores; after a
-// workgroup barrier the gate waves read their partner's strip next to their own and store the activation.
-__device__ __forceinline__ float silu_gemm(float g) { return g / (1.f + __expf(-g)); }
-#define SW_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+__device__ __forceinline__ float silu_gemm(float g) { return silu_train(g); }
 
-__device__ __forceinline__ void store_tile_swiglu(const GemmArgs& p, f32x4_t (&acc)[8][4], char* lds, int wave, int grp, int wn,
-                                                  int mbase, int hbase /* hidden-unit column of this wave's 64 */, int lane) {
-  char* strip = lds + wave * EP_STRIP;
-  const char* partner = lds + (wave + 2) * EP_STRIP;          // meaningful for the gate waves (wn < 2)
-  const bool gate = wn < 2;
-  const int cbase = gate ? hbase : p.swiglu_I + hbase;         // column of gu
+// SwiGLU in the epilogue of the 128 ... 320-row kernel (EPI_SWIGLU, round 4) WITHOUT any exchange between waves: the B tile's rows
+// 0..127 are 128 gate units and rows 128..255 the up projection of the SAME hidden units (Stager32's split_rows), and a wave's four
+// accumulator column blocks are gate units hbase .. hbase + 31 (blocks 0, 1) and their up partners (blocks 2, 3) -- gate and up of
+// a hidden unit sit in the same lane two blocks apart.  act = bf16(bf16(silu(bf16 gate)) * bf16 up) as swiglu_fwd_kernel computes
+// it; gu leaves through the wave's strip as two 64-byte pieces per row (gate | up), act as one.
+template <int MF>
+__device__ __forceinline__ void store_tile_swiglu_perm(const GemmArgs& p, f32x4_t (&acc)[MF][4], char* strip, int mbase, int hbase, int lane) {
+  constexpr int ACT_PITCH = 80;                               // 32 bf16 + 16 B: rows stay 16-byte aligned
+  char* astrip = strip + EP_ROWS * EP_PITCH_BF16;             // 4608 + 32 x 80 = 7168 B <= EP_STRIP
   bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
 #pragma unroll
-  for (int c = 0; c < 4; ++c) {
+  for (int c = 0; c < (MF + 1) / 2; ++c) {
+    const int rows_here = (2 * c + 1 < MF) ? 32 : 16;
 #pragma unroll
     for (int ii = 0; ii < 2; ++ii) {
+      if (2 * c + ii >= MF) break;
       const int row = ii * 16 + (lane & 15);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const f32x4_t v = acc[2 * c + ii][j];
-        uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
-        *reinterpret_cast<uint2*>(strip + row * EP_PITCH_BF16 + (j * 16 + (lane >> 4) * 4) * 2) = o;
+      for (int j = 0; j < 2; ++j) {
+        const f32x4_t gv = acc[2 * c + ii][j], uv = acc[2 * c + ii][j + 2];
+        float a[4];
+        uint32_t gb[4], ub[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          gb[k] = f2bf(gv[k]); ub[k] = f2bf(uv[k]);
+#if defined(UG_SWP_ABLATE) && (UG_SWP_ABLATE & 1)          // probe build: no silu arithmetic (wrong values)
+          a[k] = bf2f((bf16_t)gb[k]) * bf2f((bf16_t)ub[k]);
+#else
+          const float s = bf2f(f2bf(silu_gemm(bf2f((bf16_t)gb[k]))));
+          a[k] = s * bf2f((bf16_t)ub[k]);
+#endif
+        }
+        const int col = j * 16 + (lane >> 4) * 4;
+        *reinterpret_cast<uint2*>(strip + row * EP_PITCH_BF16 + col * 2) = make_uint2(gb[0] | (gb[1] << 16), gb[2] | (gb[3] << 16));
+        *reinterpret_cast<uint2*>(strip + row * EP_PITCH_BF16 + (32 + col) * 2) = make_uint2(ub[0] | (ub[1] << 16), ub[2] | (ub[3] << 16));
+        *reinterpret_cast<uint2*>(astrip + row * ACT_PITCH + col * 2) = make_uint2(pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3]));
       }
     }
-    SW_BARRIER();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < 4; ++q) {                             // gu: 32 rows x (4 gate + 4 up) 16-byte pieces
       const int row = q * 8 + (lane >> 3), ch = lane & 7;
       const int m = mbase + c * EP_ROWS + row;
-      const uint4 mine = *reinterpret_cast<const uint4*>(strip + row * EP_PITCH_BF16 + ch * 16);
-      if (m < p.M) *reinterpret_cast<uint4*>(C + (int64_t)m * p.ldc + cbase + ch * 8) = mine;
-      if (gate) {
-        const uint4 up = *reinterpret_cast<const uint4*>(partner + row * EP_PITCH_BF16 + ch * 16);
-        const uint32_t gw[4] = {mine.x, mine.y, mine.z, mine.w}, uw[4] = {up.x, up.y, up.z, up.w};
-        uint32_t ow[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float g0 = __uint_as_float(gw[e] << 16), g1 = __uint_as_float(gw[e] & 0xffff0000u);
-          const float u0 = __uint_as_float(uw[e] << 16), u1 = __uint_as_float(uw[e] & 0xffff0000u);
-          const float s0 = bf2f(f2bf(silu_gemm(g0))), s1 = bf2f(f2bf(silu_gemm(g1)));
-          ow[e] = pack_bf2(s0 * u0, s1 * u1);
-        }
-        if (m < p.M) *reinterpret_cast<uint4*>(p.act + (int64_t)m * p.ld_act + hbase + ch * 8) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
-      }
+      const uint4 v = *reinterpret_cast<const uint4*>(strip + row * EP_PITCH_BF16 + ch * 16);
+      const int gc = (ch >> 2) * p.swiglu_I + hbase + (ch & 3) * 8;
+      if (m < p.M && row < rows_here) *reinterpret_cast<uint4*>(C + (int64_t)m * p.ldc + gc) = v;
     }
-    SW_BARRIER();
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {                             // act: 32 rows x 4 pieces
+      const int row = q * 16 + (lane >> 2), ch = lane & 3;
+      const int m = mbase + c * EP_ROWS + row;
+      const uint4 v = *reinterpret_cast<const uint4*>(astrip + row * ACT_PITCH + ch * 16);
+#if defined(UG_SWP_ABLATE) && (UG_SWP_ABLATE & 2)          // probe build: act is not stored
+      if (m < p.M && row < rows_here && v.x == 0x12345678u)
+#else
+      if (m < p.M && row < rows_here)
+#endif
+        *reinterpret_cast<uint4*>(p.act + (int64_t)m * p.ld_act + hbase + ch * 8) = v;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
 }
 
@@ -635,8 +648,7 @@ __device__ __forceinline__ void p8_body(const GemmArgs& p, const int bid, char* 
 
   Stager32<AK> sa; Stager32<BKM> sb;
   sa.init(p.A, p.lda, m0, p.M, wave, lane);
-  if constexpr (EPI == EPI_BF16 && !AK && !BKM) sb.init(p.B, p.ldb, p.swiglu_I > 0 ? tn * 128 : n0, p.N, wave, lane, p.swiglu_I);
-  else sb.init(p.B, p.ldb, n0, p.N, wave, lane);
+  sb.init(p.B, p.ldb, n0, p.N, wave, lane);
 
   f32x4_t acc[8][4];
 #pragma unroll
@@ -802,12 +814,6 @@ __device__ __forceinline__ void p8_body(const GemmArgs& p, const int bid, char* 
     }
     return;
   }
-  if constexpr (EPI == EPI_BF16 && !AK && !BKM) {
-    if (p.swiglu_I > 0) {
-      store_tile_swiglu(p, acc, lds, wave, grp, wn, m0 + grp * 128, tn * 128 + (wn & 1) * 64, lane);
-      return;
-    }
-  }
   // interior column panel with 16-byte-addressable rows: wide stores through the (now idle) ring; ragged panels keep the
   // guarded element-wise form
   const bool wide = (n0 + PBN <= p.N) && p.wide_epilogue &&
@@ -905,7 +911,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p10(GemmArgs p) {
     asrc[i] = p.A + (int64_t)r * p.lda + swz_rowk32(row, lane & 3) * 8;
   }
   Stager32<BKM> sb;
-  sb.init(p.B, p.ldb, n0, p.N, wave, lane);
+  if constexpr (EPI == EPI_SWIGLU) sb.init(p.B, p.ldb, tn * 128, p.N, wave, lane, p.swiglu_I);      // rows 0..127 gate units, 128..255 their up rows
+  else sb.init(p.B, p.ldb, n0, p.N, wave, lane);
 
   f32x4_t acc[F0][4];
 #pragma unroll
@@ -945,7 +952,8 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p10(GemmArgs p) {
       for (int i = 0; i < FG; ++i) fa[i] = load_frag32<false>(tA, (G0 ? 0 : 16 * F0) + i * 16, lane);
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        fb[j] = load_frag32<BKM>(tB, EPI == EPI_ROPE ? (wn >> 1) * 128 + (wn & 1) * 32 + (j & 1) * 16 + (j >> 1) * 64 : wn * 64 + j * 16, lane);
+        fb[j] = load_frag32<BKM>(tB, EPI == EPI_ROPE ? (wn >> 1) * 128 + (wn & 1) * 32 + (j & 1) * 16 + (j >> 1) * 64
+                                     : EPI == EPI_SWIGLU ? (j >> 1) * 128 + wn * 32 + (j & 1) * 16 : wn * 64 + j * 16, lane);
       if constexpr (decltype(steady)::value) {
         stage_in(t + 3);
         landed(2);
@@ -964,7 +972,9 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p10(GemmArgs p) {
     for (; t + 4 < nk; ++t) iteration(t, std::true_type{});
     for (; t < nk; ++t) iteration(t, std::false_type{});
     if (G0) P_BARRIER();
-    if constexpr (EPI == EPI_ROPE)
+    if constexpr (EPI == EPI_SWIGLU)
+      store_tile_swiglu_perm<FG>(p, reinterpret_cast<f32x4_t (&)[FG][4]>(acc[0]), lds + wave * EP_STRIP, m0 + (G0 ? 0 : 16 * F0), tn * 128 + wn * 32, lane);
+    else if constexpr (EPI == EPI_ROPE)
       store_tile_lds<EPI, FG>(p, reinterpret_cast<f32x4_t (&)[FG][4]>(acc[0]), lds + wave * EP_STRIP, m0 + (G0 ? 0 : 16 * F0),
                               n0 + (wn >> 1) * 128 + (wn & 1) * 32, lane, (wn & 1) * 32, n0 < p.rope_cols);
     else
@@ -1279,7 +1289,7 @@ extern "C" int ug_gemm_bf16_swiglu(const ug_handle* h, const void* x, int64_t ld
   UG_REQUIRE(ug_aligned16(x) && ug_aligned16(w_gate_up) && ug_aligned16(gu) && ug_aligned16(act), "ug_gemm_bf16_swiglu: alignment");
   UG_REQUIRE(M < (1 << 30) && I < (1 << 29) && K < (1 << 30), "ug_gemm_bf16_swiglu: dims too large");
   const int64_t tiles = ((M + PBM - 1) / PBM) * (2 * I / PBN);
-  if (I % 128 != 0 || tiles < 200) {
+  if (I % 128 != 0 || tiles < 64 || K % PBK != 0 || 2 * I / PBN > (1 << 20)) {
     // shapes the 256x256 kernel is not chosen for: the projection and the activation as two launches (identical values)
     if (int rc = ug_gemm_bf16(h, x, ldx, 0, w_gate_up, ldw, 0, gu, ld_gu, M, 2 * I, K, EPI_BF16, nullptr, nullptr, 0, 0, nullptr, -1, stream))
       return rc;
@@ -1290,11 +1300,29 @@ extern "C" int ug_gemm_bf16_swiglu(const ug_handle* h, const void* x, int64_t ld
   a.A = (const bf16_t*)x; a.B = (const bf16_t*)w_gate_up; a.C = gu;
   a.M = (int)M; a.N = (int)(2 * I); a.K = (int)K;
   a.lda = ldx; a.ldb = ldw; a.ldc = ld_gu;
-  a.tiles_m = (int)((M + PBM - 1) / PBM); a.tiles_n = (int)(2 * I / PBN);
-  a.full_tiles = a.tiles_m * a.tiles_n; a.tail_split = 1; a.tail_private = 1; a.wide_epilogue = 1;
+  a.tail_split = 1; a.tail_private = 1; a.wide_epilogue = 1;
   a.swiglu_I = (int)I; a.act = (bf16_t*)act; a.ld_act = ld_act;
-  hipLaunchKernelGGL((gemm_kernel_p8<EPI_BF16, false, false>), dim3(a.full_tiles), dim3(512), 0, stream, a);
-  UG_CHECK_LAUNCH("ug_gemm_bf16_swiglu");
+  // round 4: the 128 ... 320-row kernel with gate and up of a hidden unit in one lane (EPI_SWIGLU); tile height by rounds(h) x t(h)
+  static const int heights[] = {128, 160, 192, 208, 224, 256, 288, 320};
+  int hb = 320; float best = 1e30f;
+  for (int h_ : heights) {
+    const int64_t wgs = ((M + h_ - 1) / h_) * (2 * I / PBN);
+    const float cost = (float)((wgs + 255) / 256) * (0.35f + 0.00254f * (float)h_);
+    if (cost < best) { best = cost; hb = h_; }
+  }
+  a.tiles_m = (int)((M + hb - 1) / hb); a.tiles_n = (int)(2 * I / PBN);
+  const dim3 grid(a.tiles_m * a.tiles_n), block(512);
+  switch (hb) {
+    case 320: hipLaunchKernelGGL((gemm_kernel_p10<EPI_SWIGLU, false, 10, 10>), grid, block, 0, stream, a); break;
+    case 288: hipLaunchKernelGGL((gemm_kernel_p10<EPI_SWIGLU, false, 9, 9>), grid, block, 0, stream, a); break;
+    case 256: hipLaunchKernelGGL((gemm_kernel_p10<EPI_SWIGLU, false, 8, 8>), grid, block, 0, stream, a); break;
+    case 224: hipLaunchKernelGGL((gemm_kernel_p10<EPI_SWIGLU, false, 7, 7>), grid, block, 0, stream, a); break;
+    case 208: hipLaunchKernelGGL((gemm_kernel_p10<EPI_SWIGLU, false, 7, 6>), grid, block, 0, stream, a); break;
+    case 192: hipLaunchKernelGGL((gemm_kernel_p10<EPI_SWIGLU, false, 6, 6>), grid, block, 0, stream, a); break;
+    case 160: hipLaunchKernelGGL((gemm_kernel_p10<EPI_SWIGLU, false, 5, 5>), grid, block, 0, stream, a); break;
+    default: hipLaunchKernelGGL((gemm_kernel_p10<EPI_SWIGLU, false, 4, 4>), grid, block, 0, stream, a); break;
+  }
+  UG_CHECK_LAUNCH("ug_gemm_bf16_swiglu(p10)");
   return UG_OK;
 }
 

@@ -92,17 +92,18 @@ def gemm(a, b, out=None, *, M=None, N=None, K=None, a_kmajor=False, b_kmajor=Fal
     return out
 
 
-# Off by default: measured on one box, interleaved (bench.py, 8 steps): 156.21 / 156.36 ms fused vs 156.43 / 156.22 ms as two
-# launches, with the GEMM launches 4 ms per step longer -- the 256x256 kernel owns its CU, so whatever its epilogue does is
-# serial time; the separate HBM-bound kernel costs the same.  UNIGEN_FUSED_SWIGLU=1 enables it (bit-identical values).
-FUSED_SWIGLU = __import__("os").environ.get("UNIGEN_FUSED_SWIGLU", "0") == "1"
+# On since round 4 (UNIGEN_FUSED_SWIGLU=0: two launches): the 128 ... 320-row kernel keeps gate and up of a hidden unit in one lane
+# (permuted weight rows), so the activation is register arithmetic in the epilogue with no exchange between waves: per layer 611 ->
+# 561 us for projection + activation, step -0.95 ms, forward + backward -0.8 ... -1.2 ms (two A/B pairs; values bit-identical to the
+# two-launch form).  Round 3's form on the 256x256 kernel (partner strips + workgroup barriers) had cost +1.8 ms per step.
+FUSED_SWIGLU = __import__("os").environ.get("UNIGEN_FUSED_SWIGLU", "1") == "1"
 
 
 def gemm_swiglu(x, w_gate_up):
     """x bf16 [M, K], fused weight bf16 [2I, K] (gate rows | up rows) -> (gu bf16 [M, 2I], act bf16 [M, I]): the gate_up
     projection with the SwiGLU activation written by its epilogue (include/unigen_hip.h: ug_gemm_bf16_swiglu)."""
     _need_cuda(x, w_gate_up)
-    if not FUSED_SWIGLU:                      # default: projection and activation as two launches (see FUSED_SWIGLU above)
+    if not FUSED_SWIGLU or GEMM_POLICY != -1:  # (a pinned tile policy applies to the two-launch form)
         gu = gemm(x, w_gate_up)
         return gu, swiglu_fwd(gu)
     M, K = x.shape

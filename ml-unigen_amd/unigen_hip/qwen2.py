@@ -216,7 +216,7 @@ class Qwen2Engine:
         o, lse = ops.attn_fwd(qkv, mb, Hq, Hk, hd)
         h_mid = ops.gemm_nt(o, fp.w(f"l{i}.wo"), epilogue=ops.UG_EPI_RESID, resid=h)
         xn2, rstd2 = ops.rmsnorm_fwd(h_mid, fp.p(f"l{i}.ln2"), d.rms_norm_eps)
-        gu, act = ops.gemm_swiglu(xn2, fp.w(f"l{i}.wgu"))           # projection + SwiGLU (one launch with UNIGEN_FUSED_SWIGLU=1)
+        gu, act = ops.gemm_swiglu(xn2, fp.w(f"l{i}.wgu"))           # projection + SwiGLU in its epilogue (one launch; UNIGEN_FUSED_SWIGLU=0: two)
         h_out = ops.gemm_nt(act, fp.w(f"l{i}.wdown"), epilogue=ops.UG_EPI_RESID, resid=h_mid)
         if save is not None:
             s = _Saved()

@@ -1428,16 +1428,21 @@ def test_siglip_fused_attention_matches_fp64(dev, B, T, H, hd):
         assert err < 3e-6, (mag, err)
 
 
-@pytest.mark.parametrize("M,I,K", [(12336, 8960, 1536), (4000, 4096, 512), (771, 512, 256), (300, 8960, 1536), (5000, 1000, 128)])
+@pytest.mark.parametrize("M,I,K", [(12336, 8960, 1536), (4000, 4096, 512), (771, 512, 256), (300, 8960, 1536), (5000, 1000, 128), (9288, 8960, 64),
+                                   (1542, 1024, 96), (200, 2048, 40)])
 def test_gemm_swiglu_fused_epilogue_is_bit_identical(dev, M, I, K):
-    """ug_gemm_bf16_swiglu (gate_up projection whose epilogue also writes act = bf16(bf16(silu(gate)) * up); a 256x256 tile =
-    128 gate + the same hidden units' 128 up weight rows) against the two-launch form GEMM -> ug_swiglu_fwd: gu and act
-    bit-identical -- fused path (first two shapes: >= 200 tiles, ragged M) and the fallback shapes alike."""
+    """ug_gemm_bf16_swiglu (gate_up projection whose epilogue also writes act = bf16(bf16(silu(gate)) * up); a 128 ... 320 x 256 tile =
+    128 gate + the same hidden units' 128 up weight rows, gate and up of a unit in one lane) against the two-launch form GEMM ->
+    ug_swiglu_fwd: gu and act bit-identical -- fused path (ragged M, several tile heights) and the fallback shapes alike."""
     ops = _ops()
     g = torch.Generator(device=dev).manual_seed(M + I)
     x = (torch.randn(M, K, device=dev, generator=g)).to(torch.bfloat16)
     w = (torch.randn(2 * I, K, device=dev, generator=g) * (K ** -0.5)).to(torch.bfloat16)
-    gu_ref = ops.gemm(x, w)
+    ops.set_gemm_tile_policy(3)                     # the reference GEMM on the 256 x 256 kernel: another kernel, the same values
+    try:
+        gu_ref = ops.gemm(x, w)
+    finally:
+        ops.set_gemm_tile_policy(-1)
     act_ref = ops.swiglu_fwd(gu_ref)
     was, ops.FUSED_SWIGLU = ops.FUSED_SWIGLU, True
     try:
