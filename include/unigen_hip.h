@@ -72,6 +72,13 @@ int ug_gemm_bf16(const ug_handle* h, const void* A, int64_t lda, int a_kmajor, c
 
 int ug_cast_f32_bf16(const float* in, void* out, int64_t n, hipStream_t stream);
 
+/* The down projection's dgrad with the SwiGLU backward in its epilogue (autograd of Qwen2MLP.forward, modeling_qwen2.py:46-48, under bf16
+ * autocast; reference call site models/unigen.py:274-285 through loss.backward(), training/train.py:775): dgu[M, 2I] = d(gate | up) from
+ * dy[M, K] (gradient of the down projection's output), W_down stored [K, I] (row stride ldw) and the forward's gu[M, 2I] -- the values of
+ * ug_gemm_bf16 (B k-major) followed by ug_swiglu_bwd, bit for bit; d(act) never reaches HBM.  Needs I % 256 == 0, K % 32 == 0 and 16-byte
+ * aligned rows; other shapes are refused (UG_ERR_ARG) and run as those two launches.  ABI v5. */
+int ug_gemm_bf16_swiglu_bwd(const ug_handle* h, const void* dy, int64_t ld_dy, const void* w_down, int64_t ldw, const void* gu,
+                            int64_t ld_gu, void* dgu, int64_t ld_dgu, int64_t M, int64_t I, int64_t K, hipStream_t stream);
 /* The fused q/k/v projection of a decoder layer (transformers modeling_qwen2.py:200-215 q_proj / k_proj / v_proj + apply_rotary_pos_emb
  * :131-135; reference call site models/unigen.py:274-285): qkv[M, N] = bf16(x[M, K] W[N, K]^T + bias) with rotate-half RoPE (tables
  * [L, head_dim / 2] fp32, row m at position m % L) applied in the GEMM's epilogue to the first rope_cols columns (the q and k heads) --

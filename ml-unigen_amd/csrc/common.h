@@ -88,6 +88,21 @@ __device__ __forceinline__ float silu_train(float g) {
   return (d > 3.0e38f) ? g * 0.f : v;
 }
 
+// One element of the SwiGLU backward (autograd of act = bf16(bf16(silu(gate)) * up) under bf16 autocast, Qwen2MLP.forward,
+// modeling_qwen2.py:46-48): shared by swiglu_bwd_kernel and the down-projection dgrad's epilogue (EPI_SWIGLU_BWD) with contraction off,
+// so the fused and the two-launch forms are bit-identical to each other.  sigmoid = rcp + one Newton step (divisor in [1, inf)).
+__device__ __forceinline__ void swiglu_bwd_elem(float gf, float uf, float df, float& dgate, float& dup) {
+#pragma clang fp contract(off)
+  const float d = 1.f + __expf(-gf);
+  const float y0 = __builtin_amdgcn_rcpf(d);
+  const float y1 = __builtin_fmaf(y0, __builtin_fmaf(-d, y0, 1.f), y0);
+  const float sg = (d > 3.0e38f) ? 0.f : y1;
+  const float s = bf2f(f2bf(gf * sg));                    // bf16 silu output saved by autograd
+  const float dsilu = bf2f(f2bf(df * uf));                // grad wrt silu output (bf16 mul backward)
+  dup = df * s;
+  dgate = dsilu * (sg * (1.f + gf * (1.f - sg)));
+}
+
 // ---------------------------------------------------------------- wave reductions (64 lanes)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -275,12 +275,10 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restric
     bf16x8_t og, ou;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const float gf = bf2f((bf16_t)g[k]), uf = bf2f((bf16_t)u[k]), df = bf2f((bf16_t)d[k]);
-      const float sg = 1.f / (1.f + __expf(-gf));
-      const float s = bf2f(f2bf(gf * sg));                    // bf16 silu output saved by autograd
-      const float dsilu = bf2f(f2bf(df * uf));                // grad wrt silu output (bf16 mul backward)
-      ou[k] = (short)f2bf(df * s);
-      og[k] = (short)f2bf(dsilu * (sg * (1.f + gf * (1.f - sg))));
+      float dg_, du_;
+      swiglu_bwd_elem(bf2f((bf16_t)g[k]), bf2f((bf16_t)u[k]), bf2f((bf16_t)d[k]), dg_, du_);      // (common.h: shared with the dgrad epilogue)
+      ou[k] = (short)f2bf(du_);
+      og[k] = (short)f2bf(dg_);
     }
     st_stream<NT>(reinterpret_cast<bf16x8_t*>(dgu + t * 2 * I + c), og);
     st_stream<NT>(reinterpret_cast<bf16x8_t*>(dgu + t * 2 * I + I + c), ou);

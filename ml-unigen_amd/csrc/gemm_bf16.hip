@@ -56,7 +56,7 @@ constexpr int P8_GROUP_M = UG_P8_GROUP_M;    // row panels per column sweep of t
                                              // K = 1536 launch stay in an XCD's 4 MB L2 while its 32 workgroups walk the columns
                                              // (8: 8192^3 1325 -> 1385, gate_up forward / weight gradients +1..2 %; probe builds override it)
 
-enum Epi { EPI_BF16 = 0, EPI_F32 = 1, EPI_RESID = 2, EPI_ROPE = 3, EPI_SWIGLU = 4 };    // EPI_ROPE: EPI_BF16 + rotate-half RoPE on the first rope_cols columns (128...320-row kernel only)
+enum Epi { EPI_BF16 = 0, EPI_F32 = 1, EPI_RESID = 2, EPI_ROPE = 3, EPI_SWIGLU = 4, EPI_SWIGLU_BWD = 5 };    // EPI_ROPE: EPI_BF16 + rotate-half RoPE on the first rope_cols columns (128...320-row kernel only)
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -72,6 +72,7 @@ struct GemmArgs {
   int M, N, K;
   int64_t lda, ldb, ldc, ldr;
   int beta;                // EPI_F32: 1 => C += acc
+  const bf16_t* sw_gu; int64_t ld_gu;      // EPI_SWIGLU_BWD: the forward's gate | up [M, 2 * swiglu_I] (C = d(gate | up))
   const float* rope_cos; const float* rope_sin; int rope_L, rope_cols;     // EPI_ROPE: tables [rope_L, 64] fp32, row m sits at position m % rope_L
   int tiles_m, tiles_n;
   // staggered kernel, partial last round: the first `full_tiles` tiles run whole, every remaining tile is cut into
@@ -404,6 +405,85 @@ __device__ __forceinline__ void store_tile_swiglu_perm(const GemmArgs& p, f32x4_
       if (m < p.M && row < rows_here)
 #endif
         *reinterpret_cast<uint4*>(p.act + (int64_t)m * p.ld_act + hbase + ch * 8) = v;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
+// SwiGLU backward in the epilogue of the down projection's dgrad (EPI_SWIGLU_BWD, round 4): the tile is d(act) for 256 hidden units;
+// it is rounded to bf16 (what the two-launch form stores), turned through the wave's strip into 16-byte row pieces, and each lane
+// combines its 8 values with the forward's gate and up values of the same units (two 16-byte loads) into d(gate) and d(up) -- two
+// 16-byte stores into d(gate | up).  d(act) itself never reaches HBM and the swiglu_bwd pass (1.1 GB per layer) disappears.
+// The gate / up loads of chunk c + 1 are issued before chunk c is processed; they are inline assembly with hand-counted waits
+// (loads and stores in flight together make hipcc drain vmcnt(0), see adamw_lean2_kernel): at most the 8 loads of the next chunk
+// may be outstanding when a chunk's operands are used, which also retires the previous chunk's stores.
+typedef unsigned int gu4_t __attribute__((ext_vector_type(4)));
+template <int MF>
+__device__ __forceinline__ void store_tile_swiglu_bwd(const GemmArgs& p, f32x4_t (&acc)[MF][4], char* strip, int mbase, int nbase, int lane) {
+  constexpr int NCH = (MF + 1) / 2;
+  bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
+  const int I = p.swiglu_I;
+  gu4_t gq[2][4], uq[2][4];
+  auto fetch = [&](int c, gu4_t (&g)[4], gu4_t (&u)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = q * 8 + (lane >> 3), ch = lane & 7;
+      const int m = min(mbase + c * EP_ROWS + row, p.M - 1);
+      const bf16_t* gp = p.sw_gu + (int64_t)m * p.ld_gu + nbase + ch * 8;
+#if defined(UG_SWB_ABLATE) && (UG_SWB_ABLATE & 2)          // probe build: no gate / up loads (wrong values)
+      g[q] = gu4_t{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}; u[q] = g[q]; (void)gp;
+#else
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(g[q]) : "v"(gp) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(u[q]) : "v"(gp + I) : "memory");
+#endif
+    }
+  };
+  fetch(0, gq[0], uq[0]);
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int rows_here = (2 * c + 1 < MF) ? 32 : 16;
+    gu4_t (&g)[4] = gq[c & 1];
+    gu4_t (&u)[4] = uq[c & 1];
+    if (c + 1 < NCH) fetch(c + 1, gq[(c + 1) & 1], uq[(c + 1) & 1]);
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii) {
+      if (2 * c + ii >= MF) break;
+      const int row = ii * 16 + (lane & 15);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4_t v = acc[2 * c + ii][j];
+        *reinterpret_cast<uint2*>(strip + row * EP_PITCH_BF16 + (j * 16 + (lane >> 4) * 4) * 2) = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]));
+      }
+    }
+    if (c + 1 < NCH)
+      asm volatile("s_waitcnt vmcnt(8)" : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]), "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]) : : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(g[0]), "+v"(g[1]), "+v"(g[2]), "+v"(g[3]), "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]) : : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = q * 8 + (lane >> 3), ch = lane & 7;
+      const int m = mbase + c * EP_ROWS + row;
+      const uint4 dv = *reinterpret_cast<const uint4*>(strip + row * EP_PITCH_BF16 + ch * 16);
+      const uint32_t dw[4] = {dv.x, dv.y, dv.z, dv.w};
+      uint32_t og[4], ou[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float g0, g1, u0, u1;
+#if defined(UG_SWB_ABLATE) && (UG_SWB_ABLATE & 1)          // probe build: no arithmetic (wrong values)
+        g0 = __uint_as_float(dw[e] << 16) + __uint_as_float(g[q][e] << 16); g1 = __uint_as_float(dw[e] & 0xffff0000u);
+        u0 = __uint_as_float(u[q][e] << 16); u1 = g1;
+#else
+        swiglu_bwd_elem(__uint_as_float(g[q][e] << 16), __uint_as_float(u[q][e] << 16), __uint_as_float(dw[e] << 16), g0, u0);
+        swiglu_bwd_elem(__uint_as_float(g[q][e] & 0xffff0000u), __uint_as_float(u[q][e] & 0xffff0000u), __uint_as_float(dw[e] & 0xffff0000u), g1, u1);
+#endif
+        og[e] = pack_bf2(g0, g1); ou[e] = pack_bf2(u0, u1);
+      }
+      if (m < p.M && row < rows_here) {
+        bf16_t* cp = C + (int64_t)m * p.ldc + nbase + ch * 8;
+        *reinterpret_cast<uint4*>(cp) = make_uint4(og[0], og[1], og[2], og[3]);
+        *reinterpret_cast<uint4*>(cp + I) = make_uint4(ou[0], ou[1], ou[2], ou[3]);
+      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
@@ -972,7 +1052,9 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p10(GemmArgs p) {
     for (; t + 4 < nk; ++t) iteration(t, std::true_type{});
     for (; t < nk; ++t) iteration(t, std::false_type{});
     if (G0) P_BARRIER();
-    if constexpr (EPI == EPI_SWIGLU)
+    if constexpr (EPI == EPI_SWIGLU_BWD)
+      store_tile_swiglu_bwd<FG>(p, reinterpret_cast<f32x4_t (&)[FG][4]>(acc[0]), lds + wave * EP_STRIP, m0 + (G0 ? 0 : 16 * F0), n0 + wn * 64, lane);
+    else if constexpr (EPI == EPI_SWIGLU)
       store_tile_swiglu_perm<FG>(p, reinterpret_cast<f32x4_t (&)[FG][4]>(acc[0]), lds + wave * EP_STRIP, m0 + (G0 ? 0 : 16 * F0), tn * 128 + wn * 32, lane);
     else if constexpr (EPI == EPI_ROPE)
       store_tile_lds<EPI, FG>(p, reinterpret_cast<f32x4_t (&)[FG][4]>(acc[0]), lds + wave * EP_STRIP, m0 + (G0 ? 0 : 16 * F0),
@@ -1375,5 +1457,46 @@ extern "C" int ug_gemm_bf16_qkv_rope(const ug_handle* h, const void* x, int64_t 
     default: hipLaunchKernelGGL((gemm_kernel_p10<EPI_ROPE, false, 4, 4>), grid, block, 0, stream, a); break;
   }
   UG_CHECK_LAUNCH("ug_gemm_bf16_qkv_rope");
+  return UG_OK;
+}
+
+
+// The down projection's dgrad with the SwiGLU backward in its epilogue (EPI_SWIGLU_BWD above): dgu[M, 2I] = swiglu_bwd(gu, dy W_down)
+// -- the values of ug_gemm_bf16 (B k-major) followed by ug_swiglu_bwd, bit for bit, without d(act) in HBM.  Shapes the kernel does
+// not cover (I % 256, K % 32, unaligned rows) are refused with UG_ERR_ARG: the caller runs the two launches (it owns the d(act) buffer).
+extern "C" int ug_gemm_bf16_swiglu_bwd(const ug_handle* h, const void* dy, int64_t ld_dy, const void* w_down, int64_t ldw, const void* gu,
+                                       int64_t ld_gu, void* dgu, int64_t ld_dgu, int64_t M, int64_t I, int64_t K, hipStream_t stream) {
+  (void)h;
+  UG_REQUIRE(M > 0 && I > 0 && K > 0 && M < (1 << 30) && I < (1 << 29) && K < (1 << 30), "ug_gemm_bf16_swiglu_bwd: bad problem M=%ld I=%ld K=%ld", (long)M, (long)I, (long)K);
+  UG_REQUIRE(I % PBN == 0 && K % PBK == 0 && I / PBN <= (1 << 20), "ug_gemm_bf16_swiglu_bwd: fused form needs I %% 256 == 0 and K %% 32 == 0 (I=%ld K=%ld): run ug_gemm_bf16 + ug_swiglu_bwd", (long)I, (long)K);
+  UG_REQUIRE(ld_dy % 8 == 0 && ldw % 8 == 0 && ld_gu % 8 == 0 && ld_dgu % 8 == 0 && ld_dy >= K && ldw >= I && ld_gu >= 2 * I && ld_dgu >= 2 * I,
+             "ug_gemm_bf16_swiglu_bwd: row strides must be multiples of 8 elements and cover the rows");
+  UG_REQUIRE(ug_aligned16(dy) && ug_aligned16(w_down) && ug_aligned16(gu) && ug_aligned16(dgu), "ug_gemm_bf16_swiglu_bwd: alignment");
+  GemmArgs a{};
+  a.A = (const bf16_t*)dy; a.B = (const bf16_t*)w_down; a.C = dgu;
+  a.M = (int)M; a.N = (int)I; a.K = (int)K; a.lda = ld_dy; a.ldb = ldw; a.ldc = ld_dgu;
+  a.sw_gu = (const bf16_t*)gu; a.ld_gu = ld_gu; a.swiglu_I = (int)I;
+  a.tail_split = 1; a.tail_private = 1; a.wide_epilogue = 1;
+  static const int heights[] = {128, 160, 192, 208, 224, 256, 272, 288, 320};
+  int hb = 320; float best = 1e30f;
+  for (int h_ : heights) {
+    const int64_t wgs = ((M + h_ - 1) / h_) * (I / PBN);
+    const float cost = (float)((wgs + 255) / 256) * (0.35f + 0.00254f * (float)h_);
+    if (cost < best) { best = cost; hb = h_; }
+  }
+  a.tiles_m = (int)((M + hb - 1) / hb); a.tiles_n = (int)(I / PBN);
+  const dim3 grid(a.tiles_m * a.tiles_n), block(512);
+  switch (hb) {
+    case 320: hipLaunchKernelGGL((gemm_kernel_p10<EPI_SWIGLU_BWD, true, 10, 10>), grid, block, 0, stream, a); break;
+    case 288: hipLaunchKernelGGL((gemm_kernel_p10<EPI_SWIGLU_BWD, true, 9, 9>), grid, block, 0, stream, a); break;
+    case 272: hipLaunchKernelGGL((gemm_kernel_p10<EPI_SWIGLU_BWD, true, 9, 8>), grid, block, 0, stream, a); break;
+    case 256: hipLaunchKernelGGL((gemm_kernel_p10<EPI_SWIGLU_BWD, true, 8, 8>), grid, block, 0, stream, a); break;
+    case 224: hipLaunchKernelGGL((gemm_kernel_p10<EPI_SWIGLU_BWD, true, 7, 7>), grid, block, 0, stream, a); break;
+    case 208: hipLaunchKernelGGL((gemm_kernel_p10<EPI_SWIGLU_BWD, true, 7, 6>), grid, block, 0, stream, a); break;
+    case 192: hipLaunchKernelGGL((gemm_kernel_p10<EPI_SWIGLU_BWD, true, 6, 6>), grid, block, 0, stream, a); break;
+    case 160: hipLaunchKernelGGL((gemm_kernel_p10<EPI_SWIGLU_BWD, true, 5, 5>), grid, block, 0, stream, a); break;
+    default: hipLaunchKernelGGL((gemm_kernel_p10<EPI_SWIGLU_BWD, true, 4, 4>), grid, block, 0, stream, a); break;
+  }
+  UG_CHECK_LAUNCH("ug_gemm_bf16_swiglu_bwd");
   return UG_OK;
 }

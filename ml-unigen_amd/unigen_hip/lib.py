@@ -25,6 +25,7 @@ SIGNATURES = {
     "ug_destroy": [P],
     "ug_gemm_bf16": [P, P, I64, I32, P, I64, I32, P, I64, I64, I64, I64, I32, P, P, I64, I32, P, I32, P],
     "ug_gemm_bf16_qkv_rope": [P, P, I64, P, I64, P, P, I64, I64, I64, I64, P, P, I64, I64, I32, P],
+    "ug_gemm_bf16_swiglu_bwd": [P, P, I64, P, I64, P, I64, P, I64, I64, I64, I64, P],
     "ug_gemm_bf16_swiglu": [P, P, I64, P, I64, P, I64, P, I64, I64, I64, I64, P],
     "ug_cast_f32_bf16": [P, P, I64, P],
     "ug_rmsnorm_fwd": [P, P, P, P, I64, I64, F32, I32, P],

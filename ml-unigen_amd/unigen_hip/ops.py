@@ -299,6 +299,34 @@ def swiglu_fwd(gu):
     return act
 
 
+FUSED_SWIGLU_BWD = __import__("os").environ.get("UNIGEN_FUSED_SWIGLU_BWD", "1") == "1"
+
+
+def gemm_swiglu_bwd(dy, w_down, gu):
+    """dy bf16 [M, K] (gradient of the down projection's output), w_down bf16 [K, I] (the down weight as stored: the dgrad reads it
+    k-major), gu bf16 [M, 2I] (the forward's gate | up) -> dgu bf16 [M, 2I]: the down projection's dgrad with the SwiGLU backward in
+    its epilogue (include/unigen_hip.h: ug_gemm_bf16_swiglu_bwd) -- the values of gemm(dy, w_down, b_kmajor=True) + swiglu_bwd, bit
+    for bit; shapes the fused kernel does not cover, a pinned tile policy and UNIGEN_FUSED_SWIGLU_BWD=0 take the two launches."""
+    _need_cuda(dy, w_down, gu)
+    M, K = dy.shape
+    I = gu.shape[1] // 2
+    ok = (FUSED_SWIGLU_BWD and GEMM_POLICY == -1 and I % 256 == 0 and K % 32 == 0 and w_down.shape == (K, I)
+          and dy.stride(0) % 8 == 0 and w_down.stride(0) % 8 == 0 and gu.stride(0) % 8 == 0)
+    if not ok:
+        return swiglu_bwd(gu, gemm(dy, w_down, b_kmajor=True))
+    dgu = torch.empty_like(gu)
+    prof = GEMM_PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _l.check(_l.load().ug_gemm_bf16_swiglu_bwd(_handle(), _p(dy), dy.stride(0), _p(w_down), w_down.stride(0), _p(gu), gu.stride(0),
+                                                _p(dgu), dgu.stride(0), M, I, K, _stream()), "ug_gemm_bf16_swiglu_bwd")
+    if prof is not None:
+        e1.record()
+        prof.append((e0, e1, 2.0 * M * I * K))
+    return dgu
+
+
 def swiglu_bwd(gu, dact):
     dgu = torch.empty_like(gu)
     _l.check(_l.load().ug_swiglu_bwd(_p(gu), _p(dact), _p(dgu), gu.shape[0], gu.shape[1] // 2, _stream()),

@@ -292,8 +292,7 @@ class Qwen2Engine:
         wg = lambda key, dy, x: (dy, x, fp.g(key), fp.beta_for(key))
         dyd = dh_bf16 if dh_bf16 is not None else ops.cast_bf16(dh)
         w_down = wg(f"l{i}.wdown", dyd, s.act)
-        dact = ops.gemm(dyd, fp.w(f"l{i}.wdown"), b_kmajor=True)
-        dgu = ops.swiglu_bwd(s.gu, dact)
+        dgu = ops.gemm_swiglu_bwd(dyd, fp.w(f"l{i}.wdown"), s.gu)          # down dgrad + SwiGLU backward in its epilogue: d(act) never stored
         w_gu = wg(f"l{i}.wgu", dgu, s.xn2)
         dxn2 = ops.gemm(dgu, fp.w(f"l{i}.wgu"), b_kmajor=True)
         dyo = ops.rmsnorm_bwd(dxn2, s.h_mid, s.rstd2, fp.p(f"l{i}.ln2"), dh, fp.g(f"l{i}.ln2"), want_bf16=True)

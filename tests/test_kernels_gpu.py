@@ -161,6 +161,32 @@ def test_gemm_qkv_rope_is_gemm_then_rope(dev, M, L, N, rope_heads, K):
     assert torch.equal(nob, ops.rope_(ops.gemm(x, w), cos, sin, L, rope_heads, hd))
 
 
+@pytest.mark.parametrize("M,I,K", [(12336, 8960, 1536), (9288, 8960, 64), (771, 512, 256), (1542, 1024, 96), (200, 2048, 32), (4000, 1000, 128),
+                                   (3084, 768, 160), (64, 256, 40)])
+def test_gemm_swiglu_bwd_fused_epilogue_is_bit_identical(dev, M, I, K):
+    """`ug_gemm_bf16_swiglu_bwd` (the down projection's dgrad whose epilogue turns d(act) into d(gate | up), round 4) against
+    gemm(dy, W_down k-major) + `ug_swiglu_bwd`: bit-identical d(gate | up) -- fused shapes over several tile heights with ragged
+    last row tiles, and the shapes that take the two launches (I % 256 != 0, K % 32 != 0); and against fp32 autograd on the host."""
+    ops = _ops()
+    g = torch.Generator(device=dev).manual_seed(M + I + K)
+    dy = (torch.randn(M, K, device=dev, generator=g) * 0.5).to(torch.bfloat16)
+    wd = (torch.randn(K, I, device=dev, generator=g) * (K ** -0.5)).to(torch.bfloat16)
+    gu = (torch.randn(M, 2 * I, device=dev, generator=g) * 2).to(torch.bfloat16)
+    gu[0, :8] = torch.tensor([-200.0, -90.0, 90.0, 200.0, 0.0, -0.0, 1e-30, -1e-30], device=dev).to(torch.bfloat16)     # exp overflow / zeros
+    ops.set_gemm_tile_policy(3)                      # the reference path on the 256 x 256 kernel
+    try:
+        want = ops.swiglu_bwd(gu, ops.gemm(dy, wd, b_kmajor=True))
+    finally:
+        ops.set_gemm_tile_policy(-1)
+    got = ops.gemm_swiglu_bwd(dy, wd, gu)
+    assert got.shape == (M, 2 * I) and torch.equal(got, want) and torch.isfinite(got.float()).all()
+    if M <= 1542:                                                                    # autograd of the bf16-op chain in fp32 on the host
+        dact = (dy.float().cpu() @ wd.float().cpu()).to(torch.bfloat16).float()
+        g32 = gu.float().cpu().clone().requires_grad_(True)
+        (F.silu(g32[:, :I]) * g32[:, I:]).backward(dact)
+        assert _rel(got[1:].float().cpu(), g32.grad[1:]) < 1.2e-2
+
+
 def test_gemm_bf16_long_contraction_slices_up_to_199_tiles(dev):
     """132 output tiles of 256 x 256 with a 65 528-long contraction (the pt1 mixed batch's lm-head dgrad has 174 with K = 159 867):
     the automatic selection cuts every tile along K into private fp32 partials (round 4: up to 199 tiles, was 128) -- against
