@@ -604,13 +604,13 @@ def main():
         # contains the gradient exchange -- and rank 0 records
         from unigen_hip import lib as ug_lib
         if rank == 0:
-            ops.GEMM_PROFILE = []
+            ops.GEMM_PROFILE, ops.GEMM_PROFILE_FUSED = [], []
         step()
         torch.cuda.synchronize()
         # ... and one with events around EVERY library launch, filed by family (a separate step: nested inside the GEMM events
         # above, the second pair of event records per launch cost the GEMM figure 2-3 ms per step)
-        rec_gemm = ops.GEMM_PROFILE
-        ops.GEMM_PROFILE = None
+        rec_gemm, rec_fused = ops.GEMM_PROFILE, set(ops.GEMM_PROFILE_FUSED or [])
+        ops.GEMM_PROFILE, ops.GEMM_PROFILE_FUSED = None, None
         if rank == 0:
             ug_lib.PROFILE = {}
         step()
@@ -638,6 +638,18 @@ def main():
                 "launches_per_step": len(rec), "avg_launch_ms": round(tot_ms / len(rec), 4),
                 "flops_per_launch": round(tot_fl / len(rec) / 1e9, 2), "gemm_ms_per_step": round(tot_ms, 2),
                 "step_frac_of_bf16_peak": round(value / world * FLOP_SAMPLE / PEAK_BF16, 4)}
+        # since round 4 three launches per layer carry element-wise work in their epilogue (q/k/v + RoPE, gate_up + SwiGLU, down dgrad +
+        # SwiGLU backward: ~5 ms per step that used to be separate HBM-bound kernels): `frac` above counts their whole duration
+        # against their MFMA flops; the same ratio over the launches WITHOUT such an epilogue is reported next to it
+        if rec_fused:
+            p_ms = sum(e0.elapsed_time(e1) for i, (e0, e1, _) in enumerate(rec) if i not in rec_fused)
+            p_fl = sum(f for i, (_, _, f) in enumerate(rec) if i not in rec_fused)
+            f_ms = tot_ms - p_ms
+            roof["plain_launches"] = {"launches": len(rec) - len(rec_fused), "ms_per_step": round(p_ms, 2), "achieved": round(p_fl / (p_ms * 1e-3) / 1e12, 1),
+                                      "frac": round(p_fl / (p_ms * 1e-3) / 1e12 / 2500.0, 4)}
+            roof["fused_epilogue_launches"] = {"launches": len(rec_fused), "ms_per_step": round(f_ms, 2), "achieved": round((tot_fl - p_fl) / (f_ms * 1e-3) / 1e12, 1),
+                                               "frac": round((tot_fl - p_fl) / (f_ms * 1e-3) / 1e12 / 2500.0, 4),
+                                               "what": "q/k/v projection + RoPE, gate_up + SwiGLU, down dgrad + SwiGLU backward: element-wise passes of rounds 1-3 (~11 ms per step) now inside these launches"}
         # launch time by kernel family in the same instrumented step (HIP events around every library launch, on the launch
         # stream) against each family's own bound; algorithmic work per step from SURVEY.md section 8d
         fam_ms = {k: sum(e0.elapsed_time(e1) for e0, e1, _ in v) for k, v in (fam_rec or {}).items()}

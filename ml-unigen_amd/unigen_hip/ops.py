@@ -12,6 +12,7 @@ _MASK_DTYPES = {torch.float32: 0, torch.bfloat16: 1, torch.int64: 2, torch.bool:
 
 # bench.py sets this to a list to time every GEMM launch with HIP events on the launch stream
 GEMM_PROFILE = None
+GEMM_PROFILE_FUSED = None     # with GEMM_PROFILE: indices of the launches whose epilogue carries element-wise work (RoPE, SwiGLU forward / backward)
 
 
 def _stream():
@@ -119,6 +120,8 @@ def gemm_swiglu(x, w_gate_up):
     if prof is not None:
         e1.record()
         prof.append((e0, e1, 2.0 * M * 2 * I * K))
+        if GEMM_PROFILE_FUSED is not None:
+            GEMM_PROFILE_FUSED.append(len(prof) - 1)
     return gu, act
 
 
@@ -289,6 +292,8 @@ def gemm_qkv_rope(x, w, bias, cos, sin, L, nheads, head_dim):
     if prof is not None:
         e1.record()
         prof.append((e0, e1, 2.0 * M * N * K))
+        if GEMM_PROFILE_FUSED is not None:
+            GEMM_PROFILE_FUSED.append(len(prof) - 1)
     return qkv
 
 
@@ -324,6 +329,8 @@ def gemm_swiglu_bwd(dy, w_down, gu):
     if prof is not None:
         e1.record()
         prof.append((e0, e1, 2.0 * M * I * K))
+        if GEMM_PROFILE_FUSED is not None:
+            GEMM_PROFILE_FUSED.append(len(prof) - 1)
     return dgu
 
 

@@ -24,13 +24,23 @@ which = sys.argv[1] if len(sys.argv) > 1 else "all"      # "layers" | "head" | "
 ops._handle()                                            # the stream's workspace exists before the counted launches
 torch.cuda.synchronize()
 if which in ("layers", "all"):
+    cos, sin = ops.rope_tables(771, 128, 1e6, dev)
+    bq = torch.zeros(2048, dtype=torch.bfloat16, device=dev)
+    gu_saved = torch.randn(M, 17920, device=dev).to(torch.bfloat16)
     for name, (x, w, dy, gw) in zip(shapes, bufs):
+        # forward as the step launches it: q/k/v with RoPE in the epilogue, o / down with the fp32 residual epilogue, gate_up with SwiGLU
         if name in ("o", "down"):
             res = torch.randn(M, w.shape[0], device=dev)
             ops.gemm(x, w, out=torch.empty_like(res), epilogue=ops.UG_EPI_RESID, resid=res)
+        elif name == "qkv":
+            ops.gemm_qkv_rope(x, w, bq, cos, sin, 771, 14, 128)
         else:
-            ops.gemm(x, w)
-        ops.gemm(dy, w, b_kmajor=True)
+            ops.gemm_swiglu(x, w)
+        # dgrad: the down projection's with the SwiGLU backward in its epilogue (round 4)
+        if name == "down":
+            ops.gemm_swiglu_bwd(dy, w, gu_saved)
+        else:
+            ops.gemm(dy, w, b_kmajor=True)
     ops.gemm_wgrad_group([(dy, x, gw, 1) for x, w, dy, gw in bufs])
 if which in ("head", "all"):
     ops.gemm(hn, emb, out=logits, N=V, K=H)
