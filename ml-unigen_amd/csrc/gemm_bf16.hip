@@ -682,6 +682,12 @@ __device__ __forceinline__ bf16x8_t load_frag32(const char* tile, int r0, int la
     const int j = (i & 1) ? 3 - jj : jj;                                                                                   \
     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);                                  \
     __builtin_amdgcn_sched_barrier(0); }
+#elif UG_MFMA_ORDER == 4                         /* serpentine with the column block outer: the B fragment stays for NI instructions */
+#define UG_MFMA_BLOCK(NI)                                                                                                  \
+  _Pragma("unroll") for (int j = 0; j < 4; ++j) _Pragma("unroll") for (int ii = 0; ii < (NI); ++ii) {                       \
+    const int i = (j & 1) ? (NI) - 1 - ii : ii;                                                                            \
+    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);                                  \
+    __builtin_amdgcn_sched_barrier(0); }
 #elif UG_MFMA_ORDER == 3                         /* order 0 with the order pinned (control for the sched_barrier itself) */
 #define UG_MFMA_BLOCK(NI)                                                                                                  \
   _Pragma("unroll") for (int i = 0; i < (NI); ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) {                          \
