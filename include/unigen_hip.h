@@ -368,6 +368,8 @@ int ug_conv2d_f32(const float* x, const float* w_packed, const float* bias, cons
  * arguments and the same reference call sites as ug_conv2d_f32. */
 int ug_conv_split_weights(const float* w_packed, uint16_t* w_split, int taps, int Cin, int cout_pad, hipStream_t stream);
 int ug_amax_f32(const float* x, int64_t rows, int64_t cols, int64_t ld, float* out_amax, hipStream_t stream);
+/* the same into a slot the caller keeps zeroed (no memset ahead of the launch; ABI v5) */
+int ug_amax_f32_into_zeroed(const float* x, int64_t rows, int64_t cols, int64_t ld, float* out_amax, hipStream_t stream);
 int ug_conv2d_split(const float* x, const float* x_amax, const uint16_t* w_split, const float* bias, const float* residual,
                     float* y, int64_t B, int Hin, int Win, int Cin, int Cout, int cout_pad, int ksize, int stride,
                     int pad_top, int pad_left, int Hout, int Wout, int upsample2x, double* out_stats, int out_groups,

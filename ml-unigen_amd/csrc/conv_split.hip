@@ -876,8 +876,8 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ x, 
   if (threadIdx.x == 0 && m > 0.f) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(m));
 }
 
-int launch_amax(const float* x, int64_t rows, int64_t cols, int64_t ld, float* out, hipStream_t st) {
-  UG_HIP(hipMemsetAsync(out, 0, sizeof(float), st));
+int launch_amax(const float* x, int64_t rows, int64_t cols, int64_t ld, float* out, hipStream_t st, bool zeroed = false) {
+  if (!zeroed) UG_HIP(hipMemsetAsync(out, 0, sizeof(float), st));
   int64_t g = (rows * cols / 4 + 255) / 256;
   if (g > 2048) g = 2048;
   if (g < 1) g = 1;
@@ -906,6 +906,13 @@ static inline int64_t split_tile_elems(int taps, int Cin, int cout_pad) {
 extern "C" int ug_amax_f32(const float* x, int64_t rows, int64_t cols, int64_t ld, float* out_amax, hipStream_t st) {
   UG_REQUIRE(x && out_amax && rows > 0 && cols > 0 && ld >= cols, "ug_amax_f32: bad args");
   return launch_amax(x, rows, cols, ld, out_amax, st);
+}
+
+// ... into a slot the CALLER keeps zeroed (a pool cleared once): no memset node ahead of the launch -- the SigLIP tower measures 135 bounds
+// per forward and the 4-byte memset + its command boundary cost more than the pass over the tensor (34.6 us per bound)
+extern "C" int ug_amax_f32_into_zeroed(const float* x, int64_t rows, int64_t cols, int64_t ld, float* out_amax, hipStream_t st) {
+  UG_REQUIRE(x && out_amax && rows > 0 && cols > 0 && ld >= cols, "ug_amax_f32_into_zeroed: bad args");
+  return launch_amax(x, rows, cols, ld, out_amax, st, true);
 }
 
 extern "C" int ug_conv_split_weights(const float* w_packed, uint16_t* w_split, int taps, int Cin, int cout_pad,

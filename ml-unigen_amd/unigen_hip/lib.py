@@ -76,6 +76,7 @@ SIGNATURES = {
     "ug_conv2d_f32": [P, P, P, P, P, I64, I32, I32, I32, I32, I32, I32, I32, I32, I32, I32, I32, I32, P],
     "ug_conv_split_weights": [P, P, I32, I32, I32, P],
     "ug_amax_f32": [P, I64, I64, I64, P, P],
+    "ug_amax_f32_into_zeroed": [P, I64, I64, I64, P, P],
     "ug_conv2d_split": [P, P, P, P, P, P, I64, I32, I32, I32, I32, I32, I32, I32, I32, I32, I32, I32, I32, P, I32, P],
     "ug_conv3x3_split": [P, P, P, P, P, P, I64, I32, I32, I32, I32, I32, P, P, P, I32, I32, P, I32, P],
     "ug_groupnorm_finalize": [P, P, I64, I64, I32, I32, F32, P],

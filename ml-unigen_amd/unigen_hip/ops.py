@@ -741,14 +741,30 @@ def amax(x2d):
     """max|x| of a 2-D (or any contiguous) fp32 tensor as a device scalar: the scale bound of `conv2d_nhwc(w_split=)` /
     `linear_split` for inputs whose range is not known by construction."""
     _need_cuda(x2d)
-    out = torch.empty((1,), dtype=torch.float32, device=x2d.device)
+    out = _amax_slot(x2d.device)
     if x2d.dim() == 2 and x2d.stride(1) == 1:
         rows, cols, ld = x2d.shape[0], x2d.shape[1], x2d.stride(0)
     else:
         x2d = x2d.contiguous()
         rows, cols, ld = 1, x2d.numel(), x2d.numel()
-    _l.check(_l.load().ug_amax_f32(_p(x2d), rows, cols, ld, _p(out), _stream()), "ug_amax_f32")
+    _l.check(_l.load().ug_amax_f32_into_zeroed(_p(x2d), rows, cols, ld, _p(out), _stream()), "ug_amax_f32")
     return out
+
+
+_AMAX_POOL = {}
+
+
+def _amax_slot(device):
+    """A zeroed fp32 scalar from a pool cleared 1024 slots at a time (one fill per 1024 bounds instead of a memset per bound); a slot is
+    handed out once -- the returned view keeps its pool alive for as long as the bound is in use."""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    pool = _AMAX_POOL.get(key)
+    if pool is None or pool[1] >= pool[0].numel():
+        pool = [torch.zeros(1024, dtype=torch.float32, device=device), 0]      # (on the current stream: ordered before its users)
+        _AMAX_POOL[key] = pool
+    i = pool[1]
+    pool[1] = i + 1
+    return pool[0][i:i + 1]
 
 
 def conv2d_nhwc(x, wp, cout_pad, bias, cout, ksize, *, stride=1, pad=None, residual=None, upsample=False,

@@ -1422,6 +1422,14 @@ def test_amax_and_saturating_bound(dev):
         xd = x.to(dev)[:, :cols]
         assert float(ops.amax(xd)) == float(x[:, :cols].abs().max())
     assert float(ops.amax(torch.zeros(8, 8, device=dev))) == 0.0
+    # the entry with its own memset (ug_amax_f32) on a slot full of garbage, and the pooled zeroed slots across a pool refill
+    from unigen_hip import lib as ug_lib
+    xd = torch.full((3, 7), -2.5, device=dev)
+    out = torch.full((1,), 9.0e9, device=dev)
+    ug_lib.check(ug_lib.load().ug_amax_f32(xd.data_ptr(), 3, 7, 7, out.data_ptr(), torch.cuda.current_stream().cuda_stream), "ug_amax_f32")
+    assert float(out) == 2.5
+    bounds = [ops.amax(torch.full((2, 4), float(i % 97 + 1), device=dev)) for i in range(1100)]
+    assert [float(b) for b in bounds[::50]] == [float(i % 97 + 1) for i in range(0, 1100, 50)]
     M, N, K = 64, 128, 64
     x = torch.ones(M, K) * 3.0
     x[0, 0] = 1.0e6                                                   # 2^14 / 4 * 1e6 >> 65504 under the bound below
