@@ -443,19 +443,27 @@ class PowerSampler:
             self.proc.wait(timeout=5)
             cards = {}
             for line in open(self.path):
-                f = line.split()
-                if len(f) < 3 or not (w0 <= float(f[0]) <= w1):
+                try:                                             # (the last line may be cut off by the terminate above)
+                    f = line.split()
+                    if len(f) < 3 or len(f) % 2 == 0 or not (w0 <= float(f[0]) <= w1):
+                        continue
+                    row = [(int(f[1 + 2 * c]) / 1e6, int(f[2 + 2 * c]) / 1e6) for c in range((len(f) - 1) // 2)]
+                except ValueError:
                     continue
-                for c in range((len(f) - 1) // 2):
-                    cards.setdefault(c, []).append((int(f[1 + 2 * c]) / 1e6, int(f[2 + 2 * c]) / 1e6))
+                for c, smp_c in enumerate(row):
+                    cards.setdefault(c, []).append(smp_c)
             os.remove(self.path)
-            busy = [v for v in cards.values() if v and sum(s[0] for s in v) / len(v) > 500.0]      # cards that ran the steps
-            if not busy:
+            # (hwmon's power reading is itself a running average: the first third of the window still remembers what ran before)
+            tails = [v[len(v) // 3:] for v in cards.values() if len(v) >= 3]
+            means = [sum(s[0] for s in t) / len(t) for t in tails]
+            if not means or max(means) < 300.0:
                 return None
-            smp = [s for v in busy for s in v]
-            return {"mean_w": round(sum(s[0] for s in smp) / len(smp), 1), "cap_w": self.cap,
-                    "mean_sclk_mhz": round(sum(s[1] for s in smp) / len(smp), 1), "nominal_sclk_mhz": 2400, "gpus_sampled": len(busy),
-                    "samples": len(smp), "source": "hwmon power1_input / freq1_input every 20 ms over the timed steps"}
+            busy = [t for t, m_ in zip(tails, means) if m_ >= 0.8 * max(means)]                      # the cards that ran the steps
+            smp = [s for t in busy for s in t]
+            return {"mean_w": round(sum(s[0] for s in smp) / len(smp), 1), "max_w": round(max(s[0] for s in smp), 1), "cap_w": self.cap,
+                    "mean_sclk_mhz": round(sum(s[1] for s in smp) / len(smp), 1), "min_sclk_mhz": round(min(s[1] for s in smp), 1),
+                    "nominal_sclk_mhz": 2400, "gpus_sampled": len(busy), "samples": len(smp),
+                    "source": "hwmon power1_input / freq1_input every 20 ms over the last two thirds of the timed steps"}
         except Exception:
             return None
 
