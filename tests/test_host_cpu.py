@@ -162,3 +162,35 @@ def test_bench_self_launch_refuses_more_ranks_than_gpus():
     import torch
     if torch.cuda.device_count() < 2:
         assert r.returncode != 0 and "one GPU per rank" in (r.stderr + r.stdout)
+
+
+def test_bench_power_report_reads_the_busy_card_and_survives_a_cut_off_line(tmp_path):
+    """bench.py's `power` object (round 4): from the sampler's file -- two cards of which one ran the steps, a running-average ramp at the
+    start of the window, samples outside the window, a last line cut off by the terminate -- the report is the busy card's last two
+    thirds; without samples (no hwmon here) it is None and the benchmark goes on."""
+    import importlib.util
+    import subprocess
+    import sys
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        spec.loader.exec_module(bench)
+    finally:
+        sys.argv = argv
+    ps = bench.PowerSampler.__new__(bench.PowerSampler)
+    ps.cap, ps.path = 1400.0, str(tmp_path / "samples.txt")
+    ps.proc = subprocess.Popen([sys.executable, "-c", "import time; time.sleep(30)"])
+    lines = ["%.4f %d %d %d %d" % (99.0 + 0.02 * i, 240000000, 100000000, 40000000, 90000000) for i in range(10)]          # before the window
+    for i in range(30):                                                    # card 0 ramps 600 -> 1340 W over the first third; card 1 idles
+        w = 600 + min(i, 10) * 74
+        lines.append("%.4f %d %d %d %d" % (100.0 + 0.02 * i, w * 1000000, 1950000000, 41000000, 95000000))
+    lines.append("100.6100 1340000000 19")                                # cut off mid-write
+    open(ps.path, "w").write("\n".join(lines))
+    rep = ps.report(100.0, 100.6)
+    assert rep["gpus_sampled"] == 1 and rep["samples"] == 20 and rep["cap_w"] == 1400.0
+    assert rep["mean_w"] == 1340.0 and rep["max_w"] == 1340.0 and rep["mean_sclk_mhz"] == 1950.0
+    assert not os.path.exists(ps.path) and ps.proc.poll() is not None
+    none = bench.PowerSampler.__new__(bench.PowerSampler)
+    none.proc = None
+    assert none.report(0.0, 1.0) is None
