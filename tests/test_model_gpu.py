@@ -481,6 +481,39 @@ def test_gradient_accumulation_and_fresh_write_semantics(dev):
         _check("params[n].grad", params[n].grad, once[n], 2e-3)
 
 
+def test_fused_epilogues_give_the_same_step_as_the_separate_kernels(dev, monkeypatch):
+    """Round 4: gate_up + SwiGLU, down dgrad + SwiGLU backward and q/k/v + RoPE run inside GEMM epilogues (ops.gemm_swiglu,
+    ops.gemm_swiglu_bwd, ops.gemm_qkv_rope).  The tiny golden model stepped with the fusions on and with the separate kernels
+    (ops.FUSED_SWIGLU / FUSED_SWIGLU_BWD off, the projection + ug_rope pair through a pinned-policy-free wrapper): the same losses and
+    the same gradients, bit for bit -- the epilogues share their element functions with the kernels they replace."""
+    from unigen_hip import ops
+    g = golden("g2_tiny_unigen.pt")
+    mask = additive(g["mask_allow"]).to(dev)
+    ids, labels = g["input_ids"].to(dev), g["labels"].to(dev)
+    names = ["model.embed_tokens.weight", "model.layers.0.self_attn.q_proj.weight", "model.layers.0.self_attn.k_proj.bias",
+             "model.layers.1.mlp.gate_proj.weight", "model.layers.1.mlp.up_proj.weight", "model.layers.1.mlp.down_proj.weight",
+             "model.layers.0.post_attention_layernorm.weight", "model.norm.weight"]
+    unfused_rope = lambda x, w, b, cos, sin, L, nh, hd: ops.rope_(ops.gemm(x, w, bias=b), cos, sin, L, nh, hd)
+    got = {}
+    for fused in (True, False):
+        monkeypatch.setattr(ops, "FUSED_SWIGLU", fused)
+        monkeypatch.setattr(ops, "FUSED_SWIGLU_BWD", fused)
+        if not fused:
+            monkeypatch.setattr(ops, "gemm_qkv_rope", unfused_rope)
+        model, _ = _tiny_unigen(g, dev)
+        model.train()
+        params = dict(model.llm.named_parameters())
+        _, l1, l2, l3 = model(input_ids=ids, attention_mask=mask, labels=labels, **g["kw"])
+        (l1 + 0.1 * l2 + l3).backward()
+        got[fused] = ([float(l1.detach()), float(l2.detach()), float(l3.detach())], {n: params[n].grad.clone() for n in names})
+    assert got[True][0] == got[False][0]
+    for n in names:
+        if not n.endswith("proj.weight"):                        # (scatter-add, bias column sums and norm-weight sums use fp32 atomics: not bit-reproducible run to run)
+            _check(n, got[True][1][n], got[False][1][n], 1e-5)
+        else:
+            assert torch.equal(got[True][1][n], got[False][1][n]), n
+
+
 def test_deferred_head_weight_gradient_is_the_same_gradient(dev, monkeypatch):
     """Round 4: the tied head's weight gradient is a leaf of the backward graph and rides, slice by slice, on the decoder layers'
     grouped weight-gradient launches (unigen_hip/qwen2.py: head_bwd / _head_wgrad_slice / flush_deferred_head).  Forced on for the
