@@ -16,29 +16,30 @@ sys.path.insert(0, os.path.join(ROOT, "ml-unigen_amd"))
 import torch
 from unigen_hip import ops
 
-hw = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
-hw = [h for h in hw if os.path.exists(os.path.join(h, "power1_input")) or os.path.exists(os.path.join(h, "power1_average"))][0]
-PW = os.path.join(hw, "power1_input") if os.path.exists(os.path.join(hw, "power1_input")) else os.path.join(hw, "power1_average")
-FQ = os.path.join(hw, "freq1_input")
-cap = int(open(os.path.join(hw, "power1_cap")).read()) / 1e6
+hws = [h for h in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")) if os.path.exists(os.path.join(h, "power1_input"))]
+cap = int(open(os.path.join(hws[0], "power1_cap")).read()) / 1e6
+PW = "power1_input of every card; the busiest card of each window is reported"
 dev = torch.device("cuda:0")
 
 
 SAMPLER = """
 import sys, time
-pw, fq, out = sys.argv[1:4]
+out, hws = sys.argv[1], sys.argv[2:]
 with open(out, "w") as f:
     while True:
-        try:
-            f.write("%.4f %d %d\\n" % (time.time(), int(open(pw).read()), int(open(fq).read()))); f.flush()
-        except (OSError, ValueError):
-            pass
+        row = []
+        for h in hws:
+            try:
+                row += [open(h + "/power1_input").read().strip(), open(h + "/freq1_input").read().strip()]
+            except (OSError, ValueError):
+                row += ["0", "0"]
+        f.write("%.4f %s\\n" % (time.time(), " ".join(row))); f.flush()
         time.sleep(0.02)
 """
 import subprocess
 import tempfile
 LOG = os.path.join(tempfile.gettempdir(), "power_probe_samples.txt")
-sampler = subprocess.Popen([sys.executable, "-c", SAMPLER, PW, FQ, LOG])      # its own process: never waits for this one's GIL
+sampler = subprocess.Popen([sys.executable, "-c", SAMPLER, LOG] + hws)      # its own process: never waits for this one's GIL
 
 
 def run(name, fn, seconds=4.0, unit=None, per_call=None):
@@ -54,11 +55,17 @@ def run(name, fn, seconds=4.0, unit=None, per_call=None):
     dt = (time.perf_counter() - t0) / reps
     w1 = time.time()
     w0 += (w1 - w0) / 4                                         # steady state: drop the ramp
-    smp = []
+    cards = {}
     for line in open(LOG):
-        t, a, b = line.split()
-        if w0 <= float(t) <= w1:
-            smp.append((int(a) / 1e6, int(b) / 1e6))
+        f = line.split()
+        try:
+            if len(f) < 3 or len(f) % 2 == 0 or not (w0 <= float(f[0]) <= w1):
+                continue
+            for c in range((len(f) - 1) // 2):
+                cards.setdefault(c, []).append((int(f[1 + 2 * c]) / 1e6, int(f[2 + 2 * c]) / 1e6))
+        except ValueError:
+            continue
+    smp = max(cards.values(), key=lambda v: sum(s[0] for s in v) / len(v))      # the card that ran the workload
     pw = sum(s[0] for s in smp) / len(smp); fq = sum(s[1] for s in smp) / len(smp)
     rate = f"{per_call / dt / 1e12:.0f} {unit}" if per_call else ""
     print(f"| {name} | {dt * 1e3:.3f} | {rate} | {pw:.0f} | {max(s[0] for s in smp):.0f} | {fq:.0f} | {min(s[1] for s in smp):.0f} | {len(smp)} |", flush=True)
@@ -105,4 +112,19 @@ vq = MAGVITv2().to(dev).eval().requires_grad_(False)
 init_magvit_device(vq, 10084)
 images = torch.rand(16, 3, 256, 256, device=dev) * 2 - 1
 run("tokenizer get_code (16 x 256^2)", lambda: vq.get_code(images))
+
+# the matrix cores alone (tools/probes/mfma_peak.hip: v_mfma_f32_16x16x32_bf16, 16 independent accumulators, two waves per SIMD, no operand stream)
+import ctypes
+so = os.path.join(ROOT, "gpurun_out", "mfma_peak.so")
+os.makedirs(os.path.dirname(so), exist_ok=True)
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-shared", "-fPIC", os.path.join(ROOT, "tools", "probes", "mfma_peak.hip"), "-o", so])
+burn = ctypes.CDLL(so)
+sink = torch.empty(1 << 20, device=dev)
+for data in ("randn", "zeros"):
+    seed = (torch.zeros(4096) if data == "zeros" else torch.randn(4096)).to(torch.bfloat16).view(torch.int16).to(dev)
+    blocks, threads, iters, nacc = 512, 256, 20000, 16
+    args = (ctypes.c_void_p(seed.data_ptr()), ctypes.c_void_p(sink.data_ptr()), blocks, threads, iters, nacc,
+            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    run(f"MFMA only (16x16x32 bf16, two waves per SIMD), {data} operands", lambda: burn.mfma_burn_launch(*args), unit="TF/s",
+        per_call=blocks * (threads // 64) * iters * nacc * 2.0 * 16 * 16 * 32)
 sampler.terminate()
