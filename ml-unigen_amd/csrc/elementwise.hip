@@ -785,6 +785,10 @@ extern "C" int ug_adamw_flat(float* p, const float* g, float* m, float* v, void*
   // side stream beside MFMA-bound kernels -- it leaves the register file and LDS to them and lives off spare HBM bandwidth
   dim3 grid(max_blocks > 0 ? grid_for(n / 4 + 1, 256, max_blocks) : grid_for(n / 4 + 1)), block(256);
   static const int lean = [] { const char* e = getenv("UNIGEN_ADAMW_LEAN"); return e ? atoi(e) : 1; }();
+  // round 4: the pipelined small-grid kernel is also the fastest form ALONE (tools/probes/adamw_alone.py, 400 M elements: 6.14 TB/s on 256
+  // workgroups against 5.35 for the whole-chip four-element kernel), so the default grid (max_blocks = 0) takes it too
+  static const int piped_default = [] { const char* e = getenv("UNIGEN_ADAMW_PIPED"); return e ? atoi(e) : 1; }();
+  if (max_blocks == 0 && lean && piped_default && n < (1LL << 29)) max_blocks = 256;
   if (max_blocks > 0 && lean) {
     const int wgs = lean > 1 ? lean : max_blocks;
     dim3 lgrid(grid_for(n / 2 + 1, 256, wgs));

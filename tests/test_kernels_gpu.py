@@ -523,6 +523,31 @@ def test_adamw_small_grid_form_is_the_same_update(dev, n):
             assert torch.equal(a, b)
 
 
+def test_adamw_whole_chip_kernel_beyond_32_bit_indices(dev):
+    """Flat runs of 2^29 elements and more keep the whole-chip four-element kernel (`adamw_kernel`, 64-bit indices; everything smaller
+    runs the pipelined small-grid kernel since round 4): one update over 2^29 + 5 elements against the pipelined kernel on the two
+    halves of a copy -- the same element function, the same bits."""
+    ops = _ops()
+    n = (1 << 29) + 5
+    gen = torch.Generator(device=dev).manual_seed(11)
+    p0 = torch.randn(n, device=dev, generator=gen)
+    g = torch.randn(n, device=dev, generator=gen)
+    outs = []
+    for split in (False, True):
+        p = p0.clone(); m = torch.full((n,), 0.01, device=dev); v = torch.full((n,), 0.02, device=dev)
+        pb = torch.zeros(n, dtype=torch.bfloat16, device=dev)
+        if not split:
+            ops.adamw_flat_(p, g, m, v, pb, 1e-3, 0.9, 0.999, 1e-8, 0.01, 2)
+        else:
+            h = (n // 2) & ~7
+            for lo, hi in ((0, h), (h, n)):
+                ops.adamw_flat_(p[lo:hi], g[lo:hi], m[lo:hi], v[lo:hi], pb[lo:hi], 1e-3, 0.9, 0.999, 1e-8, 0.01, 2)
+        outs.append((p, m, v, pb))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    del outs
+
+
 # ------------------------------------------------------------------ cross entropy
 def test_ce_fwd_bwd(dev):
     ops = _ops()
