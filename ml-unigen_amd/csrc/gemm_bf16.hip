@@ -229,6 +229,13 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, f32x4_t (&acc)[4][
 // to 32-byte pieces of 16 different rows each (the no-store ablation put the scattered form at ~20 % of a K = 1536 GEMM).
 //   strip pitch: bf16 144 B (36 dwords: the 16 rows of a ds_write_b64 group fall on 8 bank quads, 2-way at worst; rows stay
 //   16-byte aligned for the ds_read_b128 that follows), fp32 272 B (68 dwords: ds_write_b128's 8-lane groups conflict-free).
+// 16-byte epilogue store; probe builds (-DUG_EPI_NT) make it non-temporal (outputs that are next read a backward pass later)
+#ifdef UG_EPI_NT
+#define UG_ST16(ptr, val) __builtin_nontemporal_store(__builtin_bit_cast(gnt4_t, (val)), reinterpret_cast<gnt4_t*>(ptr))
+#else
+#define UG_ST16(ptr, val) (*reinterpret_cast<uint4*>(ptr) = (val))
+#endif
+typedef unsigned int gnt4_t __attribute__((ext_vector_type(4)));
 constexpr int EP_ROWS = 32;
 constexpr int EP_PITCH_BF16 = 144, EP_PITCH_F32 = 272;
 constexpr int EP_STRIP = EP_ROWS * EP_PITCH_F32;            // 8704 B per wave (the bf16 strip needs 4608)
@@ -320,7 +327,7 @@ __device__ __forceinline__ void store_tile_lds(const GemmArgs& p, f32x4_t (&acc)
         const int m = mbase + c * EP_ROWS + row;
         const uint4 v = *reinterpret_cast<const uint4*>(strip + row * EP_PITCH_BF16 + ch * 16);
         const int gc = EPI == EPI_ROPE ? (ch & 3) * 8 + (ch >> 2) * 64 : ch * 8;        // (two 64-byte pieces per row with EPI_ROPE)
-        if (m < p.M && row < rows_here) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc + nbase + gc) = v;
+        if (m < p.M && row < rows_here) UG_ST16(reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc + nbase + gc, v);
       }
     } else {
 #pragma unroll
@@ -392,7 +399,7 @@ __device__ __forceinline__ void store_tile_swiglu_perm(const GemmArgs& p, f32x4_
       const int m = mbase + c * EP_ROWS + row;
       const uint4 v = *reinterpret_cast<const uint4*>(strip + row * EP_PITCH_BF16 + ch * 16);
       const int gc = (ch >> 2) * p.swiglu_I + hbase + (ch & 3) * 8;
-      if (m < p.M && row < rows_here) *reinterpret_cast<uint4*>(C + (int64_t)m * p.ldc + gc) = v;
+      if (m < p.M && row < rows_here) UG_ST16(C + (int64_t)m * p.ldc + gc, v);
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {                             // act: 32 rows x 4 pieces
@@ -404,7 +411,7 @@ __device__ __forceinline__ void store_tile_swiglu_perm(const GemmArgs& p, f32x4_
 #else
       if (m < p.M && row < rows_here)
 #endif
-        *reinterpret_cast<uint4*>(p.act + (int64_t)m * p.ld_act + hbase + ch * 8) = v;
+        UG_ST16(p.act + (int64_t)m * p.ld_act + hbase + ch * 8, v);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
@@ -481,8 +488,8 @@ __device__ __forceinline__ void store_tile_swiglu_bwd(const GemmArgs& p, f32x4_t
       }
       if (m < p.M && row < rows_here) {
         bf16_t* cp = C + (int64_t)m * p.ldc + nbase + ch * 8;
-        *reinterpret_cast<uint4*>(cp) = make_uint4(og[0], og[1], og[2], og[3]);
-        *reinterpret_cast<uint4*>(cp + I) = make_uint4(ou[0], ou[1], ou[2], ou[3]);
+        UG_ST16(cp, make_uint4(og[0], og[1], og[2], og[3]));
+        UG_ST16(cp + I, make_uint4(ou[0], ou[1], ou[2], ou[3]));
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
