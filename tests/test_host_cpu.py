@@ -194,3 +194,14 @@ def test_bench_power_report_reads_the_busy_card_and_survives_a_cut_off_line(tmp_
     none = bench.PowerSampler.__new__(bench.PowerSampler)
     none.proc = None
     assert none.report(0.0, 1.0) is None
+
+
+def test_gemm_traffic_record_belongs_to_the_shipped_gemm_source():
+    """bench.py reports `roofline.traffic` only while profiles/gemm_traffic_current.json carries the sha256 of the gemm_bf16.hip it runs
+    (a stale record reads as null): an edit of the GEMM source without `bash tools/refresh_traffic.sh` on the GPU box fails here."""
+    import hashlib
+    import json
+    rec = json.load(open(os.path.join(ROOT, "profiles", "gemm_traffic_current.json")))
+    src = open(os.path.join(ROOT, "ml-unigen_amd", "csrc", "gemm_bf16.hip"), "rb").read()
+    assert rec["gemm_src_sha256"] == hashlib.sha256(src).hexdigest()
+    assert rec["launches_per_step"] == 255 and 0.5e9 < rec["traffic_bytes_per_launch"] < 2e9
