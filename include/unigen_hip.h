@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define UG_ABI_VERSION 5
+#define UG_ABI_VERSION 6
 
 /* ---- library ---------------------------------------------------------------------------- */
 const char* ug_last_error(void);
@@ -79,6 +79,10 @@ int ug_cast_f32_bf16(const float* in, void* out, int64_t n, hipStream_t stream);
  * aligned rows; other shapes are refused (UG_ERR_ARG) and run as those two launches.  ABI v5. */
 int ug_gemm_bf16_swiglu_bwd(const ug_handle* h, const void* dy, int64_t ld_dy, const void* w_down, int64_t ldw, const void* gu,
                             int64_t ld_gu, void* dgu, int64_t ld_dgu, int64_t M, int64_t I, int64_t K, hipStream_t stream);
+/* Tile height of the three fused-epilogue launches above (128 ... 320 rows in steps of 16; 0 = automatic, the default): tests and
+ * A/B runs force every instantiated height this way; a height the called entry point does not instantiate is refused (UG_ERR_ARG).
+ * Process-wide.  ABI v6. */
+int ug_gemm_set_fused_tile_height(int rows);
 /* The fused q/k/v projection of a decoder layer (transformers modeling_qwen2.py:200-215 q_proj / k_proj / v_proj + apply_rotary_pos_emb
  * :131-135; reference call site models/unigen.py:274-285): qkv[M, N] = bf16(x[M, K] W[N, K]^T + bias) with rotate-half RoPE (tables
  * [L, head_dim / 2] fp32, row m at position m % L) applied in the GEMM's epilogue to the first rope_cols columns (the q and k heads) --

@@ -42,6 +42,7 @@
 // are passed swapped to the MFMA so each lane ends up with four consecutive output columns.
 #include "common.h"
 #include <type_traits>
+#include <atomic>
 #include "unigen_hip.h"
 
 namespace {
@@ -1374,6 +1375,35 @@ extern "C" int ug_gemm_bf16_wgrad_group(int n, const void* const* dy, const int6
   return UG_OK;
 }
 
+
+// Tile height of the fused-epilogue launches (ug_gemm_bf16_swiglu / _qkv_rope / _swiglu_bwd): rounds(h) x t(h) over the heights the
+// entry point instantiates -- or the height ug_gemm_set_fused_tile_height() forces (tests and A/B runs reach every instantiation
+// that way; 0 = automatic).  A forced height the entry point does not instantiate is refused.
+static std::atomic<int> g_fused_height{0};
+extern "C" int ug_gemm_set_fused_tile_height(int rows) {
+  UG_REQUIRE(rows == 0 || (rows >= 128 && rows <= 320 && rows % 16 == 0), "ug_gemm_set_fused_tile_height: 0 (automatic) or 128 ... 320 in steps of 16 (%d)", rows);
+  g_fused_height.store(rows);
+  return UG_OK;
+}
+template <size_t NH>
+static int pick_fused_height(const int (&heights)[NH], int64_t M, int64_t col_tiles, const char* who, int* out) {
+  const int forced = g_fused_height.load();
+  if (forced) {
+    for (int h_ : heights)
+      if (h_ == forced) { *out = forced; return UG_OK; }
+    ug_set_error("%s: tile height %d forced by ug_gemm_set_fused_tile_height is not instantiated for this epilogue", who, forced);
+    return UG_ERR_ARG;
+  }
+  int hb = heights[NH - 1]; float best = 1e30f;
+  for (int h_ : heights) {
+    const int64_t wgs = ((M + h_ - 1) / h_) * col_tiles;
+    const float cost = (float)((wgs + 255) / 256) * (0.35f + 0.00254f * (float)h_);
+    if (cost < best) { best = cost; hb = h_; }
+  }
+  *out = hb;
+  return UG_OK;
+}
+
 extern "C" int ug_swiglu_fwd(const void* gate_up, void* act, int64_t tokens, int64_t I, hipStream_t st);
 
 extern "C" int ug_gemm_bf16_swiglu(const ug_handle* h, const void* x, int64_t ldx, const void* w_gate_up, int64_t ldw, void* gu,
@@ -1399,12 +1429,8 @@ extern "C" int ug_gemm_bf16_swiglu(const ug_handle* h, const void* x, int64_t ld
   a.swiglu_I = (int)I; a.act = (bf16_t*)act; a.ld_act = ld_act;
   // round 4: the 128 ... 320-row kernel with gate and up of a hidden unit in one lane (EPI_SWIGLU); tile height by rounds(h) x t(h)
   static const int heights[] = {128, 160, 192, 208, 224, 256, 288, 320};
-  int hb = 320; float best = 1e30f;
-  for (int h_ : heights) {
-    const int64_t wgs = ((M + h_ - 1) / h_) * (2 * I / PBN);
-    const float cost = (float)((wgs + 255) / 256) * (0.35f + 0.00254f * (float)h_);
-    if (cost < best) { best = cost; hb = h_; }
-  }
+  int hb = 320;
+  if (int rc = pick_fused_height(heights, M, 2 * I / PBN, "ug_gemm_bf16_swiglu", &hb)) return rc;
   a.tiles_m = (int)((M + hb - 1) / hb); a.tiles_n = (int)(2 * I / PBN);
   const dim3 grid(a.tiles_m * a.tiles_n), block(512);
   switch (hb) {
@@ -1451,12 +1477,8 @@ extern "C" int ug_gemm_bf16_qkv_rope(const ug_handle* h, const void* x, int64_t 
   a.tail_split = 1; a.tail_private = 1; a.wide_epilogue = 1;
   // tile height: rounds(h) x t(h), the rule of launch() (one round: the smallest height that fits)
   static const int heights[] = {128, 160, 192, 208, 224, 256, 288, 320};
-  int hb = 320; float best = 1e30f;
-  for (int h_ : heights) {
-    const int64_t wgs = ((M + h_ - 1) / h_) * (N / PBN);
-    const float cost = (float)((wgs + 255) / 256) * (0.35f + 0.00254f * (float)h_);
-    if (cost < best) { best = cost; hb = h_; }
-  }
+  int hb = 320;
+  if (int rc = pick_fused_height(heights, M, N / PBN, "ug_gemm_bf16_qkv_rope", &hb)) return rc;
   a.tiles_m = (int)((M + hb - 1) / hb); a.tiles_n = (int)(N / PBN);
   const dim3 grid(a.tiles_m * a.tiles_n), block(512);
   switch (hb) {
@@ -1491,12 +1513,8 @@ extern "C" int ug_gemm_bf16_swiglu_bwd(const ug_handle* h, const void* dy, int64
   a.sw_gu = (const bf16_t*)gu; a.ld_gu = ld_gu; a.swiglu_I = (int)I;
   a.tail_split = 1; a.tail_private = 1; a.wide_epilogue = 1;
   static const int heights[] = {128, 160, 192, 208, 224, 256, 272, 288, 320};
-  int hb = 320; float best = 1e30f;
-  for (int h_ : heights) {
-    const int64_t wgs = ((M + h_ - 1) / h_) * (I / PBN);
-    const float cost = (float)((wgs + 255) / 256) * (0.35f + 0.00254f * (float)h_);
-    if (cost < best) { best = cost; hb = h_; }
-  }
+  int hb = 320;
+  if (int rc = pick_fused_height(heights, M, I / PBN, "ug_gemm_bf16_swiglu_bwd", &hb)) return rc;
   a.tiles_m = (int)((M + hb - 1) / hb); a.tiles_n = (int)(I / PBN);
   const dim3 grid(a.tiles_m * a.tiles_n), block(512);
   switch (hb) {

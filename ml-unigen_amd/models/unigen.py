@@ -19,6 +19,7 @@ Behavioural notes (all mirror the reference unless stated):
 """
 import json
 import os
+import time
 import weakref
 from typing import Optional
 
@@ -629,7 +630,19 @@ class UniGen(ModelMixin, ConfigMixin):
                 else:
                     x.copy_(embed(torch.cat([nxt, nxt]) + text_vocab_size)[:, 0])
 
+        timing = kwargs.get("timing")               # optional dict: wall seconds per phase (adds host syncs; measurement runs only)
+
+        def mark(name, t0=[None]):
+            if timing is not None:
+                torch.cuda.synchronize()
+                now = time.perf_counter()
+                if t0[0] is not None:
+                    timing[name] = timing.get(name, 0.0) + now - t0[0]
+                t0[0] = now
+
+        mark("setup")
         sample(eng.prefill(st, prefix, key_valid))
+        mark("prefill")
         if not fused:
             out_tokens[:, 0] = tok[:, 0]
 
@@ -641,10 +654,12 @@ class UniGen(ModelMixin, ConfigMixin):
         for i in range(1, n):
             if use_graph and (generator is None or fused) and i == 2:
                 # step 1 ran eagerly (warm-up: allocations, lazy inits); capture step 2 and replay it from then on
+                mark("eager_step")
                 torch.cuda.synchronize()
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
                     step()
+                mark("capture")
                 graph.replay()                      # capture only records: this replay IS step 2
             elif graph is not None:
                 graph.replay()
@@ -652,6 +667,7 @@ class UniGen(ModelMixin, ConfigMixin):
                 step()
             if not fused:
                 out_tokens[:, i] = tok[:, 0]
+        mark("replay")
         eng.last_decode_graph = graph is not None
         return out_tokens
 

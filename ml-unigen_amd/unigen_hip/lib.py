@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
 LIB_PATH = os.environ.get("UNIGEN_HIP_LIB") or os.path.join(CSRC_DIR, "libunigen_hip.so")     # (probe builds: tools/probes/_build/*.so)
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 P = ctypes.c_void_p
 I64 = ctypes.c_int64
 I32 = ctypes.c_int
@@ -50,6 +50,7 @@ SIGNATURES = {
     "ug_decode_gemv": [P, I64, I64, P, I64, P, I64, I64, I64, P, I64, P, I64, P, P],
     "ug_decode_gemv_resid_norm": [P, P, I64, P, P, P, I64, P, I64, P, I64, I64, I64, P, I64, P, I64, P, P],
     "ug_decode_gemv_swiglu": [P, I64, P, F32, I64, I64, P, I64, P, I64, I64, I64, P, I64, P, I64, P, P],
+    "ug_gemm_set_fused_tile_height": [I32],
     "ug_attn_decode_fused": [P, I64, P, F32, I64, P, P, P, P, P, P, P, P, I64, I64, I32, I32, I32, I64, I64, F32, P],
     "ug_decode_finish_resid_norm": [P, I64, P, P, P, I64, I64, F32, P, P, P],
     "ug_t2i_assemble": [P, P, P, I64, P, I64, P, P, I64, I64, I64, I64, I64, I64, I64, P, P, P, P],

@@ -177,6 +177,12 @@ def set_gemm_tile_policy(policy):
         GEMM_POLICY = policy
 
 
+def set_fused_tile_height(rows):
+    """Tile height of the fused-epilogue GEMM launches (gemm_swiglu / gemm_qkv_rope / gemm_swiglu_bwd): 0 = automatic; tests force
+    every instantiated height (include/unigen_hip.h: ug_gemm_set_fused_tile_height)."""
+    _l.check(_l.load().ug_gemm_set_fused_tile_height(int(rows)), "ug_gemm_set_fused_tile_height")
+
+
 def gemm_nt(a, b, out=None, **kw):
     """Both operands row-major: out = a[M,K] @ b[N,K]^T."""
     return gemm(a, b, out, **kw)

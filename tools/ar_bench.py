@@ -25,6 +25,12 @@ def run(n_img=8, prefix=138, n_tok=256, use_graph=True, reps=2):
     un = torch.randint(0, 151643, (n_img, L), device=dev, generator=g)
     am = torch.ones((2 * n_img, L), dtype=torch.long, device=dev)
     best = None
+    if os.environ.get("AR_PHASES"):                # where the call's wall time goes (adds host syncs: not the reported number)
+        for _ in range(2):
+            ph = {}
+            model.t2i_generate_ar(input_ids=ids, uncond_input_ids=un, attention_mask=am, guidance_scale=6.0, temperature=1.0,
+                                  text_vocab_size=TEXT_VOCAB, image_token_num_per_image=n_tok, use_graph=use_graph, timing=ph)
+        print(json.dumps({"phases_ms": {k: round(v * 1e3, 3) for k, v in ph.items()}}), flush=True)
     for _ in range(reps + 1):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
