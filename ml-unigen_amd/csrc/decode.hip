@@ -551,22 +551,33 @@ enum { XIN_BF16 = 0, XIN_RESID_NORM = 1, XIN_SWIGLU = 2 };
 struct DecodeIn {
   const float* x_in; const float* pend; int64_t ld_pend; const float* norm_w; float* x_out; float* ss_out;   // RESID_NORM
   const float* gu; int64_t ld_gu; const float* ss_in; float eps; int norm_cols;                              // SWIGLU
-  float* zero0; int64_t n0; float* zero1; int64_t n1; float* ss_zero;                                        // clears
+  float* zero0; float* zero1; float* ss_zero;                                                               // clears
+  int n0_4, per0, n1_4, per1;           // float4 counts and every workgroup's share of them (set_clear_shares, on the host)
 };
 
-__device__ __forceinline__ void decode_clear(const DecodeIn& f, int tid, int bid, int nblocks) {
+// Round 5: everything uniform is 32-bit and comes from the host.  The round-4 form divided int64 counts by the grid size in every
+// workgroup -- ~150 dependent scalar instructions per division, twice, AHEAD of the kernel's first load (the compiler hoists them
+// over the early-exit of surplus workgroups): 540-600 instructions and 1.5-2 us between a wave's first instruction and its first
+// load (profiles/r05_ar_prefetch.md, section 3).
+__device__ __forceinline__ void decode_clear(const DecodeIn& f, int tid, int bid) {
   const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
   const int nt = blockDim.x;
   if (f.zero0) {
-    const int64_t n4 = f.n0 >> 2, per = (n4 + nblocks - 1) / nblocks, lo = bid * per, hi = min(n4, lo + per);
-    for (int64_t i = lo + tid; i < hi; i += nt) reinterpret_cast<float4*>(f.zero0)[i] = z;
+    const int lo = bid * f.per0, hi = min(f.n0_4, lo + f.per0);
+    for (int i = lo + tid; i < hi; i += nt) reinterpret_cast<float4*>(f.zero0)[i] = z;
   }
   if (f.zero1) {
-    const int64_t n4 = f.n1 >> 2, per = (n4 + nblocks - 1) / nblocks, lo = bid * per, hi = min(n4, lo + per);
-    for (int64_t i = lo + tid; i < hi; i += nt) reinterpret_cast<float4*>(f.zero1)[i] = z;
+    const int lo = bid * f.per1, hi = min(f.n1_4, lo + f.per1);
+    for (int i = lo + tid; i < hi; i += nt) reinterpret_cast<float4*>(f.zero1)[i] = z;
   }
   if (f.ss_zero && bid == 0 && tid < 32) f.ss_zero[tid] = 0.f;
 }
+
+// linear workgroup id (x fastest: the order the dispatcher deals workgroups out to the XCDs in)
+__device__ __forceinline__ int linear_block() { return (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x; }
+// workgroup barrier for an LDS hand-off: __syncthreads() also drains vmcnt (its fence covers global memory), i.e. waits for the
+// weight tiles in flight and the clears' write acknowledgements, which no wave needs at this point
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __device__ __forceinline__ float silu_bf(float g) { return bf2f(f2bf(g / (1.f + __expf(-g)))); }
 
@@ -575,13 +586,13 @@ template <int XIN>
 __device__ __forceinline__ void decode_operand_load(const DecodeIn& f, int ar, int k0, int K, float4 (&a)[2], float4 (&b)[2],
                                                     float4 (&w)[2]) {
   if constexpr (XIN == XIN_RESID_NORM) {
-    const float* xp = f.x_in + (int64_t)ar * K + k0;
-    const float* pp = f.pend + (int64_t)ar * f.ld_pend + k0;
+    const float* xp = f.x_in + (__umul24(ar, K) + k0);
+    const float* pp = f.pend + (__umul24(ar, (int)f.ld_pend) + k0);
     a[0] = *reinterpret_cast<const float4*>(xp); a[1] = *reinterpret_cast<const float4*>(xp + 4);
     b[0] = *reinterpret_cast<const float4*>(pp); b[1] = *reinterpret_cast<const float4*>(pp + 4);
     w[0] = *reinterpret_cast<const float4*>(f.norm_w + k0); w[1] = *reinterpret_cast<const float4*>(f.norm_w + k0 + 4);
   } else {
-    const float* gp = f.gu + (int64_t)ar * f.ld_gu + k0;
+    const float* gp = f.gu + (__umul24(ar, (int)f.ld_gu) + k0);
     a[0] = *reinterpret_cast<const float4*>(gp); a[1] = *reinterpret_cast<const float4*>(gp + 4);
     b[0] = *reinterpret_cast<const float4*>(gp + K); b[1] = *reinterpret_cast<const float4*>(gp + K + 4);
   }
@@ -614,28 +625,47 @@ __device__ __forceinline__ bf16x8_t decode_operand_make(const DecodeIn& f, const
   return o;
 }
 
-// XIN_BF16: one wave per workgroup (see above).
-template <int RB, int KW>
-__global__ __launch_bounds__(64) void gemv_ring_kernel(const bf16_t* __restrict__ x, int64_t ldx, int R,
-                                                       const bf16_t* __restrict__ W, int64_t ldw, float* __restrict__ acc,
-                                                       int64_t sr, int64_t sn, int N, int K, int nslabs, DecodeIn f) {
-  __shared__ __attribute__((aligned(1024))) char tile[2][8192];
-  const int lane = threadIdx.x, g = lane >> 4, row = lane & 15;
-  const int grp0 = (blockIdx.x / nslabs) * KW;
-  const int kbase = (blockIdx.x % nslabs) * 256;
-  int roff[8], kc[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    roff[i] = 2 * i + (lane >> 5);
-    kc[i] = min(kbase + ((lane & 31) ^ roff[i]) * 8, K - 8);       // chunks past K are never consumed
-  }
-  auto stage = [&](int t) {
+// Addressing shared by the two ring kernels (round 5: 32-bit, 24-bit multiplies at full VALU rate; the host checks the ranges).
+// A weight tile = 16 rows x 256 k of W [N][K] (row stride ldw elements); DMA instruction i of a tile covers rows 2i, 2i + 1 x 512
+// bytes: lane -> row 2i + (lane >> 5), 16-byte chunk (lane & 31) ^ row (the bank swizzle, applied on the SOURCE side).
+struct TileAddr {
+  int lane_off[8];                               // element offset of this lane inside a tile for DMA instruction i (row clamp aside)
+  __device__ __forceinline__ void init(int lane, int kbase, int K, int ldw) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const bf16_t* src = W + (int64_t)min((grp0 + t) * 16 + roff[i], N - 1) * ldw + kc[i];
-      // aux = 2: non-temporal -- every weight byte is read once per step by one CU; leaving it out of the caches shortens
-      // issue -> landed (guide, price list row nt-weights)
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile[t & 1] + i * 1024), 16, 0, 2);
+      const int r = 2 * i + (lane >> 5);
+      lane_off[i] = __umul24(r, ldw) + min(kbase + ((lane & 31) ^ r) * 8, K - 8);       // chunks past K are never consumed
+    }
+  }
+  // N % 16 != 0: the last group's missing rows re-read row N - 1 (their products are never stored)
+  static __device__ __forceinline__ int ragged(int lane, int row0, int i, int kbase, int N, int K, int ldw) {
+    const int r = 2 * i + (lane >> 5);
+    return __umul24(min(row0 + r, N - 1), ldw) + min(kbase + ((lane & 31) ^ r) * 8, K - 8);
+  }
+};
+
+// XIN_BF16: one wave per workgroup (see above).  Grid (k-slabs, groups of KW weight-row groups).
+template <int RB, int KW>
+__global__ __launch_bounds__(64) void gemv_ring_kernel(const bf16_t* __restrict__ x, int ldx, int R, const bf16_t* __restrict__ W,
+                                                       int ldw, float* __restrict__ acc, int sr, int sn, int N, int K, DecodeIn f) {
+  __shared__ __attribute__((aligned(1024))) char tile[2][8192];
+  const int lane = threadIdx.x, g = lane >> 4, row = lane & 15;
+  const int grp0 = blockIdx.y * KW;
+  const int kbase = blockIdx.x * 256;
+  const bool whole = (N & 15) == 0;                                 // every 16-row group is complete: no per-row clamp
+  TileAddr ta;
+  ta.init(lane, kbase, K, ldw);
+  auto stage = [&](int t) {
+    // aux = 2: non-temporal -- every weight byte is read once per step by one CU; leaving it out of the caches shortens
+    // issue -> landed (guide, price list row nt-weights)
+    if (whole) {
+      const bf16_t* base = W + __umul24(min((grp0 + t) * 16, N - 16), ldw);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) __builtin_amdgcn_global_load_lds((gptr_t)(base + ta.lane_off[i]), (lptr_t)(tile[t & 1] + i * 1024), 16, 0, 2);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        __builtin_amdgcn_global_load_lds((gptr_t)(W + ta.ragged(lane, (grp0 + t) * 16, i, kbase, N, K, ldw)), (lptr_t)(tile[t & 1] + i * 1024), 16, 0, 2);
     }
   };
   stage(0);
@@ -643,11 +673,11 @@ __global__ __launch_bounds__(64) void gemv_ring_kernel(const bf16_t* __restrict_
   bf16x8_t xf[RB][8];
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
-    const bf16_t* xp = x + (int64_t)min(rb * 16 + row, R - 1) * ldx + g * 8;
+    const bf16_t* xp = x + (__umul24(min(rb * 16 + row, R - 1), ldx) + g * 8);
 #pragma unroll
     for (int u = 0; u < 8; ++u) xf[rb][u] = *reinterpret_cast<const bf16x8_t*>(xp + min(kbase + u * 32, K - 32));
   }
-  decode_clear(f, lane, blockIdx.x, gridDim.x);
+  decode_clear(f, lane, linear_block());
 #pragma unroll
   for (int t = 0; t < KW; ++t) {
     if (t + 1 < KW) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -669,14 +699,14 @@ __global__ __launch_bounds__(64) void gemv_ring_kernel(const bf16_t* __restrict_
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) d[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[rb][u], wf[u], d[rb], 0, 0, 0);
       }
-    const int grp = grp0 + t;
+    const int n = (grp0 + t) * 16 + row;
+    float* ap = acc + __umul24(n, sn);
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
-      const int n = grp * 16 + row;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int r = rb * 16 + g * 4 + j;
-        if (r < R && n < N) atomicAdd(acc + (int64_t)r * sr + (int64_t)n * sn, d[rb][j]);
+        if (r < R && n < N) atomicAdd(ap + __umul24(r, sr), d[rb][j]);
       }
     }
   }
@@ -686,43 +716,23 @@ __global__ __launch_bounds__(64) void gemv_ring_kernel(const bf16_t* __restrict_
 // The operand fragments are built cooperatively -- wave w converts k-steps 2w, 2w+1 for all rows and parks them in
 // LDS -- because every wave re-reading the fp32 slab itself costs more L2 bandwidth than the weights cost HBM
 // (measured: gate_up 14.5 -> 28.8 us).
+// Grid: (k-slabs, chunks of NW x KW weight-row groups), or -- many slabs (the down projection) -- (8, chunks, ceil(slabs / 8)):
+// the workgroups that share a slab -- and therefore its fp32 operand, which the previous launch's atomics left at the device
+// coherence point -- then sit on ONE XCD (workgroups go to the XCDs round robin in x-fastest linear order), so the slab comes
+// through the slow path once per XCD instead of once per workgroup (7.7 -> 1.1 MB per launch); surplus workgroups of the padded
+// grid (slab >= nslabs) only take part in the clears.  Either way slab = x + 8 z, chunk = y: no division in the kernel.
 template <int RB, int KW, int XIN, int NW>
-__global__ __launch_bounds__(64 * NW) void gemv_ring4_kernel(int R, const bf16_t* __restrict__ W, int64_t ldw,
-                                                             float* __restrict__ acc, int64_t sr, int64_t sn, int N, int K,
-                                                             int nslabs, int xcd_chunks, DecodeIn f) {
+__global__ __launch_bounds__(64 * NW) void gemv_ring4_kernel(int R, const bf16_t* __restrict__ W, int ldw, float* __restrict__ acc,
+                                                             int sr, int sn, int N, int K, int nslabs, DecodeIn f) {
   __shared__ __attribute__((aligned(1024))) char tile[NW][2][8192];
   __shared__ __attribute__((aligned(16))) bf16x8_t frag[RB][8][64];
   constexpr int UPW = (8 + NW - 1) / NW;           // k-steps of the operand each wave converts
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, row = lane & 15;
-  // (chunk of weight rows, k-slab) of this workgroup.  xcd_chunks > 0 (many slabs: the down projection): the `xcd_chunks`
-  // workgroups that share a slab -- and therefore its fp32 operand, which the previous launch's atomics left at the device
-  // coherence point -- sit on ONE XCD (block b runs on XCD b % 8), so the slab comes through the slow path once per XCD instead
-  // of once per workgroup (7.7 -> 1.1 MB per launch); surplus workgroups of the padded grid only take part in the clears.
-  int chunk, slab;
-  if (xcd_chunks > 0) {
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    slab = xcd + 8 * (j / xcd_chunks);
-    chunk = j % xcd_chunks;
-    if (slab >= nslabs) { decode_clear(f, threadIdx.x, blockIdx.x, gridDim.x); return; }
-  } else {
-    chunk = blockIdx.x / nslabs;
-    slab = blockIdx.x % nslabs;
-  }
+  const int slab = blockIdx.x + 8 * blockIdx.z, chunk = blockIdx.y;
+  if (slab >= nslabs) { decode_clear(f, threadIdx.x, linear_block()); return; }
   const int grp0 = (chunk * NW + wave) * KW;
   const int kbase = slab * 256;
-  int roff[8], kc[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    roff[i] = 2 * i + (lane >> 5);
-    kc[i] = min(kbase + ((lane & 31) ^ roff[i]) * 8, K - 8);
-  }
-  auto stage = [&](int t) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const bf16_t* src = W + (int64_t)min((grp0 + t) * 16 + roff[i], N - 1) * ldw + kc[i];
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(tile[wave][t & 1] + i * 1024), 16, 0, 2);
-    }
-  };
+  const bool whole = (N & 15) == 0;
   // operand loads of this wave's k-steps go out first, then the weight DMA
   float4 a[RB][UPW][2], b[RB][UPW][2], w[RB][UPW][2];
   float rs[RB];
@@ -737,9 +747,22 @@ __global__ __launch_bounds__(64 * NW) void gemv_ring4_kernel(int R, const bf16_t
       decode_operand_load<XIN>(f, ar, min(kbase + u * 32, K - 32) + g * 8, K, a[rb][uu], b[rb][uu], w[rb][uu]);
     }
   }
+  TileAddr ta;
+  ta.init(lane, kbase, K, ldw);
+  auto stage = [&](int t) {
+    if (whole) {
+      const bf16_t* base = W + __umul24(min((grp0 + t) * 16, N - 16), ldw);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) __builtin_amdgcn_global_load_lds((gptr_t)(base + ta.lane_off[i]), (lptr_t)(tile[wave][t & 1] + i * 1024), 16, 0, 2);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        __builtin_amdgcn_global_load_lds((gptr_t)(W + ta.ragged(lane, (grp0 + t) * 16, i, kbase, N, K, ldw)), (lptr_t)(tile[wave][t & 1] + i * 1024), 16, 0, 2);
+    }
+  };
   stage(0);
   if constexpr (KW > 1) stage(1);
-  decode_clear(f, threadIdx.x, blockIdx.x, gridDim.x);
+  decode_clear(f, threadIdx.x, linear_block());
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
     const int ar = min(rb * 16 + row, R - 1);
@@ -752,7 +775,7 @@ __global__ __launch_bounds__(64 * NW) void gemv_ring4_kernel(int R, const bf16_t
       if (u < 8) {
         const bool in_k = kbase + u * 32 < K;                        // clamped (re-read) steps carry no new data
         float part = 0.f;
-        float* op = XIN == XIN_RESID_NORM ? f.x_out + (int64_t)ar * K + kbase + u * 32 + g * 8 : nullptr;
+        float* op = XIN == XIN_RESID_NORM ? f.x_out + (__umul24(ar, K) + kbase + u * 32 + g * 8) : nullptr;
         frag[rb][u][lane] = decode_operand_make<XIN>(f, a[rb][uu], b[rb][uu], w[rb][uu], rs[rb], chunk == 0 && live && in_k, op, part);
         if (in_k) ssq += part;
       }
@@ -763,7 +786,7 @@ __global__ __launch_bounds__(64 * NW) void gemv_ring4_kernel(int R, const bf16_t
       if (chunk == 0 && live && g == 0 && f.ss_out && ssq != 0.f) atomicAdd(f.ss_out + rb * 16 + row, ssq);
     }
   }
-  __syncthreads();
+  lds_barrier();
   bf16x8_t xf[RB][8];
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb)
@@ -790,14 +813,14 @@ __global__ __launch_bounds__(64 * NW) void gemv_ring4_kernel(int R, const bf16_t
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) d[rb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[rb][u], wf[u], d[rb], 0, 0, 0);
       }
-    const int grp = grp0 + t;
+    const int n = (grp0 + t) * 16 + row;
+    float* ap = acc + __umul24(n, sn);
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
-      const int n = grp * 16 + row;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int r = rb * 16 + g * 4 + j;
-        if (r < R && n < N) atomicAdd(acc + (int64_t)r * sr + (int64_t)n * sn, d[rb][j]);
+        if (r < R && n < N) atomicAdd(ap + __umul24(r, sr), d[rb][j]);
       }
     }
   }
@@ -816,16 +839,25 @@ void launch_gemv(int U, dim3 grid, hipStream_t st, const bf16_t* x, int64_t ldx,
   }
 }
 
+// every workgroup's share of the clears a launch carries (float4 units; the kernels only multiply)
+void set_clear_shares(DecodeIn& f, float* zero0, int64_t n0, float* zero1, int64_t n1, float* ss_zero, unsigned nblocks) {
+  f.zero0 = zero0; f.zero1 = zero1; f.ss_zero = ss_zero;
+  f.n0_4 = (int)(n0 >> 2); f.n1_4 = (int)(n1 >> 2);
+  f.per0 = (int)((f.n0_4 + nblocks - 1) / nblocks); f.per1 = (int)((f.n1_4 + nblocks - 1) / nblocks);
+}
+
 // measured on MI355X (tools/gemv_bench.py): two row groups per wave once there are >= 3000 tiles, else one
 template <int XIN>
-void launch_ring_auto(hipStream_t st, const bf16_t* x, int64_t ldx, int R, const bf16_t* W, int64_t ldw, float* acc, int64_t sr,
-                      int64_t sn, int N, int K, const DecodeIn& f) {
+void launch_ring_auto(hipStream_t st, const bf16_t* x, int ldx, int R, const bf16_t* W, int ldw, float* acc, int sr, int sn, int N,
+                      int K, DecodeIn f, float* zero0 = nullptr, int64_t n0 = 0, float* zero1 = nullptr, int64_t n1 = 0,
+                      float* ss_zero = nullptr) {
   const int64_t groups = (N + 15) / 16;
   const int nslabs = (K + 255) / 256;
   const int KW = groups * nslabs >= 3000 ? 2 : 1;
   if constexpr (XIN == XIN_BF16) {
-    dim3 grid((unsigned)(((groups + KW - 1) / KW) * nslabs));
-#define UG_RING1(RBV, KWV) hipLaunchKernelGGL((gemv_ring_kernel<RBV, KWV>), grid, dim3(64), 0, st, x, ldx, R, W, ldw, acc, sr, sn, N, K, nslabs, f)
+    const dim3 grid((unsigned)nslabs, (unsigned)((groups + KW - 1) / KW));
+    set_clear_shares(f, zero0, n0, zero1, n1, ss_zero, grid.x * grid.y);
+#define UG_RING1(RBV, KWV) hipLaunchKernelGGL((gemv_ring_kernel<RBV, KWV>), grid, dim3(64), 0, st, x, ldx, R, W, ldw, acc, sr, sn, N, K, f)
     if (R <= 16) { if (KW == 2) UG_RING1(1, 2); else UG_RING1(1, 1); }
     else { if (KW == 2) UG_RING1(2, 2); else UG_RING1(2, 1); }
 #undef UG_RING1
@@ -851,14 +883,22 @@ void launch_ring_auto(hipStream_t st, const bf16_t* x, int64_t ldx, int R, const
       if (chunks8 * ((nslabs + 7) / 8) <= 32) { NWc = 8; KWc = 2; xcd_chunks = (int)chunks8; }
     }
     // (dealing the nslabs % 8 left-over slabs' workgroups over all XCDs for equal bytes per XCD measured no better: 10.50 vs 10.33 us)
-    dim3 grid(xcd_chunks ? (unsigned)(8 * ((nslabs + 7) / 8) * xcd_chunks) : (unsigned)(((groups + NWc * KWc - 1) / (NWc * KWc)) * nslabs));
-#define UG_RING4(RBV, KWV, NWV) hipLaunchKernelGGL((gemv_ring4_kernel<RBV, KWV, XIN, NWV>), grid, dim3(64 * NWV), 0, st, R, W, ldw, acc, sr, sn, N, K, nslabs, xcd_chunks, f)
+    const dim3 grid = xcd_chunks ? dim3(8, (unsigned)xcd_chunks, (unsigned)((nslabs + 7) / 8))
+                                 : dim3((unsigned)nslabs, (unsigned)((groups + NWc * KWc - 1) / (NWc * KWc)));
+    set_clear_shares(f, zero0, n0, zero1, n1, ss_zero, grid.x * grid.y * grid.z);
+#define UG_RING4(RBV, KWV, NWV) hipLaunchKernelGGL((gemv_ring4_kernel<RBV, KWV, XIN, NWV>), grid, dim3(64 * NWV), 0, st, R, W, ldw, acc, sr, sn, N, K, nslabs, f)
     if (R <= 16) {
       if (NWc == 9) UG_RING4(1, 3, 9); else if (NWc == 8) UG_RING4(1, 2, 8); else if (NWc == 7) UG_RING4(1, 2, 7); else if (KWc == 2) UG_RING4(1, 2, 4); else UG_RING4(1, 1, 4);
     } else { if (KWc == 2) UG_RING4(2, 2, 4); else UG_RING4(2, 1, 4); }
 #undef UG_RING4
   }
 }
+
+// 32-bit / 24-bit ranges of the ring kernels' addressing (weights up to 2^31 elements, strides below 2^24)
+#define UG_RING_RANGES(name, N, K, ldw, sr, sn)                                                                                      \
+  UG_REQUIRE((N) < (1 << 24) && (K) < (1 << 24) && (ldw) < (1 << 24) && (int64_t)(N) * (ldw) < (1ll << 31) && (sr) < (1 << 24) &&    \
+                 (sn) < (1 << 24) && (int64_t)(N) * (sn) + 32 * (int64_t)(sr) < (1ll << 31),                                         \
+             name ": sizes beyond the kernels' 32-bit addressing (N=%ld K=%ld ldw=%ld)", (long)(N), (long)(K), (long)(ldw))
 
 }  // namespace
 
@@ -870,7 +910,9 @@ extern "C" int ug_gemv_bf16(const void* x, int64_t ldx, int64_t R, const void* W
   const bf16_t* xb = (const bf16_t*)x;
   const bf16_t* wb = (const bf16_t*)W;
   if (K >= 256) {
-    launch_ring_auto<XIN_BF16>(st, xb, ldx, (int)R, wb, ldw, acc, acc_stride_r, acc_stride_n, (int)N, (int)K, DecodeIn{});
+    UG_RING_RANGES("ug_gemv_bf16", N, K, ldw, acc_stride_r, acc_stride_n);
+    UG_REQUIRE(ldx < (1 << 24), "ug_gemv_bf16: ldx beyond 2^24");
+    launch_ring_auto<XIN_BF16>(st, xb, (int)ldx, (int)R, wb, (int)ldw, acc, (int)acc_stride_r, (int)acc_stride_n, (int)N, (int)K, DecodeIn{});
     UG_CHECK_LAUNCH("ug_gemv_bf16");
     return UG_OK;
   }
@@ -888,16 +930,18 @@ extern "C" int ug_gemv_bf16(const void* x, int64_t ldx, int64_t R, const void* W
 #define UG_DECODE_COMMON(name)                                                                                              \
   UG_REQUIRE(R > 0 && R <= 32 && K >= 256 && K % 32 == 0 && N > 0 && ldw % 8 == 0 && ug_aligned16(W) && acc &&              \
                  ug_aligned16(acc) && ldacc % 4 == 0 && n0 % 4 == 0 && n1 % 4 == 0 && ug_aligned16(zero0) && ug_aligned16(zero1), \
-             name ": need 1 <= rows <= 32, K >= 256, K %% 32 == 0, 16-byte aligned operands (rows=%ld K=%ld)", (long)R, (long)K)
+             name ": need 1 <= rows <= 32, K >= 256, K %% 32 == 0, 16-byte aligned operands (rows=%ld K=%ld)", (long)R, (long)K);                        \
+  UG_RING_RANGES(name, N, K, ldw, ldacc, 1);                                                                                 \
+  UG_REQUIRE(n0 < (1ll << 31) && n1 < (1ll << 31), name ": clears beyond 2^31 floats")
 
 extern "C" int ug_decode_gemv(const void* x, int64_t ldx, int64_t R, const void* W, int64_t ldw, float* acc, int64_t ldacc,
                               int64_t N, int64_t K, float* zero0, int64_t n0, float* zero1, int64_t n1, float* ss_zero,
                               hipStream_t st) {
   UG_DECODE_COMMON("ug_decode_gemv");
   UG_REQUIRE(x && ldx % 8 == 0 && ug_aligned16(x), "ug_decode_gemv: activations must be 16-byte aligned rows");
-  DecodeIn f{};
-  f.zero0 = zero0; f.n0 = n0; f.zero1 = zero1; f.n1 = n1; f.ss_zero = ss_zero;
-  launch_ring_auto<XIN_BF16>(st, (const bf16_t*)x, ldx, (int)R, (const bf16_t*)W, ldw, acc, ldacc, 1, (int)N, (int)K, f);
+  UG_REQUIRE(ldx < (1 << 24), "ug_decode_gemv: ldx beyond 2^24");
+  launch_ring_auto<XIN_BF16>(st, (const bf16_t*)x, (int)ldx, (int)R, (const bf16_t*)W, (int)ldw, acc, (int)ldacc, 1, (int)N, (int)K, DecodeIn{},
+                             zero0, n0, zero1, n1, ss_zero);
   UG_CHECK_LAUNCH("ug_decode_gemv");
   return UG_OK;
 }
@@ -912,8 +956,8 @@ extern "C" int ug_decode_gemv_resid_norm(const float* x_in, const float* pending
              "ug_decode_gemv_resid_norm: bad args (x_in and x_out must be distinct, 16-byte aligned fp32 buffers)");
   DecodeIn f{};
   f.x_in = x_in; f.pend = pending; f.ld_pend = ld_pending; f.norm_w = norm_w; f.x_out = x_out; f.ss_out = ss_out;
-  f.zero0 = zero0; f.n0 = n0; f.zero1 = zero1; f.n1 = n1; f.ss_zero = ss_zero;
-  launch_ring_auto<XIN_RESID_NORM>(st, nullptr, 0, (int)R, (const bf16_t*)W, ldw, acc, ldacc, 1, (int)N, (int)K, f);
+  UG_REQUIRE(ld_pending < (1 << 24), "ug_decode_gemv_resid_norm: ld_pending beyond 2^24");
+  launch_ring_auto<XIN_RESID_NORM>(st, nullptr, 0, (int)R, (const bf16_t*)W, (int)ldw, acc, (int)ldacc, 1, (int)N, (int)K, f, zero0, n0, zero1, n1, ss_zero);
   UG_CHECK_LAUNCH("ug_decode_gemv_resid_norm");
   return UG_OK;
 }
@@ -926,8 +970,8 @@ extern "C" int ug_decode_gemv_swiglu(const float* gate_up_acc, int64_t ld_gu, co
              "ug_decode_gemv_swiglu: bad args");
   DecodeIn f{};
   f.gu = gate_up_acc; f.ld_gu = ld_gu; f.ss_in = ss_in; f.eps = eps; f.norm_cols = (int)norm_cols;
-  f.zero0 = zero0; f.n0 = n0; f.zero1 = zero1; f.n1 = n1; f.ss_zero = ss_zero;
-  launch_ring_auto<XIN_SWIGLU>(st, nullptr, 0, (int)R, (const bf16_t*)W, ldw, acc, ldacc, 1, (int)N, (int)K, f);
+  UG_REQUIRE(ld_gu < (1 << 24), "ug_decode_gemv_swiglu: ld_gu beyond 2^24");
+  launch_ring_auto<XIN_SWIGLU>(st, nullptr, 0, (int)R, (const bf16_t*)W, (int)ldw, acc, (int)ldacc, 1, (int)N, (int)K, f, zero0, n0, zero1, n1, ss_zero);
   UG_CHECK_LAUNCH("ug_decode_gemv_swiglu");
   return UG_OK;
 }

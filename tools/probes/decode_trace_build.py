@@ -26,16 +26,16 @@ __device__ unsigned long long* g_trace = nullptr;
 // stamps stay in registers (s_memtime, the shader clock) and are written once at the kernel's end; slot 7 = s_memrealtime at entry
 #define UG_STAMP(k) ug_st[k] = clock64()
 """)
-sub("""  const int nmain = gridDim.x - max(pf.count, 0);
-  constexpr int UPW""", """  const int nmain = gridDim.x - max(pf.count, 0);
+sub("""  constexpr int UPW = (8 + NW - 1) / NW;           // k-steps of the operand each wave converts
+""", """  constexpr int UPW = (8 + NW - 1) / NW;           // k-steps of the operand each wave converts
   unsigned long long* const ug_tr = g_trace;
   unsigned long long ug_st[8];
   ug_st[7] = wall_clock64();
   UG_STAMP(0);
-  constexpr int UPW""")
+""")
 sub("""  stage(0);
   if constexpr (KW > 1) stage(1);
-  decode_clear(f, threadIdx.x, blockIdx.x, nmain);
+  decode_clear(f, threadIdx.x, linear_block());
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
     const int ar = min(rb * 16 + row, R - 1);
@@ -44,12 +44,12 @@ sub("""  stage(0);
   UG_STAMP(1);
   if constexpr (KW > 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   UG_STAMP(2);
-  decode_clear(f, threadIdx.x, blockIdx.x, nmain);
+  decode_clear(f, threadIdx.x, linear_block());
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
     const int ar = min(rb * 16 + row, R - 1);
     const bool live""")
-sub("""  __syncthreads();
+sub("""  lds_barrier();
   bf16x8_t xf[RB][8];
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb)
@@ -59,7 +59,7 @@ sub("""  __syncthreads();
   for (int t = 0; t < KW; ++t) {
     if (t + 1 < KW) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const char* tr = tile[wave][t & 1] + row * 512;""", """  __syncthreads();
+    const char* tr = tile[wave][t & 1] + row * 512;""", """  lds_barrier();
   UG_STAMP(3);
   bf16x8_t xf[RB][8];
 #pragma unroll
@@ -72,16 +72,15 @@ sub("""  __syncthreads();
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (t == 0) UG_STAMP(4);
     const char* tr = tile[wave][t & 1] + row * 512;""")
-sub("""        if (r < R && n < N) atomicAdd(acc + (int64_t)r * sr + (int64_t)n * sn, d[rb][j]);
+sub("""        if (r < R && n < N) atomicAdd(ap + __umul24(r, sr), d[rb][j]);
       }
     }
   }
-  prefetch_done(pf_vals);
 }
 
 
 template <int RB>
-void launch_gemv(""", """        if (r < R && n < N) atomicAdd(acc + (int64_t)r * sr + (int64_t)n * sn, d[rb][j]);
+void launch_gemv(""", """        if (r < R && n < N) atomicAdd(ap + __umul24(r, sr), d[rb][j]);
       }
     }
   }
@@ -89,12 +88,12 @@ void launch_gemv(""", """        if (r < R && n < N) atomicAdd(acc + (int64_t)r 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   UG_STAMP(6);
   if (ug_tr && (threadIdx.x & 63) == 0) {
-    unsigned long long* o = ug_tr + ((XIN == XIN_RESID_NORM ? (NW == 9 ? 0 : 1) : 2) * 4096 + blockIdx.x * 16 + (threadIdx.x >> 6)) * 8;
+    unsigned long long* o = ug_tr + ((XIN == XIN_RESID_NORM ? (NW == 9 ? 0 : 1) : 2) * 4096 + linear_block() * 16 + (threadIdx.x >> 6)) * 8;
 #pragma unroll
     for (int k = 0; k < 8; ++k) o[k] = ug_st[k];
   }
-  prefetch_done(pf_vals);
 }
+
 
 template <int RB>
 void launch_gemv(""")
