@@ -266,7 +266,7 @@ def extra_cases(model, vq, opt, dev, args, steps=2):
     # 386 shifted positions instead of 256 label rows: 3 x (1.0141 + 0.0186 + 386/256 x 0.1257) + 0.355
     fl = Bt * (3.475e12 + 0.3551e12) + Bm * (3 * (1.0141e12 + 0.0186e12 + 386 / 256 * 0.1257e12) + 0.3551e12)
     out["pt1_mixed_L387"] = {"ms_per_step": round(ms, 2), "samples_per_s": round((Bt + Bm) / ms * 1e3, 2), "rows": f"{Bt} t2i + {Bm} mmu",
-                             "seq_len": L, "step_frac_of_bf16_peak": round(fl / (ms * 1e-3) / PEAK_BF16, 4),
+                             "seq_len": L, "step_tflop": round(fl / 1e12, 2), "step_frac_of_bf16_peak": round(fl / (ms * 1e-3) / PEAK_BF16, 4),
                              "by_family_ms": by_family(step_pt1)}
 
     # ---- DPO: 10 pairs at L = 387 (a second, frozen copy of the model as the reference policy)
@@ -301,8 +301,13 @@ def extra_cases(model, vq, opt, dev, args, steps=2):
         opt.zero_grad(set_to_none=True)
         dpo_loss.append(loss.detach())
     ms = timed(step_dpo)
+    # algorithmic FLOPs: every row is a t2i row at L = 387 (1.0141 linear + 0.0186 attention + 0.1257 head at its 256
+    # label positions = 1.1584 TFLOP forward); the policy runs forward + backward (x 3), the frozen reference one more forward;
+    # + the tokenizer's 0.3551 per image
+    fl = Bd * ((3 + 1) * 1.1584e12 + 0.3551e12)
     out["dpo_L387"] = {"ms_per_step": round(ms, 2), "pairs_per_s": round(pairs / ms * 1e3, 2), "pairs": pairs, "seq_len": L,
-                       "loss": round(float(dpo_loss[-1]), 4), "by_family_ms": by_family(step_dpo)}
+                       "loss": round(float(dpo_loss[-1]), 4), "step_tflop": round(fl / 1e12, 2),
+                       "step_frac_of_bf16_peak": round(fl / (ms * 1e-3) / PEAK_BF16, 4), "by_family_ms": by_family(step_dpo)}
     del ref
     torch.cuda.empty_cache()
 
@@ -370,8 +375,20 @@ def extra_cases(model, vq, opt, dev, args, steps=2):
         opt.zero_grad(set_to_none=True)
         sft_loss.append(torch.stack([l1.detach(), l2.detach(), l3.detach()]))
     ms = timed(step_sft)
+    # algorithmic FLOPs (the mm_projector's 0.02 TFLOP per image is left out): linear 2.6204 GFLOP per token; attention
+    # 172 032 FLOP per unmasked (q, k) pair over the 28 layers -- t2i row T (T + 1) / 2 + 258 (T + 258) with T = L - 258, lm row
+    # L (L + 1) / 2, mmu_vit row the causal pairs + the image columns [20, 20 + 729) above the diagonal; head 0.4911 GFLOP per
+    # position -- 256 label rows of a t2i row, the L - 1 shifted positions of an lm / mmu row (the convention of pt1_mixed_L387);
+    # x 3 for forward + backward; + tokenizer 0.3551 per generation image and the frozen SigLIP tower 0.642 per understanding image
+    T_ = Ls - 258
+    pairs_t2i, pairs_lm = T_ * (T_ + 1) // 2 + 258 * (T_ + 258), Ls * (Ls + 1) // 2
+    pairs_mmu = pairs_lm + 20 * n_tok + n_tok * (n_tok - 1) // 2
+    fwd = ((bt + bl + bm) * Ls * 2.6204e9 + 172032.0 * (bt * pairs_t2i + bl * pairs_lm + bm * pairs_mmu)
+           + 0.4911e9 * (bt * NVQ + (bl + bm) * (Ls - 1)))
+    fl = 3 * fwd + bt * 0.3551e12 + bm * 0.642e12
     out["sft_L1603"] = {"ms_per_step": round(ms, 2), "samples_per_s": round((bt + bl + bm) / ms * 1e3, 2), "rows": f"{bt} t2i + {bl} lm + {bm} mmu",
                         "seq_len": Ls, "siglip_images": bm, "losses": [round(float(x), 3) for x in sft_loss[-1]],
+                        "step_tflop": round(fl / 1e12, 2), "step_frac_of_bf16_peak": round(fl / (ms * 1e-3) / PEAK_BF16, 4),
                         "by_family_ms": by_family(step_sft)}
     model.llm.engine.check_errors()
     return out
@@ -379,12 +396,27 @@ def extra_cases(model, vq, opt, dev, args, steps=2):
 
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): start the N ranks through torch.distributed.run as a
-    child process and relay its stdout / exit code.  This parent never initialises the GPU (it only counts devices, which does not)
-    and never replaces itself (no exec): on this pool an exec from a GPU-initialised process takes the machine down."""
+    child process and relay its stdout / exit code.  The parent must only ever SPAWN a child, never replace itself (no exec): on this
+    pool an exec from a process that has touched the GPU runtime takes the machine down, and counting devices through HIP may
+    initialise it -- so the devices are counted from sysfs (the KFD topology), without any HIP call."""
+    import glob
     import socket
     import subprocess
-    have = torch.cuda.device_count()
-    if have < n and os.environ.get("UNIGEN_BENCH_ONE_DEVICE") != "1":
+
+    def gpu_nodes():
+        n_gpu = 0
+        for prop in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+            try:
+                kv = dict(line.split(None, 1) for line in open(prop).read().splitlines() if " " in line)
+                n_gpu += int(kv.get("simd_count", "0").strip()) > 0          # CPU nodes have no SIMDs
+            except (OSError, ValueError):
+                pass
+        vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES")
+        if vis:
+            n_gpu = min(n_gpu, len([v for v in vis.split(",") if v.strip() != ""])) if n_gpu else len([v for v in vis.split(",") if v.strip() != ""])
+        return n_gpu
+    have = gpu_nodes()
+    if 0 < have < n and os.environ.get("UNIGEN_BENCH_ONE_DEVICE") != "1":          # (no KFD topology in sysfs: let the ranks find out)
         raise SystemExit(f"--gpus {n} but this node exposes {have} GPU(s); a weak-scaling number needs one GPU per rank "
                          "(UNIGEN_DIST_BACKEND=gloo UNIGEN_BENCH_ONE_DEVICE=1 rehearses the path on one device)")
     s = socket.socket()

@@ -1180,7 +1180,10 @@ int launch(GemmArgs a, const ug_handle* h, int policy, hipStream_t st) {
       for (int h_ : heights) {
         if (!heights_on && h_ != QBM) continue;                  // (round 3's choice: 320 rows or nothing)
         const int64_t wgs = (int64_t)((a.M + h_ - 1) / h_) * (a.N / PBN);
-        if (wgs <= 256) { if (wgs >= 64) hb = h_; break; }        // (measured down to 78 workgroups: tools/gemm_shape_sweep.py at M = 1 542)
+        // (measured down to 78 workgroups: tools/gemm_shape_sweep.py at M = 1 542.)  Few workgroups AND a very long contraction
+        // (an lm-head dgrad whose vocabulary is a multiple of 32: >= 2048 k-tiles on < 200 CUs) stay with the k-sliced form
+        // below, which cuts every tile along K over the whole chip (measured 632 -> 1 094 TF/s at 174 tiles, K = 159 867)
+        if (wgs <= 256) { if (wgs >= 64 && !(a.K / PBK >= 2048 && wgs < 200)) hb = h_; break; }
       }
       if (hb == 256 && p8_fits) hb = 0;                          // (the 256 x 256 kernel's own one-round case)
     }

@@ -48,6 +48,8 @@ import os
 import torch
 import torch.distributed as dist
 
+from .lib import UniGenHipError
+
 
 class FlatGradSync:
     """engine: anything exposing .fp.grad (flat tensor), .fp.off (key -> (offset, shape)), .dims.num_hidden_layers and a
@@ -244,32 +246,38 @@ class FlatGradSync:
         """True while a backward pass that exchanges gradients keeps embedding-lookup gradients aside as (id, row) pairs."""
         return self.active and self.enabled and self.sparse_embed
 
-    def _agree_capacity(self, rows_live):
-        """Start of a backward pass: every rank's count of lookup rows recorded on its autograd graphs (known on the HOST since
-        the forward) -> the MAX over ranks = the padded length of the end-of-backward all-gather.  On a GPU transport the
-        collective and the copy back to pinned memory run on the side stream, which is idle now: the result is on the host long
-        before finish() asks for it."""
-        n = int(rows_live)
+    def _agree_capacity(self, rows_live, heads_live=0):
+        """Start of a backward pass: every rank announces (a) its count of lookup rows recorded on its autograd graphs (known on the
+        HOST since the forward) -> the MAX over ranks = the padded length of the end-of-backward all-gather, and (b) its count of
+        recorded head segments (dense writers of the tied table) -> the early hand-over of the table right after the heads'
+        backward is used in this pass ONLY if every rank announces the same, non-zero count.  Both decisions change the
+        sequence of collectives a rank issues, so neither may be taken from local state alone (ranks that diverge
+        -- one falls back to the dense lookup gradient, a head is outside the loss on one rank -- would pair different
+        collectives: a hang, not an error).  On a GPU transport the collective and the copy back to pinned memory run on the side
+        stream, which is idle now: the result is on the host long before anything asks for it."""
+        n, h = int(rows_live), int(heads_live)
         if not self.cuda or self.backend not in ("nccl", "ug_comm(rccl)"):
             if self.world == 1:
-                self._cap = n
+                self._cap = (n, h > 0)
                 return
-            t = torch.tensor([n], dtype=torch.int64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.pg)
-            self._cap = int(t.item())
+            mine = torch.tensor([n, h], dtype=torch.int64)
+            every = [torch.zeros(2, dtype=torch.int64) for _ in range(self.world)]
+            dist.all_gather(every, mine, group=self.pg)
+            every = torch.stack(every)
+            self._cap = (int(every[:, 0].max()), bool((every[:, 1] == every[0, 1]).all()) and int(every[0, 1]) > 0)
         else:                                     # (also at world size 1 with the exchange forced on: the one-GPU boxes drive this path)
             dev = self.engine.fp.grad.device
             if self._pin is None:
-                self._pin = (torch.zeros(1, dtype=torch.int64).pin_memory(), torch.zeros(self.world, dtype=torch.int64).pin_memory(),
-                             torch.zeros(1, dtype=torch.int64, device=dev), torch.zeros(self.world, dtype=torch.int64, device=dev))
+                self._pin = (torch.zeros(2, dtype=torch.int64).pin_memory(), torch.zeros(2 * self.world, dtype=torch.int64).pin_memory(),
+                             torch.zeros(2, dtype=torch.int64, device=dev), torch.zeros(2 * self.world, dtype=torch.int64, device=dev))
             src, dst, d_src, d_all = self._pin
-            src[0] = n
+            src[0], src[1] = n, h
             with torch.cuda.stream(self.stream):
                 d_src.copy_(src, non_blocking=True)
                 if self._comm is not None:
                     from . import lib as _l
                     side = torch.cuda.current_stream().cuda_stream
-                    _l.check(self._lib.ug_comm_allgather(self._comm, d_src.data_ptr(), d_all.data_ptr(), 8, side), "ug_comm_allgather")
+                    _l.check(self._lib.ug_comm_allgather(self._comm, d_src.data_ptr(), d_all.data_ptr(), 16, side), "ug_comm_allgather")
                     _l.check(self._lib.ug_comm_wait(self._comm, side), "ug_comm_wait")
                 else:
                     dist.all_gather_into_tensor(d_all, d_src, group=self.pg)
@@ -278,12 +286,22 @@ class FlatGradSync:
                 ev.record()
             self._cap = (ev, dst)
 
-    def _capacity(self):
-        if isinstance(self._cap, tuple):
+    def _plan(self):
+        """(agreed row capacity, early hand-over agreed) of the running pass"""
+        if self._cap is None:
+            return 0, False
+        if not isinstance(self._cap[0], int):
             ev, dst = self._cap
             ev.synchronize()
-            self._cap = int(dst.max().item())
-        return self._cap or 0
+            every = dst.view(self.world, 2)
+            self._cap = (int(every[:, 0].max()), bool((every[:, 1] == every[0, 1]).all()) and int(every[0, 1]) > 0)
+        return self._cap
+
+    def _capacity(self):
+        return self._plan()[0]
+
+    def early_handover_agreed(self):
+        return self._plan()[1]
 
     def add_lookup(self, ids, rows):
         """An embedding lookup's backward: ids int64 [n], rows fp32 [n, H] (kept, not copied)."""
@@ -295,6 +313,11 @@ class FlatGradSync:
         (what is there is the mean over ranks already: averaging identical values again changes nothing)."""
         if not self._embed_done:
             return
+        if self.world > 1:
+            # the other ranks will not exchange the table a second time: carrying on would pair different collectives (a hang)
+            raise UniGenHipError("data-parallel exchange: a dense writer of the tied embedding table ran after the table's agreed early "
+                                 "hand-over on this rank (an embedding lookup that was not recorded before backward started, or more "
+                                 "lookup rows than announced); the ranks' collectives would no longer pair")
         if self.cuda:
             if self._comm is not None:
                 from . import lib as _l
@@ -361,10 +384,11 @@ class FlatGradSync:
             table.index_add_(0, ids_all[keep], rows_all[keep], alpha=1.0 / W)       # sequential on the host: deterministic
 
     # ------------------------------------------------------------------ driven by backward
-    def begin(self, enabled=True, lookup_rows=0):
+    def begin(self, enabled=True, lookup_rows=0, heads_live=0):
         """Start of a backward pass.  enabled=False: a gradient-accumulation micro-step (DDP's no_sync): nothing is
         exchanged, gradients keep accumulating locally.  lookup_rows: embedding-lookup rows recorded on this rank's live
-        autograd graphs (an upper bound of what this pass will keep aside)."""
+        autograd graphs (an upper bound of what this pass will keep aside); heads_live: recorded head segments (dense writers of
+        the tied table) -- the ranks agree on both before anything depends on them (_agree_capacity)."""
         self.enabled = bool(enabled)
         self._hi = None
         self._overlap = True
@@ -372,7 +396,7 @@ class FlatGradSync:
         self._lookups = []
         self._cap = None
         if self.wants_lookups():
-            self._agree_capacity(lookup_rows)
+            self._agree_capacity(lookup_rows, heads_live)
 
     def set_overlap(self, on):
         """Called at the start of every decoder-stack segment of a backward pass: only the LAST segment that writes the
@@ -388,13 +412,15 @@ class FlatGradSync:
         if tag == "head":
             # the last recorded head has written its dense weight gradient into the tied table: nothing but lookups (kept
             # aside) is expected to touch it any more in this pass
-            if self.enabled and self.active and self.sparse_embed and not self._embed_done and self._embed_end > 0:
+            if (self.enabled and self.active and self.sparse_embed and not self._embed_done and self._embed_end > 0
+                    and self.early_handover_agreed()):
                 self._flush(0, self._embed_end)
                 self._embed_done = True
                 self.early_embed_handovers += 1
             return
         if not self.enabled or not self._overlap:
             return
+        self._check_early_done()
         if tag == "norm":
             self._hi = self._numel
             return
@@ -407,6 +433,15 @@ class FlatGradSync:
                 self._flush(lo, self._hi)
                 self._hi = lo
 
+    def _check_early_done(self):
+        """Every rank announced the same number of recorded heads, so every OTHER rank has handed the table over as its first
+        collective of the pass; a rank whose heads did not all run (a head outside the loss) must not issue anything else."""
+        if (self.world > 1 and self.sparse_embed and self._embed_end > 0 and not self._embed_done and self._cap is not None
+                and self.early_handover_agreed()):
+            raise UniGenHipError("data-parallel exchange: the ranks agreed on handing the tied embedding table over right after the heads' "
+                                 "backward, but on this rank not every recorded head segment has run its backward (a head output that is "
+                                 "not part of the loss?); the ranks' collectives would no longer pair")
+
     def finish(self):
         """End of backward: flush what no hook has covered (always the embedding table; everything if no hook fired or
         overlapping was off), average the ordinary parameters' gradients, and make the current stream (the host, on CPU)
@@ -414,6 +449,7 @@ class FlatGradSync:
         if not self.enabled or not self.active:
             self._hi = None
             return
+        self._check_early_done()
         if self._hi is None:
             self._hi = self._numel
         lo = self._embed_end if self._embed_done else 0

@@ -497,7 +497,7 @@ class TrainEngine(Qwen2Engine):
             if sync is not None:
                 self._in_backward = True
                 self._lookup_rows_cap, self._lookup_rows_kept = self._lookup_rows_live, 0
-                sync.begin(enabled=self._sync_this_pass(), lookup_rows=self._lookup_rows_live)
+                sync.begin(enabled=self._sync_this_pass(), lookup_rows=self._lookup_rows_live, heads_live=self._head_graphs_live)
                 torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
 
     def mask_bits(self, attention_mask, B, L):

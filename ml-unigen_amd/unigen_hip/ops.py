@@ -747,12 +747,19 @@ def amax(x2d):
     """max|x| of a 2-D (or any contiguous) fp32 tensor as a device scalar: the scale bound of `conv2d_nhwc(w_split=)` /
     `linear_split` for inputs whose range is not known by construction."""
     _need_cuda(x2d)
-    out = _amax_slot(x2d.device)
     if x2d.dim() == 2 and x2d.stride(1) == 1:
         rows, cols, ld = x2d.shape[0], x2d.shape[1], x2d.stride(0)
     else:
         x2d = x2d.contiguous()
         rows, cols, ld = 1, x2d.numel(), x2d.numel()
+    if torch.cuda.is_current_stream_capturing():
+        # a pool slot is zeroed ONCE, when its pool is created: replays of a captured graph would keep taking the maximum into a
+        # slot nobody clears (the bound would only ever grow).  Under capture the bound gets its own scalar and the launch that
+        # carries a memset node (ug_amax_f32), so every replay starts from zero.
+        out = torch.empty(1, dtype=torch.float32, device=x2d.device)
+        _l.check(_l.load().ug_amax_f32(_p(x2d), rows, cols, ld, _p(out), _stream()), "ug_amax_f32")
+        return out
+    out = _amax_slot(x2d.device)
     _l.check(_l.load().ug_amax_f32_into_zeroed(_p(x2d), rows, cols, ld, _p(out), _stream()), "ug_amax_f32")
     return out
 

@@ -221,11 +221,15 @@ def _worker_multi_lookup(rank, world, port, sparse, q):
             eng.grad_ready_hook(i)
 
     ok = True
-    for case in ("one segment", "two segments", "late dense writer", "no head"):
+    from unigen_hip.lib import UniGenHipError
+    for case in ("one segment", "two segments", "no head", "head counts differ", "late dense writer"):
         grad.zero_()
         total.zero_()
         rows_live = 3 * (11 + 2 * rank) + (5 if case == "two segments" else 0)      # ranks look up different numbers of rows
-        sync.begin(lookup_rows=rows_live)
+        # recorded head segments as the engine announces them at the start of backward: the early hand-over of the tied table is
+        # used only when EVERY rank announces the same non-zero count (the decision changes the collective sequence)
+        heads = {"one segment": 1, "two segments": 2, "no head": 0, "late dense writer": 1, "head counts differ": 1 + (rank == 1)}[case]
+        sync.begin(lookup_rows=rows_live, heads_live=heads)
         if case == "two segments":
             head()                                       # e.g. the rejected half of a DPO pair: not the last head, no hand-over
             stack_segment(False)                         # ... and its stack hooks must not flush
@@ -233,11 +237,21 @@ def _worker_multi_lookup(rank, world, port, sparse, q):
         if case != "no head":
             head()
             eng.grad_ready_hook("head")                  # last recorded head: the table's dense part travels from here on
-            assert sync._embed_done == sparse
+            # (rank 1 of "head counts differ" recorded a second head that is outside the loss: nobody hands over early)
+            assert sync._embed_done == (sparse and case != "head counts differ")
         stack_segment(True)
         if case == "late dense writer":
-            head()                                       # an unrecorded dense writer after the hand-over: must wait + re-exchange
-            assert not sync._embed_done
+            # an unrecorded dense writer after the agreed hand-over: the other ranks would not exchange the table again, so with
+            # more than one rank this is refused loudly instead of pairing different collectives (before round 5: a re-exchange
+            # decided from local state -- a hang when only one rank did it)
+            if sparse:
+                try:
+                    head()
+                    ok = False
+                except UniGenHipError:
+                    pass
+                break                                    # (the pass is abandoned on every rank alike)
+            head()
         for _ in range(3):                               # three lookups (text / t2i / mmu parts): three 'embed' hooks
             lookup(11 + 2 * rank)
         sync.finish()

@@ -187,18 +187,85 @@ def test_gemm_swiglu_bwd_fused_epilogue_is_bit_identical(dev, M, I, K):
         assert _rel(got[1:].float().cpu(), g32.grad[1:]) < 1.2e-2
 
 
-def test_gemm_bf16_long_contraction_slices_up_to_199_tiles(dev):
+FUSED_HEIGHTS = {"swiglu": (128, 160, 192, 208, 224, 256, 288, 320), "rope": (128, 160, 192, 208, 224, 256, 288, 320),
+                 "swiglu_bwd": (128, 160, 192, 208, 224, 256, 272, 288, 320)}
+
+
+@pytest.mark.parametrize("kind,height", [(k, h) for k, hs in FUSED_HEIGHTS.items() for h in hs])
+def test_fused_epilogue_every_instantiated_tile_height(dev, kind, height):
+    """the fused entry points pick their tile height from a cost model, so the bit-identity tests above reach only the
+    heights their shapes happen to select.  `ug_gemm_set_fused_tile_height` forces each instantiated height in turn (ragged last
+    row tile, several column tiles, the hand-counted `s_waitcnt vmcnt` of the SwiGLU-backward epilogue's prefetch included) and
+    the result must equal GEMM + element-wise kernel bit for bit; a height an entry point does not instantiate is refused."""
+    ops = _ops()
+    from unigen_hip.lib import UniGenHipError
+    g = torch.Generator(device=dev).manual_seed(height)
+    M, K = 3 * 333, 160                                  # 999 rows: every height leaves a ragged last row tile
+    try:
+        if kind == "swiglu":
+            I = 2048                                     # 4 x 16 = 64 tiles of 256 x 256: the smallest problem the fused form takes
+            x = torch.randn(M, K, device=dev, generator=g).to(torch.bfloat16)
+            w = (torch.randn(2 * I, K, device=dev, generator=g) * (K ** -0.5)).to(torch.bfloat16)
+            ops.set_gemm_tile_policy(3)
+            gu_ref = ops.gemm(x, w)
+            ops.set_gemm_tile_policy(-1)
+            act_ref = ops.swiglu_fwd(gu_ref)
+            ops.set_fused_tile_height(height)
+            was, ops.FUSED_SWIGLU = ops.FUSED_SWIGLU, True
+            try:
+                gu, act = ops.gemm_swiglu(x, w)
+            finally:
+                ops.FUSED_SWIGLU = was
+            assert torch.equal(gu, gu_ref) and torch.equal(act, act_ref)
+        elif kind == "rope":
+            L, N, heads, hd = 333, 1024, 6, 128
+            x = torch.randn(M, K, device=dev, generator=g).to(torch.bfloat16)
+            w = (torch.randn(N, K, device=dev, generator=g) * 0.2).to(torch.bfloat16)
+            b = torch.randn(N, device=dev, generator=g).to(torch.bfloat16)
+            cos, sin = ops.rope_tables(L, hd, 1e6, dev)
+            want = ops.rope_(ops.gemm(x, w, bias=b), cos, sin, L, heads, hd)
+            ops.set_fused_tile_height(height)
+            assert torch.equal(ops.gemm_qkv_rope(x, w, b, cos, sin, L, heads, hd), want)
+        else:
+            I = 1024
+            dy = (torch.randn(M, K, device=dev, generator=g) * 0.5).to(torch.bfloat16)
+            wd = (torch.randn(K, I, device=dev, generator=g) * (K ** -0.5)).to(torch.bfloat16)
+            gu = (torch.randn(M, 2 * I, device=dev, generator=g) * 2).to(torch.bfloat16)
+            ops.set_gemm_tile_policy(3)
+            want = ops.swiglu_bwd(gu, ops.gemm(dy, wd, b_kmajor=True))
+            ops.set_gemm_tile_policy(-1)
+            ops.set_fused_tile_height(height)
+            assert torch.equal(ops.gemm_swiglu_bwd(dy, wd, gu), want)
+        if kind != "swiglu_bwd":                         # 272 exists only for the SwiGLU backward
+            ops.set_fused_tile_height(272)
+            with pytest.raises(UniGenHipError):
+                if kind == "swiglu":
+                    was, ops.FUSED_SWIGLU = ops.FUSED_SWIGLU, True
+                    try:
+                        ops.gemm_swiglu(x, w)
+                    finally:
+                        ops.FUSED_SWIGLU = was
+                else:
+                    ops.gemm_qkv_rope(x, w, b, cos, sin, L, heads, hd)
+    finally:
+        ops.set_gemm_tile_policy(-1)
+        ops.set_fused_tile_height(0)
+
+
+@pytest.mark.parametrize("M,N,K", [(2900, 2816, 65528), (2000, 2816, 65536)])
+def test_gemm_bf16_long_contraction_slices_up_to_199_tiles(dev, M, N, K):
     """132 output tiles of 256 x 256 with a 65 528-long contraction (the pt1 mixed batch's lm-head dgrad has 174 with K = 159 867):
     the automatic selection cuts every tile along K into private fp32 partials (round 4: up to 199 tiles, was 128) -- against
-    sampled rows in fp64 on the host and against the 128 x 128 kernel (policy 0) on the whole output."""
+    sampled rows in fp64 on the host and against the 128 x 128 kernel (policy 0) on the whole output.  Second case (round 5, ADVICE
+    r4): K % 32 == 0 makes the shape eligible for the one-round 128 ... 320-row kernel, which would run its 2 048 k-tiles on 176
+    workgroups; the selection leaves such shapes (>= 2 048 k-tiles, < 200 workgroups) to the k-sliced form."""
     ops = _ops()
-    M, N, K = 2900, 2816, 65528            # (K % 32 != 0: not eligible for the 128 ... 320-row one-round kernel, which would win)
     g = torch.Generator().manual_seed(5)
     a = (torch.randn(M, K, generator=g) * 0.25).to(torch.bfloat16)
     b = (torch.randn(K, N, generator=g) * 0.25).to(torch.bfloat16)          # k-major B: the dgrad layout
     A, B = a.to(dev), b.to(dev)
     out = ops.gemm(A, B, b_kmajor=True)
-    rows = torch.tensor([0, 1, 255, 256, 1337, 2559, 2560, 2899])
+    rows = torch.tensor([0, 1, 255, 256, 1337, M - 341, M - 340, M - 1])
     want = a[rows].double() @ b.double()
     assert _rel(out[rows.to(dev)].double().cpu(), want) < 4e-3
     ops.set_gemm_tile_policy(0)
