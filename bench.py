@@ -416,7 +416,7 @@ def self_launch(n):
             n_gpu = min(n_gpu, len([v for v in vis.split(",") if v.strip() != ""])) if n_gpu else len([v for v in vis.split(",") if v.strip() != ""])
         return n_gpu
     have = gpu_nodes()
-    if 0 < have < n and os.environ.get("UNIGEN_BENCH_ONE_DEVICE") != "1":          # (no KFD topology in sysfs: let the ranks find out)
+    if have < n and os.environ.get("UNIGEN_BENCH_ONE_DEVICE") != "1":          # (no KFD topology in sysfs = no ROCm device at all)
         raise SystemExit(f"--gpus {n} but this node exposes {have} GPU(s); a weak-scaling number needs one GPU per rank "
                          "(UNIGEN_DIST_BACKEND=gloo UNIGEN_BENCH_ONE_DEVICE=1 rehearses the path on one device)")
     s = socket.socket()

@@ -480,19 +480,6 @@ constexpr int XQ = QP_ROWS * SBK;
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-// Phase timeline of workgroup 0 (probe builds only, -DUG_CONV_TRACE; tools/probes/conv_trace.py): s_memtime stamps of waves 0
-// and 4 at the phase boundaries of the first 64 taps.
-#ifdef UG_CONV_TRACE
-__device__ unsigned long long g_conv_trace[2 * 64 * 4];
-#define C_STAMP(slot)                                                                                          \
-  do { if (blockIdx.x == 0 && blockIdx.y == 0 && (wave & 3) == 0 && lane == 0 && slab * 9 + tap < 64)                 \
-         g_conv_trace[((wave >> 2) * 64 + slab * 9 + tap) * 4 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
-extern "C" int ug_conv_trace_read(unsigned long long* host) {
-  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_conv_trace), sizeof(unsigned long long) * 2 * 64 * 4) == hipSuccess ? 0 : -1;
-}
-#else
-#define C_STAMP(slot) do {} while (0)
-#endif
 
 template <bool GN>
 __global__ __launch_bounds__(512) void conv3x3_patch16_kernel(PatchArgs p) {
@@ -586,7 +573,6 @@ __global__ __launch_bounds__(512) void conv3x3_patch16_kernel(PatchArgs p) {
       const bool next_slab = tap == 8 && slab + 1 < p.kslabs;
       const int dy = tap / 3, dx = tap % 3;
       // ---------------- L phase
-      C_STAMP(0);
       h16x8_t w1[4], w2[4], x1[4], x2[4];
       const bf16_t* wl = cur + wrow;
 #pragma unroll
@@ -606,10 +592,8 @@ __global__ __launch_bounds__(512) void conv3x3_patch16_kernel(PatchArgs p) {
       if (next_slab) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else if (has2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      C_STAMP(1);
       RAW_BARRIER();
       // ---------------- M phase: three partial products per block, the small ones first (same order as mma_slab)
-      C_STAMP(2);
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -623,7 +607,6 @@ __global__ __launch_bounds__(512) void conv3x3_patch16_kernel(PatchArgs p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[i], x1[j], acc[i][j], 0, 0, 0);
         }
       __builtin_amdgcn_s_setprio(0);
-      C_STAMP(3);
       RAW_BARRIER();
     }
     if (grp == 0) RAW_BARRIER();                                // back in step: every wave is done with this slab's patch

@@ -160,9 +160,6 @@ __global__ __launch_bounds__(64 * AD_WAVES) void attn_decode_kernel(const bf16_t
 }
 
 constexpr int ADF_WAVES = 8;            // one 64-key chunk per wave up to 512 keys: no serialized second chunk
-#ifndef UG_ADF_ABLATE                   // probe builds only (tools/probes/build_variant.py): 1 no K/V loads, 2 no score / PV
-#define UG_ADF_ABLATE 0                 // arithmetic, 4 no prologue loads, 8 return at once -- timing probes, wrong results
-#endif
 // Cache attention of one decode step fed by the RAW qkv accumulator: every (row, query head) workgroup rebuilds
 // q and its kv head's new k / v row itself (no dependency between workgroups; the first query head of each kv head
 // also appends the row to the cache), attends to cache keys [0, pos) exactly like attn_decode_kernel, and merges
@@ -192,7 +189,6 @@ __global__ __launch_bounds__(64 * ADF_WAVES) void attn_decode_fused_kernel(
   const int grp = xcd + 8 * (slot / per);                 // (row, kv head) group
   if (grp >= R * HKV) return;
   const int r = grp / HKV, hk = grp % HKV, h = hk * per + slot % per;
-  if constexpr (UG_ADF_ABLATE & 8) return;
   const bf16_t* kb = ck + ((int64_t)r * HKV + hk) * Tmax * DHD;
   const bf16_t* vb = cv + ((int64_t)r * HKV + hk) * Tmax * DHD;
   const int kq = lane >> 4, dc = lane & 15;
@@ -202,11 +198,6 @@ __global__ __launch_bounds__(64 * ADF_WAVES) void attn_decode_fused_kernel(
   // tokens/s: every wave then loads a chunk at every step, visible or not.)
   bf16x8_t vf[16];
   auto load_chunk = [&](int t0, int last) {
-    if constexpr (UG_ADF_ABLATE & 1) {
-#pragma unroll
-      for (int c = 0; c < 16; ++c) vf[c] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
-      return;
-    }
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int k = i * 4 + kq;                                    // key of the chunk this lane's 16 bytes belong to
@@ -229,7 +220,7 @@ __global__ __launch_bounds__(64 * ADF_WAVES) void attn_decode_fused_kernel(
   const int col0 = wave == 0 ? h * DHD : wave == 1 ? (H + hk) * DHD : (H + HKV + hk) * DHD;
   const int rpos = min(pos0, max_pos - 1);
   float a1 = 0.f, a2 = 0.f, b1 = 0.f, b2 = 0.f, rc = 1.f, rsn = 0.f, ssr = 1.f;
-  if (wave < 3 && !(UG_ADF_ABLATE & 4)) {
+  if (wave < 3) {
     ssr = ss[r];
     a1 = arow[col0 + lane]; a2 = arow[col0 + lane + DHD / 2];
     if (bias) { b1 = bf2f(bias[col0 + lane]); b2 = bf2f(bias[col0 + lane + DHD / 2]); }
@@ -251,7 +242,6 @@ __global__ __launch_bounds__(64 * ADF_WAVES) void attn_decode_fused_kernel(
         const float q1 = x2 * rsn, q2 = x1 * rsn;
         x1 = bf2f(f2bf(p1 - q1)); x2 = bf2f(f2bf(p2 + q2));
       }
-      if constexpr (UG_ADF_ABLATE & 4) { x1 = 0.01f * lane; x2 = -0.02f * lane; }
     }
     float* dst = wave == 0 ? qs : wave == 1 ? kn : vn;
     dst[lane] = x1; dst[lane + DHD / 2] = x2;
@@ -274,8 +264,6 @@ __global__ __launch_bounds__(64 * ADF_WAVES) void attn_decode_fused_kernel(
       load_chunk(t0, len - 1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the chunk's K rows have landed in LDS (this wave's own DMA)
-    if constexpr (UG_ADF_ABLATE & 2) { if (t < len) s = 0.001f * lane + bf2f((bf16_t)(*reinterpret_cast<const bf16x8_t*>(ktile[wave] + lane * 256))[0]); }
-    else
     if (t < len && (!key_valid || key_valid[(int64_t)r * Tmax + t])) {
       float d = 0.f;
       const char* krow = ktile[wave] + lane * (DHD * 2);
@@ -300,10 +288,6 @@ __global__ __launch_bounds__(64 * ADF_WAVES) void attn_decode_fused_kernel(
     const float pb = bf2f(f2bf(p));
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] *= alpha;
-    if constexpr (UG_ADF_ABLATE & 2) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] += pb * bf2f((bf16_t)vf[e][e]) + bf2f((bf16_t)vf[e + 8][e]);
-    } else
 #pragma unroll
     for (int jj = 0; jj < 16; ++jj) {
       const float pj = __shfl(pb, jj * 4 + kq, 64);

@@ -12,7 +12,7 @@
 namespace {
 
 // Streaming accesses.  NT bit 0 = non-temporal stores, bit 1 = non-temporal loads; UNIGEN_EW_NT = four hex digits, AdamW |
-// rmsnorm_bwd | swiglu_bwd | swiglu_fwd.  Default 0x3032, measured inside the step (tools/probes/run_r3p.sh): the SwiGLU backward
+// rmsnorm_bwd | swiglu_bwd | swiglu_fwd.  Default 0x3032, measured inside the step (tools/probes/ab.sh env UNIGEN_EW_NT ...): the SwiGLU backward
 // reads gate | up and d(act) for the last time and nothing reads d(gate | up) before the two GEMMs that follow evict it anyway
 // (203 -> ~185 us per launch); the forward's gate | up is next read in the backward, its output at once by the down projection
 // (so only its loads); the optimizer touches every byte once per step.  Together 132.8 -> 131.7 ms per step; the RMSNorm
@@ -403,28 +403,15 @@ __global__ __launch_bounds__(256) void adamw_lean_kernel(float* __restrict__ p, 
   const int64_t n2 = n >> 1;
   const AdamConsts c = adam_consts(lr, beta1, beta2, eps, wd, bc1, bc2_sqrt, grad_scale);
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n2; i += (int64_t)gridDim.x * blockDim.x) {
-#if defined(UG_ADAMW_ABLATE) && UG_ADAMW_ABLATE == 2      // probe build: the arithmetic without the memory streams (wrong results)
-    const float seed = (float)(i & 1023) * 1e-3f;
-    float2 pp = make_float2(seed, seed + 1.f), mm = make_float2(seed * .5f, seed), vv = make_float2(seed * seed, seed);
-    const float2 gg = make_float2(seed - .5f, seed + .25f);
-#else
     float2 pp = ld_stream<NT>(reinterpret_cast<const float2*>(p) + i);
     const float2 gg = ld_stream<NT>(reinterpret_cast<const float2*>(g) + i);
     float2 mm = ld_stream<NT>(reinterpret_cast<const float2*>(m) + i);
     float2 vv = ld_stream<NT>(reinterpret_cast<const float2*>(v) + i);
-#endif
     float* pa = &pp.x; const float* ga = &gg.x; float* ma = &mm.x; float* va = &vv.x;
-#if defined(UG_ADAMW_ABLATE) && UG_ADAMW_ABLATE == 1      // probe build: the memory streams without the arithmetic (wrong results)
-    pa[0] += ga[0]; pa[1] += ga[1];
-#else
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       adamw_element(pa[k], ga[k], ma[k], va[k], c);
     }
-#endif
-#if defined(UG_ADAMW_ABLATE) && UG_ADAMW_ABLATE == 2
-    if (pp.x == 1234.5f && mm.y == 5432.1f && vv.x == -1.f)       // never: keeps the arithmetic alive
-#endif
     {
     st_stream<NT>(reinterpret_cast<float2*>(p) + i, pp);
     st_stream<NT>(reinterpret_cast<float2*>(m) + i, mm);
@@ -444,7 +431,7 @@ __global__ __launch_bounds__(256) void adamw_lean_kernel(float* __restrict__ p, 
 // The lean kernel as a three-stage software pipeline (round 4): the loads of element pairs k+1 and k+2 are in flight while pair k is
 // computed and stored.  One wave per SIMD is all that fits beside the convolutions, and with loads -> wait -> ~80 VALU operations ->
 // stores in sequence that wave kept ONE request batch in flight: 11.2 ms alone against 7.05 for its memory streams without the
-// arithmetic and 2.5 for the arithmetic without the streams (tools/probes/run_adamw_ablate.sh), 22.1 ms beside the tokenizer.
+// arithmetic and 2.5 for the arithmetic without the streams (probe switch UG_ADAMW_ABLATE of tools/probes/probe_switches.patch), 22.1 ms beside the tokenizer.
 // The loads are inline assembly with hand-counted waits: hipcc's wait-count pass treats loads and stores in flight together as
 // unordered on gfx9 (one counter) and drains vmcnt(0) before the first use of any load issued ahead of a store.  vmcnt(8) is safe
 // whatever the stores do: loads return in order among themselves, so at most eight operations outstanding means at most the eight
@@ -641,7 +628,7 @@ extern "C" int ug_rmsnorm_fwd(const float* x, const float* w, void* y, float* rs
   UG_REQUIRE(rows > 0 && cols > 0 && cols % 4 == 0, "ug_rmsnorm_fwd: cols=%ld must be a positive multiple of 4", (long)cols);
   UG_REQUIRE(ug_aligned16(x) && ug_aligned16(w) && ug_aligned16(y), "ug_rmsnorm_fwd: pointers must be 16B aligned");
   dim3 grid((unsigned)((rows + 3) / 4)), block(256);
-  // rows per wave of the register form (0: the two-pass kernel).  In the step (tools/probes/run_r3v.sh): 27.7 us two-pass, 21.0 at one
+  // rows per wave of the register form (0: the two-pass kernel).  In the step (tools/probes/ab.sh env): 27.7 us two-pass, 21.0 at one
   // row per wave, 22.2 at two, 25.4 at four
   static const int reg = [] { const char* e = getenv("UNIGEN_RN_FWD_REG"); return e ? atoi(e) : 1; }();
   if (reg > 0 && cols <= 2048 && !out_f32) {
@@ -675,9 +662,6 @@ extern "C" int ug_rmsnorm_bwd(const void* dy, const float* x, const float* rstd,
     case 1: UG_RNB(1); break;
     case 2: UG_RNB(2); break;
     case 3: UG_RNB(3); break;
-#ifdef UG_EW_PROBE                           // probe builds only: digit 4 drops the dw atomics (wrong norm-weight gradients)
-    case 4: UG_RNB(4); break;
-#endif
     default: UG_RNB(0);
   }
 #undef UG_RNB

@@ -50,12 +50,9 @@ namespace {
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;   // 16 KiB per operand tile (either layout)
 constexpr int GROUP_M = 8;
-#ifndef UG_P8_GROUP_M
-#define UG_P8_GROUP_M 4
-#endif
-constexpr int P8_GROUP_M = UG_P8_GROUP_M;    // row panels per column sweep of the 256-wide kernels: the four 786 KB A panels of a
+constexpr int P8_GROUP_M = 4;    // row panels per column sweep of the 256-wide kernels: the four 786 KB A panels of a
                                              // K = 1536 launch stay in an XCD's 4 MB L2 while its 32 workgroups walk the columns
-                                             // (8: 8192^3 1325 -> 1385, gate_up forward / weight gradients +1..2 %; probe builds override it)
+                                             // (8: 8192^3 1325 -> 1385, gate_up forward / weight gradients +1..2 %)
 
 enum Epi { EPI_BF16 = 0, EPI_F32 = 1, EPI_RESID = 2, EPI_ROPE = 3, EPI_SWIGLU = 4, EPI_SWIGLU_BWD = 5 };    // EPI_ROPE: EPI_BF16 + rotate-half RoPE on the first rope_cols columns (128...320-row kernel only)
 
@@ -230,12 +227,8 @@ __device__ __forceinline__ void store_tile(const GemmArgs& p, f32x4_t (&acc)[4][
 // to 32-byte pieces of 16 different rows each (the no-store ablation put the scattered form at ~20 % of a K = 1536 GEMM).
 //   strip pitch: bf16 144 B (36 dwords: the 16 rows of a ds_write_b64 group fall on 8 bank quads, 2-way at worst; rows stay
 //   16-byte aligned for the ds_read_b128 that follows), fp32 272 B (68 dwords: ds_write_b128's 8-lane groups conflict-free).
-// 16-byte epilogue store; probe builds (-DUG_EPI_NT) make it non-temporal (outputs that are next read a backward pass later)
-#ifdef UG_EPI_NT
-#define UG_ST16(ptr, val) __builtin_nontemporal_store(__builtin_bit_cast(gnt4_t, (val)), reinterpret_cast<gnt4_t*>(ptr))
-#else
+// 16-byte epilogue store (a non-temporal form measured neutral in the step: tools/probes/probe_switches.patch, -DUG_EPI_NT)
 #define UG_ST16(ptr, val) (*reinterpret_cast<uint4*>(ptr) = (val))
-#endif
 typedef unsigned int gnt4_t __attribute__((ext_vector_type(4)));
 constexpr int EP_ROWS = 32;
 constexpr int EP_PITCH_BF16 = 144, EP_PITCH_F32 = 272;
@@ -380,12 +373,8 @@ __device__ __forceinline__ void store_tile_swiglu_perm(const GemmArgs& p, f32x4_
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           gb[k] = f2bf(gv[k]); ub[k] = f2bf(uv[k]);
-#if defined(UG_SWP_ABLATE) && (UG_SWP_ABLATE & 1)          // probe build: no silu arithmetic (wrong values)
-          a[k] = bf2f((bf16_t)gb[k]) * bf2f((bf16_t)ub[k]);
-#else
           const float s = bf2f(f2bf(silu_gemm(bf2f((bf16_t)gb[k]))));
           a[k] = s * bf2f((bf16_t)ub[k]);
-#endif
         }
         const int col = j * 16 + (lane >> 4) * 4;
         *reinterpret_cast<uint2*>(strip + row * EP_PITCH_BF16 + col * 2) = make_uint2(gb[0] | (gb[1] << 16), gb[2] | (gb[3] << 16));
@@ -407,11 +396,7 @@ __device__ __forceinline__ void store_tile_swiglu_perm(const GemmArgs& p, f32x4_
       const int row = q * 16 + (lane >> 2), ch = lane & 3;
       const int m = mbase + c * EP_ROWS + row;
       const uint4 v = *reinterpret_cast<const uint4*>(astrip + row * ACT_PITCH + ch * 16);
-#if defined(UG_SWP_ABLATE) && (UG_SWP_ABLATE & 2)          // probe build: act is not stored
-      if (m < p.M && row < rows_here && v.x == 0x12345678u)
-#else
       if (m < p.M && row < rows_here)
-#endif
         UG_ST16(p.act + (int64_t)m * p.ld_act + hbase + ch * 8, v);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -438,12 +423,8 @@ __device__ __forceinline__ void store_tile_swiglu_bwd(const GemmArgs& p, f32x4_t
       const int row = q * 8 + (lane >> 3), ch = lane & 7;
       const int m = min(mbase + c * EP_ROWS + row, p.M - 1);
       const bf16_t* gp = p.sw_gu + (int64_t)m * p.ld_gu + nbase + ch * 8;
-#if defined(UG_SWB_ABLATE) && (UG_SWB_ABLATE & 2)          // probe build: no gate / up loads (wrong values)
-      g[q] = gu4_t{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}; u[q] = g[q]; (void)gp;
-#else
       asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(g[q]) : "v"(gp) : "memory");
       asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(u[q]) : "v"(gp + I) : "memory");
-#endif
     }
   };
   fetch(0, gq[0], uq[0]);
@@ -478,13 +459,8 @@ __device__ __forceinline__ void store_tile_swiglu_bwd(const GemmArgs& p, f32x4_t
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float g0, g1, u0, u1;
-#if defined(UG_SWB_ABLATE) && (UG_SWB_ABLATE & 1)          // probe build: no arithmetic (wrong values)
-        g0 = __uint_as_float(dw[e] << 16) + __uint_as_float(g[q][e] << 16); g1 = __uint_as_float(dw[e] & 0xffff0000u);
-        u0 = __uint_as_float(u[q][e] << 16); u1 = g1;
-#else
         swiglu_bwd_elem(__uint_as_float(g[q][e] << 16), __uint_as_float(u[q][e] << 16), __uint_as_float(dw[e] << 16), g0, u0);
         swiglu_bwd_elem(__uint_as_float(g[q][e] & 0xffff0000u), __uint_as_float(u[q][e] & 0xffff0000u), __uint_as_float(dw[e] & 0xffff0000u), g1, u1);
-#endif
         og[e] = pack_bf2(g0, g1); ou[e] = pack_bf2(u0, u1);
       }
       if (m < p.M && row < rows_here) {
@@ -589,14 +565,9 @@ constexpr int PBM = 256, PBN = 256, PBK = 32;
 constexpr int P_TILE = PBM * PBK * 2;          // 16 KiB per operand per stage
 constexpr int P_STAGE = 2 * P_TILE;            // 32 KiB
 constexpr int P_NST = 4;
-// Cache policy of the operand streams' LDS-DMA (probe builds: -DUG_CPOL_STAGER=n / -DUG_CPOL_P10A=n; 1 = sc0, 2 = nt, 16 = sc1): measured
-// round 4 (tools/probes/run_cpol.sh), see DESIGN 4.1.
-#ifndef UG_CPOL_STAGER
-#define UG_CPOL_STAGER 0
-#endif
-#ifndef UG_CPOL_P10A
-#define UG_CPOL_P10A 0
-#endif
+// Cache policy of the operand streams' LDS-DMA: the default (aux 0).  sc0 / nt / sc1 measured in round 4 (probe switches
+// UG_CPOL_STAGER / UG_CPOL_P10A of tools/probes/probe_switches.patch), see docs/experiments.md.
+constexpr int CPOL_STAGER = 0, CPOL_P10A = 0;
 
 __device__ __forceinline__ int swz_rowk32(int row, int chunk) { return chunk ^ ((0 - (row >> 2)) & 3); }
 
@@ -635,17 +606,13 @@ struct Stager32 {                // 256-row x 32-k operand tile, 8 waves: 2 one-
     const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-#ifdef UG_GEMM_ABLATE_SRC                       // probe builds only: every k-tile re-fetches tile kt & 1 (cache-resident source)
-      const bf16_t* s = src[i] + (kt & 1) * step[i];
-#else
       const bf16_t* s = src[i] + kt * step[i];
-#endif
       if constexpr (CHECK) {
         const bool past = kt * PBK + kofs[i] >= (KMAJOR ? K : ((K + 7) & ~7));
         s = reinterpret_cast<const bf16_t*>(past ? reinterpret_cast<uintptr_t>(zero) : reinterpret_cast<uintptr_t>(s));
       }
       char* dst = lds_tile + (i * 8 + wave) * 1024;
-      __builtin_amdgcn_global_load_lds((gptr_t)s, (lptr_t)dst, 16, 0, UG_CPOL_STAGER);
+      __builtin_amdgcn_global_load_lds((gptr_t)s, (lptr_t)dst, 16, 0, CPOL_STAGER);
     }
   }
 };
@@ -670,56 +637,16 @@ __device__ __forceinline__ bf16x8_t load_frag32(const char* tile, int r0, int la
 
 #define P_BARRIER() asm volatile("s_barrier" ::: "memory")
 
-// The MFMA block of one k-tile: acc[i][j] += A block i x B block j.  Issue order (probe builds, -DUG_MFMA_ORDER=n): 0 = row block
-// outer (the A fragment stays on the operand port for four instructions), 1 = column block outer (the B fragment stays for NI),
-// 2 = serpentine (row block outer, columns alternately up and down: one operand unchanged between ANY two consecutive instructions).
-// Shipped: 2 -- measured at the power cap (tools/probes/run_mfma_order.sh, two passes, TF/s): gate_up forward 1 275 / 1 268 -> 1 283 / 1 282,
+// The MFMA block of one k-tile: acc[i][j] += A block i x B block j, issued serpentine (row block outer, columns alternately up and
+// down: one operand unchanged between ANY two consecutive instructions).  Against row-block-outer and column-block-outer orders
+// (probe switch UG_MFMA_ORDER of tools/probes/probe_switches.patch) -- measured at the power cap (tools/probes/ab.sh lib "ship mo1 mo4", two passes, TF/s): gate_up forward 1 275 / 1 268 -> 1 283 / 1 282,
 // gate_up dgrad 1 394 / 1 392 -> 1 408 / 1 408, down dgrad 1 340 / 1 343 -> 1 354 / 1 366; in the step (three A/B pairs) GEMM launches
 // -0.7 ... -0.9 ms.  Fewer operand-port toggles per instruction is fewer joules per flop, and joules are what the step is bound by.
-#ifndef UG_MFMA_ORDER
-#define UG_MFMA_ORDER 2
-#endif
-#if UG_MFMA_ORDER == 1
-#define UG_MFMA_BLOCK(NI)                                                                                                  \
-  _Pragma("unroll") for (int j = 0; j < 4; ++j) _Pragma("unroll") for (int i = 0; i < (NI); ++i) {                          \
-    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);                                  \
-    __builtin_amdgcn_sched_barrier(0); }
-#elif UG_MFMA_ORDER == 2
 #define UG_MFMA_BLOCK(NI)                                                                                                  \
   _Pragma("unroll") for (int i = 0; i < (NI); ++i) _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                       \
     const int j = (i & 1) ? 3 - jj : jj;                                                                                   \
     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);                                  \
     __builtin_amdgcn_sched_barrier(0); }
-#elif UG_MFMA_ORDER == 4                         /* serpentine with the column block outer: the B fragment stays for NI instructions */
-#define UG_MFMA_BLOCK(NI)                                                                                                  \
-  _Pragma("unroll") for (int j = 0; j < 4; ++j) _Pragma("unroll") for (int ii = 0; ii < (NI); ++ii) {                       \
-    const int i = (j & 1) ? (NI) - 1 - ii : ii;                                                                            \
-    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);                                  \
-    __builtin_amdgcn_sched_barrier(0); }
-#elif UG_MFMA_ORDER == 3                         /* order 0 with the order pinned (control for the sched_barrier itself) */
-#define UG_MFMA_BLOCK(NI)                                                                                                  \
-  _Pragma("unroll") for (int i = 0; i < (NI); ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) {                          \
-    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);                                  \
-    __builtin_amdgcn_sched_barrier(0); }
-#else
-#define UG_MFMA_BLOCK(NI)                                                                                                  \
-  _Pragma("unroll") for (int i = 0; i < (NI); ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j)                            \
-    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-#endif
-
-// Phase timeline of workgroup 0 (probe builds only, -DUG_GEMM_TRACE; tools/probes/gemm_trace.py): s_memtime stamps of
-// waves 0 and 4 at the four boundaries of every k-tile iteration.
-#ifdef UG_GEMM_TRACE
-__device__ unsigned long long g_gemm_trace[2 * 4 * 512];
-#define P_STAMP(slot)                                                                                     \
-  do { if (blockIdx.x == 0 && wn == 0 && t < 512 && lane == 0)                                              \
-         g_gemm_trace[(grp * 512 + t) * 4 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
-extern "C" int ug_gemm_trace_read(unsigned long long* host) {
-  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gemm_trace), sizeof(unsigned long long) * 2 * 4 * 512) == hipSuccess ? 0 : -1;
-}
-#else
-#define P_STAMP(slot) do {} while (0)
-#endif
 
 // the workgroup `bid` of one launch (or of one problem of a grouped launch)
 template <int EPI, bool AK, bool BKM, bool ONEBAR>
@@ -757,9 +684,6 @@ __device__ __forceinline__ void p8_body(const GemmArgs& p, const int bid, char* 
   if (nk <= 0) return;
   const bool ragged = (p.K % PBK) != 0;
   auto stage_in = [&](int lt) {                 // 4 DMA instructions per wave
-#ifdef UG_GEMM_ABLATE_DMA                       // probe builds only (tools/probes/gemm_ablate.py): the loop without its operand stream
-    if (lt > 2) return;
-#endif
     const int kt = kt0 + lt;
     char* st = lds + (lt & (P_NST - 1)) * P_STAGE;
     if (ragged && kt + 1 == nk_all) { sa.template issue<true>(kt, p.K, st, wave); sb.template issue<true>(kt, p.K, st + P_TILE, wave); }
@@ -769,9 +693,6 @@ __device__ __forceinline__ void p8_body(const GemmArgs& p, const int bid, char* 
   // iteration carries no scalar branch between the fragment reads and the barrier; the last four iterations take the checked
   // form.  (Three to four branches per k-tile cost 5-10 % of the loop: measured when a run-time prefetch distance was tried.)
   auto stage_whole = [&](int lt) {
-#ifdef UG_GEMM_ABLATE_DMA
-    return;
-#endif
     char* st = lds + (lt & (P_NST - 1)) * P_STAGE;
     sa.template issue<false>(kt0 + lt, p.K, st, wave);
     sb.template issue<false>(kt0 + lt, p.K, st + P_TILE, wave);
@@ -823,15 +744,11 @@ __device__ __forceinline__ void p8_body(const GemmArgs& p, const int bid, char* 
     if (grp == 0) {
       auto interval = [&](int t, auto steady) {
         P_BARRIER();
-        P_STAMP(0);
         read_frags(t);
         request(t, steady);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        P_STAMP(1);
         mfmas(1);
-        P_STAMP(2);
         landed(t, steady);
-        P_STAMP(3);
       };
       int t = 0;
       for (; t < nk_steady; ++t) interval(t, STEADY);
@@ -845,15 +762,11 @@ __device__ __forceinline__ void p8_body(const GemmArgs& p, const int bid, char* 
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       auto interval = [&](int t, auto steady) {
         P_BARRIER();
-        P_STAMP(0);
         mfmas(2);
-        P_STAMP(1);
         read_frags(t);
         request(t, steady);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        P_STAMP(2);
         landed(t, steady);
-        P_STAMP(3);
       };
       int t = 1;
       for (; t < nk_steady; ++t) interval(t, STEADY);
@@ -867,19 +780,15 @@ __device__ __forceinline__ void p8_body(const GemmArgs& p, const int bid, char* 
     if (grp == 1) P_BARRIER();                    // stagger: group 1 runs one phase behind group 0
     auto iteration = [&](int t, auto steady) {
       // ---------------- L phase: fragments of tile t into registers, DMA of tile t+3, retire tile t+1's DMA
-      P_STAMP(0);
       read_frags(t);
       request(t, steady);
       // this wave's share of tile t+1 must have landed before the barrier that opens the interval in which
       // group 0 reads it; newer batches (t+2, t+3) may stay in flight
       landed(t, steady);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      P_STAMP(1);
       P_BARRIER();
       // ---------------- M phase
-      P_STAMP(2);
       mfmas(1);
-      P_STAMP(3);
       P_BARRIER();
     };
     int t = 0;
@@ -965,10 +874,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p8_wgrad_group(GroupArgs g
 // 40 MFMAs per k-tile, 160 accumulator registers).  Restricted to what those launches need: A row-major, K % 32 == 0,
 // N % 256 == 0, bf16 / residual epilogues through the LDS strips, no k-slices.  The 20 A instructions of a k-tile go two
 // per wave plus a third for the waves of group 0, so the counted waits are per group (5 / 4 DMA instructions per tile).
-#ifndef UG_P10_GROUP_M
-#define UG_P10_GROUP_M 4
-#endif
-constexpr int P10_GROUP_M = UG_P10_GROUP_M;
+constexpr int P10_GROUP_M = 4;
 constexpr int QBM = 320;
 constexpr int Q_TILE_A = QBM * PBK * 2;        // 20 KiB
 constexpr int Q_STAGE = Q_TILE_A + P_TILE;     // 36 KiB; four stages = 144 KiB
@@ -1024,7 +930,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p10(GemmArgs p) {
       char* st = lds + (lt & (P_NST - 1)) * STAGE;
 #pragma unroll
       for (int i = 0; i < NA; ++i)
-        __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + (int64_t)lt * PBK), (lptr_t)(st + (i * 8 + wave) * 1024), 16, 0, UG_CPOL_P10A);
+        __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + (int64_t)lt * PBK), (lptr_t)(st + (i * 8 + wave) * 1024), 16, 0, CPOL_P10A);
       sb.template issue<false>(lt, p.K, st + TILE_A, wave);
     };
     auto landed = [&](int in_flight) {            // batches of this wave's DMA that may stay in flight
@@ -1081,9 +987,6 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p10(GemmArgs p) {
   else { if (more) run(std::false_type{}, std::integral_constant<int, LO + (REM ? 1 : 0)>{}); else run(std::false_type{}, std::integral_constant<int, LO>{}); }
 }
 
-#ifdef UG_GEMM_R4                                // probe builds only: the rejected register-blocked 4-wave kernel lives in tools/probes/
-#include "../../tools/probes/gemm_r4_kernel.inc"
-#endif
 
 // Epilogue of the k-sliced tail tiles: scratch -> C with the launch's epilogue, scratch re-zeroed.
 template <int EPI>
@@ -1265,15 +1168,6 @@ int launch(GemmArgs a, const ug_handle* h, int policy, hipStream_t st) {
       return UG_OK;
     }
   }
-#ifdef UG_GEMM_R4
-  if (g_tile_policy == 12) {                      // register-blocked 4-wave kernel, whole tiles only (A/B runs)
-    a.tiles_m = (a.M + PBM - 1) / PBM; a.tiles_n = (a.N + PBN - 1) / PBN;
-    a.full_tiles = tiles_p8; a.tail_split = 1; a.tail_private = 1; a.tail_ws = ws;
-    hipLaunchKernelGGL((gemm_kernel_r4<EPI, AK, BKM>), dim3(tiles_p8), dim3(256), 0, st, a);
-    UG_CHECK_LAUNCH("ug_gemm_bf16(r4)");
-    return UG_OK;
-  }
-#endif
   if (g_tile_policy == 3 || g_tile_policy == 6 || (g_tile_policy < 0 && (p8_fits || tail_s > 1))) {
     a.tiles_m = (a.M + PBM - 1) / PBM; a.tiles_n = (a.N + PBN - 1) / PBN;
     a.full_tiles = tiles_p8 - tail_r; a.tail_split = tail_s;

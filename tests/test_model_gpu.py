@@ -8,7 +8,7 @@ import os
 import pytest
 import torch
 
-from helpers import additive, fp32_yardstick, golden, llm_config_dir, oracle_lm
+from helpers import additive, check_logits, fp32_yardstick, golden, llm_config_dir, oracle_lm
 
 pytestmark = pytest.mark.gpu
 
@@ -56,9 +56,9 @@ def test_tiny_unigen_step_matches_reference_golden(dev):
     assert ((got - want["losses"]).abs() / want["losses"]).max().item() < 1e-3, (got, want["losses"])
     dense = logits.materialize().float().cpu()
     assert dense.shape == want["logits"].shape
-    _check("dense", dense, want["logits"], 1e-2)
+    check_logits("G2 dense", dense, want["logits"])
     sl = logits[:2, -17:-1, 312:-1].float().cpu()
-    _check("sl", sl, want["logits"][:2, -17:-1, 312:-1], 1e-2)
+    check_logits("G2 lazy slice", sl, want["logits"][:2, -17:-1, 312:-1])
     fp32_yardstick("G2 dense logits", dense, want["logits"], g["fp32"]["logits"])
     loss = 1.0 * l1 + 0.1 * l2 + 1.0 * l3
     loss.backward()
@@ -127,7 +127,7 @@ def test_tiny_unigen_vs_cpu_oracle_fresh_batch(dev):
                                batch_size_t2i=B, num_vq_tokens=n)
     assert l2 == 0. and l3 == 0.
     assert abs(l1.item() - r1.item()) / r1.item() < 1e-3
-    _check("logits[:", logits[:, -(n + 1):-1].float(), lo[:, -(n + 1):-1], 1e-2)
+    check_logits("tiny fresh batch", logits[:, -(n + 1):-1].float(), lo[:, -(n + 1):-1])
     with torch.no_grad():
         lo32 = qwen2_ref.unigen_forward_ref(lm, seq, mask, None, autocast=False)
     fp32_yardstick("tiny fresh batch", logits[:, -(n + 1):-1].float(), lo[:, -(n + 1):-1], lo32[:, -(n + 1):-1])
@@ -283,7 +283,7 @@ def test_wide_layer_matches_reference_golden(dev):
                          **g["kw"])
     assert abs(l1.item() - g["loss"].item()) < 1e-3 * g["loss"].item(), (l1.item(), g["loss"].item())
     got = logits[:, -257:-1, :].float().cpu()[:, ::8]
-    _check("got", got, g["logits_rows"], 1e-2)
+    check_logits("G3 wide layer", got, g["logits_rows"])
     # the fixture holds the real reference's bf16 logits; its fp32 logits come from the oracle (bit-identical to the reference
     # on CPU, tools/make_golden.py) with the same seeded weights
     from oracle import qwen2_ref

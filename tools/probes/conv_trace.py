@@ -9,21 +9,12 @@ import os
 import subprocess
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-src = os.path.join(ROOT, "ml-unigen_amd", "csrc")
-out = os.path.join(ROOT, "gpurun_out", "ctrace")
-os.makedirs(out, exist_ok=True)
-so = os.path.join(out, "libunigen_hip.so")
-objs = []
-for f in sorted(os.listdir(src)):
-    if not f.endswith(".hip"):
-        continue
-    o = os.path.join(src, f.replace(".hip", ".o"))
-    if f == "conv_split.hip":
-        o = os.path.join(out, "conv_trace.o")
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-DUG_CONV_TRACE",
-                               "-I" + src, "-I" + os.path.join(ROOT, "include"), "-c", os.path.join(src, f), "-o", o])
-    objs.append(o)
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", so])
+def _probe_build(name, target, flags):
+    """tools/probes/build_variant.py: product source + probe_switches.patch, compiled with the given -D flags"""
+    bv = os.path.join(ROOT, "tools", "probes", "build_variant.py")
+    return subprocess.check_output([sys.executable, bv, name, target, *flags], text=True).strip().splitlines()[-1]
+
+so = _probe_build("ctrace", "conv_split.hip", ["-DUG_CONV_TRACE"])
 sys.path.insert(0, os.path.join(ROOT, "ml-unigen_amd"))
 import numpy as np
 import torch

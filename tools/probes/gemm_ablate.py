@@ -17,24 +17,15 @@ import os
 import subprocess
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-src = os.path.join(ROOT, "ml-unigen_amd", "csrc")
-out = os.path.join(ROOT, "gpurun_out", "ablate")
-os.makedirs(out, exist_ok=True)
+def _probe_build(name, target, flags):
+    """tools/probes/build_variant.py: product source + probe_switches.patch, compiled with the given -D flags"""
+    bv = os.path.join(ROOT, "tools", "probes", "build_variant.py")
+    return subprocess.check_output([sys.executable, bv, name, target, *flags], text=True).strip().splitlines()[-1]
+
 variant = sys.argv[1] if len(sys.argv) > 1 else "full"
 flags = {"full": [], "nodma": ["-DUG_GEMM_ABLATE_DMA"], "hotsrc": ["-DUG_GEMM_ABLATE_SRC"],
          "q2": ["-DUG_P10_GROUP_M=2"], "q4": ["-DUG_P10_GROUP_M=4"], "q8": ["-DUG_P10_GROUP_M=8"], "q3": ["-DUG_P10_GROUP_M=3"], "q6": ["-DUG_P10_GROUP_M=6"], "gm2": ["-DUG_P8_GROUP_M=2"], "gm8": ["-DUG_P8_GROUP_M=8"], "gm6": ["-DUG_P8_GROUP_M=6"], "gm16": ["-DUG_P8_GROUP_M=16"]}[variant]
-so = os.path.join(out, f"libunigen_hip_{variant}.so")
-objs = []
-for f in sorted(os.listdir(src)):
-    if not f.endswith(".hip"):
-        continue
-    o = os.path.join(src, f.replace(".hip", ".o"))
-    if f == "gemm_bf16.hip":
-        o = os.path.join(out, f"gemm_{variant}.o")
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", *flags,
-                               "-I" + src, "-I" + os.path.join(ROOT, "include"), "-c", os.path.join(src, f), "-o", o])
-    objs.append(o)
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", so])
+so = _probe_build(f"abl_{variant}", "gemm_bf16.hip", flags)
 sys.path.insert(0, os.path.join(ROOT, "ml-unigen_amd"))
 import torch
 from unigen_hip import lib as L, ops

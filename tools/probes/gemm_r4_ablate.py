@@ -20,21 +20,8 @@ extra = [a for a in sys.argv[1:] if a.startswith("-D")]
 
 
 def build(variant):
-    os.makedirs(out, exist_ok=True)
-    so = os.path.join(out, f"libunigen_hip_{variant}.so")
-    objs = []
-    for f in sorted(os.listdir(src)):
-        if not f.endswith(".hip"):
-            continue
-        o = os.path.join(src, f.replace(".hip", ".o"))
-        if f == "gemm_bf16.hip":
-            o = os.path.join(out, f"gemm_{variant}.o")
-            subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
-                                   *VARIANTS[variant], *extra, "-I" + src, "-I" + os.path.join(ROOT, "include"), "-c", os.path.join(src, f), "-o", o])
-        objs.append(o)
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", so])
-    os.remove(os.path.join(out, f"gemm_{variant}.o"))
-    return so
+    bv = os.path.join(ROOT, "tools", "probes", "build_variant.py")          # product source + probe_switches.patch + the flags
+    return subprocess.check_output([sys.executable, bv, variant, "gemm_bf16.hip", *VARIANTS[variant], *extra], text=True).strip().splitlines()[-1]
 
 
 if len(sys.argv) > 1 and sys.argv[1] == "build":
