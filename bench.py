@@ -394,6 +394,35 @@ def extra_cases(model, vq, opt, dev, args, steps=2):
     return out
 
 
+RCCL_LOG = None            # NCCL_DEBUG_FILE of this rank (set before init_process_group at N > 1 on the nccl backend)
+
+
+def rccl_debug_summary(path=None, text=None):
+    """What RCCL said about the communicator at init (NCCL_DEBUG=INFO, subsystems INIT / GRAPH / TUNING, written to a per-rank
+    file): channel counts, the ring / tree lines of this rank, the transports of its connections.  A single driver run at N > 1
+    then tells ring from tree, how many channels the collectives use (each is a workgroup that takes a CU -- and watts -- from
+    the GEMMs) and whether the links are xGMI (P2P/IPC) or something slower.  None when there is no log (gloo rehearsal)."""
+    import re
+    if text is None:
+        path = path or RCCL_LOG
+        if not path or not os.path.exists(path):
+            return None
+        text = open(path, errors="replace").read()
+    lines = text.splitlines()
+    pick = lambda pat: [re.sub(r"^.*?NCCL INFO ", "", l).strip() for l in lines if re.search(pat, l)]
+    chan = pick(r"coll channels|nChannels|Channels? \d+ .*per")
+    out = {"version": (pick(r"NCCL version|RCCL version") or [None])[0],
+           "channels": chan[:4],
+           "rings": pick(r"\bRing \d+ :")[:4], "trees": pick(r"\bTrees? \[")[:2],
+           "connected": pick(r"Connected all (rings|trees)")[:4],
+           "transports": sorted({m.group(1) for l in lines for m in [re.search(r"via (P2P/\S+|SHM\S*|NET/\S+|direct\S*)", l)] if m}),
+           "algo_proto_table": pick(r"Algorithm|Algo/Proto|Latency/AlgBw")[:3],
+           "log_lines": len(lines)}
+    m = [int(x) for l in chan for x in re.findall(r"(\d+) coll channels", l)]
+    out["coll_channels"] = m[0] if m else None
+    return out
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): start the N ranks through torch.distributed.run as a
     child process and relay its stdout / exit code.  The parent must only ever SPAWN a child, never replace itself (no exec): on this
@@ -530,6 +559,12 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
+            # RCCL's own account of the communicator (rings / trees / channels / transports) into a per-rank file that
+            # rccl_debug_summary() condenses into the line's `exchange.rccl` -- unless the caller configured the debug output already
+            global RCCL_LOG
+            if "NCCL_DEBUG" not in os.environ and "NCCL_DEBUG_FILE" not in os.environ:
+                RCCL_LOG = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"unigen_rccl_rank{rank}_{os.getpid()}.log")
+                os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,GRAPH,TUNING", NCCL_DEBUG_FILE=RCCL_LOG)
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
@@ -587,6 +622,8 @@ def main():
     barrier()
     sync = model.llm.engine.grad_sync               # the flat-gradient exchange the engine installed (None at N = 1)
     wire0 = (sync.bytes_on_wire, sync.lookup_bytes_on_wire) if sync is not None else (0, 0)
+    if sync is not None:
+        sync.record_timeline = True                 # event pairs around every bucket of every pass (no host syncs): read after the run
     w0 = time.time()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -605,7 +642,11 @@ def main():
         exchange = dict(sync.describe(), ranks_seen=sync.ranks_seen(),
                         bytes_on_wire_per_step=int((sync.bytes_on_wire - wire0[0]) / args.steps),
                         lookup_bytes_on_wire_per_step=int((sync.lookup_bytes_on_wire - wire0[1]) / args.steps),
-                        early_embed_handovers=sync.early_embed_handovers)
+                        early_embed_handovers=sync.early_embed_handovers,
+                        # the last timed step's buckets (rank 0): when each left, how long it queued, how long its collective took, and
+                        # how long the compute stream stood waiting for the exchange at the end of backward (the exposed tail)
+                        last_step=sync.timeline_report(), rccl=rccl_debug_summary())
+        sync.record_timeline = False
         if exchange["ranks_seen"] != world:
             raise SystemExit(f"the exchange's communicator saw {exchange['ranks_seen']} ranks, expected {world}")
     ms = dt / args.steps * 1e3

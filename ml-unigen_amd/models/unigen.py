@@ -594,19 +594,42 @@ class UniGen(ModelMixin, ConfigMixin):
         greedy = bool(kwargs.get("greedy", False))          # argmax instead of multinomial: deterministic parity tests
         use_graph = bool(kwargs.get("use_graph", True))
         code_lo, code_hi = text_vocab_size, self.vocab_size - 1          # logits[..., text_vocab_size:-1]
-        st = DecodeState(eng.dims, R, P + n, dev, key_valid=key_valid)
-        out_tokens = torch.zeros((bsz, n), dtype=torch.int, device=dev)
-        x = torch.empty((R, eng.dims.hidden_size), dtype=torch.float32, device=dev)      # static: next token's embedding
-        tok = torch.zeros((bsz, 1), dtype=torch.long, device=dev)                        # static: last sampled token
         V = code_hi - code_lo
         fused = (R <= 32 and eng.dims.hidden_size >= 256 and eng.dims.hidden_size % 32 == 0 and not kwargs.get("torch_sampler", False)
                  and not gen)
+        # The captured decode step is kept ACROSS calls (round 5): Best-of-N generation calls this method once per prompt with the
+        # same shapes (evaluation/inference_unigen_cot.py:318-331), and capturing costs ~6 ms of a 330 ms call (an eager warm-up
+        # step + the capture).  A session = every buffer the graph reads or writes (cache, position, accumulators, token /
+        # embedding slots, uniforms) + the graph; it is reused only when every size, every sampling constant baked into a kernel
+        # argument and the weight storage are the same (UNIGEN_AR_GRAPH_CACHE=0 turns the reuse off), and dropped on any error.
+        sess_key = (R, P, n, bsz, V, int(text_vocab_size), greedy, float(guidance_scale), float(temperature), key_valid is None, str(dev),
+                    bool(getattr(eng, "decode_fused", True)),
+                    eng.fp.w("embed").data_ptr(), eng.fp.w("l0.wqkv").data_ptr(), eng.fp.p("embed").data_ptr(), eng.fp.p("norm").data_ptr())
+        sess = getattr(eng, "_ar_session", None) if (use_graph and fused and os.environ.get("UNIGEN_AR_GRAPH_CACHE", "1") != "0") else None
+        if sess is not None and sess["key"] != sess_key:
+            sess = None
+        eng._ar_session = None                       # (put back at the end of a call that completed)
+        if sess is not None:
+            st, out_tokens, x, tok = sess["st"], sess["out_tokens"], sess["x"], sess["tok"]
+            if key_valid is not None:
+                st.key_valid[:, :P].copy_(key_valid)
+        else:
+            st = DecodeState(eng.dims, R, P + n, dev, key_valid=key_valid)
+            out_tokens = torch.zeros((bsz, n), dtype=torch.int, device=dev)
+            x = torch.empty((R, eng.dims.hidden_size), dtype=torch.float32, device=dev)      # static: next token's embedding
+            tok = torch.zeros((bsz, 1), dtype=torch.long, device=dev)                        # static: last sampled token
         if fused:
             # lm-head as a weight-streaming GEMV into a raw fp32 accumulator + ONE sampling kernel per step (CFG mix,
             # temperature, softmax, inverse-CDF draw on uniforms taken from `generator` up front, next input embedding)
-            acc_head = torch.zeros((R, V), dtype=torch.float32, device=dev)
             u_dev = dev if generator is None else generator.device
-            uniforms = None if greedy else torch.rand((n, bsz), device=u_dev, generator=generator).to(dev)
+            fresh = None if greedy else torch.rand((n, bsz), device=u_dev, generator=generator).to(dev)
+            if sess is not None:
+                acc_head, uniforms = sess["acc_head"], sess["uniforms"]
+                if uniforms is not None:
+                    uniforms.copy_(fresh)
+            else:
+                acc_head = torch.zeros((R, V), dtype=torch.float32, device=dev)
+                uniforms = fresh
             w_head = eng.fp.w("embed")[code_lo:code_hi]
             w_embed = eng.fp.p("embed")
 
@@ -650,9 +673,9 @@ class UniGen(ModelMixin, ConfigMixin):
             hn = eng.decode_step(st, x)            # (also advances the cache position)
             sample(hn)
 
-        graph = None
+        graph = sess["graph"] if sess is not None else None
         for i in range(1, n):
-            if use_graph and (generator is None or fused) and i == 2:
+            if graph is None and use_graph and (generator is None or fused) and i == 2:
                 # step 1 ran eagerly (warm-up: allocations, lazy inits); capture step 2 and replay it from then on
                 mark("eager_step")
                 torch.cuda.synchronize()
@@ -669,6 +692,10 @@ class UniGen(ModelMixin, ConfigMixin):
                 out_tokens[:, i] = tok[:, 0]
         mark("replay")
         eng.last_decode_graph = graph is not None
+        if graph is not None and fused and os.environ.get("UNIGEN_AR_GRAPH_CACHE", "1") != "0":
+            eng._ar_session = {"key": sess_key, "st": st, "out_tokens": out_tokens, "x": x, "tok": tok, "acc_head": acc_head,
+                               "uniforms": uniforms, "graph": graph}
+            return out_tokens.clone()                # (the session's buffer is overwritten by the next call)
         return out_tokens
 
     # ------------------------------------------------------------------ plain causal generation

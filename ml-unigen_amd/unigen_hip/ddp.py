@@ -102,6 +102,9 @@ class FlatGradSync:
         self._embed_done = False        # the table's dense part has been handed over in this pass
         self._lookups = []              # (ids int64 [n], rows fp32 [n, H]) kept aside in this pass
         self._cap = None                # agreed per-rank row capacity of this pass: int, or (event, pinned tensor) until read
+        self.record_timeline = False    # bench: keep (bytes, issue / start / end events) of every bucket of the running pass
+        self.timeline = []              # [(what, bytes, ev_issue on the compute stream, ev_start, ev_end on the exchange stream)]
+        self._exposed = None            # (ev before, ev after) the compute stream's wait for the exchange at the end of backward
         self._pin = None
         engine.grad_ready_hook = self.on_ready
         if self.transport == "ug_comm":
@@ -222,10 +225,15 @@ class FlatGradSync:
             self._comm_bucket(buf)
             return
         from . import ops
-        ev = torch.cuda.Event()
+        rec = self.record_timeline
+        ev = torch.cuda.Event(enable_timing=rec)
         ev.record(torch.cuda.current_stream())
         with torch.cuda.stream(self.stream):
             self.stream.wait_event(ev)
+            if rec:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                self.timeline.append((f"[{lo}, {hi})", (hi - lo) * 4, ev, e0, e1))
             if self.reduce == "bf16":
                 stage = self._stage_for(hi - lo)[:hi - lo]
                 ops.grad_pack_bf16(buf, stage, 1.0 / self.world)
@@ -240,6 +248,8 @@ class FlatGradSync:
             else:
                 self._allreduce_mean_(buf)
                 self.bytes_on_wire += buf.numel() * 4
+            if rec:
+                e1.record()
 
     # ------------------------------------------------------------------ embedding lookups kept aside
     def wants_lookups(self):
@@ -395,6 +405,8 @@ class FlatGradSync:
         self._embed_done = False
         self._lookups = []
         self._cap = None
+        self.timeline = []
+        self._exposed = None
         if self.wants_lookups():
             self._agree_capacity(lookup_rows, heads_live)
 
@@ -488,7 +500,13 @@ class FlatGradSync:
                 with torch.cuda.stream(self.stream):
                     self.stream.wait_stream(torch.cuda.current_stream())
                     self._average_extra(extra)
+            if self.record_timeline:
+                w0, w1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                w0.record(torch.cuda.current_stream())
             torch.cuda.current_stream().wait_stream(self.stream)
+            if self.record_timeline:
+                w1.record(torch.cuda.current_stream())
+                self._exposed = (w0, w1)
         else:
             self._drain_pending()
             if extra:
@@ -512,6 +530,25 @@ class FlatGradSync:
                 "tied_embedding": "dense head gradient after the head's backward, lookups as (id, row) pairs at the end"
                                   if self.sparse_embed else "one dense exchange at the end of backward",
                 "layers_per_bucket": self.layers_per_bucket}
+
+    def timeline_report(self):
+        """Per bucket of the LAST backward pass (record_timeline on, torch transport on a GPU; call after a device sync): bytes, how
+        long after the first bucket's hand-over it was handed over, how long it waited for the exchange stream, how long the
+        collective took; and the exposed tail -- the time the compute stream stood waiting for the exchange at the end of backward.
+        One driver run at N > 1 then says where the exchange's time is."""
+        if not self.timeline:
+            return None
+        first = self.timeline[0][2]
+        rows = []
+        for what, nbytes, ev_issue, e0, e1 in self.timeline:
+            ms = e0.elapsed_time(e1)
+            rows.append({"span": what, "mb": round(nbytes / 1e6, 1), "issued_ms": round(first.elapsed_time(ev_issue), 3),
+                         "queued_ms": round(ev_issue.elapsed_time(e0), 3), "collective_ms": round(ms, 3),
+                         "gb_per_s": round(nbytes / max(ms, 1e-6) / 1e6, 1)})
+        out = {"buckets": rows, "collective_ms_total": round(sum(r["collective_ms"] for r in rows), 3)}
+        if self._exposed is not None:
+            out["exposed_wait_ms"] = round(self._exposed[0].elapsed_time(self._exposed[1]), 3)
+        return out
 
     def ranks_seen(self):
         """Number of ranks that answer on the communicator the buckets move through: every rank marks its own slot of a

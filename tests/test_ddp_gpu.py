@@ -232,3 +232,10 @@ def test_bench_runs_end_to_end_with_two_ranks(dev):
     assert out["ranks_seen"] == 2 and ex["ranks_seen"] == 2 and ex["reduce"] == "fp32" and ex["transport"] == "torch"
     # fp32 payload: every element of the flat gradient buffer once per step + the lookups' (id, row) pairs of both ranks
     assert ex["bytes_on_wire_per_step"] >= 4 * 1.5e9 and ex["lookup_bytes_on_wire_per_step"] == 2 * 16 * 771 * (8 + 4 * 1536)
+    # round 5: the line explains the exchange by itself -- every bucket of the last timed step with its hand-over time, queueing
+    # and collective duration, the exposed wait of the compute stream at the end of backward, and RCCL's own init summary
+    # (None on this gloo rehearsal)
+    last = ex["last_step"]
+    assert last["buckets"] and all(b["collective_ms"] > 0 and b["mb"] > 0 for b in last["buckets"]) and last["exposed_wait_ms"] >= 0
+    assert abs(sum(b["mb"] for b in last["buckets"]) * 1e6 - ex["bytes_on_wire_per_step"]) < 0.02 * ex["bytes_on_wire_per_step"]
+    assert "rccl" in ex and ex["rccl"] is None

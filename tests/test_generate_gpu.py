@@ -55,6 +55,47 @@ def test_ar_generation_matches_reference_trajectory(dev):
     model.llm.engine.decode_fused = True
 
 
+def test_ar_decode_session_is_reused_across_calls_and_never_stale(dev, monkeypatch):
+    """Round 5: the captured decode step and its static buffers are kept across `t2i_generate_ar` calls of the same shape
+    (Best-of-N calls it once per prompt).  A reused session must give exactly the tokens of a fresh capture -- also when the
+    prompt, the key-validity mask or the uniforms differ from the call that captured -- and a different shape or sampling constant
+    must not reuse it."""
+    g = golden("g9_generate.pt")
+    model = _model(g, dev, g["weight_std"])
+    eng = model.llm.engine
+    ar, tv = g["ar"], g["ids"]["text_vocab"]
+
+    def run(cond, uncond, am, scale, seed=None, greedy=True):
+        gen = None if seed is None else torch.Generator(device=dev).manual_seed(seed)
+        return model.t2i_generate_ar(input_ids=cond.to(dev), uncond_input_ids=uncond.to(dev), attention_mask=am.to(dev), guidance_scale=scale,
+                                     temperature=1.0, text_vocab_size=tv, image_token_num_per_image=ar["n"], greedy=greedy, generator=gen).cpu()
+    first = run(ar["cond"], ar["uncond"], ar["attention_mask"], ar["scale"])
+    sess = eng._ar_session
+    assert sess is not None
+    again = run(ar["cond"], ar["uncond"], ar["attention_mask"], ar["scale"])
+    assert eng._ar_session["graph"] is sess["graph"] and torch.equal(first, again)
+    # other prompts and another padding pattern through the SAME session vs a fresh capture of that call
+    cond2, am2 = ar["cond"].flip(0).clone(), ar["attention_mask"].clone()
+    am2[:, :3] = 0
+    reused = run(cond2, ar["uncond"], am2, ar["scale"])
+    assert eng._ar_session["graph"] is sess["graph"]
+    monkeypatch.setenv("UNIGEN_AR_GRAPH_CACHE", "0")
+    fresh = run(cond2, ar["uncond"], am2, ar["scale"])
+    monkeypatch.delenv("UNIGEN_AR_GRAPH_CACHE")
+    assert torch.equal(reused, fresh)
+    # sampling with uniforms from a seeded generator: the session's uniform buffer is refilled per call
+    eng._ar_session = None
+    a = run(ar["cond"], ar["uncond"], ar["attention_mask"], ar["scale"], seed=5, greedy=False)
+    s2 = eng._ar_session
+    b = run(ar["cond"], ar["uncond"], ar["attention_mask"], ar["scale"], seed=6, greedy=False)
+    c = run(ar["cond"], ar["uncond"], ar["attention_mask"], ar["scale"], seed=5, greedy=False)
+    assert eng._ar_session["graph"] is s2["graph"] and not torch.equal(a, b)
+    print(f"sampled tokens equal for equal seeds through a reused session: {(a == c).float().mean().item():.3f} of positions")
+    # a sampling constant that is baked into a kernel argument: new session
+    run(ar["cond"], ar["uncond"], ar["attention_mask"], ar["scale"] + 1.0)
+    assert eng._ar_session["graph"] is not s2["graph"]
+
+
 def test_mmu_generate_matches_reference_trajectory(dev):
     """G9-mmu: tokens of the REAL reference's mmu_generate (bf16 autocast, greedy, its mmu mask) from the KV-cached path,
     the recompute path and row 0 of the batched path; early stop on eot_token follows the reference rule."""

@@ -205,3 +205,31 @@ def test_gemm_traffic_record_belongs_to_the_shipped_gemm_source():
     src = open(os.path.join(ROOT, "ml-unigen_amd", "csrc", "gemm_bf16.hip"), "rb").read()
     assert rec["gemm_src_sha256"] == hashlib.sha256(src).hexdigest()
     assert rec["launches_per_step"] == 255 and 0.5e9 < rec["traffic_bytes_per_launch"] < 2e9
+
+
+def test_bench_rccl_debug_summary_parses_an_init_log():
+    """bench.py's `exchange.rccl`: the summary of RCCL's NCCL_DEBUG=INFO init output -- channels, this rank's
+    rings / trees, transports -- from a log of the usual shape; None without a log (the gloo rehearsal)."""
+    import importlib.util
+    import sys
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        spec.loader.exec_module(bench)
+    finally:
+        sys.argv = argv
+    log = """host:101:101 [0] NCCL INFO NCCL version 2.21.5+hip6.3 HEAD:abc
+host:101:140 [0] NCCL INFO Channel 00/16 :    0   1   2   3   4   5   6   7
+host:101:140 [0] NCCL INFO Ring 00 : 7 -> 0 -> 1
+host:101:140 [0] NCCL INFO Ring 01 : 3 -> 0 -> 5
+host:101:140 [0] NCCL INFO Trees [0] 1/-1/-1->0->-1 [1] 5/-1/-1->0->-1
+host:101:140 [0] NCCL INFO Channel 00/0 : 0[0] -> 1[1] via P2P/IPC
+host:101:140 [0] NCCL INFO Connected all rings
+host:101:140 [0] NCCL INFO Connected all trees
+host:101:140 [0] NCCL INFO 16 coll channels, 0 collnet channels, 0 nvls channels, 32 p2p channels, 4 p2p channels per peer
+"""
+    out = bench.rccl_debug_summary(text=log)
+    assert out["coll_channels"] == 16 and out["transports"] == ["P2P/IPC"] and len(out["rings"]) == 2 and out["trees"]
+    assert out["connected"] == ["Connected all rings", "Connected all trees"] and "2.21.5" in out["version"]
+    assert bench.rccl_debug_summary(path="/nonexistent/rccl.log") is None
