@@ -664,7 +664,7 @@ class UniGen(ModelMixin, ConfigMixin):
                 t0[0] = now
 
         mark("setup")
-        sample(eng.prefill(st, prefix, key_valid))
+        sample(eng.prefill(st, prefix, key_valid))         # (capturing the prefill too was measured: 10.3 vs 10.6 ms, it is GPU-bound at 2 208 tokens)
         mark("prefill")
         if not fused:
             out_tokens[:, 0] = tok[:, 0]

@@ -13,7 +13,7 @@ TEXT_VOCAB, CODEBOOK = 151674, 8192
 VOCAB = TEXT_VOCAB + CODEBOOK + 1
 
 
-def run(n_img=8, prefix=138, n_tok=256, use_graph=True, reps=2):
+def run(n_img=8, prefix=138, n_tok=256, use_graph=True, reps=3):
     dev = torch.device("cuda:0")
     model = UniGen(w_und_encoder=False, vocab_size=VOCAB, llm_vocab_size=TEXT_VOCAB, llm_model_path="Qwen2.5-1.5B-Instruct",
                    codebook_size=CODEBOOK, num_vq_tokens=n_tok, device=dev, init_seed=-1)
@@ -26,7 +26,7 @@ def run(n_img=8, prefix=138, n_tok=256, use_graph=True, reps=2):
     am = torch.ones((2 * n_img, L), dtype=torch.long, device=dev)
     best = None
     if os.environ.get("AR_PHASES"):                # where the call's wall time goes (adds host syncs: not the reported number)
-        for _ in range(2):
+        for _ in range(4):
             ph = {}
             model.t2i_generate_ar(input_ids=ids, uncond_input_ids=un, attention_mask=am, guidance_scale=6.0, temperature=1.0,
                                   text_vocab_size=TEXT_VOCAB, image_token_num_per_image=n_tok, use_graph=use_graph, timing=ph)
@@ -48,7 +48,7 @@ def run(n_img=8, prefix=138, n_tok=256, use_graph=True, reps=2):
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "graph":          # profiling runs: the captured path only, one repetition after the warm-up
-        print(json.dumps(run(use_graph=True, reps=1)), flush=True)
+        print(json.dumps(run(use_graph=True, reps=3)), flush=True)
     else:
         for ug in (False, True):
             print(json.dumps(run(use_graph=ug)), flush=True)
