@@ -48,7 +48,7 @@ def fake_flush_piece(self, lo, hi):
             STATE["moved"] += traffic
 
 
-def main(steps=4):
+def main(steps=8):
     dist.init_process_group("gloo", rank=0, world_size=1)
     dev = torch.device("cuda:0")
     model = UniGen(w_und_encoder=False, vocab_size=bench.VOCAB, llm_vocab_size=bench.TEXT_VOCAB, llm_model_path="Qwen2.5-1.5B-Instruct",
@@ -77,14 +77,17 @@ def main(steps=4):
     for fmt, bpe in (("fp32", 4), ("bf16", 2)):
         for groups in (0, 8, 16, 32, 64):
             STATE.update(groups=groups, bytes_per_elem=bpe, moved=0)
+            sampler = bench.PowerSampler()              # round 5: the copy workgroups draw watts the GEMMs lose -- package W / MHz per row
             step()
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
+            w0, t0 = time.time(), time.perf_counter()
             for _ in range(steps):
                 step()
             torch.cuda.synchronize()
             ms = (time.perf_counter() - t0) / steps * 1e3
-            rows.append({"wire": fmt, "workgroups": groups, "ms_per_step": round(ms, 2), "GB_per_step": round(STATE["moved"] / (steps + 1) / 1e9, 2)})
+            pw = sampler.report(w0, time.time()) or {}
+            rows.append({"wire": fmt, "workgroups": groups, "ms_per_step": round(ms, 2), "GB_per_step": round(STATE["moved"] / (steps + 1) / 1e9, 2),
+                         "package_w": pw.get("mean_w"), "sclk_mhz": pw.get("mean_sclk_mhz")})
             print(json.dumps(rows[-1]), flush=True)
             if groups == 0 and fmt == "bf16":
                 pass
