@@ -184,11 +184,16 @@ __global__ __launch_bounds__(64 * ADF_WAVES) void attn_decode_fused_kernel(
   // b runs on XCD b % 8 and every XCD has its own L2): dealt out head-major they landed on six different XCDs and each XCD
   // fetched the same K / V from HBM -- 36 MB per layer instead of 6, the part of this kernel that grew with the context
   // (8.2 us at 171 keys, 11.2 at 363).
+  // Grid (8, H / HKV, ceil(R HKV / 8)): x = XCD, y = query head inside the kv group, z = block of eight groups -- the linear
+  // workgroup id is what it was (8 (z per + y) + x), and no division is left ahead of the first load (round 5).
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int per = H / HKV, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int grp = xcd + 8 * (slot / per);                 // (row, kv head) group
+  const int per = gridDim.y, hq = blockIdx.y;
+  const int grp = blockIdx.x + 8 * blockIdx.z;            // (row, kv head) group
   if (grp >= R * HKV) return;
-  const int r = grp / HKV, hk = grp % HKV, h = hk * per + slot % per;
+  int r, hk;
+  if ((HKV & (HKV - 1)) == 0) { r = grp >> (31 - __builtin_clz(HKV)); hk = grp & (HKV - 1); }
+  else { r = grp / HKV; hk = grp - r * HKV; }
+  const int h = hk * per + hq;
   const bf16_t* kb = ck + ((int64_t)r * HKV + hk) * Tmax * DHD;
   const bf16_t* vb = cv + ((int64_t)r * HKV + hk) * Tmax * DHD;
   const int kq = lane >> 4, dc = lane & 15;
@@ -245,7 +250,7 @@ __global__ __launch_bounds__(64 * ADF_WAVES) void attn_decode_fused_kernel(
     }
     float* dst = wave == 0 ? qs : wave == 1 ? kn : vn;
     dst[lane] = x1; dst[lane + DHD / 2] = x2;
-    if (wave > 0 && h % (H / HKV) == 0 && pos0 < Tmax) {
+    if (wave > 0 && hq == 0 && pos0 < Tmax) {
       bf16_t* row = (wave == 1 ? ck : cv) + (((int64_t)r * HKV + hk) * Tmax + pos0) * DHD;
       row[lane] = f2bf(x1); row[lane + DHD / 2] = f2bf(x2);
     }
@@ -1016,9 +1021,9 @@ extern "C" int ug_attn_decode_fused(const float* acc_qkv, int64_t ldacc, const f
                                     int H, int HKV, int head_dim, int64_t Tmax, int64_t max_pos, float scale, hipStream_t st) {
   UG_REQUIRE(rows > 0 && head_dim == DHD && H % HKV == 0 && acc_qkv && ss_in && norm_cols > 0 && pos_dev && cache_k && cache_v && o,
              "ug_attn_decode_fused: bad args");
-  // 1-D block index (XCD-aware placement inside the kernel)
-  const unsigned nblk = 8u * (unsigned)((rows * HKV + 7) / 8) * (unsigned)(H / HKV);
-  hipLaunchKernelGGL(attn_decode_fused_kernel, dim3(nblk, 1), dim3(64 * ADF_WAVES), 0, st, acc_qkv, ldacc, ss_in, eps,
+  // (XCD-aware placement: see the kernel)
+  const dim3 grid(8u, (unsigned)(H / HKV), (unsigned)((rows * HKV + 7) / 8));
+  hipLaunchKernelGGL(attn_decode_fused_kernel, grid, dim3(64 * ADF_WAVES), 0, st, acc_qkv, ldacc, ss_in, eps,
                      (int)norm_cols, (const bf16_t*)bias, cos_tab, sin_tab, pos_dev, (bf16_t*)cache_k, (bf16_t*)cache_v, key_valid,
                      (bf16_t*)o, ldo, (int)rows, H, HKV, (int)Tmax, (int)max_pos, scale);
   UG_CHECK_LAUNCH("ug_attn_decode_fused");

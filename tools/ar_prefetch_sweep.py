@@ -1,5 +1,7 @@
-"""AR decode: A/B of weight-prefetch plans (UNIGEN_DECODE_PREFETCH) on ONE model instance -- tokens/s per plan and whether the
-tokens equal the plan-free run's (they must: prefetchers only load).  Usage: python tools/ar_prefetch_sweep.py [plan ...]"""
+"""AR decode: A/B of weight-prefetch plans (UNIGEN_DECODE_PREFETCH) on ONE model instance -- tokens/s per plan.  The plans only exist
+with `tools/probes/decode_prefetch_r5.patch` applied (the experiment was measured slower and is not in the product:
+profiles/r05_ar_prefetch.md); without the patch every plan is the plan-free run.  (Sampled tokens are NOT comparable between runs:
+the split-K atomics make the logits' last bits run-dependent.)  Usage: python tools/ar_prefetch_sweep.py [plan ...]"""
 import json
 import os
 import sys
