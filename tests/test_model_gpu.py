@@ -267,12 +267,14 @@ def test_maskgit_generation_first_round_matches_oracle(dev):
     assert full.shape == (N, n) and int(full.min()) >= 0 and int(full.max()) < 20
 
 
-def test_wide_layer_matches_reference_golden(dev):
-    """G3: the real reference's forward + backward through one decoder layer of the 1.5B model's width at L = 387
-    (left padding, MaskGIT labels) vs the HIP path: loss, image-position logits, every parameter's gradient."""
+@pytest.mark.parametrize("fixture", ["g3_wide_layer.pt", "g16_wide_layer_L771.pt"])
+def test_wide_layer_matches_reference_golden(dev, fixture):
+    """G3 / G16: the real reference's forward + backward through one decoder layer of the 1.5B model's width at L = 387 and (round 5)
+    at the benchmarked L = 771, both rows left-padded (290 / 45 pads at L = 771), MaskGIT labels, vs the HIP path: loss,
+    image-position logits, every parameter's gradient."""
     from models import UniGen
     from oracle import weights
-    g = golden("g3_wide_layer.pt")
+    g = golden(fixture)
     cfg, ids = g["cfg"], g["ids"]
     m = UniGen(w_und_encoder=False, vocab_size=cfg["vocab_size"], llm_vocab_size=ids["text_vocab"], llm_model_path=llm_config_dir(cfg),
                codebook_size=g["codebook"], num_vq_tokens=256, load_from_pretrained=True, device=dev, init_seed=1)
@@ -283,14 +285,14 @@ def test_wide_layer_matches_reference_golden(dev):
                          **g["kw"])
     assert abs(l1.item() - g["loss"].item()) < 1e-3 * g["loss"].item(), (l1.item(), g["loss"].item())
     got = logits[:, -257:-1, :].float().cpu()[:, ::8]
-    check_logits("G3 wide layer", got, g["logits_rows"])
+    check_logits(f"{fixture} wide layer", got, g["logits_rows"])
     # the fixture holds the real reference's bf16 logits; its fp32 logits come from the oracle (bit-identical to the reference
     # on CPU, tools/make_golden.py) with the same seeded weights
     from oracle import qwen2_ref
     lm, _ = oracle_lm(cfg, g["weight_seed"])
     with torch.no_grad():
         lo32 = qwen2_ref.unigen_forward_ref(lm, g["input_ids"], additive(g["mask_allow"]), None, autocast=False)[:, -257:-1][:, ::8]
-    fp32_yardstick("G3 wide layer", got, g["logits_rows"], lo32)
+    fp32_yardstick(f"{fixture} wide layer", got, g["logits_rows"], lo32)
     l1.backward()
     params = dict(m.llm.named_parameters())
     for n, v in g["grad_norms"].items():

@@ -3,6 +3,8 @@ reference (tools/make_golden.py).  This is what pins the oracle; the GPU suite t
 path against the oracle and against the same fixtures."""
 import math
 
+import pytest
+
 import torch
 
 from helpers import golden, oracle_lm, additive
@@ -95,10 +97,12 @@ def test_dpo_logps_oracle_matches_reference():
             assert torch.equal(got, g[f"{mode}_{int(avg)}"]), (mode, avg)
 
 
-def test_wide_layer_oracle_bit_exact_vs_reference():
-    """One decoder layer at the 1.5B model's width (1536 / 8960 / 12:2 heads) on the pt1 sequence shape L = 387."""
+@pytest.mark.parametrize("fixture", ["g3_wide_layer.pt", "g16_wide_layer_L771.pt"])
+def test_wide_layer_oracle_bit_exact_vs_reference(fixture):
+    """One decoder layer at the 1.5B model's width (1536 / 8960 / 12:2 heads) on the pt1 sequence shape L = 387 (G3) and on the
+    benchmarked L = 771 with left padding (G16, round 5)."""
     from oracle import qwen2_ref
-    g = golden("g3_wide_layer.pt")
+    g = golden(fixture)
     lm, _ = oracle_lm(g["cfg"], g["weight_seed"])
     logits, l1, _, _ = qwen2_ref.unigen_forward_ref(lm, g["input_ids"], additive(g["mask_allow"], torch.float32), g["labels"],
                                                     autocast=True, batch_size_t2i=2, num_vq_tokens=256)

@@ -362,14 +362,15 @@ WIDE = dict(hidden_size=1536, intermediate_size=8960, num_hidden_layers=1, num_a
             rope_theta=1e6, rms_norm_eps=1e-6)
 
 
-def golden_wide():
+def golden_wide(MAXTXT=128, text_lens=(37, 101), fname="g3_wide_layer.pt", tag="G3"):
     """The real reference UniGen (transformers Qwen2 under it) with ONE decoder layer of the 1.5B model's width on the
-    pt1 sequence shape (128 text + 256 image + 3 = 387, left padding), bf16 autocast, forward + backward."""
+    pt1 sequence shape (128 text + 256 image + 3 = 387, left padding), bf16 autocast, forward + backward.  Round 5 (VERDICT r4
+    next 6): the same at the benchmarked shape, 512 text + 256 image + 3 = 771 with left padding (`wide771` -> G16)."""
     import math
     from models import UniGen
     from training.prompting_utils import UniversalPromptingQwen2, create_attention_mask_predict_next
     tok = FakeTok()
-    NVQ, CODEBOOK, MAXTXT = 256, 64, 128
+    NVQ, CODEBOOK = 256, 64
     up = UniversalPromptingQwen2(tok, max_seq_len=MAXTXT + NVQ + 3, cond_dropout_prob=0.0, ignore_id=-100)
     V = len(tok) + CODEBOOK + 1
     mask_id = V - 1
@@ -386,11 +387,11 @@ def golden_wide():
     img = torch.randint(0, CODEBOOK, (2, NVQ), generator=g) + len(tok)
     ts, sc = torch.tensor([0.15, 0.8]), torch.rand(2, NVQ, generator=g)
     in_img, lab_img, _ = host_ref.maskgit_train_mask_ref(img, mask_id, ts, sc, lambda x: torch.cos(x * math.pi * 0.5))
-    texts = ["".join(chr(97 + v) for v in torch.randint(0, 26, (k,), generator=g).tolist()) for k in (37, 101)]
+    texts = ["".join(chr(97 + v) for v in torch.randint(0, 26, (k,), generator=g).tolist()) for k in text_lens]
     ids, _, labels = up((list(texts), in_img, lab_img), 't2i')
     PAD, SOI, EOI = int(up.sptids_dict['<|pad|>']), int(up.sptids_dict['<|soi|>']), int(up.sptids_dict['<|eoi|>'])
     mask = create_attention_mask_predict_next(ids, pad_id=PAD, soi_id=SOI, eoi_id=EOI, rm_pad_in_image=True).to(torch.float32)
-    assert ids.shape == (2, 387)
+    assert ids.shape == (2, MAXTXT + NVQ + 3) and bool((ids[:, 0] == PAD).all())          # left padding on both rows
     kw = dict(batch_size_t2i=2, batch_size_lm=0, batch_size_mmu=0, max_seq_length=MAXTXT, num_vq_tokens=NVQ)
     with torch.autocast("cpu", dtype=torch.bfloat16):
         logits, l1, _, _ = model(input_ids=ids, attention_mask=mask, labels=labels, **kw)
@@ -401,7 +402,7 @@ def golden_wide():
     lo, r1, _, _ = qwen2_ref.unigen_forward_ref(lm_ref, ids, mask, labels, autocast=True, batch_size_t2i=2, num_vq_tokens=NVQ)
     r1.backward()
     gd = max(maxdiff(grads[n], p.grad) for n, p in lm_ref.named_parameters())
-    print(f"G3 oracle vs reference: logits {maxdiff(lo, logits):.3e} loss {abs(r1.item() - l1.item()):.2e} grads {gd:.3e}")
+    print(f"{tag} oracle vs reference: logits {maxdiff(lo, logits):.3e} loss {abs(r1.item() - l1.item()):.2e} grads {gd:.3e}")
     assert maxdiff(lo, logits) == 0 and gd == 0, "oracle is not bit-identical to the reference on CPU"
     out = {"cfg": dict(WIDE, vocab_size=V), "weight_seed": 33, "input_ids": ids, "labels": labels, "mask_allow": (mask[:, 0] == 0),
            "kw": kw, "ids": dict(pad=PAD, soi=SOI, eoi=EOI, mask=mask_id, text_vocab=len(tok)), "codebook": CODEBOOK,
@@ -409,14 +410,16 @@ def golden_wide():
            "grad_norms": {n: gg.norm().item() for n, gg in grads.items()},
            "grad_o_rows": grads["model.layers.0.self_attn.o_proj.weight"][:2].clone(),
            "grad_gate_rows": grads["model.layers.0.mlp.gate_proj.weight"][:2].clone()}
-    torch.save(out, os.path.join(OUT, "g3_wide_layer.pt"))
-    print("G3 wide layer: captured")
+    torch.save(out, os.path.join(OUT, fname))
+    print(f"{tag} wide layer: captured (L = {ids.shape[1]}, pads per row {[int((r == PAD).sum()) for r in ids]})")
 
 
 if __name__ == "__main__" and "dpo" in sys.argv[1:]:
     golden_dpo()
 if __name__ == "__main__" and "wide" in sys.argv[1:]:
     golden_wide()
+if __name__ == "__main__" and "wide771" in sys.argv[1:]:
+    golden_wide(MAXTXT=512, text_lens=(203, 448), fname="g16_wide_layer_L771.pt", tag="G16")
 
 
 # ------------------------------------------------------------------ G9: greedy generation trajectories (AR image tokens, mmu text)
