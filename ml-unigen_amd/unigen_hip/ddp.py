@@ -432,7 +432,7 @@ class FlatGradSync:
             return
         if not self.enabled or not self._overlap:
             return
-        self._check_early_done()
+        self._ensure_early_done()
         if tag == "norm":
             self._hi = self._numel
             return
@@ -445,14 +445,18 @@ class FlatGradSync:
                 self._flush(lo, self._hi)
                 self._hi = lo
 
-    def _check_early_done(self):
-        """Every rank announced the same number of recorded heads, so every OTHER rank has handed the table over as its first
-        collective of the pass; a rank whose heads did not all run (a head outside the loss) must not issue anything else."""
-        if (self.world > 1 and self.sparse_embed and self._embed_end > 0 and not self._embed_done and self._cap is not None
+    def _ensure_early_done(self):
+        """Every rank announced the same non-zero number of recorded heads, so every rank hands the table over as its FIRST
+        collective of the pass.  Normally that happens at the 'head' tag.  If this rank reaches its first other collective without it
+        -- a head segment that was recorded but is not part of this loss (its graph was dropped, or it belongs to another
+        backward) keeps the count from reaching zero -- the hand-over is issued here, at the same position in the collective
+        sequence: the heads run first in any backward, so what they wrote is in the table by now.  A dense writer that still
+        shows up afterwards is refused (before_dense_embed_write), never re-exchanged from local state."""
+        if (self.sparse_embed and self._embed_end > 0 and not self._embed_done and self._cap is not None
                 and self.early_handover_agreed()):
-            raise UniGenHipError("data-parallel exchange: the ranks agreed on handing the tied embedding table over right after the heads' "
-                                 "backward, but on this rank not every recorded head segment has run its backward (a head output that is "
-                                 "not part of the loss?); the ranks' collectives would no longer pair")
+            self._flush(0, self._embed_end)
+            self._embed_done = True
+            self.early_embed_handovers += 1
 
     def finish(self):
         """End of backward: flush what no hook has covered (always the embedding table; everything if no hook fired or
@@ -461,7 +465,7 @@ class FlatGradSync:
         if not self.enabled or not self.active:
             self._hi = None
             return
-        self._check_early_done()
+        self._ensure_early_done()
         if self._hi is None:
             self._hi = self._numel
         lo = self._embed_end if self._embed_done else 0

@@ -222,24 +222,32 @@ def _worker_multi_lookup(rank, world, port, sparse, q):
 
     ok = True
     from unigen_hip.lib import UniGenHipError
-    for case in ("one segment", "two segments", "no head", "head counts differ", "late dense writer"):
+    for case in ("one segment", "two segments", "no head", "head counts differ", "stale head count", "late dense writer"):
         grad.zero_()
         total.zero_()
         rows_live = 3 * (11 + 2 * rank) + (5 if case == "two segments" else 0)      # ranks look up different numbers of rows
         # recorded head segments as the engine announces them at the start of backward: the early hand-over of the tied table is
         # used only when EVERY rank announces the same non-zero count (the decision changes the collective sequence)
-        heads = {"one segment": 1, "two segments": 2, "no head": 0, "late dense writer": 1, "head counts differ": 1 + (rank == 1)}[case]
+        # ("stale head count": every rank recorded a second head segment whose graph was dropped -- the count never reaches zero, the
+        #  'head' tag never fires, and the hand-over is issued at the first other collective instead: same sequence on every rank)
+        heads = {"one segment": 1, "two segments": 2, "no head": 0, "late dense writer": 1, "head counts differ": 1 + (rank == 1),
+                 "stale head count": 2}[case]
         sync.begin(lookup_rows=rows_live, heads_live=heads)
         if case == "two segments":
             head()                                       # e.g. the rejected half of a DPO pair: not the last head, no hand-over
             stack_segment(False)                         # ... and its stack hooks must not flush
             lookup(5)                                    # its lookup arrives BEFORE the last head has written
-        if case != "no head":
+        if case == "stale head count":
+            head()                                       # the one head of this loss; no 'head' tag: the engine still counts two
+            assert not sync._embed_done
+        elif case != "no head":
             head()
             eng.grad_ready_hook("head")                  # last recorded head: the table's dense part travels from here on
             # (rank 1 of "head counts differ" recorded a second head that is outside the loss: nobody hands over early)
             assert sync._embed_done == (sparse and case != "head counts differ")
         stack_segment(True)
+        if case == "stale head count":
+            assert sync._embed_done == sparse            # handed over at the first bucket of the stack
         if case == "late dense writer":
             # an unrecorded dense writer after the agreed hand-over: the other ranks would not exchange the table again, so with
             # more than one rank this is refused loudly instead of pairing different collectives (before round 5: a re-exchange
