@@ -159,6 +159,7 @@ __global__ __launch_bounds__(64 * AD_WAVES) void attn_decode_kernel(const bf16_t
   }
 }
 
+typedef __bf16 bf16pair_t __attribute__((ext_vector_type(2)));
 constexpr int ADF_WAVES = 8;            // one 64-key chunk per wave up to 512 keys: no serialized second chunk
 // Cache attention of one decode step fed by the RAW qkv accumulator: every (row, query head) workgroup rebuilds
 // q and its kv head's new k / v row itself (no dependency between workgroups; the first query head of each kv head
@@ -170,6 +171,7 @@ __global__ __launch_bounds__(64 * ADF_WAVES) void attn_decode_fused_kernel(
     bf16_t* __restrict__ ck, bf16_t* __restrict__ cv, const uint8_t* __restrict__ key_valid, bf16_t* __restrict__ o, int64_t ldo,
     int R, int H, int HKV, int Tmax, int max_pos, float scale) {
   __shared__ float qs[DHD], kn[DHD], vn[DHD];
+  __shared__ __attribute__((aligned(16))) bf16_t qb[DHD];       // q again, as bf16 pairs (q IS bf16-rounded): the B operand of v_dot2c_f32_bf16
   __shared__ float om[ADF_WAVES][DHD];
   __shared__ float ml[ADF_WAVES][2];
   // K rows of a wave's 64-key chunk: 16 KB, CONTIGUOUS in the cache ([row][kv head][t][128]).  Round 3 let lane j load "its" key
@@ -250,6 +252,7 @@ __global__ __launch_bounds__(64 * ADF_WAVES) void attn_decode_fused_kernel(
     }
     float* dst = wave == 0 ? qs : wave == 1 ? kn : vn;
     dst[lane] = x1; dst[lane + DHD / 2] = x2;
+    if (wave == 0) { qb[lane] = f2bf(x1); qb[lane + DHD / 2] = f2bf(x2); }
     if (wave > 0 && hq == 0 && pos0 < Tmax) {
       bf16_t* row = (wave == 1 ? ck : cv) + (((int64_t)r * HKV + hk) * Tmax + pos0) * DHD;
       row[lane] = f2bf(x1); row[lane + DHD / 2] = f2bf(x2);
@@ -270,16 +273,18 @@ __global__ __launch_bounds__(64 * ADF_WAVES) void attn_decode_fused_kernel(
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the chunk's K rows have landed in LDS (this wave's own DMA)
     if (t < len && (!key_valid || key_valid[(int64_t)r * Tmax + t])) {
+      // 64 v_dot2c_f32_bf16 (two bf16 products + fp32 add each) instead of 128 conversions + 128 fmas: K pairs straight from the
+      // tile, q pairs from its bf16 image (broadcast reads: hoisting all 64 pairs would not fit 8 waves' registers)
       float d = 0.f;
       const char* krow = ktile[wave] + lane * (DHD * 2);
 #pragma unroll
       for (int c = 0; c < DHD / 8; ++c) {
-        // q is re-read from LDS (broadcast) where it is used: hoisting all 128 values would not fit 8 waves' registers
-        const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(krow + ((c ^ (lane & 15)) << 4));
-        const float4 q0 = *reinterpret_cast<const float4*>(&qs[c * 8]);
-        const float4 q1 = *reinterpret_cast<const float4*>(&qs[c * 8 + 4]);
-        d += bf2f((bf16_t)kf[0]) * q0.x + bf2f((bf16_t)kf[1]) * q0.y + bf2f((bf16_t)kf[2]) * q0.z + bf2f((bf16_t)kf[3]) * q0.w;
-        d += bf2f((bf16_t)kf[4]) * q1.x + bf2f((bf16_t)kf[5]) * q1.y + bf2f((bf16_t)kf[6]) * q1.z + bf2f((bf16_t)kf[7]) * q1.w;
+        const uint4 kf = *reinterpret_cast<const uint4*>(krow + ((c ^ (lane & 15)) << 4));
+        const uint4 qq = *reinterpret_cast<const uint4*>(&qb[c * 8]);
+        d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16pair_t, kf.x), __builtin_bit_cast(bf16pair_t, qq.x), d, false);
+        d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16pair_t, kf.y), __builtin_bit_cast(bf16pair_t, qq.y), d, false);
+        d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16pair_t, kf.z), __builtin_bit_cast(bf16pair_t, qq.z), d, false);
+        d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16pair_t, kf.w), __builtin_bit_cast(bf16pair_t, qq.w), d, false);
       }
       s = d * scale;
     }
