@@ -298,11 +298,21 @@ __global__ __launch_bounds__(64 * ADF_WAVES) void attn_decode_fused_kernel(
     const float pb = bf2f(f2bf(p));
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[e] *= alpha;
+    // P.V two keys at a time: the two keys' values of a dim pair are interleaved by v_perm_b32 into (v[j][d], v[j+1][d]) and meet
+    // the probability pair (p_j, p_j+1; both bf16-exact) in one v_dot2c_f32_bf16 -- 8 perm + 8 dot2 per key pair instead of 16
+    // conversions + 16 fmas
 #pragma unroll
-    for (int jj = 0; jj < 16; ++jj) {
-      const float pj = __shfl(pb, jj * 4 + kq, 64);
+    for (int jj = 0; jj < 16; jj += 2) {
+      const uint32_t pp = pack_bf2(__shfl(pb, jj * 4 + kq, 64), __shfl(pb, (jj + 1) * 4 + kq, 64));
+      const uint4 va = __builtin_bit_cast(uint4, vf[jj]), vb = __builtin_bit_cast(uint4, vf[jj + 1]);
+      const uint32_t wa[4] = {va.x, va.y, va.z, va.w}, wb[4] = {vb.x, vb.y, vb.z, vb.w};
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] += pj * bf2f((bf16_t)vf[jj][e]);
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t lo = __builtin_amdgcn_perm(wb[i], wa[i], 0x05040100u);      // (a.lo16, b.lo16): dim 2 i of keys j, j + 1
+        const uint32_t hi = __builtin_amdgcn_perm(wb[i], wa[i], 0x07060302u);      // (a.hi16, b.hi16): dim 2 i + 1
+        acc[2 * i] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16pair_t, lo), __builtin_bit_cast(bf16pair_t, pp), acc[2 * i], false);
+        acc[2 * i + 1] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16pair_t, hi), __builtin_bit_cast(bf16pair_t, pp), acc[2 * i + 1], false);
+      }
     }
   }
 #pragma unroll
