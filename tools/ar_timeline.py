@@ -77,3 +77,23 @@ if per:
         print(f"| `{short(nm)}` | {(st - t0) / 1e3:.2f} | {(en - t0) / 1e3:.2f} | {(en - st) / 1e3:.2f} | {(st - s[j - 1][1]) / 1e3:.2f} |")
     print(f"\nlayer period (start to next layer's start): {(s[j0 + per][0] - t0) / 1e3:.2f} us; "
           f"mean over the averaged steps: {sum(body[j0:j0 + per]) + sum(gap[j0:j0 + per]):.2f} us")
+
+# HBM rate per launch at the benchmark shape (Qwen2.5-1.5B, 16 rows): the weight bytes a launch must stream / its mean body, next to
+# round 4's bodies (profiles/r04_ar_timeline.md) -- VERDICT r4 next 1 asked for this table.  Attention: K + V of the mean visible context of
+# the averaged steps (prefix 138, steps 128..255 -> ~330 keys) x 16 rows x 2 kv heads x 256 B.
+BYTES = {"gemv_ring4_kernel<1, 3, 1, 9>": ("gate_up", 17920 * 1536 * 2), "gemv_ring4_kernel<1, 2, 2, 8>": ("down", 1536 * 8960 * 2),
+         "gemv_ring4_kernel<1, 2, 2, 7>": ("down", 1536 * 8960 * 2), "gemv_ring4_kernel<1, 1, 1, 4>": ("q/k/v", 2048 * 1536 * 2),
+         "gemv_ring_kernel<1, 1>": ("o", 1536 * 1536 * 2), "attn_decode_fused_kernel": ("attention (K / V cache)", 330 * 16 * 2 * 2 * 256),
+         "gemv_ring_kernel<1, 2>": ("lm-head slice", 8192 * 1536 * 2)}
+R4 = {"gate_up": 14.66, "down": 10.77, "attention (K / V cache)": 7.92, "q/k/v": 6.30, "o": 4.76, "lm-head slice": 7.99}
+rows = [(BYTES[nm][0], BYTES[nm][1], b / c) for nm, (c, b, g) in agg.items() if nm in BYTES]
+if rows:
+    print("\nHBM rate per launch (bytes the launch must stream / mean body, the 1.5 us launch boundary included in the body):\n")
+    print("| launch | MB | round 4 us | round 4 TB/s | now us | now TB/s |\n|---|---|---|---|---|---|")
+    for what, nb, us in sorted(rows, key=lambda r: -r[1]):
+        r4 = R4.get(what)
+        print(f"| {what} | {nb / 1e6:.1f} | {r4} | {nb / r4 / 1e6:.2f} | {us:.2f} | {nb / us / 1e6:.2f} |")
+    layer = [r for r in rows if r[0] != "lm-head slice"]
+    tot_b, tot_now = sum(r[1] for r in layer), sum(r[2] for r in layer)
+    tot_r4 = sum(R4[r[0]] for r in layer)
+    print(f"| one layer | {tot_b / 1e6:.1f} | {tot_r4:.2f} | {tot_b / tot_r4 / 1e6:.2f} | {tot_now:.2f} | {tot_b / tot_now / 1e6:.2f} |")
