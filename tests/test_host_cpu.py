@@ -233,3 +233,38 @@ host:101:140 [0] NCCL INFO 16 coll channels, 0 collnet channels, 0 nvls channels
     assert out["coll_channels"] == 16 and out["transports"] == ["P2P/IPC"] and len(out["rings"]) == 2 and out["trees"]
     assert out["connected"] == ["Connected all rings", "Connected all trees"] and "2.21.5" in out["version"]
     assert bench.rccl_debug_summary(path="/nonexistent/rccl.log") is None
+
+
+def test_no_register_spills_in_kernels_with_counted_waits():
+    """tools/check_spills.py (also run by __graft_entry__.build()): no kernel of the must-not-spill set -- GEMM, attention, decode,
+    convolution kernels, all with hand-counted `s_waitcnt` -- spills registers, the six audited exceptions aside."""
+    import subprocess
+    import sys
+    objs = [f for f in os.listdir(os.path.join(ROOT, "ml-unigen_amd", "csrc")) if f.endswith(".o")]
+    if not objs:
+        pytest.skip("objects not built (run __graft_entry__.build())")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_spills.py")], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-3000:]
+    assert "0 spilling in the must-not-spill set" in res.stdout
+
+
+def test_probe_switch_patch_applies_to_the_product_kernels(tmp_path):
+    """The timing / ablation / trace switches live in tools/probes/probe_switches.patch, not in the product kernels (VERDICT r4 weak 9);
+    the patch must keep applying to the shipped sources (tools/probes/build_variant.py depends on it), and the product sources must
+    not contain a probe switch."""
+    import shutil
+    import subprocess
+    csrc = os.path.join(ROOT, "ml-unigen_amd", "csrc")
+    dst = tmp_path / "ml-unigen_amd" / "csrc"
+    dst.mkdir(parents=True)
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".h")):
+            shutil.copy(os.path.join(csrc, f), dst)
+            for line in open(os.path.join(csrc, f)):
+                code = line.split("//")[0]                   # (comments may name a switch when they point at the patch)
+                for sw in ("UG_MFMA_ORDER", "UG_CPOL_", "UG_EPI_NT", "UG_SWP_ABLATE", "UG_SWB_ABLATE", "UG_GEMM_ABLATE", "UG_GEMM_TRACE", "UG_GEMM_R4",
+                           "UG_ADAMW_ABLATE", "UG_EW_PROBE", "UG_ADF_ABLATE", "UG_CONV_TRACE"):
+                    assert sw not in code, (f, sw, line)
+    res = subprocess.run(["patch", "-p1", "--dry-run", "-i", os.path.join(ROOT, "tools", "probes", "probe_switches.patch")], cwd=tmp_path,
+                         capture_output=True, text=True)
+    assert res.returncode == 0 and "FAILED" not in res.stdout, res.stdout[-2000:]
