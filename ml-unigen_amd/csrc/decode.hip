@@ -4,11 +4,15 @@
 //   cache layout: K,V [rows][HKV][Tmax][128] bf16 (keys of one (row, kv-head) contiguous)
 #include "common.h"
 #include "unigen_hip.h"
+#include "vmem_asm.h"
 #include <stdlib.h>
 
 namespace {
 
 constexpr int DHD = 128;
+// workgroup barrier for an LDS hand-off: __syncthreads() also drains vmcnt (its fence covers global memory), i.e. waits for the
+// weight tiles in flight and the clears' write acknowledgements, which no wave needs at this point
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 typedef const __attribute__((address_space(1))) void* gptr_t;      // LDS-DMA operands (global_load_lds)
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -203,38 +207,44 @@ __global__ __launch_bounds__(64 * ADF_WAVES) void attn_decode_fused_kernel(
   // round trip (accumulator, bias, RoPE table) so the two latencies overlap.  (Requesting them before the position word
   // as well -- clamped to the cache instead of the visible length, masked afterwards -- measured SLOWER, 5 730 vs 5 885
   // tokens/s: every wave then loads a chunk at every step, visible or not.)
+  // Every load of this kernel is hand-issued (vmem_asm.h): with the builtins the prologue's LDS writes were preceded by a compiler-inserted
+  // s_waitcnt vmcnt(0), i.e. the new token's q / k / v were built only after the wave's whole K / V chunk had landed.
   bf16x8_t vf[16];
+  const uint32_t kt_lds = __builtin_amdgcn_readfirstlane(lds_addr_of(ktile[wave]));
   auto load_chunk = [&](int t0, int last) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int k = i * 4 + kq;                                    // key of the chunk this lane's 16 bytes belong to
       const bf16_t* src = kb + (int64_t)min(t0 + k, last) * DHD + ((dc ^ (k & 15)) << 3);
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(ktile[wave] + i * 1024), 16, 0, 0);
+      dma16(src, kt_lds + i * 1024);
     }
 #pragma unroll
     for (int jj = 0; jj < 16; ++jj) {
       const int tt = min(t0 + jj * 4 + kq, last);
-      vf[jj] = *reinterpret_cast<const bf16x8_t*>(vb + (int64_t)tt * DHD + dc * 8);
+      ld16(vf[jj], vb + (int64_t)tt * DHD + dc * 8);
     }
   };
   const int pos0 = *pos_dev;
   const int len = min(pos0, Tmax);                         // cache keys visible to the new token
   // The new token's q / k / v pair of this lane (waves 0-2): its loads -- the raw accumulator the projection's atomics left at
   // the device coherence point, bias, RoPE table: one ~2 us round trip -- go out FIRST, the chunk's K / V requests behind them.
-  // Memory returns a wave's loads in order, so issued the other way round (round 3) the prologue's data sat behind 32 K / V
-  // loads per lane and its arithmetic + the workgroup barrier started only after the whole chunk had landed.
   const float* arow = acc_qkv + (int64_t)r * lda;
   const int col0 = wave == 0 ? h * DHD : wave == 1 ? (H + hk) * DHD : (H + HKV + hk) * DHD;
   const int rpos = min(pos0, max_pos - 1);
-  float a1 = 0.f, a2 = 0.f, b1 = 0.f, b2 = 0.f, rc = 1.f, rsn = 0.f, ssr = 1.f;
+  float a1 = 0.f, a2 = 0.f, rc = 1.f, rsn = 0.f, ssr = 1.f;
+  uint32_t bb1 = 0, bb2 = 0;
   if (wave < 3) {
-    ssr = ss[r];
-    a1 = arow[col0 + lane]; a2 = arow[col0 + lane + DHD / 2];
-    if (bias) { b1 = bf2f(bias[col0 + lane]); b2 = bf2f(bias[col0 + lane + DHD / 2]); }
-    if (wave < 2) { rc = cs[(int64_t)rpos * (DHD / 2) + lane]; rsn = sn[(int64_t)rpos * (DHD / 2) + lane]; }
+    ld4(ssr, ss + r);
+    ld4(a1, arow + col0 + lane); ld4(a2, arow + col0 + lane + DHD / 2);
+    if (bias) { ld2u(bb1, bias + col0 + lane); ld2u(bb2, bias + col0 + lane + DHD / 2); }
+    if (wave < 2) { ld4(rc, cs + (int64_t)rpos * (DHD / 2) + lane); ld4(rsn, sn + (int64_t)rpos * (DHD / 2) + lane); }
   }
-  if (wave * 64 < len) load_chunk(wave * 64, len - 1);
+  const bool has_chunk = wave * 64 < len;
+  if (has_chunk) load_chunk(wave * 64, len - 1);
   if (wave < 3) {
+    if (has_chunk) wait_vm<32>(); else wait_vm<0>();       // the prologue's loads are older than the chunk's 16 + 16
+    tie(ssr); tie(a1); tie(a2); tie(bb1); tie(bb2); tie(rc); tie(rsn);
+    const float b1 = bf2f((bf16_t)bb1), b2 = bf2f((bf16_t)bb2);
     float x1, x2;
     {
 #pragma clang fp contract(off)
@@ -258,7 +268,7 @@ __global__ __launch_bounds__(64 * ADF_WAVES) void attn_decode_fused_kernel(
       row[lane] = f2bf(x1); row[lane + DHD / 2] = f2bf(x2);
     }
   }
-  __syncthreads();
+  lds_barrier();                                           // (LDS hand-off only: __syncthreads() would also drain the chunk's loads)
   float m = -INFINITY, l = 0.f;
   float acc[8];
 #pragma unroll
@@ -271,7 +281,9 @@ __global__ __launch_bounds__(64 * ADF_WAVES) void attn_decode_fused_kernel(
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); //  previous chunk have returned before the DMA overwrites the tile
       load_chunk(t0, len - 1);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the chunk's K rows have landed in LDS (this wave's own DMA)
+    wait_vm<0>();                                        // the chunk's K rows have landed in LDS (this wave's own DMA), its V pieces in vf
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) tie(vf[jj]);
     if (t < len && (!key_valid || key_valid[(int64_t)r * Tmax + t])) {
       // 64 v_dot2c_f32_bf16 (two bf16 products + fp32 add each) instead of 128 conversions + 128 fmas: K pairs straight from the
       // tile, q pairs from its bf16 image (broadcast reads: hoisting all 64 pairs would not fit 8 waves' registers)
@@ -579,38 +591,35 @@ __device__ __forceinline__ void decode_clear(const DecodeIn& f, int tid, int bid
 
 // linear workgroup id (x fastest: the order the dispatcher deals workgroups out to the XCDs in)
 __device__ __forceinline__ int linear_block() { return (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x; }
-// workgroup barrier for an LDS hand-off: __syncthreads() also drains vmcnt (its fence covers global memory), i.e. waits for the
-// weight tiles in flight and the clears' write acknowledgements, which no wave needs at this point
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __device__ __forceinline__ float silu_bf(float g) { return bf2f(f2bf(g / (1.f + __expf(-g)))); }
 
-// Build this lane's operand fragment (row `ar`, 8 k-values at k0) for the fp32-operand modes.
+// Request this lane's operand pieces (row `ar`, 8 k-values at k0) for the fp32-operand modes -- hand-issued loads (vmem_asm.h): the
+// values may be used only behind the caller's wait + tie.
 template <int XIN>
-__device__ __forceinline__ void decode_operand_load(const DecodeIn& f, int ar, int k0, int K, float4 (&a)[2], float4 (&b)[2],
-                                                    float4 (&w)[2]) {
+__device__ __forceinline__ void decode_operand_load(const DecodeIn& f, int ar, int k0, int K, f32x4_t (&a)[2], f32x4_t (&b)[2],
+                                                    f32x4_t (&w)[2]) {
   if constexpr (XIN == XIN_RESID_NORM) {
     const float* xp = f.x_in + (__umul24(ar, K) + k0);
     const float* pp = f.pend + (__umul24(ar, (int)f.ld_pend) + k0);
-    a[0] = *reinterpret_cast<const float4*>(xp); a[1] = *reinterpret_cast<const float4*>(xp + 4);
-    b[0] = *reinterpret_cast<const float4*>(pp); b[1] = *reinterpret_cast<const float4*>(pp + 4);
-    w[0] = *reinterpret_cast<const float4*>(f.norm_w + k0); w[1] = *reinterpret_cast<const float4*>(f.norm_w + k0 + 4);
+    ld16(a[0], xp); ld16(a[1], xp + 4);
+    ld16(b[0], pp); ld16(b[1], pp + 4);
+    ld16(w[0], f.norm_w + k0); ld16(w[1], f.norm_w + k0 + 4);
   } else {
     const float* gp = f.gu + (__umul24(ar, (int)f.ld_gu) + k0);
-    a[0] = *reinterpret_cast<const float4*>(gp); a[1] = *reinterpret_cast<const float4*>(gp + 4);
-    b[0] = *reinterpret_cast<const float4*>(gp + K); b[1] = *reinterpret_cast<const float4*>(gp + K + 4);
+    ld16(a[0], gp); ld16(a[1], gp + 4);
+    ld16(b[0], gp + K); ld16(b[1], gp + K + 4);
   }
 }
 
 template <int XIN>
-__device__ __forceinline__ bf16x8_t decode_operand_make(const DecodeIn& f, const float4 (&a)[2], const float4 (&b)[2],
-                                                        const float4 (&w)[2], float rs, bool store, float* __restrict__ op,
-                                                        float& ssq) {
-  const float av[8] = {a[0].x, a[0].y, a[0].z, a[0].w, a[1].x, a[1].y, a[1].z, a[1].w};
-  const float bv[8] = {b[0].x, b[0].y, b[0].z, b[0].w, b[1].x, b[1].y, b[1].z, b[1].w};
+__device__ __forceinline__ bf16x8_t decode_operand_make(const DecodeIn& f, f32x4_t (&a)[2], const f32x4_t (&b)[2], const f32x4_t (&w)[2],
+                                                        float rs, float& ssq) {
+  const float av[8] = {a[0][0], a[0][1], a[0][2], a[0][3], a[1][0], a[1][1], a[1][2], a[1][3]};
+  const float bv[8] = {b[0][0], b[0][1], b[0][2], b[0][3], b[1][0], b[1][1], b[1][2], b[1][3]};
   bf16x8_t o;
   if constexpr (XIN == XIN_RESID_NORM) {
-    const float wv[8] = {w[0].x, w[0].y, w[0].z, w[0].w, w[1].x, w[1].y, w[1].z, w[1].w};
+    const float wv[8] = {w[0][0], w[0][1], w[0][2], w[0][3], w[1][0], w[1][1], w[1][2], w[1][3]};
     float xn[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -618,10 +627,10 @@ __device__ __forceinline__ bf16x8_t decode_operand_make(const DecodeIn& f, const
       o[e] = (short)f2bf(wv[e] * xn[e]);
       ssq += xn[e] * xn[e];
     }
-    if (store) {
-      *reinterpret_cast<float4*>(op) = make_float4(xn[0], xn[1], xn[2], xn[3]);
-      *reinterpret_cast<float4*>(op + 4) = make_float4(xn[4], xn[5], xn[6], xn[7]);
-    }
+    // the updated residual values stay in `a`: the workgroups of weight group 0 store them at the kernel's END (a store issued here
+    // would sit between the weight tiles' loads in the memory queue)
+    a[0] = f32x4_t{xn[0], xn[1], xn[2], xn[3]};
+    a[1] = f32x4_t{xn[4], xn[5], xn[6], xn[7]};
   } else {
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = (short)f2bf(silu_bf(bf2f(f2bf(rs * av[e]))) * bf2f(f2bf(rs * bv[e])));
@@ -633,18 +642,18 @@ __device__ __forceinline__ bf16x8_t decode_operand_make(const DecodeIn& f, const
 // A weight tile = 16 rows x 256 k of W [N][K] (row stride ldw elements); DMA instruction i of a tile covers rows 2i, 2i + 1 x 512
 // bytes: lane -> row 2i + (lane >> 5), 16-byte chunk (lane & 31) ^ row (the bank swizzle, applied on the SOURCE side).
 struct TileAddr {
-  int lane_off[8];                               // element offset of this lane inside a tile for DMA instruction i (row clamp aside)
+  uint32_t lane_off[8];                          // BYTE offset of this lane inside a tile for DMA instruction i (row clamp aside)
   __device__ __forceinline__ void init(int lane, int kbase, int K, int ldw) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int r = 2 * i + (lane >> 5);
-      lane_off[i] = __umul24(r, ldw) + min(kbase + ((lane & 31) ^ r) * 8, K - 8);       // chunks past K are never consumed
+      lane_off[i] = (uint32_t)(__umul24(r, ldw) + min(kbase + ((lane & 31) ^ r) * 8, K - 8)) * 2u;       // chunks past K are never consumed
     }
   }
   // N % 16 != 0: the last group's missing rows re-read row N - 1 (their products are never stored)
-  static __device__ __forceinline__ int ragged(int lane, int row0, int i, int kbase, int N, int K, int ldw) {
+  static __device__ __forceinline__ uint32_t ragged(int lane, int row0, int i, int kbase, int N, int K, int ldw) {
     const int r = 2 * i + (lane >> 5);
-    return __umul24(min(row0 + r, N - 1), ldw) + min(kbase + ((lane & 31) ^ r) * 8, K - 8);
+    return (uint32_t)(__umul24(min(row0 + r, N - 1), ldw) + min(kbase + ((lane & 31) ^ r) * 8, K - 8)) * 2u;
   }
 };
 
@@ -657,19 +666,21 @@ __global__ __launch_bounds__(64) void gemv_ring_kernel(const bf16_t* __restrict_
   const int grp0 = blockIdx.y * KW;
   const int kbase = blockIdx.x * 256;
   const bool whole = (N & 15) == 0;                                 // every 16-row group is complete: no per-row clamp
+  // the clears this launch carries go out first: stores behind the loads would sit between them in the memory queue
+  decode_clear(f, lane, linear_block());
   TileAddr ta;
   ta.init(lane, kbase, K, ldw);
+  const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(tile[0]));
   auto stage = [&](int t) {
-    // aux = 2: non-temporal -- every weight byte is read once per step by one CU; leaving it out of the caches shortens
-    // issue -> landed (guide, price list row nt-weights)
+    // nt: every weight byte is read once per step by one CU; leaving it out of the caches shortens issue -> landed (guide, row nt-weights)
+    const uint32_t dst = lds0 + (t & 1) * 8192;
     if (whole) {
-      const bf16_t* base = W + __umul24(min((grp0 + t) * 16, N - 16), ldw);
+      const uint64_t base = (uint64_t)(W + (int64_t)min((grp0 + t) * 16, N - 16) * ldw);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) __builtin_amdgcn_global_load_lds((gptr_t)(base + ta.lane_off[i]), (lptr_t)(tile[t & 1] + i * 1024), 16, 0, 2);
+      for (int i = 0; i < 8; ++i) dma16_nt(base, ta.lane_off[i], dst + i * 1024);
     } else {
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
-        __builtin_amdgcn_global_load_lds((gptr_t)(W + ta.ragged(lane, (grp0 + t) * 16, i, kbase, N, K, ldw)), (lptr_t)(tile[t & 1] + i * 1024), 16, 0, 2);
+      for (int i = 0; i < 8; ++i) dma16_nt((uint64_t)W, ta.ragged(lane, (grp0 + t) * 16, i, kbase, N, K, ldw), dst + i * 1024);
     }
   };
   // the activation fragments' loads go out AHEAD of the weight DMA (round 5, same-box A/B: +0.8 % tokens/s; the other order queues
@@ -679,15 +690,19 @@ __global__ __launch_bounds__(64) void gemv_ring_kernel(const bf16_t* __restrict_
   for (int rb = 0; rb < RB; ++rb) {
     const bf16_t* xp = x + (__umul24(min(rb * 16 + row, R - 1), ldx) + g * 8);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) xf[rb][u] = *reinterpret_cast<const bf16x8_t*>(xp + min(kbase + u * 32, K - 32));
+    for (int u = 0; u < 8; ++u) ld16(xf[rb][u], xp + min(kbase + u * 32, K - 32));
   }
   stage(0);
   if constexpr (KW > 1) stage(1);
-  decode_clear(f, lane, linear_block());
 #pragma unroll
   for (int t = 0; t < KW; ++t) {
-    if (t + 1 < KW) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (t + 1 < KW) wait_vm<8>(); else wait_vm<0>();               // loads issued behind tile t: tile t + 1's eight
+    if (t == 0) {
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) tie(xf[rb][u]);
+    }
     const char* tr = tile[t & 1] + row * 512;
     bf16x8_t wf[8];
 #pragma unroll
@@ -735,18 +750,24 @@ __global__ __launch_bounds__(64 * NW) void gemv_ring4_kernel(int R, const bf16_t
   constexpr int UPW = (8 + NW - 1) / NW;           // k-steps of the operand each wave converts
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, row = lane & 15;
   const int slab = blockIdx.x + 8 * blockIdx.z, chunk = blockIdx.y;
-  if (slab >= nslabs) { decode_clear(f, threadIdx.x, linear_block()); return; }
-  const int grp0 = (chunk * NW + wave) * KW;
+  // the clears this launch carries go out first (see gemv_ring_kernel)
+  decode_clear(f, threadIdx.x, linear_block());
+  if (slab >= nslabs) return;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int grp0 = (chunk * NW + wave_u) * KW;
   const int kbase = slab * 256;
   const bool whole = (N & 15) == 0;
+  // Every load of this kernel is hand-issued (vmem_asm.h).  With the builtins the operand image below -- an LDS write -- was preceded by
+  // a compiler-inserted s_waitcnt vmcnt(0): it was built only after BOTH weight tiles had landed (5-6 us into the gate/up launch), and
+  // the ring's third tile could only be requested after that.  Now the image is built as soon as the operand's own round trip ends.
   // operand loads of this wave's k-steps go out first, then the weight DMA
-  float4 a[RB][UPW][2], b[RB][UPW][2], w[RB][UPW][2];
+  f32x4_t a[RB][UPW][2], b[RB][UPW][2], w[RB][UPW][2];
   float rs[RB];
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
     const int ar = min(rb * 16 + row, R - 1);
     rs[rb] = 0.f;
-    if constexpr (XIN == XIN_SWIGLU) rs[rb] = f.ss_in[ar];
+    if constexpr (XIN == XIN_SWIGLU) ld4(rs[rb], f.ss_in + ar);
 #pragma unroll
     for (int uu = 0; uu < UPW; ++uu) {
       const int u = min(wave + uu * NW, 7);
@@ -755,24 +776,33 @@ __global__ __launch_bounds__(64 * NW) void gemv_ring4_kernel(int R, const bf16_t
   }
   TileAddr ta;
   ta.init(lane, kbase, K, ldw);
+  const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr_of(tile[wave][0]));
   auto stage = [&](int t) {
+    const uint32_t dst = lds0 + (t & 1) * 8192;
     if (whole) {
-      const bf16_t* base = W + __umul24(min((grp0 + t) * 16, N - 16), ldw);
+      const uint64_t base = (uint64_t)(W + (int64_t)min((grp0 + t) * 16, N - 16) * ldw);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) __builtin_amdgcn_global_load_lds((gptr_t)(base + ta.lane_off[i]), (lptr_t)(tile[wave][t & 1] + i * 1024), 16, 0, 2);
+      for (int i = 0; i < 8; ++i) dma16_nt(base, ta.lane_off[i], dst + i * 1024);
     } else {
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
-        __builtin_amdgcn_global_load_lds((gptr_t)(W + ta.ragged(lane, (grp0 + t) * 16, i, kbase, N, K, ldw)), (lptr_t)(tile[wave][t & 1] + i * 1024), 16, 0, 2);
+      for (int i = 0; i < 8; ++i) dma16_nt((uint64_t)W, ta.ragged(lane, (grp0 + t) * 16, i, kbase, N, K, ldw), dst + i * 1024);
     }
   };
   stage(0);
   if constexpr (KW > 1) stage(1);
-  decode_clear(f, threadIdx.x, linear_block());
+  wait_vm<(KW > 1 ? 16 : 8)>();                     // the operand's loads are older than the tiles' DMA
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
-    const int ar = min(rb * 16 + row, R - 1);
-    const bool live = rb * 16 + row < R;
+    if constexpr (XIN == XIN_SWIGLU) tie(rs[rb]);
+#pragma unroll
+    for (int uu = 0; uu < UPW; ++uu) {
+      tie(a[rb][uu][0]); tie(a[rb][uu][1]); tie(b[rb][uu][0]); tie(b[rb][uu][1]);
+      if constexpr (XIN == XIN_RESID_NORM) { tie(w[rb][uu][0]); tie(w[rb][uu][1]); }
+    }
+  }
+  float ssq_row[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
     if constexpr (XIN == XIN_SWIGLU) rs[rb] = rsqrtf(rs[rb] / (float)f.norm_cols + f.eps);
     float ssq = 0.f;
 #pragma unroll
@@ -781,16 +811,15 @@ __global__ __launch_bounds__(64 * NW) void gemv_ring4_kernel(int R, const bf16_t
       if (u < 8) {
         const bool in_k = kbase + u * 32 < K;                        // clamped (re-read) steps carry no new data
         float part = 0.f;
-        float* op = XIN == XIN_RESID_NORM ? f.x_out + (__umul24(ar, K) + kbase + u * 32 + g * 8) : nullptr;
-        frag[rb][u][lane] = decode_operand_make<XIN>(f, a[rb][uu], b[rb][uu], w[rb][uu], rs[rb], chunk == 0 && live && in_k, op, part);
+        frag[rb][u][lane] = decode_operand_make<XIN>(f, a[rb][uu], b[rb][uu], w[rb][uu], rs[rb], part);
         if (in_k) ssq += part;
       }
     }
     if constexpr (XIN == XIN_RESID_NORM) {
       ssq += __shfl_xor(ssq, 16, 64);
       ssq += __shfl_xor(ssq, 32, 64);
-      if (chunk == 0 && live && g == 0 && f.ss_out && ssq != 0.f) atomicAdd(f.ss_out + rb * 16 + row, ssq);
     }
+    ssq_row[rb] = ssq;
   }
   lds_barrier();
   bf16x8_t xf[RB][8];
@@ -800,8 +829,7 @@ __global__ __launch_bounds__(64 * NW) void gemv_ring4_kernel(int R, const bf16_t
     for (int u = 0; u < 8; ++u) xf[rb][u] = frag[rb][u][lane];
 #pragma unroll
   for (int t = 0; t < KW; ++t) {
-    if (t + 1 < KW) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (t + 1 < KW) wait_vm<8>(); else wait_vm<0>();               // loads issued behind tile t: tile t + 1's eight
     const char* tr = tile[wave][t & 1] + row * 512;
     bf16x8_t wf[8];
 #pragma unroll
@@ -827,6 +855,25 @@ __global__ __launch_bounds__(64 * NW) void gemv_ring4_kernel(int R, const bf16_t
       for (int j = 0; j < 4; ++j) {
         const int r = rb * 16 + g * 4 + j;
         if (r < R && n < N) atomicAdd(ap + __umul24(r, sr), d[rb][j]);
+      }
+    }
+  }
+  // the updated residual stream and its row statistics (weight group 0's workgroups) leave last: no store sits between the loads above
+  if constexpr (XIN == XIN_RESID_NORM) {
+    if (chunk == 0) {
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        const bool live = rb * 16 + row < R;
+#pragma unroll
+        for (int uu = 0; uu < UPW; ++uu) {
+          const int u = wave + uu * NW;
+          if (u < 8 && live && kbase + u * 32 < K) {
+            float* op = f.x_out + (__umul24(rb * 16 + row, K) + kbase + u * 32 + g * 8);
+            *reinterpret_cast<f32x4_t*>(op) = a[rb][uu][0];
+            *reinterpret_cast<f32x4_t*>(op + 4) = a[rb][uu][1];
+          }
+        }
+        if (live && g == 0 && f.ss_out && ssq_row[rb] != 0.f) atomicAdd(f.ss_out + rb * 16 + row, ssq_row[rb]);
       }
     }
   }

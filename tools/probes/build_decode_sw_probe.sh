@@ -1,0 +1,7 @@
+#!/bin/bash
+# Builds tools/probes/_build/decode_sw_probe against the in-tree library (run from the repo root; needs `make -C ml-unigen_amd/csrc` first).
+set -e
+ROOT="$(cd "$(dirname "$0")/../.." && pwd)"
+mkdir -p "$ROOT/tools/probes/_build"
+/opt/rocm/bin/hipcc -O2 -std=c++17 -x hip --offload-arch=gfx950 -I"$ROOT/include" "$ROOT/tools/probes/decode_sw_probe.cpp" \
+  -L"$ROOT/ml-unigen_amd/csrc" -lunigen_hip -Wl,-rpath,'$ORIGIN/../../../ml-unigen_amd/csrc' -o "$ROOT/tools/probes/_build/decode_sw_probe"
