@@ -228,29 +228,19 @@ int ug_attn_decode_fused(const float* acc_qkv, int64_t ldacc, const float* ss_in
                          const float* cos_tab, const float* sin_tab, const int* pos_dev, void* cache_k, void* cache_v,
                          const uint8_t* key_valid, void* o, int64_t ldo, int64_t rows, int H, int HKV, int head_dim,
                          int64_t Tmax, int64_t max_pos, float scale, hipStream_t stream);
-/* Single-writer decode layer (round 6; replaces the five-launch split-K form above for the 1.5B shapes; the same reference call
- * sites: models/unigen.py:496-502 per-token forward, transformers modeling_qwen2.py Qwen2DecoderLayer.forward).  Every output element
- * has ONE writer -- a workgroup owns a few weight rows for the whole contraction -- so there are no fp32 atomics, no raw accumulators,
- * no clears and no statistics buffers, and a step is bit-reproducible run to run.  `h` is the fp32 residual stream [R][H], finished
- * between launches; RMSNorm is applied as the reference applies it: operand = bf16(norm_w * (h * rsqrt(mean(h^2) + eps))).
- *   ug_decode_sw_qkv      q/k/v = Linear(RMSNorm(h)) + bias, RoPE at *pos_dev on q and k heads, q -> q_out bf16 [R][ldq],
- *                         k / v -> cache[:, :, *pos_dev] (Qwen2Attention.forward up to the cache update)
- *   ug_attn_decode_q      softmax(q K^T / sqrt(d)) V over cache keys [0, *pos_dev] (the new token included) -> o bf16
- *   ug_decode_sw_resid    h += bf16(Linear(x))     (o projection on the attention output, down projection on act)
- *   ug_decode_sw_gate_up  act = bf16(bf16(silu(gate)) * up), gate | up = Linear(RMSNorm(h))   (Qwen2MLP.forward)
- *   ug_decode_sw_head     logits fp32 [R][N] = Linear(RMSNorm(h)) for N rows of the tied embedding (Qwen2Model.norm + lm_head slice);
- *                         pos_inc / len_inc (both or neither) are incremented by one (the step's last reader of them has run)
- * The norm-fed entry points also sit behind a split-K producer of decode.hip's form: with `pend` (raw fp32 accumulator [R][ld_pend]) the
- * residual stream is h + float(bf16(pend)), written to x_out (a buffer other than h, or NULL) by the launch's first eight workgroups;
- * the accumulator is left as it is (a later launch clears it).
- * R <= 16; ug_decode_sw_supported() says whether a model's sizes fit this build (hidden 1536, head_dim 128, K multiples of 256). */
+/* Single-writer decode projections (round 6; the same reference call sites: models/unigen.py:496-502 per-token forward, transformers
+ * modeling_qwen2.py Qwen2DecoderLayer.forward / Qwen2MLP.forward / Qwen2Model.norm + lm_head).  Every output element has ONE writer -- a
+ * workgroup owns a few weight rows for the whole contraction -- so these launches use no fp32 atomics and leave FINISHED values:
+ *   ug_decode_sw_resid    h[r][n] += float(bf16(sum_k x[r][k] W[n][k]))  in place (o projection on the attention output; K == 1536)
+ *   ug_decode_sw_gate_up  act = bf16(bf16(silu(gate)) * up), gate | up = Linear(RMSNorm(h))   (Qwen2MLP.forward; W = [2 I][H], gate rows first)
+ *   ug_decode_sw_head     logits fp32 [R][N] = Linear(RMSNorm(h)) for N rows of the tied embedding; pos_inc / len_inc (both or
+ *                         neither) are incremented by one (the step's last reader of them has run)
+ * `h` is the fp32 residual stream [R][H]; RMSNorm is applied as the reference applies it: operand = bf16(norm_w * (h * rsqrt(mean(h^2)
+ * + eps))).  The norm-fed entry points also sit behind a split-K producer of the form above: with `pend` (raw fp32 accumulator
+ * [R][ld_pend]) the residual stream is h + float(bf16(pend)), written to x_out (a buffer other than h, or NULL) by the launch's first
+ * eight workgroups; the accumulator is left as it is (a later launch clears it).
+ * R <= 16; ug_decode_sw_supported() says whether a model's sizes fit this build (hidden 1536 = six 256-wide k-slabs, head_dim 128). */
 int ug_decode_sw_supported(int64_t hidden, int64_t inter, int64_t q_dim, int head_dim);
-int ug_decode_sw_qkv(const float* h, const float* pend, int64_t ld_pend, float* x_out, const float* norm_w, float eps, int64_t R,
-                     int64_t H, const void* W, int64_t ldw, const void* bias, const float* cos_tab, const float* sin_tab, const int* pos_dev, void* q_out, int64_t ldq,
-                     void* cache_k, void* cache_v, int Hq, int Hkv, int head_dim, int64_t Tmax, int64_t max_pos, hipStream_t stream);
-int ug_attn_decode_q(const void* q, int64_t ldq, const void* cache_k, const void* cache_v, const uint8_t* key_valid, void* o,
-                     int64_t ldo, int64_t rows, int H, int HKV, int head_dim, int64_t Tmax, const int* pos_dev, float scale,
-                     hipStream_t stream);
 int ug_decode_sw_resid(const void* x, int64_t ldx, int64_t R, const void* W, int64_t ldw, int64_t N, int64_t K, float* h,
                        hipStream_t stream);
 int ug_decode_sw_gate_up(const float* h, const float* pend, int64_t ld_pend, float* x_out, const float* norm_w, float eps, int64_t R,

@@ -44,6 +44,7 @@
 #include <type_traits>
 #include <atomic>
 #include "unigen_hip.h"
+#include "vmem_asm.h"
 
 namespace {
 
@@ -568,6 +569,7 @@ constexpr int P_NST = 4;
 // Cache policy of the operand streams' LDS-DMA: the default (aux 0).  sc0 / nt / sc1 measured in round 4 (probe switches
 // UG_CPOL_STAGER / UG_CPOL_P10A of tools/probes/probe_switches.patch), see docs/experiments.md.
 constexpr int CPOL_STAGER = 0, CPOL_P10A = 0;
+static_assert(CPOL_P10A == 0, "dma16 issues the default cache policy");
 
 __device__ __forceinline__ int swz_rowk32(int row, int chunk) { return chunk ^ ((0 - (row >> 2)) & 3); }
 
@@ -612,7 +614,12 @@ struct Stager32 {                // 256-row x 32-k operand tile, 8 waves: 2 one-
         s = reinterpret_cast<const bf16_t*>(past ? reinterpret_cast<uintptr_t>(zero) : reinterpret_cast<uintptr_t>(s));
       }
       char* dst = lds_tile + (i * 8 + wave) * 1024;
-      __builtin_amdgcn_global_load_lds((gptr_t)s, (lptr_t)dst, 16, 0, CPOL_STAGER);
+      // Hand-issued (vmem_asm.h), not __builtin_amdgcn_global_load_lds: with the builtin hipcc's wait insertion puts s_waitcnt
+      // vmcnt(0) in front of every ds_read_b64_tr_b16 of a k-major operand (it cannot tell the ring slot being read from the
+      // slots being filled), so dgrad and the weight gradients drained the WHOLE four-slot ring in every k-iteration and the counted
+      // vmcnt(8) below never held (round 6, ISA evidence: profiles/r06_gemm_vmcnt.md).  The row-major loops were not affected.
+      static_assert(CPOL_STAGER == 0, "dma16 issues the default cache policy");
+      dma16(s, __builtin_amdgcn_readfirstlane(lds_addr_of(dst)));
     }
   }
 };
@@ -930,7 +937,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kernel_p10(GemmArgs p) {
       char* st = lds + (lt & (P_NST - 1)) * STAGE;
 #pragma unroll
       for (int i = 0; i < NA; ++i)
-        __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + (int64_t)lt * PBK), (lptr_t)(st + (i * 8 + wave) * 1024), 16, 0, CPOL_P10A);
+        dma16(asrc[i] + (int64_t)lt * PBK, __builtin_amdgcn_readfirstlane(lds_addr_of(st + (i * 8 + wave) * 1024)));      // (see Stager32::issue)
       sb.template issue<false>(lt, p.K, st + TILE_A, wave);
     };
     auto landed = [&](int in_flight) {            // batches of this wave's DMA that may stay in flight

@@ -603,7 +603,7 @@ class UniGen(ModelMixin, ConfigMixin):
         # embedding slots, uniforms) + the graph; it is reused only when every size, every sampling constant baked into a kernel
         # argument and the weight storage are the same (UNIGEN_AR_GRAPH_CACHE=0 turns the reuse off), and dropped on any error.
         sess_key = (R, P, n, bsz, V, int(text_vocab_size), greedy, float(guidance_scale), float(temperature), key_valid is None, str(dev),
-                    bool(getattr(eng, "decode_fused", True)),
+                    bool(getattr(eng, "decode_fused", True)), os.environ.get("UNIGEN_DECODE_SW", "1"),
                     eng.fp.w("embed").data_ptr(), eng.fp.w("l0.wqkv").data_ptr(), eng.fp.p("embed").data_ptr(), eng.fp.p("norm").data_ptr())
         sess = getattr(eng, "_ar_session", None) if (use_graph and fused and os.environ.get("UNIGEN_AR_GRAPH_CACHE", "1") != "0") else None
         if sess is not None and sess["key"] != sess_key:
@@ -669,7 +669,15 @@ class UniGen(ModelMixin, ConfigMixin):
         if not fused:
             out_tokens[:, 0] = tok[:, 0]
 
+        # single-writer layer (csrc/decode_sw.hip): the final RMSNorm and the head slice are ONE launch behind the last layer
+        sw_head = fused and eng.decode_sw(st)
+
         def step():
+            if sw_head:
+                eng.decode_step_logits(st, x, w_head, acc_head)            # (also advances the cache position)
+                ops.ar_sample_(acc_head, bsz, V, guidance_scale, temperature, greedy, uniforms, st.pos, P, n, w_embed,
+                               text_vocab_size, tok, out_tokens, x)
+                return
             hn = eng.decode_step(st, x)            # (also advances the cache position)
             sample(hn)
 

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
 LIB_PATH = os.environ.get("UNIGEN_HIP_LIB") or os.path.join(CSRC_DIR, "libunigen_hip.so")     # (probe builds: tools/probes/_build/*.so)
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 P = ctypes.c_void_p
 I64 = ctypes.c_int64
 I32 = ctypes.c_int
@@ -53,6 +53,10 @@ SIGNATURES = {
     "ug_gemm_set_fused_tile_height": [I32],
     "ug_attn_decode_fused": [P, I64, P, F32, I64, P, P, P, P, P, P, P, P, I64, I64, I32, I32, I32, I64, I64, F32, P],
     "ug_decode_finish_resid_norm": [P, I64, P, P, P, I64, I64, F32, P, P, P],
+    "ug_decode_sw_supported": [I64, I64, I64, I32],
+    "ug_decode_sw_resid": [P, I64, I64, P, I64, I64, I64, P, P],
+    "ug_decode_sw_gate_up": [P, P, I64, P, P, F32, I64, I64, P, I64, I64, P, I64, P],
+    "ug_decode_sw_head": [P, P, I64, P, P, F32, I64, I64, P, I64, I64, P, I64, P, P, P],
     "ug_t2i_assemble": [P, P, P, I64, P, I64, P, P, I64, I64, I64, I64, I64, I64, I64, P, P, P, P],
     "ug_attn_mask_from_ids": [P, I64, I64, I64, I64, I64, I32, P, P, P, P, P],
     "ug_maskgit_train_mask": [P, P, P, I64, I64, I64, I64, P, P, P],

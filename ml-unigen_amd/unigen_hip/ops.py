@@ -603,6 +603,35 @@ def decode_gemv_swiglu_(gu_acc, ss_in, eps, norm_cols, w, acc, zero0=None, zero1
     return acc
 
 
+def decode_sw_supported(hidden, inter, q_dim, head_dim):
+    """whether the single-writer decode projections (include/unigen_hip.h: ug_decode_sw_*) are built for these sizes"""
+    return bool(_l.load().ug_decode_sw_supported(int(hidden), int(inter), int(q_dim), int(head_dim)))
+
+
+def decode_sw_resid_(x, w, h):
+    """h[r, n] += float(bf16(sum_k x[r, k] w[n, k])) in place, one writer per element (o projection of a decode step)"""
+    _l.check(_l.load().ug_decode_sw_resid(_p(x), x.stride(0), x.shape[0], _p(w), w.stride(0), w.shape[0], w.shape[1], _p(h), _stream()),
+             "ug_decode_sw_resid")
+    return h
+
+
+def decode_sw_gate_up_(h, norm_w, eps, w, act, pend=None, x_out=None):
+    """act = bf16(bf16(silu(gate)) * up) with gate | up = Linear(RMSNorm(h [+ bf16round(pend)])); w = [2 I, H], gate rows first"""
+    _l.check(_l.load().ug_decode_sw_gate_up(_p(h), _p(pend), pend.stride(0) if pend is not None else 0, _p(x_out), _p(norm_w), eps,
+                                            h.shape[0], h.shape[1], _p(w), w.stride(0), w.shape[0] // 2, _p(act), act.stride(0), _stream()),
+             "ug_decode_sw_gate_up")
+    return act
+
+
+def decode_sw_head_(h, norm_w, eps, w, logits, pend=None, x_out=None, advance=None):
+    """logits fp32 [R, N] = Linear(RMSNorm(h [+ bf16round(pend)])) for the N rows `w` of the tied embedding; advance = (pos, len)"""
+    pos, ln = advance if advance is not None else (None, None)
+    _l.check(_l.load().ug_decode_sw_head(_p(h), _p(pend), pend.stride(0) if pend is not None else 0, _p(x_out), _p(norm_w), eps,
+                                         h.shape[0], h.shape[1], _p(w), w.stride(0), w.shape[0], _p(logits), logits.stride(0),
+                                         _p(pos), _p(ln), _stream()), "ug_decode_sw_head")
+    return logits
+
+
 def attn_decode_fused(acc_qkv, ss_in, eps, norm_cols, bias, cos, sin, pos_dev, cache_k, cache_v, key_valid, out, H, HKV, hd, Tmax,
                       scale=None):
     scale = 1.0 / math.sqrt(hd) if scale is None else scale

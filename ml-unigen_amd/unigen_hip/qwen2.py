@@ -437,18 +437,25 @@ class DecodeState:
         self.pos.add_(1)
         self.len.add_(1)
 
-    def ensure_accumulators(self, dims):
-        """Persistent scratch of the five-launch decode layer: one raw fp32 accumulator per projection (row-major
-        [rows][N]; each is cleared by a later launch once fully consumed), the second residual-stream buffer, and
-        the two row sum-of-squares slots that carry the RMSNorm statistics to the accumulators' consumers."""
+    def ensure_accumulators(self, dims, sw=False):
+        """Persistent scratch of the five-launch decode layer: one raw fp32 accumulator per split-K projection (row-major
+        [rows][N]; each is cleared by a later launch once fully consumed), the second residual-stream buffer, and the row
+        sum-of-squares slots that carry the RMSNorm statistics to the accumulators' consumers.  sw: the layer whose o and gate/up
+        projections are single-writer launches (csrc/decode_sw.hip) -- no gate/up or o accumulator, a finished bf16 `act` instead,
+        and two down-projection accumulators that alternate by layer (the one layer l + 1 still reads is cleared by layer l + 1's
+        own down projection)."""
+        dev = self.pos.device
+        nqkv = (dims.num_attention_heads + 2 * dims.num_key_value_heads) * dims.head_dim
+        z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
         if getattr(self, "acc_qkv", None) is None:
-            dev = self.pos.device
-            nqkv = (dims.num_attention_heads + 2 * dims.num_key_value_heads) * dims.head_dim
-            z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
-            self.acc_qkv, self.acc_gu = z(self.rows, nqkv), z(self.rows, 2 * dims.intermediate_size)
-            self.acc_o, self.acc_down = z(self.rows, dims.hidden_size), z(self.rows, dims.hidden_size)
+            self.acc_qkv, self.acc_down = z(self.rows, nqkv), z(self.rows, dims.hidden_size)
             self.x_mid = z(self.rows, dims.hidden_size)
             self.ss_attn, self.ss_mlp = z(32), z(32)
+        if sw and getattr(self, "act", None) is None:
+            self.acc_down2, self.zeros = z(self.rows, dims.hidden_size), z(self.rows, dims.hidden_size)
+            self.act = torch.empty((self.rows, dims.intermediate_size), dtype=torch.bfloat16, device=dev)
+        if not sw and getattr(self, "acc_gu", None) is None:
+            self.acc_gu, self.acc_o = z(self.rows, 2 * dims.intermediate_size), z(self.rows, dims.hidden_size)
 
 
 def _decode_methods(cls):
@@ -470,10 +477,52 @@ def _decode_methods(cls):
         hn, _ = ops.rmsnorm_fwd(h, self.fp.p("norm"), d.rms_norm_eps, want_rstd=False)
         return hn.view(R, P, H)[:, -1].contiguous()
 
+    def decode_sw(self, st):
+        """Whether this decode state runs the layer with single-writer o / gate-up / head launches (csrc/decode_sw.hip)."""
+        d = self.dims
+        return (getattr(self, "decode_fused", True) and os.environ.get("UNIGEN_DECODE_SW", "1") != "0" and st.rows <= 16
+                and ops.decode_sw_supported(d.hidden_size, d.intermediate_size, d.num_attention_heads * d.head_dim, d.head_dim))
+
+    def _decode_layers_sw(self, st, x):
+        """The decoder stack of one decode step, five launches per layer (measured forms: profiles/r06_decode_forms.md):
+          q/k/v      split-K (operand = the stream + the previous layer's pending down projection; leaves a raw accumulator)
+          attention  finishes q/k/v from that accumulator, appends k / v, attends to the cache
+          o          single writer: the stream is FINISHED in place
+          gate/up    single writer: act = SwiGLU, finished bf16
+          down       split-K on act into this layer's accumulator; clears the accumulators consumed so far
+        -> (stream, pending): the residual stream after the last layer is stream + bf16round(pending)."""
+        d, fp = self.dims, self.fp
+        Hq, Hk, hd = d.num_attention_heads, d.num_key_value_heads, d.head_dim
+        R, H = st.rows, d.hidden_size
+        cos, sin = self.rope(st.Tmax)
+        st.ensure_accumulators(d, sw=True)
+        eps = d.rms_norm_eps
+        o = torch.empty((R, Hq * hd), dtype=torch.bfloat16, device=x.device)
+        bufs, accd = (x, st.x_mid), (st.acc_down, st.acc_down2)
+        n = d.num_hidden_layers
+        for i in range(n):
+            xin, xout = bufs[i & 1], bufs[(i + 1) & 1]
+            pend = st.zeros if i == 0 else accd[(i - 1) & 1]
+            ops.decode_gemv_resid_norm_(xin, pend, fp.p(f"l{i}.ln1"), xout, st.ss_attn, fp.w(f"l{i}.wqkv"), st.acc_qkv)
+            ops.attn_decode_fused(st.acc_qkv, st.ss_attn, eps, H, fp.w(f"l{i}.bqkv"), cos, sin, st.pos, st.k[i], st.v[i],
+                                  st.key_valid, o, Hq, Hk, hd, st.Tmax)
+            ops.decode_sw_resid_(o, fp.w(f"l{i}.wo"), xout)
+            ops.decode_sw_gate_up_(xout, fp.p(f"l{i}.ln2"), eps, fp.w(f"l{i}.wgu"), st.act)
+            ops.decode_gemv_(st.act, fp.w(f"l{i}.wdown"), accd[i & 1], zero0=st.acc_qkv, zero1=accd[(i + 1) & 1], ss_zero=st.ss_attn)
+        return bufs[n & 1], accd[(n - 1) & 1]
+
+    def decode_step_logits(self, st, x, w_head, logits):
+        """decode_step + the head slice in one go (single-writer layer only): logits fp32 [rows, N] = rows `w_head` of the tied
+        embedding applied to the final-norm hidden state; advances st.pos / st.len.  The final RMSNorm and the last layer's
+        pending residual add ride in the head launch's prologue."""
+        stream, pending = self._decode_layers_sw(st, x)
+        ops.decode_sw_head_(stream, self.fp.p("norm"), self.dims.rms_norm_eps, w_head, logits, pend=pending, advance=(st.pos, st.len))
+        return logits
+
     def decode_step(self, st, x):
         """x fp32 [rows, H] = embedding of the newest token (updated in place as the residual stream);
         appends its K/V at st.pos, ADVANCES st.pos / st.len by one and returns the final-norm hidden bf16 [rows, H].  No host sync, no
-        shape depends on the step: capturable.  Five launches per layer (see include/unigen_hip.h): each
+        shape depends on the step: capturable.  Five launches per layer (see include/unigen_hip.h): a split-K
         projection leaves its raw fp32 accumulator behind and the NEXT kernel applies bias / RoPE / residual add /
         RMSNorm / SiLU-mul while it builds its own operand, so kernel boundaries are the only synchronisation."""
         d, fp = self.dims, self.fp
@@ -481,9 +530,15 @@ def _decode_methods(cls):
         R, H, I = st.rows, d.hidden_size, d.intermediate_size
         if not getattr(self, "decode_fused", True) or R > 32 or hd != 128 or min(H, I, Hq * hd) < 256 or H % 32 or I % 32:
             return self._decode_step_wide(st, x)
+        eps = d.rms_norm_eps
+        hn = torch.empty((R, H), dtype=torch.bfloat16, device=x.device)
+        if self.decode_sw(st):
+            stream, pending = self._decode_layers_sw(st, x)
+            # pending down_proj of the last layer + final RMSNorm (also clears that accumulator)
+            ops.decode_finish_resid_norm_(pending, stream, fp.p("norm"), hn, eps, advance=(st.pos, st.len))
+            return hn
         cos, sin = self.rope(st.Tmax)
         st.ensure_accumulators(d)
-        eps = d.rms_norm_eps
         o = torch.empty((R, Hq * hd), dtype=torch.bfloat16, device=x.device)
         for i in range(d.num_hidden_layers):
             # x (+ pending down_proj of the previous layer) -> x_mid ; q/k/v accumulator ; clears gate_up acc
@@ -496,7 +551,6 @@ def _decode_methods(cls):
             ops.decode_gemv_resid_norm_(st.x_mid, st.acc_o, fp.p(f"l{i}.ln2"), x, st.ss_mlp, fp.w(f"l{i}.wgu"), st.acc_gu)
             ops.decode_gemv_swiglu_(st.acc_gu, st.ss_mlp, eps, H, fp.w(f"l{i}.wdown"), st.acc_down, zero0=st.acc_o)
         # pending down_proj of the last layer + final RMSNorm (also clears acc_down for the next step)
-        hn = torch.empty((R, H), dtype=torch.bfloat16, device=x.device)
         ops.decode_finish_resid_norm_(st.acc_down, x, fp.p("norm"), hn, eps, advance=(st.pos, st.len))
         return hn
 
@@ -528,6 +582,7 @@ def _decode_methods(cls):
         return out[:, :n]
 
     cls.prefill, cls.decode_step, cls.head_slice = prefill, decode_step, head_slice
+    cls.decode_sw, cls._decode_layers_sw, cls.decode_step_logits = decode_sw, _decode_layers_sw, decode_step_logits
     cls._decode_step_wide = _decode_step_wide
     return cls
 

@@ -30,7 +30,8 @@ lib.ug_last_error.restype = ctypes.c_char_p
 assert lib.ug_abi_version() == m.ABI_VERSION
 zero = {m.P: None, m.I64: 0, m.I32: 0, m.F32: 0.0}
 # entry points for which "nothing" is a legal argument (documented no-ops) or that need a live runtime / communicator
-NOOP_OK = {"ug_abi_version", "ug_destroy", "ug_comm_destroy", "ug_gemm_set_fused_tile_height"}     # (height 0 = automatic)
+NOOP_OK = {"ug_abi_version", "ug_destroy", "ug_comm_destroy", "ug_gemm_set_fused_tile_height",     # (height 0 = automatic)
+           "ug_decode_sw_supported"}                                                                    # (a predicate: 0 = "not built for these sizes")
 SKIP = {"ug_create", "ug_comm_unique_id", "ug_comm_init"}
 n_checked = 0
 for name, argtypes in m.SIGNATURES.items():

@@ -32,7 +32,7 @@ def test_abi_library_exports_every_declared_symbol():
     bound = set(lib.SIGNATURES) | {"ug_last_error"}
     assert set(syms) == bound, (set(syms) ^ bound)
     lib.load()
-    assert lib.load().ug_abi_version() == lib.ABI_VERSION == 6
+    assert lib.load().ug_abi_version() == lib.ABI_VERSION == 7
 
 
 def test_abi_argument_errors_are_reported_not_thrown():
