@@ -15,6 +15,7 @@
 // with 16-byte loads, and no transposed copy exists in HBM or LDS.
 #include "common.h"
 #include "unigen_hip.h"
+#include "vmem_asm.h"
 #include <stdlib.h>
 
 namespace {
@@ -483,8 +484,10 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd32_kernel(AttnArgs p) {
       const int row = inst * 4 + (lane >> 4);
       const int chunk = (lane & 15) ^ swz16(row);
       const int64_t goff = (int64_t)min(t * 64 + row, p.L - 1) * p.ldq + chunk * 8;
-      __builtin_amdgcn_global_load_lds((a_gptr_t)(kseq + goff), (a_lptr_t)(base + inst * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((a_gptr_t)(vseq + goff), (a_lptr_t)(base + T32_BYTES + inst * 1024), 16, 0, 0);
+      // hand-issued (vmem_asm.h): behind the builtin hipcc put s_waitcnt vmcnt(0) in front of the tile reads below -- the tile
+      // requested a moment ago had to LAND before the first MFMA of the current one, i.e. the ring prefetched nothing (round 6)
+      dma16(kseq + goff, __builtin_amdgcn_readfirstlane(lds_addr_of(base + inst * 1024)));
+      dma16(vseq + goff, __builtin_amdgcn_readfirstlane(lds_addr_of(base + T32_BYTES + inst * 1024)));
     }
   };
   // per-lane fragment offsets inside a tile
@@ -505,10 +508,17 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd32_kernel(AttnArgs p) {
 
   int t = next_visible(0);
   if (t < p.nW) stage(t, 0);
-  uint64_t wcur = t < p.nW ? wrow[t] : 0ull;             // the mask word of a tile is requested one tile ahead, like its K / V rows
+  // The mask word of a tile is requested one tile ahead, like its K / V rows.  It stays a compiler-visible load (a hand-issued one
+  // would be a loop-carried register in flight, which the compiler may copy before it lands); what matters is WHERE its first use
+  // sits: the compiler's wait for it knows nothing of the DMA around it, so the use (tie) comes right behind the loop-top drain,
+  // where nothing is in flight anyway -- anywhere later it would drain the tile just requested.
+  uint64_t wcur = t < p.nW ? wrow[t] : 0ull;
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) tie(qf[ks]);            // (the query fragments' own wait falls here, ahead of the loop)
   for (int it = 0; t < p.nW; ++it) {
     const int tn = next_visible(t + 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of tile t has landed
+    wait_vm<0>();                                        // this wave's share of tile t has landed (and its mask word)
+    tie(wcur);
     asm volatile("s_barrier" ::: "memory");               // ... everyone's has; everyone is past its reads of the other slot
     if (tn < p.nW && !p.ablate) stage(tn, (it + 1) & 1);
     const uint64_t wnext = tn < p.nW ? wrow[tn] : 0ull;
@@ -765,8 +775,10 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq32_kernel(AttnArgs p) {
       const int row = inst * 4 + (lane >> 4);
       const int chunk = (lane & 15) ^ swz16(row);
       const int64_t goff = (int64_t)min(t * 64 + row, p.L - 1) * p.ldq + chunk * 8;
-      __builtin_amdgcn_global_load_lds((a_gptr_t)(kseq + goff), (a_lptr_t)(base + inst * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((a_gptr_t)(vseq + goff), (a_lptr_t)(base + T32_BYTES + inst * 1024), 16, 0, 0);
+      // hand-issued (vmem_asm.h): behind the builtin hipcc put s_waitcnt vmcnt(0) in front of the tile reads below -- the tile
+      // requested a moment ago had to LAND before the first MFMA of the current one, i.e. the ring prefetched nothing (round 6)
+      dma16(kseq + goff, __builtin_amdgcn_readfirstlane(lds_addr_of(base + inst * 1024)));
+      dma16(vseq + goff, __builtin_amdgcn_readfirstlane(lds_addr_of(base + T32_BYTES + inst * 1024)));
     }
   };
   int koff[8], voff[4][2];
@@ -786,10 +798,13 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq32_kernel(AttnArgs p) {
 
   int t = next_visible(0);
   if (t < p.nW) stage(t, 0);
-  uint64_t wcur = t < p.nW ? wrow[t] : 0ull;
+  uint64_t wcur = t < p.nW ? wrow[t] : 0ull;             // (first use right behind the loop-top drain: see attn_fwd32_kernel)
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) { tie(qf[ks]); tie(dof[ks]); }
   for (int it = 0; t < p.nW; ++it) {
     const int tn = next_visible(t + 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wait_vm<0>();
+    tie(wcur);
     asm volatile("s_barrier" ::: "memory");
     if (tn < p.nW) stage(tn, (it + 1) & 1);
     const uint64_t wnext = tn < p.nW ? wrow[tn] : 0ull;
@@ -1102,30 +1117,40 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_dma_kernel(AttnArgs p) {
       const int row = inst * 4 + (lane >> 4);
       const int chunk = (lane & 15) ^ swz16b(row);
       const int gr = min(qt * 64 + row, p.L - 1);                           // rows past L repeat the last row: their mask words are 0
-      __builtin_amdgcn_global_load_lds((a_gptr_t)(qseq + (int64_t)gr * p.ldq + chunk * 8), (a_lptr_t)(base + inst * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((a_gptr_t)(doseq + (int64_t)gr * p.ldo + chunk * 8), (a_lptr_t)(base + T32_BYTES + inst * 1024), 16, 0, 0);
+      dma16(qseq + (int64_t)gr * p.ldq + chunk * 8, __builtin_amdgcn_readfirstlane(lds_addr_of(base + inst * 1024)));      // (hand-issued: see
+      dma16(doseq + (int64_t)gr * p.ldo + chunk * 8, __builtin_amdgcn_readfirstlane(lds_addr_of(base + T32_BYTES + inst * 1024)));   //  attn_fwd32_kernel)
     }
   };
   // row record of a query tile (wave 0, one lane per row): requested a tile ahead, parked in LDS before the tile's barrier
   float r_lse = 0.f, r_dl = 0.f;
   uint64_t r_word = 0ull;
-  auto fetch_rows = [&](int qt) {
+  bool r_in = false;
+  auto fetch_rows = [&](int qt) {                        // RAW values: their first use (tie) sits behind the next step's drain
     const int qr = qt * 64 + lane;
     const int qc = min(qr, p.L - 1);
-    r_lse = p.lse[((int64_t)b * p.H + h) * p.L + qc] * 1.4426950408889634f;      // exp2 domain
-    r_dl = p.delta[((int64_t)b * p.H + h) * p.L + qc] * p.scale;                  // delta scale
-    r_word = qr < p.L ? p.bits[((int64_t)b * p.L + qc) * p.nW + t] : 0ull;         // rows past L contribute nothing
+    r_lse = p.lse[((int64_t)b * p.H + h) * p.L + qc];
+    r_dl = p.delta[((int64_t)b * p.H + h) * p.L + qc];
+    r_word = p.bits[((int64_t)b * p.L + qc) * p.nW + t];   // (unconditional: a branch here makes hipcc guard the register with a wait
+    r_in = qr < p.L;                                      //  that drains the DMA just issued); rows past L contribute nothing
   };
 
   // the (head, visible query tile) sequence: head h0's tiles, then head h0 + 1's, ... -- one ring, one barrier per step
   int qt = next_visible(0);
   int hleft = qt < p.nW ? HPW - 1 : 0;                    // heads still to come after the current one
   if (qt < p.nW) { stage(qt, 0); if (wave == 0) fetch_rows(qt); }
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) { tie(kf[ks]); tie(vf[ks]); }          // (the key / value fragments' own wait falls here, ahead of the loop)
   for (int it = 0; qt < p.nW; ++it) {
     int qn = next_visible(qt + 1);
     const int slot = it & 1;
-    if (wave == 0) { lse_s[slot][lane] = r_lse; dl_s[slot][lane] = r_dl; word_s[slot][lane] = r_word; }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    wait_vm<0>();                                        // this wave's share of the tile has landed (and wave 0's row records)
+    if (wave == 0) {
+      tie(r_lse); tie(r_dl); tie(r_word);
+      lse_s[slot][lane] = r_lse * 1.4426950408889634f;     // exp2 domain
+      dl_s[slot][lane] = r_dl * p.scale;                   // delta scale
+      word_s[slot][lane] = r_in ? r_word : 0ull;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
     if (qn >= p.nW && hleft > 0) {                        // next head: its Q / dO / row records from the first visible tile on
       --hleft; ++h;

@@ -42,6 +42,8 @@ __device__ __forceinline__ void ld16(T& v, uint64_t base, uint32_t voff) {
 template <typename T>
 __device__ __forceinline__ void ld16(T& v, const void* p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(v) : "v"(p) : "memory"); }
 template <typename T>
+__device__ __forceinline__ void ld8(T& v, const void* p) { asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(v) : "v"(p) : "memory"); }
+template <typename T>
 __device__ __forceinline__ void ld4(T& v, const void* p) { asm volatile("global_load_dword %0, %1, off" : "=&v"(v) : "v"(p) : "memory"); }
 template <typename T>
 __device__ __forceinline__ void ld2u(T& v, const void* p) { asm volatile("global_load_ushort %0, %1, off" : "=&v"(v) : "v"(p) : "memory"); }
