@@ -617,7 +617,7 @@ struct Stager32 {                // 256-row x 32-k operand tile, 8 waves: 2 one-
       // Hand-issued (vmem_asm.h), not __builtin_amdgcn_global_load_lds: with the builtin hipcc's wait insertion puts s_waitcnt
       // vmcnt(0) in front of every ds_read_b64_tr_b16 of a k-major operand (it cannot tell the ring slot being read from the
       // slots being filled), so dgrad and the weight gradients drained the WHOLE four-slot ring in every k-iteration and the counted
-      // vmcnt(8) below never held (round 6, ISA evidence: profiles/r06_gemm_vmcnt.md).  The row-major loops were not affected.
+      // vmcnt(8) below never held (round 6, ISA evidence: profiles/r06_vmcnt_findings.md).  The row-major loops were not affected.
       static_assert(CPOL_STAGER == 0, "dma16 issues the default cache policy");
       dma16(s, __builtin_amdgcn_readfirstlane(lds_addr_of(dst)));
     }

@@ -3,7 +3,7 @@
 // Why: with the builtins (`__builtin_amdgcn_global_load_lds`, plain loads) hipcc's wait insertion treats ANY LDS access as a possible
 // alias of every LDS-DMA in flight and puts `s_waitcnt vmcnt(0)` in front of it.  In the decode kernels that meant: the operand image
 // (an LDS write) was built only after the WHOLE weight ring had landed, and the attention prologue only after the K / V chunk -- the
-// "4.5 us per launch that are not weight streaming" of rounds 4-5 (ISA evidence: profiles/r06_decode_vmcnt.md).  Issued through asm
+// "4.5 us per launch that are not weight streaming" of rounds 4-5 (ISA evidence: profiles/r06_vmcnt_findings.md).  Issued through asm
 // volatile the compiler sees no VMEM at all: ordering = program order of the asm statements, data readiness = the waits written here.
 // Rules: (1) every wait counts only LOADS issued behind the one waited for -- stores / atomics in between are never counted, so a wait
 // can over-wait but not under-wait whatever order stores retire in; (2) a loaded value is used only behind tie() placed after its wait.

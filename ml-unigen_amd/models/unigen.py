@@ -592,6 +592,7 @@ class UniGen(ModelMixin, ConfigMixin):
                 raise UniGenHipError("t2i_generate_ar expects the 2-D [rows, L] attention mask the reference slices")
             key_valid = attention_mask[:, :P].to(dev) != 0
         greedy = bool(kwargs.get("greedy", False))          # argmax instead of multinomial: deterministic parity tests
+        logit_trace = kwargs.get("trace")                   # optional list: fp32 [rows, V] head logits of every eager step
         use_graph = bool(kwargs.get("use_graph", True))
         code_lo, code_hi = text_vocab_size, self.vocab_size - 1          # logits[..., text_vocab_size:-1]
         V = code_hi - code_lo
@@ -633,8 +634,13 @@ class UniGen(ModelMixin, ConfigMixin):
             w_head = eng.fp.w("embed")[code_lo:code_hi]
             w_embed = eng.fp.p("embed")
 
+            def keep_logits():                     # parity tests follow the head's raw logits step by step (eager runs only)
+                if logit_trace is not None and not torch.cuda.is_current_stream_capturing():
+                    logit_trace.append(acc_head.clone())
+
             def sample(hn):
                 ops.decode_gemv_(hn, w_head, acc_head)
+                keep_logits()
                 ops.ar_sample_(acc_head, bsz, V, guidance_scale, temperature, greedy, uniforms, st.pos, P, n, w_embed,
                                text_vocab_size, tok, out_tokens, x)
         else:
@@ -675,6 +681,7 @@ class UniGen(ModelMixin, ConfigMixin):
         def step():
             if sw_head:
                 eng.decode_step_logits(st, x, w_head, acc_head)            # (also advances the cache position)
+                keep_logits()
                 ops.ar_sample_(acc_head, bsz, V, guidance_scale, temperature, greedy, uniforms, st.pos, P, n, w_embed,
                                text_vocab_size, tok, out_tokens, x)
                 return

@@ -278,12 +278,16 @@ def unigen_forward_gen_ref(lm, gen, input_ids, attention_mask, labels=None, batc
     return f(img_logits), f(loss_t2i), f(loss_lm), f(loss_mmu)
 
 
-def ar_generate_ref(lm, cond_embeds, uncond_embeds, n_tokens, guidance_scale, text_vocab, key_valid=None, autocast=True, gen=None):
+def ar_generate_ref(lm, cond_embeds, uncond_embeds, n_tokens, guidance_scale, text_vocab, key_valid=None, autocast=True, gen=None,
+                    trace=None, force_tokens=None):
     """Greedy (argmax) version of UniGen.t2i_generate_ar (models/unigen.py:457-521): prefix = embeddings with the
     last n+1 positions already cut off; KV cache grown by concatenation like DynamicCache; CFG
     `uncond + s * (cond - uncond)` on logits[text_vocab:-1]; next token embedded for both halves.
     gen (a GenHeadRef): the gen_proj_depth > 0 branch (:486-495,512-514) -- img_head on the last hidden state (codebook-wide
     logits, no slicing, no text-vocabulary offset), next input gen_projector(gen_embed(token)).
+    trace (a list): receives per step a dict with the head's code-book logits of all 2 B rows (`logits`, fp32 copy of what the head
+    returned) and the CFG mix (`mixed`).  force_tokens [B, n]: the trajectory to follow instead of this run's own argmax (teacher
+    forcing: lets an fp32 run be compared step by step with a bf16 run's trajectory); the returned tokens are still this run's argmax.
     Returns (tokens [B, n], top-2 margin of the mixed logits per step [B, n])."""
     B = cond_embeds.shape[0]
     x = torch.cat([cond_embeds, uncond_embeds])
@@ -317,6 +321,10 @@ def ar_generate_ref(lm, cond_embeds, uncond_embeds, n_tokens, guidance_scale, te
             nxt = mixed.argmax(-1, keepdim=True)
             toks.append(nxt)
             margins.append(top2[:, 0] - top2[:, 1])
+            if trace is not None:
+                trace.append({"logits": logits.float().clone(), "mixed": mixed.clone()})
+            if force_tokens is not None:
+                nxt = force_tokens[:, i:i + 1].to(nxt.dtype)
             pos = total
             x = gen.gen_projector(gen.gen_embed(torch.cat([nxt, nxt]))) if gen is not None else lm.model.embed_tokens(torch.cat([nxt, nxt]) + text_vocab)
     return torch.cat(toks, 1), torch.stack(margins, 1)

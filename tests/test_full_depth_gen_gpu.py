@@ -1,0 +1,176 @@
+"""Full-depth GENERATION parity: `ar_decode.value` times a 28-layer, 16-row, prefix-138 captured decode step that
+no parity test had run at that size -- the 1.5B-width decode kernels were compared one by one, AR / MaskGIT end to end only on the
+H = 64 fixtures (G2 / G9 / G13).  Here the WHOLE 1.5B backbone (28 layers, V = 159 867, seeded weights) generates:
+
+  AR     8 images + CFG = 16 rows, prefix 138 with left padding, 8 greedy steps through `UniGen.t2i_generate_ar`
+         (reference models/unigen.py:457-521) against `oracle.qwen2_ref.ar_generate_ref` under bf16 autocast:
+           - the head's logits of EVERY step (eager run, `trace=`) through `fp32_yardstick` -- as close to the exact (fp32,
+             teacher-forced on the same trajectory) logits as the reference-mode logits are -- for every image whose tokens so far
+             agree with the oracle's;
+           - tokens equal while the oracle's own top-2 margin is clear;
+           - captured-graph run == eager run, token for token, and a second call (the kept session) == the first.
+  MaskGIT  one parallel-decoding round (incremental form) of `UniGen.t2i_generate` (models/unigen.py:398-453) at L = 771 with CFG
+         against `oracle.qwen2_ref.maskgit_generate_ref` fed the same uniforms: tokens equal wherever the draw is not within bf16
+         noise of a CDF step.
+
+The oracle needs two prefills of 2 208 tokens through 28 layers on the host (bf16 autocast and fp32): a few minutes; set
+UNIGEN_SKIP_FULL_DEPTH=1 to skip on a small host."""
+import math
+import os
+import time
+
+import pytest
+import torch
+
+from helpers import additive, fp32_yardstick, llm_config_dir, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TV, CB, NVQ = 151674, 8192, 256
+V = TV + CB + 1
+PAD, SOI, EOI, MASK = 151643, 151665, 151666, V - 1
+SEED = 93
+# A top-2 margin of the CFG-mixed logits below this is a near-tie: the head's logits are bf16 (ulp 0.016 at |x| in [2, 4)) and the mix
+# uncond + 6 (cond - uncond) amplifies a one-ulp difference seven-fold; later tokens may then legitimately diverge.
+MARGIN = 0.2
+LOGITS_GATE_28 = 2.8e-2                         # HIP vs reference-mode bf16 logits at 28 layers (tests/test_full_depth_gpu.py)
+
+
+def _build(dev):
+    from models import UniGen
+    from oracle import qwen2_ref, weights
+    from test_full_depth_gpu import _oracle_full_depth
+    cfg = dict(qwen2_ref.QWEN25_1P5B, vocab_size=V)
+    model = UniGen(w_und_encoder=False, vocab_size=V, llm_vocab_size=TV, llm_model_path=llm_config_dir(cfg), codebook_size=CB,
+                   num_vq_tokens=NVQ, load_from_pretrained=True, device=dev, init_seed=-1).eval()
+    names = [(n, tuple(p.shape)) for n, p in model.llm.named_parameters()]
+    sd = weights.synth_llm_state(names, seed=SEED)
+    model.llm.load_state_dict(sd, strict=False)
+    return model, _oracle_full_depth(cfg, sd)
+
+
+@pytest.mark.skipif(os.environ.get("UNIGEN_SKIP_FULL_DEPTH") == "1", reason="UNIGEN_SKIP_FULL_DEPTH=1")
+def test_28_layer_ar_generation_matches_oracle(dev):
+    from oracle import qwen2_ref
+    model, lm = _build(dev)
+    eng = model.llm.engine
+    B, P, n, scale = 8, 138, 8, 6.0
+    g = torch.Generator().manual_seed(31)
+    cond = torch.randint(0, 151643, (B, P + n + 1), generator=g)
+    uncond = torch.randint(0, 151643, (B, P + n + 1), generator=g)
+    for b in range(B):                                        # left padding like t2i_gen_prompt: ragged prompts, short unconditional rows
+        cond[b, :int(torch.randint(0, 60, (1,), generator=g))] = PAD
+        uncond[b, :int(torch.randint(90, 130, (1,), generator=g))] = PAD
+    am = torch.cat([cond != PAD, uncond != PAD]).long()
+    am[:, P:] = 1
+    with torch.no_grad():
+        ce, ue = lm.model.embed_tokens(cond[:, :P]), lm.model.embed_tokens(uncond[:, :P])
+
+    # ---- HIP: eager with the logits of every step, captured graph, and the kept session
+    def run(**kw):
+        return model.t2i_generate_ar(input_ids=cond.to(dev), uncond_input_ids=uncond.to(dev), attention_mask=am.to(dev), guidance_scale=scale,
+                                     temperature=1.0, text_vocab_size=TV, image_token_num_per_image=n, greedy=True, **kw).cpu()
+    assert eng.decode_sw(type("S", (), {"rows": 2 * B})()), "the 1.5B shapes must take the single-writer decode layer"
+    hip_logits = []
+    tok_eager = run(use_graph=False, trace=hip_logits)
+    eng.check_errors()
+    assert len(hip_logits) == n and hip_logits[0].shape == (2 * B, CB)
+    tok_graph = run(use_graph=True)
+    assert eng.last_decode_graph
+    tok_kept = run(use_graph=True)                            # second call: the captured step and its buffers are reused
+    # The split-K launches of the step (q/k/v, down) sum by fp32 atomics, so two runs differ in the last bits and an argmax may flip
+    # where the mixed logits' own top-2 margin is within that noise: captured and eager runs must agree token for token up to the
+    # first such near-tie of each image (and the kept session likewise).
+    def own_margin(lg):
+        lg = lg.to(torch.bfloat16).float().cpu()
+        mixed = lg[B:] + scale * (lg[:B] - lg[B:])
+        top2 = mixed.topk(2, -1).values
+        return top2[:, 0] - top2[:, 1]
+    hip_margin = torch.stack([own_margin(lg) for lg in hip_logits], 1)           # [B, n]
+    for name, other in (("captured graph", tok_graph), ("kept session", tok_kept)):
+        agreed = 0
+        for b in range(B):
+            for i in range(n):
+                if hip_margin[b, i] < MARGIN:
+                    break
+                assert other[b, i].item() == tok_eager[b, i].item(), (name, b, i, other[b], tok_eager[b], hip_margin[b])
+                agreed += 1
+        diff = (other != tok_eager).nonzero().tolist()
+        print(f"    {name} vs eager: {agreed} of {B * n} tokens compared (up to each image's first near-tie), all equal; positions that "
+              f"differ anywhere: {[(b, i, round(float(hip_margin[b, i]), 4)) for b, i in diff]} (image, step, eager run's margin)")
+        assert agreed >= 4 * B, (name, agreed)
+
+    # ---- oracle: reference mode (bf16 autocast), then fp32 teacher-forced on the reference trajectory
+    t0 = time.time()
+    tr_bf, tr_32 = [], []
+    want, margin = qwen2_ref.ar_generate_ref(lm, ce, ue, n, scale, TV, key_valid=am[:, :P], autocast=True, trace=tr_bf)
+    qwen2_ref.ar_generate_ref(lm, ce, ue, n, scale, TV, key_valid=am[:, :P], autocast=False, trace=tr_32, force_tokens=want)
+    print(f"    oracle: two 28-layer generations of {n} steps in {time.time() - t0:.0f} s; min top-2 margin per step "
+          f"{[round(float(m), 3) for m in margin.min(0).values]}")
+
+    compared_tokens, compared_steps = 0, 0
+    for i in range(n):
+        # images whose trajectory so far is the oracle's: their step-i inputs are identical
+        same = torch.tensor([bool(torch.equal(tok_eager[b, :i].long(), want[b, :i].long())) for b in range(B)])
+        if not bool(same.any()):
+            break
+        rows = torch.cat([same, same])
+        got = hip_logits[i].cpu()[rows]
+        got = got.to(torch.bfloat16).float()                  # the head's output is bf16 (Linear under autocast); the sampler rounds it the same way
+        ref_bf, ref_32 = tr_bf[i]["logits"][rows], tr_32[i]["logits"][rows]
+        fp32_yardstick(f"AR step {i} ({int(same.sum())} of {B} images on the oracle's trajectory)", got, ref_bf, ref_32)
+        d = rel_err(got, ref_bf)
+        assert d < LOGITS_GATE_28, (i, d)
+        compared_steps += 1
+        for b in range(B):
+            if same[b] and margin[b, i] >= MARGIN:
+                assert tok_eager[b, i].item() == want[b, i].item(), (i, b, tok_eager[b], want[b], margin[b])
+                compared_tokens += 1
+    assert compared_steps >= 4 and compared_tokens >= 3 * B, (compared_steps, compared_tokens)
+
+
+@pytest.mark.skipif(os.environ.get("UNIGEN_SKIP_FULL_DEPTH") == "1", reason="UNIGEN_SKIP_FULL_DEPTH=1")
+def test_28_layer_maskgit_round_matches_oracle(dev):
+    from oracle import host_ref, qwen2_ref
+    model, lm = _build(dev)
+    N, L, n = 1, 771, NVQ
+    g = torch.Generator().manual_seed(41)
+    ids = torch.randint(0, 151643, (N, L), generator=g)
+    ids[0, :97] = PAD
+    ids[:, -(n + 2)] = SOI
+    ids[:, -1] = EOI
+    ids[:, -(n + 1):-1] = MASK
+    un = ids.clone()
+    un[0, :L - n - 2 - 5] = PAD                                # the unconditional prompt: a few tokens behind the padding
+    both = torch.cat([ids, un])
+    am = additive(host_ref.mask_predict_next_ref(both, PAD, SOI, EOI, rm_pad_in_image=True))
+    sched = lambda t: torch.cos(t * math.pi * 0.5)
+    gen = torch.Generator(device=dev).manual_seed(77)
+    state = gen.get_state()
+    u = torch.rand((2, N, n), device=dev, generator=gen).cpu()
+    gen.set_state(state)
+    got = model.t2i_generate(input_ids=ids.to(dev), uncond_input_ids=un.to(dev), attention_mask=am.to(dev), guidance_scale=6.0,
+                             temperature=1.0, timesteps=1, noise_schedule=sched, generator=gen, image_token_num_per_image=n,
+                             text_vocab_size=TV).cpu()
+    model.llm.engine.check_errors()
+    trace = []
+    want = qwen2_ref.maskgit_generate_ref(lm, ids, un, am, 6.0, 1.0, 1, sched, n, TV, MASK, qwen2_ref.InverseCdfSampler(u[0:1], u[1:2]),
+                                          autocast=True, trace=trace)
+    # How far can rounding move the inverse-CDF draw?  The reference itself answers: the same round in fp32 shifts the CDF of each
+    # position by delta = max |cdf_bf16 - cdf_fp32|; a draw further than 3 delta from the nearest CDF step cannot flip.
+    trace32 = []
+    want32 = qwen2_ref.maskgit_generate_ref(lm, ids, un, am, 6.0, 1.0, 1, sched, n, TV, MASK, qwen2_ref.InverseCdfSampler(u[0:1], u[1:2]),
+                                            autocast=False, trace=trace32)
+    cdf = trace[0]["mixed"].softmax(-1).cumsum(-1)
+    cdf32 = trace32[0]["mixed"].softmax(-1).cumsum(-1)
+    delta = (cdf - cdf32).abs().max(-1).values
+    gap = (cdf - u[0].reshape(N, n, 1)).abs().min(-1).values
+    sure = gap > 3 * delta + 1e-3
+    agree_all = float((got == want).float().mean())
+    agree_ref = float((want32 == want).float().mean())          # the control: the reference's own fp32 mode against its bf16 mode
+    print(f"    MaskGIT round at L = {L}, CFG 6: reference bf16-vs-fp32 CDF shift median {float(delta.median()):.4f} max {float(delta.max()):.4f}; "
+          f"{int(sure.sum())} of {n} draws clear of a CDF step by 3 x that, agreement on those "
+          f"{float((got[sure] == want[sure]).float().mean()):.3f}; on all positions HIP vs reference bf16 {agree_all:.3f}, "
+          f"reference fp32 vs reference bf16 {agree_ref:.3f}")
+    assert int(sure.sum()) >= 24 and torch.equal(got[sure], want[sure])
+    assert agree_all >= agree_ref - 0.08, (agree_all, agree_ref)

@@ -1579,3 +1579,82 @@ def test_gemm_swiglu_fused_epilogue_is_bit_identical(dev, M, I, K):
     assert torch.equal(gu, gu_ref) and torch.equal(act, act_ref)
     ref32 = x.float() @ w.float().t()
     assert _rel(gu, ref32) < 4e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R", [16, 5, 1])
+def test_decode_single_writer_projections_match_separate_kernels(dev, R):
+    """csrc/decode_sw.hip (round 6): the o projection (finished residual add), gate/up + SwiGLU and the head slice as single-writer
+    launches on Qwen2.5-1.5B shapes -- against the separate kernels they stand for (RMSNorm -> GEMV -> SwiGLU / residual add) and a
+    fp32 evaluation; the pending-accumulator input must equal feeding the folded stream (bit for bit), and a launch repeated on the
+    same input must reproduce itself bit for bit (no atomics)."""
+    ops = _ops()
+    assert ops.decode_sw_supported(1536, 8960, 1536, 128) and not ops.decode_sw_supported(896, 4864, 896, 64)
+    H, I, V = 1536, 8960, 8192
+    g = torch.Generator().manual_seed(600 + R)
+    mk = lambda n, k: (torch.randn(n, k, generator=g) / math.sqrt(k)).to(torch.bfloat16).to(dev)
+    wo, wgu, whead = mk(H, H), mk(2 * I, H), mk(V, H)
+    ln = (1 + 0.1 * torch.randn(H, generator=g)).to(dev)
+    h0 = torch.randn(R, H, generator=g)
+    o = torch.randn(R, H, generator=g).to(torch.bfloat16)
+    eps = 1e-6
+    # ---- o projection: h += float(bf16(o W^T)), exactly the split-K GEMV + finisher up to the fp32 summation order
+    h = h0.clone().to(dev)
+    ops.decode_sw_resid_(o.to(dev), wo, h)
+    ref = h0 + (o.float() @ wo.float().cpu().t()).to(torch.bfloat16).float()
+    assert _rel(h, ref) < 2e-3, _rel(h, ref)
+    h_again = h0.clone().to(dev)
+    ops.decode_sw_resid_(o.to(dev), wo, h_again)
+    assert torch.equal(h, h_again)
+    # ---- gate/up: RMSNorm as the reference applies it, SwiGLU in the epilogue
+    act = torch.empty(R, I, dtype=torch.bfloat16, device=dev)
+    ops.decode_sw_gate_up_(h, ln, eps, wgu, act)
+    xn, _ = ops.rmsnorm_fwd(h, ln, eps, want_rstd=False)                       # the training path's kernel: same rounding points
+    gu = ops.skinny_linear(xn, wgu)
+    act_sep = ops.swiglu_fwd(gu)
+    assert _rel(act, act_sep.float()) < 6e-3, _rel(act, act_sep.float())       # (one bf16 ulp where a gate / up sum lands on the other side)
+    hf = h.float().cpu()
+    xr = (ln.cpu() * (hf * torch.rsqrt(hf.pow(2).mean(-1, keepdim=True) + eps))).to(torch.bfloat16).float()
+    guf = (xr @ wgu.float().cpu().t()).to(torch.bfloat16).float()
+    gate, up = guf[:, :I], guf[:, I:]
+    act_ref = (torch.nn.functional.silu(gate).to(torch.bfloat16).float() * up).to(torch.bfloat16).float()
+    assert _rel(act, act_ref) < 6e-3, _rel(act, act_ref)
+    act2 = torch.empty_like(act)
+    ops.decode_sw_gate_up_(h, ln, eps, wgu, act2)
+    assert torch.equal(act, act2)
+    # ---- pending accumulator: gate_up(h, pend) == gate_up(h + float(bf16(pend))), x_out = that sum
+    pend = (0.5 * torch.randn(R, H, generator=g)).to(dev)
+    folded = h + pend.to(torch.bfloat16).float()
+    x_out = torch.zeros_like(h)
+    act3, act4 = torch.empty_like(act), torch.empty_like(act)
+    ops.decode_sw_gate_up_(h, ln, eps, wgu, act3, pend=pend, x_out=x_out)
+    ops.decode_sw_gate_up_(folded, ln, eps, wgu, act4)
+    assert torch.equal(act3, act4) and torch.equal(x_out, folded)
+    # ---- head slice (+ position advance)
+    logits = torch.zeros(R, V, device=dev)
+    pos = torch.tensor([7], dtype=torch.int32, device=dev)
+    ln_dev = torch.tensor([8], dtype=torch.int32, device=dev)
+    ops.decode_sw_head_(h, ln, eps, whead, logits, pend=pend, advance=(pos, ln_dev))
+    ff = folded.float().cpu()
+    xr = (ln.cpu() * (ff * torch.rsqrt(ff.pow(2).mean(-1, keepdim=True) + eps))).to(torch.bfloat16).float()
+    assert _rel(logits, xr @ whead.float().cpu().t()) < 2e-3
+    assert int(pos.item()) == 8 and int(ln_dev.item()) == 9
+    logits2 = torch.zeros(R, V, device=dev)
+    ops.decode_sw_head_(folded, ln, eps, whead, logits2)
+    assert torch.equal(logits, logits2) and int(pos.item()) == 8
+
+
+@pytest.mark.gpu
+def test_decode_single_writer_rejects_what_it_was_not_built_for(dev):
+    ops = _ops()
+    from unigen_hip.lib import UniGenHipError
+    w = torch.zeros(64, 1024, dtype=torch.bfloat16, device=dev)
+    with pytest.raises(UniGenHipError):
+        ops.decode_sw_resid_(torch.zeros(4, 1024, dtype=torch.bfloat16, device=dev), w, torch.zeros(4, 64, device=dev))      # K != 1536
+    with pytest.raises(UniGenHipError):
+        ops.decode_sw_gate_up_(torch.zeros(17, 1536, device=dev), torch.ones(1536, device=dev), 1e-6,
+                               torch.zeros(64, 1536, dtype=torch.bfloat16, device=dev), torch.zeros(17, 32, dtype=torch.bfloat16, device=dev))   # 17 rows
+    h = torch.zeros(4, 1536, device=dev)
+    with pytest.raises(UniGenHipError):                                                                                      # x_out must not alias h
+        ops.decode_sw_gate_up_(h, torch.ones(1536, device=dev), 1e-6, torch.zeros(64, 1536, dtype=torch.bfloat16, device=dev),
+                               torch.zeros(4, 32, dtype=torch.bfloat16, device=dev), pend=torch.zeros(4, 1536, device=dev), x_out=h)
