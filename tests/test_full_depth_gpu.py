@@ -38,7 +38,9 @@ GATES = {"weight": 6e-2, "bias": 6e-2, "norm": 6e-2, "embed": 6e-2, "norm_ratio"
 # measured: t2i_L771 worst 1.18 (a q_proj bias), median 0.986; mixed_L387 worst 1.29 (layer 10's 256-element k_proj bias: 3.77e-2 vs
 # the reference mode's 2.92e-2 from the fp32 gradient), median 1.000.  The median is the bar that means something; the worst single
 # tensor is always one of the 256 / 1536-element biases.
-TRUTH_WORST, TRUTH_MEDIAN = {"t2i_L771": 1.25, "mixed_L387": 1.40}, 1.03
+# Round 6: the worst-tensor gate is no longer a constant picked to admit the measurement (it was 1.40 for mixed_L387) but 1.05 x what a
+# second reference-mode evaluation of the SAME step needs (the control below: 1.32 / 1.18 measured), never below 1.30.
+TRUTH_MEDIAN = 1.03
 LOGITS_GATE_28 = 2.8e-2                       # HIP vs reference-mode bf16 logits at 28 layers: 2.34e-2 measured (round 5) x 1.2
 
 
@@ -160,6 +162,29 @@ def test_28_layer_1p5b_step_matches_oracle(dev, case):
     lo32 = pick(lo32.detach()).clone()
     print(f"    oracle fp32 fwd+bwd {time.time() - t0:.0f} s; fp32 loss (sum) {r32.item():.6f}")
 
+    # ---- control: a SECOND reference-mode evaluation that differs from the first only in implementation order --
+    # transformers' eager attention instead of sdpa and every Linear's contraction axis permuted (tests/test_logits_control_cpu.py).
+    # How far ITS gradient tensors sit from the fp32 gradient, relative to the first one's, is the spread the worst-tensor gate must admit.
+    from test_logits_control_cpu import eager_attention, permuted_linears
+    g32 = {}
+    for n, p_ in lm.named_parameters():
+        g32[n], p_.grad = p_.grad, None
+    t0 = time.time()
+    with eager_attention(), permuted_linears(lm, 0):
+        _, a1, a2, a3 = qwen2_ref.unigen_forward_ref(lm, seq, mask, labels, autocast=True, **kw)
+        (a1 + ((a2 + a3) if case == "mixed_L387" else 0.0)).backward()
+    alt_ratios, alt_worst = [], (0.0, None)
+    for n, p_ in lm.named_parameters():
+        r = rel_err(p_.grad, g32[n]) / max(rel_err(g16[n], g32[n]), 1e-30)
+        alt_ratios.append(r)
+        if r > alt_worst[0]:
+            alt_worst = (r, n)
+        p_.grad = g32[n]                                          # (the fp32 gradient goes back where the loop below expects it)
+    g32 = None
+    alt_med = sorted(alt_ratios)[len(alt_ratios) // 2]
+    print(f"    control, {time.time() - t0:.0f} s: a second reference-mode evaluation (eager attention, permuted contractions) -- distance to the fp32 "
+          f"gradient relative to the first one's: median {alt_med:.3f}, worst {alt_worst[0]:.3f} ({alt_worst[1]})")
+
     # ---- gradients, tensor by tensor
     ref_p = dict(lm.named_parameters())
     per_layer, ratios = {}, []
@@ -192,10 +217,14 @@ def test_28_layer_1p5b_step_matches_oracle(dev, case):
         print(f"    worst {k}: {e:.2e} ({n}), gate {GATES[k]:.0e}")
     med = sorted(ratios)[len(ratios) // 2]
     print(f"    distance to the fp32 gradient, HIP / reference mode: median over {len(ratios)} tensors {med:.3f} (gate {TRUTH_MEDIAN}), worst "
-          f"{worst_truth[0]:.3f} ({worst_truth[1]}: {worst_truth[2]:.2e} vs {worst_truth[3]:.2e}; gate {TRUTH_WORST[case]})")
+          f"{worst_truth[0]:.3f} ({worst_truth[1]}: {worst_truth[2]:.2e} vs {worst_truth[3]:.2e})")
     for k, (e, n) in worst.items():
         assert e < GATES[k], (k, n, e)
-    assert med <= TRUTH_MEDIAN and worst_truth[0] <= TRUTH_WORST[case]
+    # what the reference's own second evaluation needs, + 5 %; never below 1.30: one control run shows 1.18 ... 1.32 depending on the case
+    # (round 6, profiles/r06_full_depth_parity.txt), always on a 256- or 1536-element bias
+    worst_gate = max(1.30, 1.05 * alt_worst[0])
+    print(f"    worst-tensor gate: max(1.30, 1.05 x the control's worst {alt_worst[0]:.3f}) = {worst_gate:.3f}")
+    assert med <= TRUTH_MEDIAN and worst_truth[0] <= worst_gate, (med, worst_truth, worst_gate)
 
     # ---- logits: HIP vs reference-mode bf16, and both against the exact (fp32) logits of the same weights
     rl = rel_err(got, lo)
