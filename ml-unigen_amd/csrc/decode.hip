@@ -948,10 +948,14 @@ void launch_ring_auto(hipStream_t st, const bf16_t* x, int ldx, int R, const bf1
 }
 
 // 32-bit / 24-bit ranges of the ring kernels' addressing (weights up to 2^31 elements, strides below 2^24)
+// ... and of their grids: weight-row groups ride in grid.y (at most 65 535 workgroups: N <= 16 x 65 535 rows with one group per
+// workgroup, the smallest unit any launch shape uses), k-slabs in grid.x or, eight at a time, in grid.z
 #define UG_RING_RANGES(name, N, K, ldw, sr, sn)                                                                                      \
   UG_REQUIRE((N) < (1 << 24) && (K) < (1 << 24) && (ldw) < (1 << 24) && (int64_t)(N) * (ldw) < (1ll << 31) && (sr) < (1 << 24) &&    \
                  (sn) < (1 << 24) && (int64_t)(N) * (sn) + 32 * (int64_t)(sr) < (1ll << 31),                                         \
-             name ": sizes beyond the kernels' 32-bit addressing (N=%ld K=%ld ldw=%ld)", (long)(N), (long)(K), (long)(ldw))
+             name ": sizes beyond the kernels' 32-bit addressing (N=%ld K=%ld ldw=%ld)", (long)(N), (long)(K), (long)(ldw));         \
+  UG_REQUIRE(((N) + 15) / 16 <= 65535 && ((K) + 255) / 256 <= 65535 * 8,                                                              \
+             name ": N = %ld weight rows / K = %ld exceed the launch grid (16 x 65 535 rows, 2 048 x 65 535 columns)", (long)(N), (long)(K))
 
 }  // namespace
 

@@ -199,8 +199,14 @@ __global__ __launch_bounds__(ARS_T) void ar_sample_kernel(float* __restrict__ ac
 #pragma unroll
     for (int w = 0; w < ARS_T / 64; ++w) { const float wv = wtot[w]; if (w < wave) base += wv; total += wv; }
     const float excl = base + (incl - local);
+    // The chunks' ranges must TILE [0, total): a thread's upper bound is its neighbour's lower bound, not its own excl + local (the two
+    // differ by an ulp, so a target could fall into a gap, match nobody and force the token to the last chunk: ~3e-5 per token,
+    // ADVICE r5).  Next lane's excl within the wave; the next wave's base (= base + this wave's total, the very sum that wave forms)
+    // across waves; the grand total for the last thread.
+    float upper = __shfl_down(excl, 1, 64);
+    if (lane == 63) upper = (wave == ARS_T / 64 - 1) ? total : base + wtot[wave];
     const float target = uniforms[(int64_t)step * bsz + b] * total;
-    if (excl <= target && target < excl + local) atomicMin(&hit, t);
+    if (excl <= target && target < upper) atomicMin(&hit, t);
     __syncthreads();
     if (t == hit) {
       float run = excl;

@@ -555,6 +555,20 @@ class UniGen(ModelMixin, ConfigMixin):
         return sampled_ids
 
     # ------------------------------------------------------------------ autoregressive generation
+    def drop_decode_session(self):
+        """Release the decode step kept from the last `t2i_generate_ar` call: the static KV cache of every layer (rows x (prefix + n)
+        tokens), the decode scratch, and the captured graph with its private memory pool -- hundreds of MB that otherwise stay
+        allocated until a call with different shapes replaces them.  `train(True)` calls this (periodic evaluation inside a training
+        run must not keep generation buffers for the rest of it); `UNIGEN_AR_GRAPH_CACHE=0` disables keeping a session at all."""
+        eng = getattr(getattr(self, "llm", None), "engine", None)
+        if eng is not None:
+            eng._ar_session = None
+
+    def train(self, mode: bool = True):
+        if mode:
+            self.drop_decode_session()
+        return super().train(mode)
+
     @torch.no_grad()
     def t2i_generate_ar(
             self,
@@ -605,7 +619,10 @@ class UniGen(ModelMixin, ConfigMixin):
         # argument and the weight storage are the same (UNIGEN_AR_GRAPH_CACHE=0 turns the reuse off), and dropped on any error.
         sess_key = (R, P, n, bsz, V, int(text_vocab_size), greedy, float(guidance_scale), float(temperature), key_valid is None, str(dev),
                     bool(getattr(eng, "decode_fused", True)), os.environ.get("UNIGEN_DECODE_SW", "1"),
-                    eng.fp.w("embed").data_ptr(), eng.fp.w("l0.wqkv").data_ptr(), eng.fp.p("embed").data_ptr(), eng.fp.p("norm").data_ptr())
+                    eng.fp.w("embed").data_ptr(), eng.fp.w("l0.wqkv").data_ptr(), eng.fp.p("embed").data_ptr(), eng.fp.p("norm").data_ptr(),
+                    # (every other pointer the captured step bakes in lives in the same two flat buffers; the last layer's weights and the
+                    # RoPE tables stand in for "nothing was reallocated in between")
+                    eng.fp.w(f"l{eng.dims.num_hidden_layers - 1}.wdown").data_ptr(), tuple(t.data_ptr() for t in eng.rope(P + n)))
         sess = getattr(eng, "_ar_session", None) if (use_graph and fused and os.environ.get("UNIGEN_AR_GRAPH_CACHE", "1") != "0") else None
         if sess is not None and sess["key"] != sess_key:
             sess = None

@@ -296,12 +296,15 @@ class FlatGradSync:
                 ev.record()
             self._cap = (ev, dst)
 
-    def _plan(self):
-        """(agreed row capacity, early hand-over agreed) of the running pass"""
+    def _plan(self, block=True):
+        """(agreed row capacity, early hand-over agreed) of the running pass.  block=False: None while the ranks' answer has not
+        reached the host yet (no host wait)."""
         if self._cap is None:
             return 0, False
         if not isinstance(self._cap[0], int):
             ev, dst = self._cap
+            if not block and not ev.query():
+                return None
             ev.synchronize()
             every = dst.view(self.world, 2)
             self._cap = (int(every[:, 0].max()), bool((every[:, 1] == every[0, 1]).all()) and int(every[0, 1]) > 0)
@@ -310,8 +313,19 @@ class FlatGradSync:
     def _capacity(self):
         return self._plan()[0]
 
-    def early_handover_agreed(self):
-        return self._plan()[1]
+    def early_handover_agreed(self, block=True):
+        plan = self._plan(block)
+        return None if plan is None else plan[1]
+
+    def set_reduce(self, reduce):
+        """Switch the exchange's arithmetic between passes (bench.py times the default and `bf16_fp32acc` in one process).  Every rank
+        must switch at the same point: the modes issue different collectives."""
+        if reduce not in ("bf16", "bf16_fp32acc", "fp32", "fp32_rsag"):
+            raise ValueError(f"FlatGradSync: reduce must be 'fp32', 'fp32_rsag', 'bf16_fp32acc' or 'bf16' (got {reduce!r})")
+        if reduce.startswith("bf16") and not self.cuda:
+            raise ValueError("FlatGradSync: the bf16 exchanges pack with a HIP kernel; CPU tensors use reduce='fp32'")
+        self.reduce = reduce
+        self._mode = {"fp32": 0, "bf16_fp32acc": 1, "bf16": 2, "fp32_rsag": 3}[reduce]
 
     def add_lookup(self, ids, rows):
         """An embedding lookup's backward: ids int64 [n], rows fp32 [n, H] (kept, not copied)."""
@@ -424,8 +438,12 @@ class FlatGradSync:
         if tag == "head":
             # the last recorded head has written its dense weight gradient into the tied table: nothing but lookups (kept
             # aside) is expected to touch it any more in this pass
+            # (the ranks' agreement is READ without a host wait here: backward has only the head's kernels queued at this point, and a
+            # rank that is ahead of the others would stall its launch queue for their all-gather -- ADVICE r5.  If the answer is not on
+            # the host yet, the hand-over happens at the next tag through _ensure_early_done, at the same position in the sequence of
+            # collectives, with the layers' backward already queued behind it.)
             if (self.enabled and self.active and self.sparse_embed and not self._embed_done and self._embed_end > 0
-                    and self.early_handover_agreed()):
+                    and self.early_handover_agreed(block=False)):
                 self._flush(0, self._embed_end)
                 self._embed_done = True
                 self.early_embed_handovers += 1

@@ -239,3 +239,14 @@ def test_bench_runs_end_to_end_with_two_ranks(dev):
     assert last["buckets"] and all(b["collective_ms"] > 0 and b["mb"] > 0 for b in last["buckets"]) and last["exposed_wait_ms"] >= 0
     assert abs(sum(b["mb"] for b in last["buckets"]) * 1e6 - ex["bytes_on_wire_per_step"]) < 0.02 * ex["bytes_on_wire_per_step"]
     assert "rccl" in ex and ex["rccl"] is None
+    # round 6: the one N > 1 run also times the bf16-on-the-wire exchange, in the same process, after the block
+    # `value` is quoted on; both accounts with their bucket timelines and exposed waits
+    modes = ex["modes"]
+    assert set(modes) == {"fp32", "bf16_fp32acc"}, modes.keys()
+    for name, m in modes.items():
+        assert m["samples_per_s"] > 0 and m["last_step"]["buckets"] and m["exposed_wait_ms"] >= 0, (name, m)
+    assert abs(modes["fp32"]["samples_per_s"] - out["value"]) < 1e-2 * out["value"]
+    # (payload handed to the collectives: 4 bytes per element either way -- one fp32 all-reduce, or a bf16 all-to-all + a bf16
+    # all-gather; what differs is the traffic a ring makes of it)
+    assert modes["fp32"]["collective"].startswith("all_reduce") and modes["bf16_fp32acc"]["collective"].startswith("all_to_all")
+    assert modes["bf16_fp32acc"]["steps"] == 1

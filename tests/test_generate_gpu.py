@@ -94,6 +94,14 @@ def test_ar_decode_session_is_reused_across_calls_and_never_stale(dev, monkeypat
     # a sampling constant that is baked into a kernel argument: new session
     run(ar["cond"], ar["uncond"], ar["attention_mask"], ar["scale"] + 1.0)
     assert eng._ar_session["graph"] is not s2["graph"]
+    # round 6: the kept session -- KV cache, scratch, graph pool -- is released explicitly or on the way back to training
+    model.drop_decode_session()
+    assert eng._ar_session is None
+    run(ar["cond"], ar["uncond"], ar["attention_mask"], ar["scale"])
+    assert eng._ar_session is not None
+    model.train()
+    assert eng._ar_session is None
+    model.eval()
 
 
 def test_mmu_generate_matches_reference_trajectory(dev):

@@ -12,9 +12,31 @@ import shutil
 import subprocess
 import sys
 import tempfile
+
+import yaml
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "ml-unigen_amd", "csrc")
-LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+def _llvm_dir():
+    """The LLVM tools that belong to the hipcc the Makefile uses (HIPCC / ROCM_PATH overrides honoured), not a fixed path."""
+    hipcc = os.environ.get("HIPCC") or shutil.which("hipcc") or os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "bin", "hipcc")
+    cands = []
+    try:
+        out = subprocess.run([hipcc, "--print-prog-name=llvm-readelf"], capture_output=True, text=True, timeout=60).stdout.strip()
+        if out and os.path.isabs(out):
+            cands.append(os.path.dirname(out))
+    except (OSError, subprocess.SubprocessError):
+        pass
+    rocm = os.environ.get("ROCM_PATH") or os.path.dirname(os.path.dirname(os.path.realpath(hipcc)))
+    cands += [os.path.join(rocm, "lib", "llvm", "bin"), os.path.join(rocm, "llvm", "bin"), "/opt/rocm/lib/llvm/bin"]
+    for c in cands:
+        if os.path.exists(os.path.join(c, "llvm-readelf")) and os.path.exists(os.path.join(c, "llvm-objdump")):
+            return c
+    raise SystemExit(f"check_spills: llvm-readelf / llvm-objdump not found (looked in {cands}); set ROCM_PATH or HIPCC")
+
+
+LLVM = _llvm_dir()
 STRICT = re.compile(r"gemm_kernel|attn_|gemv_|conv3x3|conv_igemm")
 # Audited spills (round 5, ISA read: `scratch_` lines of the device assembly): name fragment -> (max spilled dwords, what spills).
 # None of them is an inline-asm load destination or sits between hand-counted loads and their `s_waitcnt vmcnt`: a scratch
@@ -39,17 +61,15 @@ def kernels_of(obj):
         out = []
         for co in cos:
             notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], capture_output=True, text=True, check=True).stdout
-            cur = {}
-            for line in notes.splitlines():
-                m = re.match(r"\s+(?:- )?\.(name|vgpr_count|vgpr_spill_count|sgpr_spill_count):\s+(\S+)", line)
-                if not m:
-                    continue
-                if m.group(1) == "name" and "name" in cur and "vgpr_count" in cur:
-                    pass
-                cur[m.group(1)] = m.group(2)
-                if len(cur) == 4:
-                    out.append((cur["name"], int(cur["vgpr_count"]), int(cur["vgpr_spill_count"]), int(cur["sgpr_spill_count"])))
-                    cur = {}
+            # the notes carry the code object's metadata as a YAML document: amdhsa.kernels is the list of kernel records
+            m = re.search(r"^\s*---\s*$(.*?)^\s*\.\.\.\s*$", notes, re.S | re.M)
+            if not m:
+                raise SystemExit(f"check_spills: no metadata document in the notes of {os.path.basename(obj)}")
+            for k in (yaml.safe_load(m.group(1)) or {}).get("amdhsa.kernels", []):
+                missing = [f for f in (".name", ".vgpr_count", ".vgpr_spill_count", ".sgpr_spill_count") if f not in k]
+                if missing:
+                    raise SystemExit(f"check_spills: kernel record in {os.path.basename(obj)} lacks {missing}: {k.get('.name')}")
+                out.append((k[".name"], int(k[".vgpr_count"]), int(k[".vgpr_spill_count"]), int(k[".sgpr_spill_count"])))
         return out
 
 
@@ -71,6 +91,9 @@ def main():
     for f, name, vg, vs, ss in bad:
         print(f"SPILL: {f}: {name}: vgpr_spill_count {vs} (vgprs {vg}, sgpr spills {ss})")
     print(f"check_spills: {total} kernels, {len(bad)} spilling in the must-not-spill set")
+    if total == 0:
+        print("check_spills: no kernel found under ml-unigen_amd/csrc (objects not built, or the metadata could not be read): that is a failure, not a pass")
+        return 1
     return 1 if bad else 0
 
 
