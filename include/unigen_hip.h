@@ -241,6 +241,11 @@ int ug_attn_decode_fused(const float* acc_qkv, int64_t ldacc, const float* ss_in
  * eight workgroups; the accumulator is left as it is (a later launch clears it).
  * R <= 16; ug_decode_sw_supported() says whether a model's sizes fit this build (hidden 1536 = six 256-wide k-slabs, head_dim 128). */
 int ug_decode_sw_supported(int64_t hidden, int64_t inter, int64_t q_dim, int head_dim);
+/* The down projection's form (its 287 KB operand rules a whole-K workgroup out): split-K in k-blocks of seven 256-wide slabs -- a
+ * workgroup owns 32 weight rows x one k-block, its seven partial tiles meet in LDS and join acc[r*ldacc + n] by ONE fp32 atomic per
+ * element (K / 1792 atomics per output instead of K / 256).  Same accumulator / clears contract as ug_decode_gemv above. */
+int ug_decode_sw_kblock(const void* x, int64_t ldx, int64_t R, const void* W, int64_t ldw, float* acc, int64_t ldacc, int64_t N, int64_t K,
+                        float* zero0, int64_t n0, float* zero1, int64_t n1, float* ss_zero, hipStream_t stream);
 int ug_decode_sw_resid(const void* x, int64_t ldx, int64_t R, const void* W, int64_t ldw, int64_t N, int64_t K, float* h,
                        hipStream_t stream);
 int ug_decode_sw_gate_up(const float* h, const float* pend, int64_t ld_pend, float* x_out, const float* norm_w, float eps, int64_t R,

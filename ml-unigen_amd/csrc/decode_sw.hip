@@ -24,7 +24,7 @@
 namespace {
 
 enum { PRO_NORM = 0, PRO_BF16 = 1 };
-enum { EPI_RESID = 1, EPI_SWIGLU = 2, EPI_STORE = 3 };
+enum { EPI_RESID = 1, EPI_SWIGLU = 2, EPI_STORE = 3, EPI_ATOMIC = 4 };
 
 struct SwArgs {
   const bf16_t* W; int ldw; int K; int R;
@@ -35,7 +35,9 @@ struct SwArgs {
   const bf16_t* xb; int ldx;                               // PRO_BF16: finished bf16 operand [R][ldx]
   float* h_io;                                             // EPI_RESID: h[r][col] += float(bf16(y))
   bf16_t* act; int ld_act; int I;                          // EPI_SWIGLU
-  float* out; int ld_out;                                  // EPI_STORE
+  float* out; int ld_out;                                  // EPI_STORE; EPI_ATOMIC: out[r][col] += y (fp32 atomics, one per k-block)
+  float* zero0; float* zero1; float* ss_zero;              // EPI_ATOMIC: accumulators this launch clears (consumed by earlier launches)
+  int n0_4, per0, n1_4, per1;                              //   float4 counts and every workgroup's share of them
   int* pos_inc; int* len_inc;                              // advanced by workgroup 0 when given (the step's last reader of pos is behind us)
 };
 
@@ -62,8 +64,11 @@ struct RowMap {
 
 // NW waves per workgroup, wave w owns k-slab w (K == 256 NW) and walks MAXT tiles of 16 weight rows through a RING-slot LDS ring of
 // MAXI KiB slots.  The whole ring is requested before the operand prologue (staging only part of it first measured no faster).
-template <int PRO, int EPI, int NW, int MAXT, int RING, int MAXI, bool PEND = false>
+// KBLK (split-K in k-blocks of NW slabs, grid.y = k-block): the partial tile of a workgroup joins the accumulator by ONE atomic per
+// element (EPI_ATOMIC) -- the down projection, whose 287 KB operand rules the whole-K cut out: 5 atomics per output instead of 35.
+template <int PRO, int EPI, int NW, int MAXT, int RING, int MAXI, bool PEND = false, bool KBLK = false>
 __global__ __launch_bounds__(64 * NW) void gemv_sw_kernel(SwArgs a) {
+  static_assert(KBLK == (EPI == EPI_ATOMIC) && (!KBLK || PRO == PRO_BF16), "k-blocks accumulate; whole-K launches store");
   static_assert(RING <= MAXT && MAXT <= RING * MAXI, "ring too small for the reduction image");
   static_assert(MAXT <= NW, "wave t finishes tile t");
   static_assert(!PEND || PRO == PRO_NORM, "a pending accumulator joins the fp32 stream only");
@@ -71,11 +76,21 @@ __global__ __launch_bounds__(64 * NW) void gemv_sw_kernel(SwArgs a) {
   __shared__ __attribute__((aligned(16))) float wn[PRO == PRO_NORM ? NW : 1][256];
   __shared__ float ssp[PRO == PRO_NORM ? NW : 1][16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, slot = lane & 15;
+  if constexpr (EPI == EPI_ATOMIC) {
+    // the clears this launch carries go out first (stores behind the loads would sit between them in the memory queue)
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int bid = blockIdx.y * gridDim.x + blockIdx.x, tid = threadIdx.x, nt = 64 * NW;
+    if (a.zero0) { const int lo = bid * a.per0, hi = min(a.n0_4, lo + a.per0); for (int i = lo + tid; i < hi; i += nt) reinterpret_cast<float4*>(a.zero0)[i] = z; }
+    if (a.zero1) { const int lo = bid * a.per1, hi = min(a.n1_4, lo + a.per1); for (int i = lo + tid; i < hi; i += nt) reinterpret_cast<float4*>(a.zero1)[i] = z; }
+    if (a.ss_zero && bid == 0 && tid < 32) a.ss_zero[tid] = 0.f;
+  }
   const int u0 = blockIdx.x * a.upw, u1 = min(a.nunits, u0 + a.upw);
   if (u0 >= u1) return;
   const int K = a.K;
   const int arow = min(slot, a.R - 1);                       // the MFMA's A row of this lane (rows past R repeat the last one)
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int slab = (KBLK ? (int)blockIdx.y * NW : 0) + wave_u;         // this wave's 256-wide k-slab
+                                                                       // (the host admits only K that is a whole number of k-blocks)
   typedef RowMap<EPI> RM;
 
   // ---- what the epilogue needs from memory is requested before anything else: the finishing wave of tile t (wave t) would otherwise
@@ -106,7 +121,7 @@ __global__ __launch_bounds__(64 * NW) void gemv_sw_kernel(SwArgs a) {
     }
     ld16<0>(wv, (uint64_t)a.norm_w, (uint32_t)(wave * 256 + lane * 4) * 4u);
   } else {
-    const uint32_t xo = (uint32_t)(__umul24(arow, a.ldx) + wave * 256 + g * 8) * 2u;
+    const uint32_t xo = (uint32_t)(__umul24(arow, a.ldx) + slab * 256 + g * 8) * 2u;
 #define UG_LDX(u) ld16<(u) * 64>(xf[u], (uint64_t)a.xb, xo);
     UG_LDX(0) UG_LDX(1) UG_LDX(2) UG_LDX(3) UG_LDX(4) UG_LDX(5) UG_LDX(6) UG_LDX(7)
 #undef UG_LDX
@@ -124,7 +139,7 @@ __global__ __launch_bounds__(64 * NW) void gemv_sw_kernel(SwArgs a) {
   auto stage = [&](int t) {
     const int nv = RM::nvalid(u0, u1, t);
     const int r0 = nv > 0 ? u0 + RM::UPT * t : u0;
-    const uint64_t base = (uint64_t)a.W + ((int64_t)r0 * a.ldw + wave_u * 256) * 2;
+    const uint64_t base = (uint64_t)a.W + ((int64_t)r0 * a.ldw + slab * 256) * 2;
     const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_addr_of(tile[wave][t % RING]));
 #pragma unroll
     for (int i = 0; i < MAXI; ++i)       // nt: every weight byte is read once per step by one CU (guide, price list row nt-weights)
@@ -242,7 +257,10 @@ __global__ __launch_bounds__(64 * NW) void gemv_sw_kernel(SwArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int r = g * 4 + j;
-          if (r < a.R) a.out[(int64_t)r * a.ld_out + col] = v[j];
+          if (r < a.R) {
+            if constexpr (EPI == EPI_ATOMIC) atomicAdd(a.out + ((int64_t)r * a.ld_out + col), v[j]);
+            else a.out[(int64_t)r * a.ld_out + col] = v[j];
+          }
         }
       }
     }
@@ -316,6 +334,27 @@ extern "C" int ug_decode_sw_resid(const void* x, int64_t ldx, int64_t R, const v
   const unsigned grid = (unsigned)((a.nunits + a.upw - 1) / a.upw);
   hipLaunchKernelGGL((gemv_sw_kernel<PRO_BF16, EPI_RESID, 6, 1, 1, 4>), dim3(grid), dim3(64 * 6), 0, st, a);
   UG_CHECK_LAUNCH("ug_decode_sw_resid");
+  return UG_OK;
+}
+
+extern "C" int ug_decode_sw_kblock(const void* x, int64_t ldx, int64_t R, const void* W, int64_t ldw, float* acc, int64_t ldacc, int64_t N,
+                                   int64_t K, float* zero0, int64_t n0, float* zero1, int64_t n1, float* ss_zero, hipStream_t st) {
+  UG_SW_COMMON("ug_decode_sw_kblock");
+  UG_REQUIRE(x && acc && K > 0 && K % (256 * 7) == 0 && ldx >= K && ldx % 8 == 0 && ldx < (1 << 20) && ldw >= K && ug_aligned16(x) &&
+                 ldacc >= N && n0 % 4 == 0 && n1 % 4 == 0 && n0 < (1ll << 31) && n1 < (1ll << 31) && ug_aligned16(zero0) && ug_aligned16(zero1),
+             "ug_decode_sw_kblock: bad args (the contraction must be a whole number of 1792-wide k-blocks: seven waves x one 256-wide "
+             "k-slab; K=%ld)", (long)K);
+  SwArgs a{};
+  a.W = (const bf16_t*)W; a.ldw = (int)ldw; a.K = (int)K; a.R = (int)R;
+  a.nunits = (int)N; a.xb = (const bf16_t*)x; a.ldx = (int)ldx; a.out = acc; a.ld_out = (int)ldacc;
+  a.upw = 32;                                                  // two 16-row tiles per workgroup
+  const dim3 grid((unsigned)((a.nunits + a.upw - 1) / a.upw), (unsigned)(K / (256 * 7)));
+  const unsigned nblocks = grid.x * grid.y;
+  a.zero0 = zero0; a.zero1 = zero1; a.ss_zero = ss_zero;
+  a.n0_4 = (int)(n0 >> 2); a.n1_4 = (int)(n1 >> 2);
+  a.per0 = (int)((a.n0_4 + nblocks - 1) / nblocks); a.per1 = (int)((a.n1_4 + nblocks - 1) / nblocks);
+  hipLaunchKernelGGL((gemv_sw_kernel<PRO_BF16, EPI_ATOMIC, 7, 2, 2, 8, false, true>), grid, dim3(64 * 7), 0, st, a);
+  UG_CHECK_LAUNCH("ug_decode_sw_kblock");
   return UG_OK;
 }
 

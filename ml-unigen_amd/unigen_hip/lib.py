@@ -54,6 +54,7 @@ SIGNATURES = {
     "ug_attn_decode_fused": [P, I64, P, F32, I64, P, P, P, P, P, P, P, P, I64, I64, I32, I32, I32, I64, I64, F32, P],
     "ug_decode_finish_resid_norm": [P, I64, P, P, P, I64, I64, F32, P, P, P],
     "ug_decode_sw_supported": [I64, I64, I64, I32],
+    "ug_decode_sw_kblock": [P, I64, I64, P, I64, P, I64, I64, I64, P, I64, P, I64, P, P],
     "ug_decode_sw_resid": [P, I64, I64, P, I64, I64, I64, P, P],
     "ug_decode_sw_gate_up": [P, P, I64, P, P, F32, I64, I64, P, I64, I64, P, I64, P],
     "ug_decode_sw_head": [P, P, I64, P, P, F32, I64, I64, P, I64, I64, P, I64, P, P, P],

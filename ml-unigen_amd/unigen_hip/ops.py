@@ -615,6 +615,13 @@ def decode_sw_resid_(x, w, h):
     return h
 
 
+def decode_sw_kblock_(x, w, acc, zero0=None, zero1=None, ss_zero=None):
+    """acc[r, n] += sum_k x[r, k] w[n, k] in k-blocks of 1 792 (one atomic per element and k-block) + the clears this launch carries"""
+    _l.check(_l.load().ug_decode_sw_kblock(_p(x), x.stride(0), x.shape[0], _p(w), w.stride(0), _p(acc), acc.stride(0), w.shape[0],
+                                           w.shape[1], *_clr(zero0), *_clr(zero1), _p(ss_zero), _stream()), "ug_decode_sw_kblock")
+    return acc
+
+
 def decode_sw_gate_up_(h, norm_w, eps, w, act, pend=None, x_out=None):
     """act = bf16(bf16(silu(gate)) * up) with gate | up = Linear(RMSNorm(h [+ bf16round(pend)])); w = [2 I, H], gate rows first"""
     _l.check(_l.load().ug_decode_sw_gate_up(_p(h), _p(pend), pend.stride(0) if pend is not None else 0, _p(x_out), _p(norm_w), eps,

@@ -489,7 +489,7 @@ def _decode_methods(cls):
           attention  finishes q/k/v from that accumulator, appends k / v, attends to the cache
           o          single writer: the stream is FINISHED in place
           gate/up    single writer: act = SwiGLU, finished bf16
-          down       split-K on act into this layer's accumulator; clears the accumulators consumed so far
+          down       split-K (k-blocks, LDS pre-reduction) on act into this layer's accumulator; clears the accumulators consumed so far
         -> (stream, pending): the residual stream after the last layer is stream + bf16round(pending)."""
         d, fp = self.dims, self.fp
         Hq, Hk, hd = d.num_attention_heads, d.num_key_value_heads, d.head_dim
@@ -500,6 +500,9 @@ def _decode_methods(cls):
         o = torch.empty((R, Hq * hd), dtype=torch.bfloat16, device=x.device)
         bufs, accd = (x, st.x_mid), (st.acc_down, st.acc_down2)
         n = d.num_hidden_layers
+        # down projection: k-blocks of seven slabs with the partial tiles pre-reduced in LDS (5 atomics per output for the 1.5B model
+        # instead of 35: 7.6 vs 8.9 us) when the intermediate size is a whole number of them, else one slab per wave
+        down = ops.decode_sw_kblock_ if d.intermediate_size % 1792 == 0 else ops.decode_gemv_
         for i in range(n):
             xin, xout = bufs[i & 1], bufs[(i + 1) & 1]
             pend = st.zeros if i == 0 else accd[(i - 1) & 1]
@@ -508,7 +511,7 @@ def _decode_methods(cls):
                                   st.key_valid, o, Hq, Hk, hd, st.Tmax)
             ops.decode_sw_resid_(o, fp.w(f"l{i}.wo"), xout)
             ops.decode_sw_gate_up_(xout, fp.p(f"l{i}.ln2"), eps, fp.w(f"l{i}.wgu"), st.act)
-            ops.decode_gemv_(st.act, fp.w(f"l{i}.wdown"), accd[i & 1], zero0=st.acc_qkv, zero1=accd[(i + 1) & 1], ss_zero=st.ss_attn)
+            down(st.act, fp.w(f"l{i}.wdown"), accd[i & 1], zero0=st.acc_qkv, zero1=accd[(i + 1) & 1], ss_zero=st.ss_attn)
         return bufs[n & 1], accd[(n - 1) & 1]
 
     def decode_step_logits(self, st, x, w_head, logits):

@@ -1658,3 +1658,24 @@ def test_decode_single_writer_rejects_what_it_was_not_built_for(dev):
     with pytest.raises(UniGenHipError):                                                                                      # x_out must not alias h
         ops.decode_sw_gate_up_(h, torch.ones(1536, device=dev), 1e-6, torch.zeros(64, 1536, dtype=torch.bfloat16, device=dev),
                                torch.zeros(4, 32, dtype=torch.bfloat16, device=dev), pend=torch.zeros(4, 1536, device=dev), x_out=h)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,N,K", [(16, 1536, 8960), (5, 100, 1792), (16, 48, 3584)])
+def test_decode_kblock_projection_accumulates_and_clears(dev, R, N, K):
+    """ug_decode_sw_kblock (the decode step's down projection): acc += x W^T in k-blocks of 1 792 with the seven partial tiles of a
+    workgroup pre-reduced in LDS; the clears it carries; a contraction that is not a whole number of k-blocks is refused."""
+    ops = _ops()
+    from unigen_hip.lib import UniGenHipError
+    g = torch.Generator().manual_seed(N + K)
+    x = torch.randn(R, K, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16)
+    acc0 = torch.randn(R, N, generator=g)
+    acc = acc0.clone().to(dev)
+    z0, z1, ss = torch.ones(16, 2048, device=dev), torch.ones(R, 1536, device=dev), torch.ones(32, device=dev)
+    ops.decode_sw_kblock_(x.to(dev), w.to(dev), acc, zero0=z0, zero1=z1, ss_zero=ss)
+    ref = acc0 + x.float() @ w.float().t()
+    assert _rel(acc, ref) < 1e-5, _rel(acc, ref)
+    assert float(z0.abs().max()) == 0.0 and float(z1.abs().max()) == 0.0 and float(ss.abs().max()) == 0.0
+    with pytest.raises(UniGenHipError):
+        ops.decode_sw_kblock_(x[:, :1536].contiguous().to(dev), w[:, :1536].contiguous().to(dev), acc)

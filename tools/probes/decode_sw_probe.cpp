@@ -108,13 +108,18 @@ int main(int argc, char** argv) {
       const float gb = rb((float)g), ub = rb((float)u); const float sl = rb(gb / (1.f + expf(-gb)));
       a1.push_back(bf2f(gact[(size_t)r * I + c])); b1.push_back(rb(sl * ub)); }
     printf("check gate_up act rel err %.3e\n", rel_err(a1, b1));
-    // down on the GPU's act
-    UG(ug_decode_sw_resid(d_act, I, R, ly[0].wdown, I, H, I, d_h, st));
+    // down on the GPU's act: split-K in k-blocks of seven slabs, partial tiles pre-reduced in LDS, one atomic per element and k-block
+    CK(hipMemsetAsync(acc_down, 0, (size_t)R * H * 4, st));
+    UG(ug_decode_sw_kblock(d_act, I, R, ly[0].wdown, I, acc_down, H, H, I, nullptr, 0, nullptr, 0, nullptr, st));
     CK(hipStreamSynchronize(st));
-    std::vector<float> gh2((size_t)R * H); CK(hipMemcpy(gh2.data(), d_h, gh2.size() * 4, hipMemcpyDeviceToHost));
-    href = gh;
-    for (int r = 0; r < R; ++r) for (int n = 0; n < H; ++n) { double a = 0; for (int k = 0; k < I; ++k) a += (double)bf2f(gact[(size_t)r * I + k]) * bf2f(h_wdown[(size_t)n * I + k]); href[r * H + n] += rb((float)a); }
-    printf("check down h rel err %.3e\n", rel_err(gh2, href));
+    std::vector<float> gd((size_t)R * H); CK(hipMemcpy(gd.data(), acc_down, gd.size() * 4, hipMemcpyDeviceToHost));
+    std::vector<float> dref((size_t)R * H);
+    for (int r = 0; r < R; ++r) for (int n = 0; n < H; ++n) { double a = 0; for (int k = 0; k < I; ++k) a += (double)bf2f(gact[(size_t)r * I + k]) * bf2f(h_wdown[(size_t)n * I + k]); dref[r * H + n] = (float)a; }
+    printf("check down (k-blocks) acc rel err %.3e\n", rel_err(gd, dref));
+    std::vector<float> gh2 = gh;
+    for (size_t i = 0; i < gh2.size(); ++i) gh2[i] += rb(gd[i]);
+    CK(hipMemcpy(d_h, gh2.data(), gh2.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemsetAsync(acc_down, 0, (size_t)R * H * 4, st));
     // head
     UG(ug_decode_sw_head(d_h, nullptr, 0, nullptr, d_lnf, EPS, R, H, d_whead, H, V, d_logits, V, nullptr, nullptr, st));
     CK(hipStreamSynchronize(st));
@@ -161,6 +166,15 @@ int main(int argc, char** argv) {
     UG(ug_decode_sw_gate_up(xout, nullptr, 0, nullptr, ly[l].ln2, EPS, R, H, ly[l].wgu, H, I, d_act, I, st));
     UG(ug_decode_gemv(d_act, I, R, ly[l].wdown, I, accD[l & 1], H, H, I, acc_qkv, (int64_t)R * NQKV, l == 0 ? nullptr : accD[(l - 1) & 1], l == 0 ? 0 : (int64_t)R * H, ss_attn, st));
   };
+  auto g2_layer = [&](int l) {                        // G1 with the down projection in k-blocks
+    float* xin = xbuf[l & 1]; float* xout = xbuf[(l + 1) & 1];
+    const float* pend = l == 0 ? zeros : accD[(l - 1) & 1];
+    UG(ug_decode_gemv_resid_norm(xin, pend, H, ly[l].ln1, xout, ss_attn, R, ly[l].wqkv, H, acc_qkv, NQKV, NQKV, H, nullptr, 0, nullptr, 0, nullptr, st));
+    UG(ug_attn_decode_fused(acc_qkv, NQKV, ss_attn, EPS, H, ly[l].bqkv, d_cs, d_sn, d_pos, ly[l].ck, ly[l].cv, nullptr, d_o, HQ * HD, R, HQ, HK, HD, TMAX, MAXPOS, scale, st));
+    UG(ug_decode_sw_resid(d_o, HQ * HD, R, ly[l].wo, H, H, HQ * HD, xout, st));
+    UG(ug_decode_sw_gate_up(xout, nullptr, 0, nullptr, ly[l].ln2, EPS, R, H, ly[l].wgu, H, I, d_act, I, st));
+    UG(ug_decode_sw_kblock(d_act, I, R, ly[l].wdown, I, accD[l & 1], H, H, I, acc_qkv, (int64_t)R * NQKV, l == 0 ? nullptr : accD[(l - 1) & 1], l == 0 ? 0 : (int64_t)R * H, ss_attn, st));
+  };
   struct Case { const char* name; std::function<void()> body; double units; };
   auto time_graph = [&](const char* name, const std::function<void()>& body, double per) {
     CK(hipMemcpyAsync(d_h, d_h0, (size_t)R * H * 4, hipMemcpyDeviceToDevice, st));
@@ -190,6 +204,8 @@ int main(int argc, char** argv) {
     CK(hipMemsetAsync(acc_down, 0, (size_t)R * H * 4, st)); CK(hipMemsetAsync(acc_o, 0, (size_t)R * H * 4, st)); CK(hipMemsetAsync(acc_qkv, 0, (size_t)R * NQKV * 4, st)); CK(hipMemsetAsync(ss_attn, 0, 128, st));
     time_graph("G1 chain (28 layers)", [&] { for (int l = 0; l < L; ++l) g1_layer(l); }, L);
     time_graph("G1 chain (28 layers)", [&] { for (int l = 0; l < L; ++l) g1_layer(l); }, L);
+    time_graph("G2 chain (28 layers)", [&] { for (int l = 0; l < L; ++l) g2_layer(l); }, L);
+    time_graph("G2 chain (28 layers)", [&] { for (int l = 0; l < L; ++l) g2_layer(l); }, L);
     time_graph("new head", [&] { for (int l = 0; l < L; ++l) UG(ug_decode_sw_head(d_h, nullptr, 0, nullptr, d_lnf, EPS, R, H, d_whead, H, V, d_logits, V, nullptr, nullptr, st)); }, L);
     time_graph("old finish+head gemv", [&] { for (int l = 0; l < L; ++l) { UG(ug_decode_finish_resid_norm(acc_down, H, d_h, d_lnf, d_hn, R, H, EPS, nullptr, nullptr, st));
                                                                          UG(ug_decode_gemv(d_hn, H, R, d_whead, H, acc_head, V, V, H, nullptr, 0, nullptr, 0, nullptr, st)); } }, L);
@@ -198,6 +214,7 @@ int main(int argc, char** argv) {
     // one kernel type x 28 layers back to back (independent weights; each launch still waits for its predecessor)
     time_graph("new o x28", [&] { for (int l = 0; l < L; ++l) UG(ug_decode_sw_resid(d_o, HQ * HD, R, ly[l].wo, H, H, HQ * HD, d_h, st)); }, L);
     time_graph("new gate_up x28", [&] { for (int l = 0; l < L; ++l) UG(ug_decode_sw_gate_up(d_h, nullptr, 0, nullptr, ly[l].ln2, EPS, R, H, ly[l].wgu, H, I, d_act, I, st)); }, L);
+    time_graph("down in k-blocks x28", [&] { for (int l = 0; l < L; ++l) UG(ug_decode_sw_kblock(d_act, I, R, ly[l].wdown, I, acc_down, H, H, I, nullptr, 0, nullptr, 0, nullptr, st)); }, L);
     time_graph("old down-as-bf16-gemv x28", [&] { for (int l = 0; l < L; ++l) UG(ug_decode_gemv(d_act, I, R, ly[l].wdown, I, acc_down, H, H, I, nullptr, 0, nullptr, 0, nullptr, st)); }, L);
     time_graph("old qkv x28", [&] { for (int l = 0; l < L; ++l) UG(ug_decode_gemv_resid_norm(d_h, acc_down, H, ly[l].ln1, x_mid, ss_attn, R, ly[l].wqkv, H, acc_qkv, NQKV, NQKV, H, nullptr, 0, nullptr, 0, nullptr, st)); }, L);
     time_graph("old attn x28", [&] { for (int l = 0; l < L; ++l) UG(ug_attn_decode_fused(acc_qkv, NQKV, ss_attn, EPS, H, ly[l].bqkv, d_cs, d_sn, d_pos, ly[l].ck, ly[l].cv, nullptr, d_o, HQ * HD, R, HQ, HK, HD, TMAX, MAXPOS, scale, st)); }, L);
