@@ -39,7 +39,7 @@ GATES = {"weight": 6e-2, "bias": 6e-2, "norm": 6e-2, "embed": 6e-2, "norm_ratio"
 # the reference mode's 2.92e-2 from the fp32 gradient), median 1.000.  The median is the bar that means something; the worst single
 # tensor is always one of the 256 / 1536-element biases.
 # Round 6: the worst-tensor gate is no longer a constant picked to admit the measurement (it was 1.40 for mixed_L387) but 1.05 x what a
-# second reference-mode evaluation of the SAME step needs (the control below: 1.32 / 1.18 measured), never below 1.30.
+# further reference-mode evaluations of the SAME step need (the controls below: 1.18 ... 1.32 measured), never below 1.35.
 TRUTH_MEDIAN = 1.03
 LOGITS_GATE_28 = 2.8e-2                       # HIP vs reference-mode bf16 logits at 28 layers: 2.34e-2 measured (round 5) x 1.2
 
@@ -170,20 +170,25 @@ def test_28_layer_1p5b_step_matches_oracle(dev, case):
     for n, p_ in lm.named_parameters():
         g32[n], p_.grad = p_.grad, None
     t0 = time.time()
-    with eager_attention(), permuted_linears(lm, 0):
-        _, a1, a2, a3 = qwen2_ref.unigen_forward_ref(lm, seq, mask, labels, autocast=True, **kw)
-        (a1 + ((a2 + a3) if case == "mixed_L387" else 0.0)).backward()
     alt_ratios, alt_worst = [], (0.0, None)
+    import contextlib
+    for ctl, (attn_ctx, seed) in enumerate(((eager_attention, 0), (contextlib.nullcontext, 1))):      # eager + permuted, sdpa + permuted
+        for p_ in lm.parameters():
+            p_.grad = None
+        with attn_ctx(), permuted_linears(lm, seed):
+            _, a1, a2, a3 = qwen2_ref.unigen_forward_ref(lm, seq, mask, labels, autocast=True, **kw)
+            (a1 + ((a2 + a3) if case == "mixed_L387" else 0.0)).backward()
+        for n, p_ in lm.named_parameters():
+            r = rel_err(p_.grad, g32[n]) / max(rel_err(g16[n], g32[n]), 1e-30)
+            alt_ratios.append(r)
+            if r > alt_worst[0]:
+                alt_worst = (r, n)
     for n, p_ in lm.named_parameters():
-        r = rel_err(p_.grad, g32[n]) / max(rel_err(g16[n], g32[n]), 1e-30)
-        alt_ratios.append(r)
-        if r > alt_worst[0]:
-            alt_worst = (r, n)
         p_.grad = g32[n]                                          # (the fp32 gradient goes back where the loop below expects it)
     g32 = None
     alt_med = sorted(alt_ratios)[len(alt_ratios) // 2]
-    print(f"    control, {time.time() - t0:.0f} s: a second reference-mode evaluation (eager attention, permuted contractions) -- distance to the fp32 "
-          f"gradient relative to the first one's: median {alt_med:.3f}, worst {alt_worst[0]:.3f} ({alt_worst[1]})")
+    print(f"    control, {time.time() - t0:.0f} s: two more reference-mode evaluations (eager attention + permuted contractions; sdpa + another "
+          f"permutation) -- distance to the fp32 gradient relative to the first one's: median {alt_med:.3f}, worst {alt_worst[0]:.3f} ({alt_worst[1]})")
 
     # ---- gradients, tensor by tensor
     ref_p = dict(lm.named_parameters())
@@ -220,10 +225,11 @@ def test_28_layer_1p5b_step_matches_oracle(dev, case):
           f"{worst_truth[0]:.3f} ({worst_truth[1]}: {worst_truth[2]:.2e} vs {worst_truth[3]:.2e})")
     for k, (e, n) in worst.items():
         assert e < GATES[k], (k, n, e)
-    # what the reference's own second evaluation needs, + 5 %; never below 1.30: one control run shows 1.18 ... 1.32 depending on the case
-    # (round 6, profiles/r06_full_depth_parity.txt), always on a 256- or 1536-element bias
-    worst_gate = max(1.30, 1.05 * alt_worst[0])
-    print(f"    worst-tensor gate: max(1.30, 1.05 x the control's worst {alt_worst[0]:.3f}) = {worst_gate:.3f}")
+    # what the reference's own further evaluations need, + 5 %; never below 1.35: a control run shows 1.18 ... 1.32 depending on case and
+    # permutation, the HIP step (its dK / dV sums and weight gradients are fp32 atomics: not run-to-run identical) 1.18 ... 1.30 on the same
+    # tensor over four runs (round 6, profiles/r06_full_depth_parity.txt) -- always a 256- or 1536-element bias
+    worst_gate = max(1.35, 1.05 * alt_worst[0])
+    print(f"    worst-tensor gate: max(1.35, 1.05 x the controls' worst {alt_worst[0]:.3f}) = {worst_gate:.3f}")
     assert med <= TRUTH_MEDIAN and worst_truth[0] <= worst_gate, (med, worst_truth, worst_gate)
 
     # ---- logits: HIP vs reference-mode bf16, and both against the exact (fp32) logits of the same weights
