@@ -174,3 +174,54 @@ def test_28_layer_maskgit_round_matches_oracle(dev):
           f"reference fp32 vs reference bf16 {agree_ref:.3f}")
     assert int(sure.sum()) >= 24 and torch.equal(got[sure], want[sure])
     assert agree_all >= agree_ref - 0.08, (agree_all, agree_ref)
+
+
+@pytest.mark.skipif(os.environ.get("UNIGEN_SKIP_FULL_DEPTH") == "1", reason="UNIGEN_SKIP_FULL_DEPTH=1")
+def test_28_layer_embeddings_driven_understanding_step_matches_oracle(dev):
+    """The SFT path at depth (VERDICT r5 missing 5; reference training/train_w_clip_vit.py:803-831): `UniGen.forward` driven by
+    `input_embeddings` -- text embeddings with a block of projected image features spliced in -- under the mmu_vit mask, through all 28
+    layers, with the loss's gradient flowing back into the embeddings (what reaches mm_projector and the SigLIP tower).  The small-model
+    tests (tests/test_sft_gpu.py) cover the projector and the tower themselves; this is the part of the chain that had only run at H = 64."""
+    from oracle import host_ref, qwen2_ref
+    model, lm = _build(dev)
+    model.train()
+    B, n_img, npre, L = 1, 256, 5, 387
+    g = torch.Generator().manual_seed(53)
+    pre = torch.randint(0, 151643, (B, npre), generator=g)
+    post = torch.randint(0, 151643, (B, L - npre - n_img), generator=g)
+    feats = (0.02 * torch.randn(B, n_img, 1536, generator=g)).to(torch.bfloat16).float()        # mm_projector's output is bf16 under autocast
+    labels = torch.full((B, L), -100)
+    labels[:, npre + n_img:] = post
+    mask = additive(host_ref.mask_mmu_vit_ref(B, L, prefix_length=npre, num_tokens=n_img))
+    rows = slice(npre + n_img - 1, L - 1)                          # positions whose logits enter the shifted loss
+
+    def oracle(autocast):
+        for p_ in lm.parameters():
+            p_.grad = None
+        with torch.no_grad():
+            e = torch.cat([lm.model.embed_tokens(pre), feats, lm.model.embed_tokens(post)], 1)
+        e.requires_grad_(True)
+        lo, _, _, l3 = qwen2_ref.unigen_forward_ref(lm, None, mask, labels, input_embeddings=e, batch_size_mmu=B, autocast=autocast)
+        l3.backward()
+        return lo[:, rows].detach().float().clone(), l3.detach().float(), e.grad.detach().float().clone()
+
+    t0 = time.time()
+    lo_bf, loss_bf, ge_bf = oracle(True)
+    lo_32, loss_32, ge_32 = oracle(False)
+    print(f"    oracle: two 28-layer forward + backward passes at L = {L} in {time.time() - t0:.0f} s")
+    embed = model.llm.model.embed_tokens
+    with torch.no_grad():
+        e = torch.cat([embed(pre.to(dev)), feats.to(dev), embed(post.to(dev))], 1).float()
+    e.requires_grad_(True)
+    logits, _, _, l3 = model(input_ids=None, input_embeddings=e, attention_mask=mask.to(dev), labels=labels.to(dev), batch_size_mmu=B)
+    model.llm.engine.check_errors()
+    l3.backward()
+    lerr = abs(l3.item() - loss_bf.item()) / abs(loss_bf.item())
+    print(f"    loss_mmu {l3.item():.6f} vs oracle {loss_bf.item():.6f}: rel {lerr:.2e} (gate 1e-3)")
+    assert lerr < 1e-3
+    fp32_yardstick("28 layers, embeddings-driven mmu row", logits[:, rows].float().cpu(), lo_bf, lo_32)
+    ge = e.grad.float().cpu()
+    d_ref, d_hip, d_pair = rel_err(ge_bf, ge_32), rel_err(ge, ge_32), rel_err(ge, ge_bf)
+    print(f"    gradient w.r.t. the input embeddings [{tuple(ge.shape)}]: distance to the fp32 gradient -- reference bf16 mode {d_ref:.3e}, HIP {d_hip:.3e} "
+          f"(ratio {d_hip / d_ref:.3f}, gate 1.05); HIP vs reference bf16 {d_pair:.3e}; image block alone {rel_err(ge[:, npre:npre + n_img], ge_bf[:, npre:npre + n_img]):.3e}")
+    assert d_hip <= 1.05 * d_ref + 1e-5 and d_pair < 6e-2
