@@ -676,16 +676,20 @@ def main():
         second = os.environ.get("UNIGEN_BENCH_SECOND_MODE", "bf16_fp32acc")
         if second and second != sync.reduce and sync.cuda:
             first = sync.reduce
-            sync.set_reduce(second)
-            for _ in range(2):
-                step()
-            barrier()
-            n2 = min(args.steps, 10)
-            dt2, acct2 = timed_block(n2)
-            modes[second] = dict(samples_per_s=round(B * world / (dt2 / n2), 3), ms_per_step=round(dt2 / n2 * 1e3, 2),
-                                 exposed_wait_ms=(acct2["last_step"] or {}).get("exposed_wait_ms"), last_step=acct2["last_step"],
-                                 bytes_on_wire_per_step=acct2["bytes_on_wire_per_step"], collective=acct2["collective"], steps=n2)
-            sync.set_reduce(first)
+            try:                                   # (the block `value` is quoted on is already measured: an error here must not cost the line)
+                sync.set_reduce(second)
+                for _ in range(2):
+                    step()
+                barrier()
+                n2 = min(args.steps, 10)
+                dt2, acct2 = timed_block(n2)
+                modes[second] = dict(samples_per_s=round(B * world / (dt2 / n2), 3), ms_per_step=round(dt2 / n2 * 1e3, 2),
+                                     exposed_wait_ms=(acct2["last_step"] or {}).get("exposed_wait_ms"), last_step=acct2["last_step"],
+                                     bytes_on_wire_per_step=acct2["bytes_on_wire_per_step"], collective=acct2["collective"], steps=n2)
+            except Exception as e:                 # noqa: BLE001 -- reported in the line, not raised
+                modes[second] = {"error": f"{type(e).__name__}: {e}"[:400]}
+            finally:
+                sync.set_reduce(first)
         exchange["modes"] = modes
     ms = dt / args.steps * 1e3
     value = B * world / (dt / args.steps)
