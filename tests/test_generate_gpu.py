@@ -254,3 +254,56 @@ def test_maskgit_accepts_the_compressed_mask_from_ids(dev):
                                        generator=torch.Generator(device=dev).manual_seed(5), image_token_num_per_image=n,
                                        text_vocab_size=ids["text_vocab"]).cpu())
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("R", [16, 5, 24])
+def test_decode_step_forms_agree_at_1p5b_width(dev, monkeypatch, R):
+    """`Qwen2Engine.decode_step` at the 1.5B model's width (two layers): the shipped layer (round 6: split-K q/k/v + attention, single-writer
+    o / gate-up, down in k-blocks; rows <= 16), the five-launch split-K layer (UNIGEN_DECODE_SW=0, and what 17-32 rows take) and the
+    separate-kernel path (`decode_fused = False`) must give the same final-norm hidden state up to bf16 rounding, append the same k / v
+    and advance the position; `decode_step_logits` (final norm + head slice in one launch) must match the head applied to that state."""
+    from models import UniGen
+    from oracle import qwen2_ref, weights
+    from unigen_hip import ops
+    from unigen_hip.qwen2 import DecodeState
+    from helpers import llm_config_dir, rel_err
+    cfg = dict(qwen2_ref.QWEN25_1P5B, num_hidden_layers=2, vocab_size=4096)
+    model = UniGen(w_und_encoder=False, vocab_size=4096, llm_vocab_size=2048, llm_model_path=llm_config_dir(cfg), codebook_size=2047,
+                   num_vq_tokens=16, load_from_pretrained=True, device=dev, init_seed=-1).eval()
+    names = [(n, tuple(p.shape)) for n, p in model.llm.named_parameters()]
+    model.llm.load_state_dict(weights.synth_llm_state(names, seed=17), strict=False)
+    eng = model.llm.engine
+    g = torch.Generator().manual_seed(R)
+    P, steps = 37, 3
+    prompt = (0.02 * torch.randn(R, P, 1536, generator=g)).to(dev)
+    xs = [(0.02 * torch.randn(R, 1536, generator=g)).to(dev) for _ in range(steps)]
+
+    def run(fused, sw):
+        monkeypatch.setenv("UNIGEN_DECODE_SW", "1" if sw else "0")
+        eng.decode_fused = fused
+        st = DecodeState(eng.dims, R, P + steps, dev)
+        eng.prefill(st, prompt)
+        assert eng.decode_sw(st) == (fused and sw and R <= 16)
+        hs = [eng.decode_step(st, x.clone()).float().cpu() for x in xs]
+        assert int(st.pos.item()) == P + steps and int(st.len.item()) == P + steps + 1
+        return hs, [k.float().cpu() for k in st.k], [v.float().cpu() for v in st.v]
+    with torch.no_grad():
+        wide = run(False, False)
+        for fused, sw in ((True, False), (True, True)):
+            got = run(fused, sw)
+            for i in range(steps):
+                e = rel_err(got[0][i], wide[0][i])
+                assert e < 1.5e-2, (fused, sw, i, e)
+            for a, b in zip(got[1] + got[2], wide[1] + wide[2]):
+                assert rel_err(a[:, :, P:], b[:, :, P:]) < 1.5e-2
+        if R <= 16:                                     # the head slice in the layer's last launch
+            monkeypatch.setenv("UNIGEN_DECODE_SW", "1")
+            eng.decode_fused = True
+            st = DecodeState(eng.dims, R, P + steps, dev)
+            eng.prefill(st, prompt)
+            w_head = eng.fp.w("embed")[2048:4095]
+            logits = torch.zeros(R, 2047, device=dev)
+            eng.decode_step_logits(st, xs[0].clone(), w_head, logits)
+            ref = wide[0][0].to(torch.bfloat16).float() @ w_head.float().cpu().t()
+            assert rel_err(logits, ref) < 1.5e-2 and int(st.pos.item()) == P + 1
+    eng.decode_fused = True
