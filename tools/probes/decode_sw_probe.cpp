@@ -13,6 +13,7 @@
 #include <string.h>
 #include <string>
 #include <vector>
+#include <algorithm>
 #include <functional>
 #include "unigen_hip.h"
 #include <algorithm>
@@ -142,6 +143,35 @@ int main(int argc, char** argv) {
       size_t da = 0, dx = 0; for (size_t i = 0; i < a1v.size(); ++i) da += a1v[i] != a2v[i]; for (size_t i = 0; i < xo.size(); ++i) dx += memcmp(&xo[i], &hs[i], 4) != 0;
       printf("check pend  act values differing %zu of %zu, x_out values differing %zu of %zu\n", da, a1v.size(), dx, xo.size());
     }
+#ifdef UG_HAVE_OGU   // needs the library built with tools/probes/decode_ogu_r6.patch applied (measured and rejected: profiles/r06_decode_forms.md)
+    // fused o + gate/up launch against the two separate launches, bit for bit, over many repetitions (any stale read of the in-launch
+    // gather would show as a differing value)
+    {
+      uint32_t* d_flags = dalloc<uint32_t>(256); uint32_t* d_err = dalloc<uint32_t>(16 + 256 * 32);
+      float *d_ha = dalloc<float>((size_t)R * H), *d_hb = dalloc<float>((size_t)R * H);
+      bf16_t *d_acta = dalloc<bf16_t>((size_t)R * I), *d_actb = dalloc<bf16_t>((size_t)R * I);
+      printf("fused o+gate/up supported: %d\n", ug_decode_sw_o_gate_up_supported(H, I, HQ * HD));
+      size_t bad_h = 0, bad_a = 0; const int NREP = 200;
+      std::vector<float> ha((size_t)R * H), hb((size_t)R * H); std::vector<bf16_t> aa((size_t)R * I), ab((size_t)R * I);
+      for (int rep = 0; rep < NREP; ++rep) {
+        const int l = rep % L;
+        std::vector<bf16_t> go2 = rand_bf16((size_t)R * HQ * HD, 1.f);
+        CK(hipMemcpyAsync(d_o, go2.data(), go2.size() * 2, hipMemcpyHostToDevice, st));
+        CK(hipMemcpyAsync(d_ha, d_h0, (size_t)R * H * 4, hipMemcpyDeviceToDevice, st)); CK(hipMemcpyAsync(d_hb, d_h0, (size_t)R * H * 4, hipMemcpyDeviceToDevice, st));
+        if (rep % 28 == 0) CK(hipMemsetAsync(d_flags, 0, 1024, st));
+        UG(ug_decode_sw_resid(d_o, HQ * HD, R, ly[l].wo, H, H, HQ * HD, d_ha, st));
+        UG(ug_decode_sw_gate_up(d_ha, nullptr, 0, nullptr, ly[l].ln2, EPS, R, H, ly[l].wgu, H, I, d_acta, I, st));
+        UG(ug_decode_sw_o_gate_up(d_o, HQ * HD, ly[l].wo, H, d_hb, ly[l].ln2, EPS, R, H, ly[l].wgu, H, I, d_actb, I, d_flags, (uint32_t)(rep % 28) + 1, d_err, st));
+        CK(hipStreamSynchronize(st));
+        CK(hipMemcpy(ha.data(), d_ha, ha.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hb.data(), d_hb, hb.size() * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(aa.data(), d_acta, aa.size() * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(ab.data(), d_actb, ab.size() * 2, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < ha.size(); ++i) bad_h += memcmp(&ha[i], &hb[i], 4) != 0;
+        for (size_t i = 0; i < aa.size(); ++i) bad_a += aa[i] != ab[i];
+      }
+      uint32_t err = 0; CK(hipMemcpy(&err, d_err, 4, hipMemcpyDeviceToHost));
+      printf("check fused o+gate/up vs separate over %d runs: h values differing %zu, act values differing %zu, err word %u\n", NREP, bad_h, bad_a, err);
+    }
+#endif
     fflush(stdout);
   }
 
@@ -175,6 +205,29 @@ int main(int argc, char** argv) {
     UG(ug_decode_sw_gate_up(xout, nullptr, 0, nullptr, ly[l].ln2, EPS, R, H, ly[l].wgu, H, I, d_act, I, st));
     UG(ug_decode_sw_kblock(d_act, I, R, ly[l].wdown, I, accD[l & 1], H, H, I, acc_qkv, (int64_t)R * NQKV, l == 0 ? nullptr : accD[(l - 1) & 1], l == 0 ? 0 : (int64_t)R * H, ss_attn, st));
   };
+#ifdef UG_HAVE_OGU
+  uint32_t* g_flags = dalloc<uint32_t>(256); uint32_t* g_err = dalloc<uint32_t>(16 + 256 * 32);      // (+ the trace of a -DUG_OGU_TRACE build)
+  auto dump_trace = [&](const char* what) {
+    std::vector<unsigned long long> tr(256 * 16); CK(hipMemcpy(tr.data(), g_err + 16, tr.size() * 8, hipMemcpyDeviceToHost));
+    if (!tr[0]) return;
+    unsigned long long t0 = ~0ull; for (int b = 0; b < 256; ++b) { t0 = std::min(t0, tr[b * 16 + 0]); t0 = std::min(t0, tr[b * 16 + 4]); }
+    const char* names[11] = {"svc start", "svc partials parked (#1)", "svc stores drained", "svc poll done", "wrk start", "wrk o tile landed", "wrk after #1", "wrk released (#2)", "wrk stream gathered", "wrk MFMA loop done", "wrk after #4"};
+    printf("timeline of the last fused launch (%s), us from the first workgroup's start: min / median / max over 256 workgroups\n", what);
+    for (int k = 0; k < 11; ++k) { std::vector<double> v; for (int b = 0; b < 256; ++b) v.push_back((double)(tr[b * 16 + k] - t0) * 0.01); std::sort(v.begin(), v.end());
+      printf("  %-28s %6.2f %6.2f %6.2f\n", names[k], v[0], v[128], v[255]); }
+    { std::vector<double> v, n; for (int b = 0; b < 256; ++b) { v.push_back((double)(tr[b * 16 + 12] - t0) * 0.01); n.push_back((double)tr[b * 16 + 13]); } std::sort(v.begin(), v.end()); std::sort(n.begin(), n.end());
+      printf("  %-28s %6.2f %6.2f %6.2f   passes %g %g %g\n", "svc first poll back", v[0], v[128], v[255], n[0], n[128], n[255]); }
+  };
+  auto g3_layer = [&](int l) {                        // G2 with the o projection and gate/up in one launch
+    float* xin = xbuf[l & 1]; float* xout = xbuf[(l + 1) & 1];
+    const float* pend = l == 0 ? zeros : accD[(l - 1) & 1];
+    if (l == 0) CK(hipMemsetAsync(g_flags, 0, 1024, st));
+    UG(ug_decode_gemv_resid_norm(xin, pend, H, ly[l].ln1, xout, ss_attn, R, ly[l].wqkv, H, acc_qkv, NQKV, NQKV, H, nullptr, 0, nullptr, 0, nullptr, st));
+    UG(ug_attn_decode_fused(acc_qkv, NQKV, ss_attn, EPS, H, ly[l].bqkv, d_cs, d_sn, d_pos, ly[l].ck, ly[l].cv, nullptr, d_o, HQ * HD, R, HQ, HK, HD, TMAX, MAXPOS, scale, st));
+    UG(ug_decode_sw_o_gate_up(d_o, HQ * HD, ly[l].wo, H, xout, ly[l].ln2, EPS, R, H, ly[l].wgu, H, I, d_act, I, g_flags, (uint32_t)l + 1, g_err, st));
+    UG(ug_decode_sw_kblock(d_act, I, R, ly[l].wdown, I, accD[l & 1], H, H, I, acc_qkv, (int64_t)R * NQKV, l == 0 ? nullptr : accD[(l - 1) & 1], l == 0 ? 0 : (int64_t)R * H, ss_attn, st));
+  };
+#endif
   struct Case { const char* name; std::function<void()> body; double units; };
   auto time_graph = [&](const char* name, const std::function<void()>& body, double per) {
     CK(hipMemcpyAsync(d_h, d_h0, (size_t)R * H * 4, hipMemcpyDeviceToDevice, st));
@@ -206,6 +259,12 @@ int main(int argc, char** argv) {
     time_graph("G1 chain (28 layers)", [&] { for (int l = 0; l < L; ++l) g1_layer(l); }, L);
     time_graph("G2 chain (28 layers)", [&] { for (int l = 0; l < L; ++l) g2_layer(l); }, L);
     time_graph("G2 chain (28 layers)", [&] { for (int l = 0; l < L; ++l) g2_layer(l); }, L);
+#ifdef UG_HAVE_OGU
+    time_graph("G3 chain (28 layers)", [&] { for (int l = 0; l < L; ++l) g3_layer(l); }, L);
+    time_graph("G3 chain (28 layers)", [&] { for (int l = 0; l < L; ++l) g3_layer(l); }, L);
+    { uint32_t err = 0; CK(hipMemcpy(&err, g_err, 4, hipMemcpyDeviceToHost)); printf("G3 err word %u\n", err); }
+    dump_trace("G3 chain");
+#endif
     time_graph("new head", [&] { for (int l = 0; l < L; ++l) UG(ug_decode_sw_head(d_h, nullptr, 0, nullptr, d_lnf, EPS, R, H, d_whead, H, V, d_logits, V, nullptr, nullptr, st)); }, L);
     time_graph("old finish+head gemv", [&] { for (int l = 0; l < L; ++l) { UG(ug_decode_finish_resid_norm(acc_down, H, d_h, d_lnf, d_hn, R, H, EPS, nullptr, nullptr, st));
                                                                          UG(ug_decode_gemv(d_hn, H, R, d_whead, H, acc_head, V, V, H, nullptr, 0, nullptr, 0, nullptr, st)); } }, L);
@@ -214,6 +273,11 @@ int main(int argc, char** argv) {
     // one kernel type x 28 layers back to back (independent weights; each launch still waits for its predecessor)
     time_graph("new o x28", [&] { for (int l = 0; l < L; ++l) UG(ug_decode_sw_resid(d_o, HQ * HD, R, ly[l].wo, H, H, HQ * HD, d_h, st)); }, L);
     time_graph("new gate_up x28", [&] { for (int l = 0; l < L; ++l) UG(ug_decode_sw_gate_up(d_h, nullptr, 0, nullptr, ly[l].ln2, EPS, R, H, ly[l].wgu, H, I, d_act, I, st)); }, L);
+#ifdef UG_HAVE_OGU
+    time_graph("fused o+gate_up x28", [&] { CK(hipMemsetAsync(g_flags, 0, 1024, st)); for (int l = 0; l < L; ++l) UG(ug_decode_sw_o_gate_up(d_o, HQ * HD, ly[l].wo, H, d_h, ly[l].ln2, EPS, R, H, ly[l].wgu, H, I, d_act, I, g_flags, (uint32_t)l + 1, g_err, st)); }, L);
+    dump_trace("fused x28");
+#endif
+    time_graph("o then gate_up x28", [&] { for (int l = 0; l < L; ++l) { UG(ug_decode_sw_resid(d_o, HQ * HD, R, ly[l].wo, H, H, HQ * HD, d_h, st)); UG(ug_decode_sw_gate_up(d_h, nullptr, 0, nullptr, ly[l].ln2, EPS, R, H, ly[l].wgu, H, I, d_act, I, st)); } }, L);
     time_graph("down in k-blocks x28", [&] { for (int l = 0; l < L; ++l) UG(ug_decode_sw_kblock(d_act, I, R, ly[l].wdown, I, acc_down, H, H, I, nullptr, 0, nullptr, 0, nullptr, st)); }, L);
     time_graph("old down-as-bf16-gemv x28", [&] { for (int l = 0; l < L; ++l) UG(ug_decode_gemv(d_act, I, R, ly[l].wdown, I, acc_down, H, H, I, nullptr, 0, nullptr, 0, nullptr, st)); }, L);
     time_graph("old qkv x28", [&] { for (int l = 0; l < L; ++l) UG(ug_decode_gemv_resid_norm(d_h, acc_down, H, ly[l].ln1, x_mid, ss_attn, R, ly[l].wqkv, H, acc_qkv, NQKV, NQKV, H, nullptr, 0, nullptr, 0, nullptr, st)); }, L);
