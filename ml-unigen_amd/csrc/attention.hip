@@ -476,18 +476,36 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_fwd32_kernel(AttnArgs p) {
     return rest ? t + __builtin_ctzll(rest) : p.nW;
   };
   // LDS-DMA of one K / V tile pair: 16 one-KiB instructions per operand, 16 / NW per wave
+  // byte offset of this lane's 16 bytes inside a 64-key tile for each of its DMA instructions: computed ONCE -- recomputed per tile
+  // (clamp, 64-bit row x stride product, swizzle) it was 43 VALU + ~40 SALU instructions = a sixth of the loop's issue slots
+  uint32_t toff[16 / NW];
+#pragma unroll
+  for (int i = 0; i < 16 / NW; ++i) {
+    const int row = (i * NW + wave) * 4 + (lane >> 4);
+    toff[i] = (uint32_t)(row * p.ldq + (((lane & 15) ^ swz16(row)) << 3)) * 2u;
+  }
   auto stage = [&](int t, int slot) {
     char* base = ring + slot * 2 * T32_BYTES;
+    const int64_t tb = (int64_t)t * 64 * p.ldq * 2;
+    const uint64_t kb = (uint64_t)kseq + tb, vb = (uint64_t)vseq + tb;
+    // hand-issued (vmem_asm.h): behind the builtin hipcc put s_waitcnt vmcnt(0) in front of the tile reads below -- the tile
+    // requested a moment ago had to LAND before the first MFMA of the current one, i.e. the ring prefetched nothing (round 6)
+    if (t * 64 + 64 <= p.L) {
 #pragma unroll
-    for (int i = 0; i < 16 / NW; ++i) {
-      const int inst = i * NW + wave;
-      const int row = inst * 4 + (lane >> 4);
-      const int chunk = (lane & 15) ^ swz16(row);
-      const int64_t goff = (int64_t)min(t * 64 + row, p.L - 1) * p.ldq + chunk * 8;
-      // hand-issued (vmem_asm.h): behind the builtin hipcc put s_waitcnt vmcnt(0) in front of the tile reads below -- the tile
-      // requested a moment ago had to LAND before the first MFMA of the current one, i.e. the ring prefetched nothing (round 6)
-      dma16(kseq + goff, __builtin_amdgcn_readfirstlane(lds_addr_of(base + inst * 1024)));
-      dma16(vseq + goff, __builtin_amdgcn_readfirstlane(lds_addr_of(base + T32_BYTES + inst * 1024)));
+      for (int i = 0; i < 16 / NW; ++i) {
+        const int inst = i * NW + wave;
+        dma16(kb, toff[i], __builtin_amdgcn_readfirstlane(lds_addr_of(base + inst * 1024)));
+        dma16(vb, toff[i], __builtin_amdgcn_readfirstlane(lds_addr_of(base + T32_BYTES + inst * 1024)));
+      }
+    } else {                                             // the sequence's last, partial tile: rows past L repeat row L - 1
+#pragma unroll
+      for (int i = 0; i < 16 / NW; ++i) {
+        const int inst = i * NW + wave;
+        const int row = inst * 4 + (lane >> 4);
+        const uint32_t off = (uint32_t)((min(t * 64 + row, p.L - 1) - t * 64) * p.ldq + (((lane & 15) ^ swz16(row)) << 3)) * 2u;
+        dma16(kb, off, __builtin_amdgcn_readfirstlane(lds_addr_of(base + inst * 1024)));
+        dma16(vb, off, __builtin_amdgcn_readfirstlane(lds_addr_of(base + T32_BYTES + inst * 1024)));
+      }
     }
   };
   // per-lane fragment offsets inside a tile
@@ -767,18 +785,36 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_dq32_kernel(AttnArgs p) {
     const uint64_t rest = t < 64 ? vis >> t : 0ull;
     return rest ? t + __builtin_ctzll(rest) : p.nW;
   };
+  // byte offset of this lane's 16 bytes inside a 64-key tile for each of its DMA instructions: computed ONCE -- recomputed per tile
+  // (clamp, 64-bit row x stride product, swizzle) it was 43 VALU + ~40 SALU instructions = a sixth of the loop's issue slots
+  uint32_t toff[16 / NW];
+#pragma unroll
+  for (int i = 0; i < 16 / NW; ++i) {
+    const int row = (i * NW + wave) * 4 + (lane >> 4);
+    toff[i] = (uint32_t)(row * p.ldq + (((lane & 15) ^ swz16(row)) << 3)) * 2u;
+  }
   auto stage = [&](int t, int slot) {
     char* base = ring + slot * 2 * T32_BYTES;
+    const int64_t tb = (int64_t)t * 64 * p.ldq * 2;
+    const uint64_t kb = (uint64_t)kseq + tb, vb = (uint64_t)vseq + tb;
+    // hand-issued (vmem_asm.h): behind the builtin hipcc put s_waitcnt vmcnt(0) in front of the tile reads below -- the tile
+    // requested a moment ago had to LAND before the first MFMA of the current one, i.e. the ring prefetched nothing (round 6)
+    if (t * 64 + 64 <= p.L) {
 #pragma unroll
-    for (int i = 0; i < 16 / NW; ++i) {
-      const int inst = i * NW + wave;
-      const int row = inst * 4 + (lane >> 4);
-      const int chunk = (lane & 15) ^ swz16(row);
-      const int64_t goff = (int64_t)min(t * 64 + row, p.L - 1) * p.ldq + chunk * 8;
-      // hand-issued (vmem_asm.h): behind the builtin hipcc put s_waitcnt vmcnt(0) in front of the tile reads below -- the tile
-      // requested a moment ago had to LAND before the first MFMA of the current one, i.e. the ring prefetched nothing (round 6)
-      dma16(kseq + goff, __builtin_amdgcn_readfirstlane(lds_addr_of(base + inst * 1024)));
-      dma16(vseq + goff, __builtin_amdgcn_readfirstlane(lds_addr_of(base + T32_BYTES + inst * 1024)));
+      for (int i = 0; i < 16 / NW; ++i) {
+        const int inst = i * NW + wave;
+        dma16(kb, toff[i], __builtin_amdgcn_readfirstlane(lds_addr_of(base + inst * 1024)));
+        dma16(vb, toff[i], __builtin_amdgcn_readfirstlane(lds_addr_of(base + T32_BYTES + inst * 1024)));
+      }
+    } else {                                             // the sequence's last, partial tile: rows past L repeat row L - 1
+#pragma unroll
+      for (int i = 0; i < 16 / NW; ++i) {
+        const int inst = i * NW + wave;
+        const int row = inst * 4 + (lane >> 4);
+        const uint32_t off = (uint32_t)((min(t * 64 + row, p.L - 1) - t * 64) * p.ldq + (((lane & 15) ^ swz16(row)) << 3)) * 2u;
+        dma16(kb, off, __builtin_amdgcn_readfirstlane(lds_addr_of(base + inst * 1024)));
+        dma16(vb, off, __builtin_amdgcn_readfirstlane(lds_addr_of(base + T32_BYTES + inst * 1024)));
+      }
     }
   };
   int koff[8], voff[4][2];
@@ -1109,16 +1145,35 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_dma_kernel(AttnArgs p) {
     const uint64_t rest = q < 64 ? vis >> q : 0ull;
     return rest ? q + __builtin_ctzll(rest) : p.nW;
   };
+  // lane offsets inside a query tile (Q rows and dO rows have their own strides), computed once (see attn_fwd32_kernel)
+  uint32_t qoff[4], dooff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (i * 4 + wave) * 4 + (lane >> 4);
+    const int c8 = ((lane & 15) ^ swz16b(row)) << 3;
+    qoff[i] = (uint32_t)(row * p.ldq + c8) * 2u;
+    dooff[i] = (uint32_t)(row * p.ldo + c8) * 2u;
+  }
   auto stage = [&](int qt, int slot) {
     char* base = ring + slot * 2 * T32_BYTES;
+    const uint64_t qb = (uint64_t)qseq + (int64_t)qt * 64 * p.ldq * 2, dob = (uint64_t)doseq + (int64_t)qt * 64 * p.ldo * 2;
+    if (qt * 64 + 64 <= p.L) {                           // (hand-issued: see attn_fwd32_kernel)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int inst = i * 4 + wave;
-      const int row = inst * 4 + (lane >> 4);
-      const int chunk = (lane & 15) ^ swz16b(row);
-      const int gr = min(qt * 64 + row, p.L - 1);                           // rows past L repeat the last row: their mask words are 0
-      dma16(qseq + (int64_t)gr * p.ldq + chunk * 8, __builtin_amdgcn_readfirstlane(lds_addr_of(base + inst * 1024)));      // (hand-issued: see
-      dma16(doseq + (int64_t)gr * p.ldo + chunk * 8, __builtin_amdgcn_readfirstlane(lds_addr_of(base + T32_BYTES + inst * 1024)));   //  attn_fwd32_kernel)
+      for (int i = 0; i < 4; ++i) {
+        const int inst = i * 4 + wave;
+        dma16(qb, qoff[i], __builtin_amdgcn_readfirstlane(lds_addr_of(base + inst * 1024)));
+        dma16(dob, dooff[i], __builtin_amdgcn_readfirstlane(lds_addr_of(base + T32_BYTES + inst * 1024)));
+      }
+    } else {                                             // rows past L repeat the last row: their mask words are 0
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int inst = i * 4 + wave;
+        const int row = inst * 4 + (lane >> 4);
+        const int c8 = ((lane & 15) ^ swz16b(row)) << 3;
+        const int rr = min(qt * 64 + row, p.L - 1) - qt * 64;
+        dma16(qb, (uint32_t)(rr * p.ldq + c8) * 2u, __builtin_amdgcn_readfirstlane(lds_addr_of(base + inst * 1024)));
+        dma16(dob, (uint32_t)(rr * p.ldo + c8) * 2u, __builtin_amdgcn_readfirstlane(lds_addr_of(base + T32_BYTES + inst * 1024)));
+      }
     }
   };
   // row record of a query tile (wave 0, one lane per row): requested a tile ahead, parked in LDS before the tile's barrier
