@@ -668,7 +668,8 @@ def _ref_masks(B, L, kind, gen):
 
 
 @pytest.mark.parametrize("kind", ["causal", "t2i", "mmu", "random"])
-@pytest.mark.parametrize("B,L,H,HKV", [(2, 70, 2, 1), (1, 200, 12, 2), (2, 129, 6, 2), (8, 333, 24, 4), (6, 400, 24, 4)])
+@pytest.mark.parametrize("B,L,H,HKV", [(2, 70, 2, 1), (1, 200, 12, 2), (2, 129, 6, 2), (8, 333, 24, 4), (6, 400, 24, 4),
+                                     (2, 128, 6, 2), (1, 256, 12, 2)])      # (whole 64-key tiles only: no clamped last tile)
 def test_attention_fwd_bwd(dev, kind, B, L, H, HKV):
     """The last two shapes have >= 512 128-row query tiles, i.e. they run the eight-wave forward kernel (ragged last
     tile at 333; at 400 the last 128-row tile has no second half)."""
