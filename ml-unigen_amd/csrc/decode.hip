@@ -195,6 +195,11 @@ __global__ __launch_bounds__(64 * ADF_WAVES) void attn_decode_fused_kernel(
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int per = gridDim.y, hq = blockIdx.y;
   const int grp = blockIdx.x + 8 * blockIdx.z;            // (row, kv head) group
+  // every argument in one batch of scalar loads (vmem_asm.h): the early exit, the power-of-two test and the position load below were
+  // three dependent round trips to the kernarg segment ahead of the first vector load
+  asm volatile("" ::"s"(acc_qkv), "s"(lda), "s"(ss), "s"(__float_as_int(eps)), "s"(norm_cols), "s"(bias), "s"(cs), "s"(sn), "s"(pos_dev), "s"(ck),
+               "s"(cv), "s"(key_valid), "s"(o), "s"(ldo), "s"(R), "s"(H), "s"(HKV), "s"(Tmax), "s"(max_pos), "s"(__float_as_int(scale)),
+               "s"(gridDim.y));
   if (grp >= R * HKV) return;
   int r, hk;
   if ((HKV & (HKV - 1)) == 0) { r = grp >> (31 - __builtin_clz(HKV)); hk = grp & (HKV - 1); }
@@ -589,6 +594,19 @@ __device__ __forceinline__ void decode_clear(const DecodeIn& f, int tid, int bid
   if (f.ss_zero && bid == 0 && tid < 32) f.ss_zero[tid] = 0.f;
 }
 
+// the arguments of the multi-wave ring GEMV, live in SGPRs by ONE asm statement (vmem_asm.h, UG_HOIST; gridDim: implicit arguments)
+#define UG_HOIST_RING4_ARGS()                                                                                                          \
+  do {                                                                                                                                 \
+    if constexpr (XIN == XIN_RESID_NORM)                                                                                               \
+      asm volatile("" ::"s"(R), "s"(W), "s"(ldw), "s"(acc), "s"(sr), "s"(sn), "s"(N), "s"(K), "s"(nslabs), "s"(gridDim.x), "s"(gridDim.y), "s"(blockDim.x), \
+                   "s"(f.zero0), "s"(f.zero1), "s"(f.ss_zero), "s"(f.n0_4), "s"(f.per0), "s"(f.n1_4), "s"(f.per1), "s"(f.x_in), "s"(f.pend), \
+                   "s"(f.ld_pend), "s"(f.norm_w), "s"(f.x_out), "s"(f.ss_out));                                                        \
+    else                                                                                                                               \
+      asm volatile("" ::"s"(R), "s"(W), "s"(ldw), "s"(acc), "s"(sr), "s"(sn), "s"(N), "s"(K), "s"(nslabs), "s"(gridDim.x), "s"(gridDim.y), "s"(blockDim.x), \
+                   "s"(f.zero0), "s"(f.zero1), "s"(f.ss_zero), "s"(f.n0_4), "s"(f.per0), "s"(f.n1_4), "s"(f.per1), "s"(f.gu), "s"(f.ld_gu),   \
+                   "s"(f.ss_in), "s"(__float_as_int(f.eps)), "s"(f.norm_cols));                                                        \
+  } while (0)
+
 // linear workgroup id (x fastest: the order the dispatcher deals workgroups out to the XCDs in)
 __device__ __forceinline__ int linear_block() { return (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x; }
 
@@ -750,6 +768,7 @@ __global__ __launch_bounds__(64 * NW) void gemv_ring4_kernel(int R, const bf16_t
   constexpr int UPW = (8 + NW - 1) / NW;           // k-steps of the operand each wave converts
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, row = lane & 15;
   const int slab = blockIdx.x + 8 * blockIdx.z, chunk = blockIdx.y;
+  UG_HOIST_RING4_ARGS();                           // every argument in one batch of scalar loads (vmem_asm.h)
   // the clears this launch carries go out first (see gemv_ring_kernel)
   decode_clear(f, threadIdx.x, linear_block());
   if (slab >= nslabs) return;

@@ -62,6 +62,28 @@ struct RowMap {
   }
 };
 
+// Every kernel argument an instantiation reads, made live in SGPRs by ONE asm statement at the top of the kernel (vmem_asm.h, UG_HOIST:
+// several statements would each end a scheduling region and bring the dependent round trips back).
+#define UG_SW_COMMON_ARGS "s"(a.W), "s"(a.ldw), "s"(a.K), "s"(a.R), "s"(a.nunits), "s"(a.upw)
+template <int PRO, int EPI, bool PEND>
+__device__ __forceinline__ void hoist_sw_args(const SwArgs& a) {
+  if constexpr (PRO == PRO_NORM && EPI == EPI_SWIGLU && PEND)
+    asm volatile("" ::UG_SW_COMMON_ARGS, "s"(a.h), "s"(a.norm_w), "s"(__float_as_int(a.eps)), "s"(a.pend), "s"(a.ld_pend), "s"(a.x_out), "s"(a.act),
+                 "s"(a.ld_act), "s"(a.I));
+  else if constexpr (PRO == PRO_NORM && EPI == EPI_SWIGLU)
+    asm volatile("" ::UG_SW_COMMON_ARGS, "s"(a.h), "s"(a.norm_w), "s"(__float_as_int(a.eps)), "s"(a.act), "s"(a.ld_act), "s"(a.I));
+  else if constexpr (PRO == PRO_NORM && EPI == EPI_STORE && PEND)
+    asm volatile("" ::UG_SW_COMMON_ARGS, "s"(a.h), "s"(a.norm_w), "s"(__float_as_int(a.eps)), "s"(a.pend), "s"(a.ld_pend), "s"(a.x_out), "s"(a.out),
+                 "s"(a.ld_out), "s"(a.pos_inc), "s"(a.len_inc));
+  else if constexpr (PRO == PRO_NORM && EPI == EPI_STORE)
+    asm volatile("" ::UG_SW_COMMON_ARGS, "s"(a.h), "s"(a.norm_w), "s"(__float_as_int(a.eps)), "s"(a.out), "s"(a.ld_out), "s"(a.pos_inc), "s"(a.len_inc));
+  else if constexpr (PRO == PRO_BF16 && EPI == EPI_RESID)
+    asm volatile("" ::UG_SW_COMMON_ARGS, "s"(a.xb), "s"(a.ldx), "s"(a.h_io));
+  else if constexpr (PRO == PRO_BF16 && EPI == EPI_ATOMIC)
+    asm volatile("" ::UG_SW_COMMON_ARGS, "s"(a.xb), "s"(a.ldx), "s"(a.out), "s"(a.ld_out), "s"(a.zero0), "s"(a.zero1), "s"(a.ss_zero), "s"(a.n0_4),
+                 "s"(a.per0), "s"(a.n1_4), "s"(a.per1), "s"(gridDim.x));                 // (gridDim: an implicit argument)
+}
+
 // NW waves per workgroup, wave w owns k-slab w (K == 256 NW) and walks MAXT tiles of 16 weight rows through a RING-slot LDS ring of
 // MAXI KiB slots.  The whole ring is requested before the operand prologue (staging only part of it first measured no faster).
 // KBLK (split-K in k-blocks of NW slabs, grid.y = k-block): the partial tile of a workgroup joins the accumulator by ONE atomic per
@@ -76,6 +98,7 @@ __global__ __launch_bounds__(64 * NW) void gemv_sw_kernel(SwArgs a) {
   __shared__ __attribute__((aligned(16))) float wn[PRO == PRO_NORM ? NW : 1][256];
   __shared__ float ssp[PRO == PRO_NORM ? NW : 1][16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, slot = lane & 15;
+  hoist_sw_args<PRO, EPI, PEND>(a);                  // every argument this instantiation reads in ONE batch of scalar loads
   if constexpr (EPI == EPI_ATOMIC) {
     // the clears this launch carries go out first (stores behind the loads would sit between them in the memory queue)
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);

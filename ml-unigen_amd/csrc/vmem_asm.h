@@ -51,3 +51,10 @@ __device__ __forceinline__ void ld2u(T& v, const void* p) { asm volatile("global
 template <typename T>
 __device__ __forceinline__ void tie(T& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ uint32_t lds_addr_of(const void* p) { return (uint32_t)(uintptr_t)p; }      // low half of a generic LDS pointer
+// Kernel arguments are fetched by scalar loads where the compiler first needs them; behind an early exit or a data-dependent branch that
+// is a second, third ... DEPENDENT round trip to the kernarg segment before the kernel's first vector load (a decode launch lives
+// ~4 us; ISA scan: tools/probes/prologue_scan.py).  UG_HOIST(x) at the top of a kernel makes x a live SGPR THERE, so that every
+// argument comes in one batch of s_load behind one wait.
+#define UG_HOIST(x) asm volatile("" ::"s"(x))
+#define UG_HOISTF(x) asm volatile("" ::"s"(__float_as_int(x)))
+
