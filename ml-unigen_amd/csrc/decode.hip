@@ -169,11 +169,13 @@ constexpr int ADF_WAVES = 8;            // one 64-key chunk per wave up to 512 k
 // q and its kv head's new k / v row itself (no dependency between workgroups; the first query head of each kv head
 // also appends the row to the cache), attends to cache keys [0, pos) exactly like attn_decode_kernel, and merges
 // the new token as one more (m, l, O) partial.
+// (Argument order: the first 14 dwords are what the kernel's first loads need -- with -mllvm -amdgpu-kernarg-preload-count=16 hipcc preloads
+// that many, they arrive in SGPRs with the wave; the rest comes by one batch of scalar loads.)
 __global__ __launch_bounds__(64 * ADF_WAVES) void attn_decode_fused_kernel(
-    const float* __restrict__ acc_qkv, int64_t lda, const float* __restrict__ ss, float eps, int norm_cols,
-    const bf16_t* __restrict__ bias, const float* __restrict__ cs, const float* __restrict__ sn, const int* __restrict__ pos_dev,
-    bf16_t* __restrict__ ck, bf16_t* __restrict__ cv, const uint8_t* __restrict__ key_valid, bf16_t* __restrict__ o, int64_t ldo,
-    int R, int H, int HKV, int Tmax, int max_pos, float scale) {
+    const float* __restrict__ acc_qkv, const float* __restrict__ ss, const int* __restrict__ pos_dev, bf16_t* __restrict__ ck,
+    bf16_t* __restrict__ cv, int R, int HKV, int H, int lda, int Tmax, int max_pos,
+    const bf16_t* __restrict__ bias, const float* __restrict__ cs, const float* __restrict__ sn, const uint8_t* __restrict__ key_valid,
+    bf16_t* __restrict__ o, int64_t ldo, float eps, int norm_cols, float scale) {
   __shared__ float qs[DHD], kn[DHD], vn[DHD];
   __shared__ __attribute__((aligned(16))) bf16_t qb[DHD];       // q again, as bf16 pairs (q IS bf16-rounded): the B operand of v_dot2c_f32_bf16
   __shared__ float om[ADF_WAVES][DHD];
@@ -193,21 +195,20 @@ __global__ __launch_bounds__(64 * ADF_WAVES) void attn_decode_fused_kernel(
   // Grid (8, H / HKV, ceil(R HKV / 8)): x = XCD, y = query head inside the kv group, z = block of eight groups -- the linear
   // workgroup id is what it was (8 (z per + y) + x), and no division is left ahead of the first load (round 5).
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int per = gridDim.y, hq = blockIdx.y;
+  const int hq = blockIdx.y;
   const int grp = blockIdx.x + 8 * blockIdx.z;            // (row, kv head) group
-  // every argument in one batch of scalar loads (vmem_asm.h): the early exit, the power-of-two test and the position load below were
-  // three dependent round trips to the kernarg segment ahead of the first vector load
-  asm volatile("" ::"s"(acc_qkv), "s"(lda), "s"(ss), "s"(__float_as_int(eps)), "s"(norm_cols), "s"(bias), "s"(cs), "s"(sn), "s"(pos_dev), "s"(ck),
-               "s"(cv), "s"(key_valid), "s"(o), "s"(ldo), "s"(R), "s"(H), "s"(HKV), "s"(Tmax), "s"(max_pos), "s"(__float_as_int(scale)),
-               "s"(gridDim.y));
+  // Arguments in two batches (vmem_asm.h, UG_HOIST): the early exit, the power-of-two test and the position load used to be three
+  // DEPENDENT round trips to the kernarg segment ahead of the first vector load.  Batch 1 = the kernel's first 14 argument dwords --
+  // everything the accumulator loads (the ~2 us chain) need -- which arrive in SGPRs with the wave when the
+  // code object is built with kernarg preload; batch 2 is requested behind the accumulator loads.
+  asm volatile("" ::"s"(acc_qkv), "s"(ss), "s"(pos_dev), "s"(ck), "s"(cv), "s"(R), "s"(HKV), "s"(H), "s"(lda));
   if (grp >= R * HKV) return;
-  int r, hk;
-  if ((HKV & (HKV - 1)) == 0) { r = grp >> (31 - __builtin_clz(HKV)); hk = grp & (HKV - 1); }
-  else { r = grp / HKV; hk = grp - r * HKV; }
+  int r, hk, per;
+  if ((HKV & (HKV - 1)) == 0) { const int sh = 31 - __builtin_clz(HKV); r = grp >> sh; hk = grp & (HKV - 1); per = H >> sh; }
+  else { r = grp / HKV; hk = grp - r * HKV; per = H / HKV; }          // (= gridDim.y, but that is an implicit ARGUMENT: one more scalar load)
   const int h = hk * per + hq;
-  const bf16_t* kb = ck + ((int64_t)r * HKV + hk) * Tmax * DHD;
-  const bf16_t* vb = cv + ((int64_t)r * HKV + hk) * Tmax * DHD;
   const int kq = lane >> 4, dc = lane & 15;
+  const bf16_t *kb, *vb;                                   // this (row, kv head)'s cache rows: set behind the second argument batch
   // the first key chunk's K rows / V pieces do not depend on the new token: request them before the prologue's own
   // round trip (accumulator, bias, RoPE table) so the two latencies overlap.  (Requesting them before the position word
   // as well -- clamped to the cache instead of the visible length, masked afterwards -- measured SLOWER, 5 730 vs 5 885
@@ -229,18 +230,27 @@ __global__ __launch_bounds__(64 * ADF_WAVES) void attn_decode_fused_kernel(
       ld16(vf[jj], vb + (int64_t)tt * DHD + dc * 8);
     }
   };
-  const int pos0 = *pos_dev;
-  const int len = min(pos0, Tmax);                         // cache keys visible to the new token
+  int pos0;
+  sld4(pos0, pos_dev);                                     // (hand-issued scalar load: vmem_asm.h)
   // The new token's q / k / v pair of this lane (waves 0-2): its loads -- the raw accumulator the projection's atomics left at
   // the device coherence point, bias, RoPE table: one ~2 us round trip -- go out FIRST, the chunk's K / V requests behind them.
   const float* arow = acc_qkv + (int64_t)r * lda;
   const int col0 = wave == 0 ? h * DHD : wave == 1 ? (H + hk) * DHD : (H + HKV + hk) * DHD;
-  const int rpos = min(pos0, max_pos - 1);
   float a1 = 0.f, a2 = 0.f, rc = 1.f, rsn = 0.f, ssr = 1.f;
   uint32_t bb1 = 0, bb2 = 0;
   if (wave < 3) {
     ld4(ssr, ss + r);
     ld4(a1, arow + col0 + lane); ld4(a2, arow + col0 + lane + DHD / 2);
+  }
+  asm volatile("" ::"s"(Tmax), "s"(max_pos), "s"(bias), "s"(cs), "s"(sn), "s"(key_valid), "s"(o), "s"(ldo), "s"(__float_as_int(eps)),
+               "s"(norm_cols), "s"(__float_as_int(scale)));  // batch 2
+  wait_lgkm0();                                            // (the position word; the batch above is behind the same counter)
+  tie_s(pos0);
+  kb = ck + ((int64_t)r * HKV + hk) * Tmax * DHD;
+  vb = cv + ((int64_t)r * HKV + hk) * Tmax * DHD;
+  const int len = min(pos0, Tmax);                         // cache keys visible to the new token
+  const int rpos = min(pos0, max_pos - 1);
+  if (wave < 3) {
     if (bias) { ld2u(bb1, bias + col0 + lane); ld2u(bb2, bias + col0 + lane + DHD / 2); }
     if (wave < 2) { ld4(rc, cs + (int64_t)rpos * (DHD / 2) + lane); ld4(rsn, sn + (int64_t)rpos * (DHD / 2) + lane); }
   }
@@ -1110,9 +1120,10 @@ extern "C" int ug_attn_decode_fused(const float* acc_qkv, int64_t ldacc, const f
              "ug_attn_decode_fused: bad args");
   // (XCD-aware placement: see the kernel)
   const dim3 grid(8u, (unsigned)(H / HKV), (unsigned)((rows * HKV + 7) / 8));
-  hipLaunchKernelGGL(attn_decode_fused_kernel, grid, dim3(64 * ADF_WAVES), 0, st, acc_qkv, ldacc, ss_in, eps,
-                     (int)norm_cols, (const bf16_t*)bias, cos_tab, sin_tab, pos_dev, (bf16_t*)cache_k, (bf16_t*)cache_v, key_valid,
-                     (bf16_t*)o, ldo, (int)rows, H, HKV, (int)Tmax, (int)max_pos, scale);
+  UG_REQUIRE(ldacc > 0 && ldacc < (1ll << 31), "ug_attn_decode_fused: ldacc out of range");
+  hipLaunchKernelGGL(attn_decode_fused_kernel, grid, dim3(64 * ADF_WAVES), 0, st, acc_qkv, ss_in, pos_dev, (bf16_t*)cache_k,
+                     (bf16_t*)cache_v, (int)rows, HKV, H, (int)ldacc, (int)Tmax, (int)max_pos, (const bf16_t*)bias, cos_tab, sin_tab,
+                     key_valid, (bf16_t*)o, ldo, eps, (int)norm_cols, scale);
   UG_CHECK_LAUNCH("ug_attn_decode_fused");
   return UG_OK;
 }

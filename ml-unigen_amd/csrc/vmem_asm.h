@@ -57,4 +57,11 @@ __device__ __forceinline__ uint32_t lds_addr_of(const void* p) { return (uint32_
 // argument comes in one batch of s_load behind one wait.
 #define UG_HOIST(x) asm volatile("" ::"s"(x))
 #define UG_HOISTF(x) asm volatile("" ::"s"(__float_as_int(x)))
+// A wave-uniform word ANOTHER launch wrote (the decode position): hipcc may not treat it as constant, so it reads it with a VECTOR load
+// and waits vmcnt(0) for it on the spot -- a serialised L2 round trip at the top of the kernel.  Hand-issued scalar load instead (the
+// scalar cache is invalidated at every kernel start); use the value behind wait_lgkm0() + tie_s().
+__device__ __forceinline__ void sld4(int& v, const void* p) { asm volatile("s_load_dword %0, %1, 0x0" : "=&s"(v) : "s"(p) : "memory"); }
+__device__ __forceinline__ void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+template <typename T>
+__device__ __forceinline__ void tie_s(T& v) { asm volatile("" : "+s"(v)); }
 
