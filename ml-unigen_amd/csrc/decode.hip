@@ -604,19 +604,6 @@ __device__ __forceinline__ void decode_clear(const DecodeIn& f, int tid, int bid
   if (f.ss_zero && bid == 0 && tid < 32) f.ss_zero[tid] = 0.f;
 }
 
-// the arguments of the multi-wave ring GEMV, live in SGPRs by ONE asm statement (vmem_asm.h, UG_HOIST; gridDim: implicit arguments)
-#define UG_HOIST_RING4_ARGS()                                                                                                          \
-  do {                                                                                                                                 \
-    if constexpr (XIN == XIN_RESID_NORM)                                                                                               \
-      asm volatile("" ::"s"(R), "s"(W), "s"(ldw), "s"(acc), "s"(sr), "s"(sn), "s"(N), "s"(K), "s"(nslabs), "s"(gridDim.x), "s"(gridDim.y), "s"(blockDim.x), \
-                   "s"(f.zero0), "s"(f.zero1), "s"(f.ss_zero), "s"(f.n0_4), "s"(f.per0), "s"(f.n1_4), "s"(f.per1), "s"(f.x_in), "s"(f.pend), \
-                   "s"(f.ld_pend), "s"(f.norm_w), "s"(f.x_out), "s"(f.ss_out));                                                        \
-    else                                                                                                                               \
-      asm volatile("" ::"s"(R), "s"(W), "s"(ldw), "s"(acc), "s"(sr), "s"(sn), "s"(N), "s"(K), "s"(nslabs), "s"(gridDim.x), "s"(gridDim.y), "s"(blockDim.x), \
-                   "s"(f.zero0), "s"(f.zero1), "s"(f.ss_zero), "s"(f.n0_4), "s"(f.per0), "s"(f.n1_4), "s"(f.per1), "s"(f.gu), "s"(f.ld_gu),   \
-                   "s"(f.ss_in), "s"(__float_as_int(f.eps)), "s"(f.norm_cols));                                                        \
-  } while (0)
-
 // linear workgroup id (x fastest: the order the dispatcher deals workgroups out to the XCDs in)
 __device__ __forceinline__ int linear_block() { return (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x; }
 
@@ -625,16 +612,16 @@ __device__ __forceinline__ float silu_bf(float g) { return bf2f(f2bf(g / (1.f + 
 // Request this lane's operand pieces (row `ar`, 8 k-values at k0) for the fp32-operand modes -- hand-issued loads (vmem_asm.h): the
 // values may be used only behind the caller's wait + tie.
 template <int XIN>
-__device__ __forceinline__ void decode_operand_load(const DecodeIn& f, int ar, int k0, int K, f32x4_t (&a)[2], f32x4_t (&b)[2],
-                                                    f32x4_t (&w)[2]) {
-  if constexpr (XIN == XIN_RESID_NORM) {
-    const float* xp = f.x_in + (__umul24(ar, K) + k0);
-    const float* pp = f.pend + (__umul24(ar, (int)f.ld_pend) + k0);
+__device__ __forceinline__ void decode_operand_load(const float* p0, const float* p1, int ld1, const float* nw, int ar, int k0, int K,
+                                                    f32x4_t (&a)[2], f32x4_t (&b)[2], f32x4_t (&w)[2]) {
+  if constexpr (XIN == XIN_RESID_NORM) {          // p0 = x_in [.][K], p1 = pending accumulator [.][ld1], nw = norm weight
+    const float* xp = p0 + (__umul24(ar, K) + k0);
+    const float* pp = p1 + (__umul24(ar, ld1) + k0);
     ld16(a[0], xp); ld16(a[1], xp + 4);
     ld16(b[0], pp); ld16(b[1], pp + 4);
-    ld16(w[0], f.norm_w + k0); ld16(w[1], f.norm_w + k0 + 4);
-  } else {
-    const float* gp = f.gu + (__umul24(ar, (int)f.ld_gu) + k0);
+    ld16(w[0], nw + k0); ld16(w[1], nw + k0 + 4);
+  } else {                                        // p0 = gate / up accumulator [.][ld1]
+    const float* gp = p0 + (__umul24(ar, ld1) + k0);
     ld16(a[0], gp); ld16(a[1], gp + 4);
     ld16(b[0], gp + K); ld16(b[1], gp + K + 4);
   }
@@ -770,17 +757,31 @@ __global__ __launch_bounds__(64) void gemv_ring_kernel(const bf16_t* __restrict_
 // coherence point -- then sit on ONE XCD (workgroups go to the XCDs round robin in x-fastest linear order), so the slab comes
 // through the slow path once per XCD instead of once per workgroup (7.7 -> 1.1 MB per launch); surplus workgroups of the padded
 // grid (slab >= nslabs) only take part in the clears.  Either way slab = x + 8 z, chunk = y: no division in the kernel.
-template <int RB, int KW, int XIN, int NW>
-__global__ __launch_bounds__(64 * NW) void gemv_ring4_kernel(int R, const bf16_t* __restrict__ W, int ldw, float* __restrict__ acc,
-                                                             int sr, int sn, int N, int K, int nslabs, DecodeIn f) {
+// Argument order: the 14 dwords in front are what the operand loads and the weight tiles need (p0 / p1 / ld1 / nw: see
+// decode_operand_load; p1 = the statistics slot for XIN_SWIGLU); built with kernarg preload (Makefile) they arrive in SGPRs with the wave.
+// CLR = the launch carries clears (its first memory operations, so their arguments are fetched up front); a launch without them
+// fetches the rest of its arguments behind the first tiles' requests.
+template <int RB, int KW, int XIN, int NW, bool CLR>
+__global__ __launch_bounds__(64 * NW) void gemv_ring4_kernel(const float* __restrict__ p0, const float* __restrict__ p1, const float* __restrict__ nw,
+                                                             const bf16_t* __restrict__ W, int R, int K, int ld1, int ldw, int N, int nslabs,
+                                                             float* __restrict__ acc, int sr, int sn, DecodeIn f) {
   __shared__ __attribute__((aligned(1024))) char tile[NW][2][8192];
   __shared__ __attribute__((aligned(16))) bf16x8_t frag[RB][8][64];
   constexpr int UPW = (8 + NW - 1) / NW;           // k-steps of the operand each wave converts
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, row = lane & 15;
   const int slab = blockIdx.x + 8 * blockIdx.z, chunk = blockIdx.y;
-  UG_HOIST_RING4_ARGS();                           // every argument in one batch of scalar loads (vmem_asm.h)
-  // the clears this launch carries go out first (see gemv_ring_kernel)
-  decode_clear(f, threadIdx.x, linear_block());
+  asm volatile("" ::"s"(p0), "s"(p1), "s"(nw), "s"(W), "s"(R), "s"(K), "s"(ld1), "s"(ldw), "s"(N), "s"(nslabs));      // batch 1 (vmem_asm.h, UG_HOIST)
+  auto rest_of_args = [&] {                        // batch 2: ONE asm statement (gridDim / blockDim are implicit arguments)
+    if constexpr (CLR)
+      asm volatile("" ::"s"(acc), "s"(sr), "s"(sn), "s"(gridDim.x), "s"(gridDim.y), "s"(blockDim.x), "s"(f.zero0), "s"(f.zero1), "s"(f.ss_zero),
+                   "s"(f.n0_4), "s"(f.per0), "s"(f.n1_4), "s"(f.per1), "s"(f.x_out), "s"(f.ss_out), "s"(__float_as_int(f.eps)), "s"(f.norm_cols));
+    else
+      asm volatile("" ::"s"(acc), "s"(sr), "s"(sn), "s"(f.x_out), "s"(f.ss_out), "s"(__float_as_int(f.eps)), "s"(f.norm_cols));
+  };
+  if constexpr (CLR) {
+    rest_of_args();
+    decode_clear(f, threadIdx.x, linear_block());  // the clears this launch carries go out first (see gemv_ring_kernel)
+  }
   if (slab >= nslabs) return;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int grp0 = (chunk * NW + wave_u) * KW;
@@ -796,11 +797,11 @@ __global__ __launch_bounds__(64 * NW) void gemv_ring4_kernel(int R, const bf16_t
   for (int rb = 0; rb < RB; ++rb) {
     const int ar = min(rb * 16 + row, R - 1);
     rs[rb] = 0.f;
-    if constexpr (XIN == XIN_SWIGLU) ld4(rs[rb], f.ss_in + ar);
+    if constexpr (XIN == XIN_SWIGLU) ld4(rs[rb], p1 + ar);
 #pragma unroll
     for (int uu = 0; uu < UPW; ++uu) {
       const int u = min(wave + uu * NW, 7);
-      decode_operand_load<XIN>(f, ar, min(kbase + u * 32, K - 32) + g * 8, K, a[rb][uu], b[rb][uu], w[rb][uu]);
+      decode_operand_load<XIN>(p0, p1, ld1, nw, ar, min(kbase + u * 32, K - 32) + g * 8, K, a[rb][uu], b[rb][uu], w[rb][uu]);
     }
   }
   TileAddr ta;
@@ -819,6 +820,7 @@ __global__ __launch_bounds__(64 * NW) void gemv_ring4_kernel(int R, const bf16_t
   };
   stage(0);
   if constexpr (KW > 1) stage(1);
+  if constexpr (!CLR) rest_of_args();               // (their round trip hides under the operand's)
   wait_vm<(KW > 1 ? 16 : 8)>();                     // the operand's loads are older than the tiles' DMA
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
@@ -968,7 +970,18 @@ void launch_ring_auto(hipStream_t st, const bf16_t* x, int ldx, int R, const bf1
     const dim3 grid = xcd_chunks ? dim3(8, (unsigned)xcd_chunks, (unsigned)((nslabs + 7) / 8))
                                  : dim3((unsigned)nslabs, (unsigned)((groups + NWc * KWc - 1) / (NWc * KWc)));
     set_clear_shares(f, zero0, n0, zero1, n1, ss_zero, grid.x * grid.y * grid.z);
-#define UG_RING4(RBV, KWV, NWV) hipLaunchKernelGGL((gemv_ring4_kernel<RBV, KWV, XIN, NWV>), grid, dim3(64 * NWV), 0, st, R, W, ldw, acc, sr, sn, N, K, nslabs, f)
+    // leading arguments: see the kernel
+    const float* p0 = XIN == XIN_RESID_NORM ? f.x_in : f.gu;
+    const float* p1 = XIN == XIN_RESID_NORM ? f.pend : f.ss_in;
+    const int64_t ld1 = XIN == XIN_RESID_NORM ? f.ld_pend : f.ld_gu;          // (< 2^24: checked by the entry points)
+    const bool clr = zero0 || zero1 || ss_zero;
+#define UG_RING4(RBV, KWV, NWV)                                                                                                              \
+  do {                                                                                                                                       \
+    if (clr) hipLaunchKernelGGL((gemv_ring4_kernel<RBV, KWV, XIN, NWV, true>), grid, dim3(64 * NWV), 0, st, p0, p1, f.norm_w, W, R, K, (int)ld1, ldw, \
+                                N, nslabs, acc, sr, sn, f);                                                                                  \
+    else hipLaunchKernelGGL((gemv_ring4_kernel<RBV, KWV, XIN, NWV, false>), grid, dim3(64 * NWV), 0, st, p0, p1, f.norm_w, W, R, K, (int)ld1, ldw, \
+                            N, nslabs, acc, sr, sn, f);                                                                                      \
+  } while (0)
     if (R <= 16) {
       if (NWc == 9) UG_RING4(1, 3, 9); else if (NWc == 8) UG_RING4(1, 2, 8); else if (NWc == 7) UG_RING4(1, 2, 7); else if (KWc == 2) UG_RING4(1, 2, 4); else UG_RING4(1, 1, 4);
     } else { if (KWc == 2) UG_RING4(2, 2, 4); else UG_RING4(2, 1, 4); }

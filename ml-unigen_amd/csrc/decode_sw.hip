@@ -51,8 +51,8 @@ __device__ __forceinline__ float silu_bf(float g) { return bf2f(f2bf(g / (1.f + 
 template <int EPI>
 struct RowMap {
   static constexpr int UPT = EPI == EPI_SWIGLU ? 8 : 16;                                 // units per tile
-  static __device__ __forceinline__ int rel_row(const SwArgs& a, int s) {                // weight row of slot s relative to the tile's first
-    if constexpr (EPI == EPI_SWIGLU) return s < 8 ? s : a.I + (s - 8);
+  static __device__ __forceinline__ int rel_row(int I, int s) {                          // weight row of slot s relative to the tile's first
+    if constexpr (EPI == EPI_SWIGLU) return s < 8 ? s : I + (s - 8);
     else return s;
   }
   static __device__ __forceinline__ int nvalid(int u0, int u1, int t) { return min(max(u1 - (u0 + UPT * t), 0), UPT); }
@@ -62,34 +62,21 @@ struct RowMap {
   }
 };
 
-// Every kernel argument an instantiation reads, made live in SGPRs by ONE asm statement at the top of the kernel (vmem_asm.h, UG_HOIST:
-// several statements would each end a scheduling region and bring the dependent round trips back).
-#define UG_SW_COMMON_ARGS "s"(a.W), "s"(a.ldw), "s"(a.K), "s"(a.R), "s"(a.nunits), "s"(a.upw)
-template <int PRO, int EPI, bool PEND>
-__device__ __forceinline__ void hoist_sw_args(const SwArgs& a) {
-  if constexpr (PRO == PRO_NORM && EPI == EPI_SWIGLU && PEND)
-    asm volatile("" ::UG_SW_COMMON_ARGS, "s"(a.h), "s"(a.norm_w), "s"(__float_as_int(a.eps)), "s"(a.pend), "s"(a.ld_pend), "s"(a.x_out), "s"(a.act),
-                 "s"(a.ld_act), "s"(a.I));
-  else if constexpr (PRO == PRO_NORM && EPI == EPI_SWIGLU)
-    asm volatile("" ::UG_SW_COMMON_ARGS, "s"(a.h), "s"(a.norm_w), "s"(__float_as_int(a.eps)), "s"(a.act), "s"(a.ld_act), "s"(a.I));
-  else if constexpr (PRO == PRO_NORM && EPI == EPI_STORE && PEND)
-    asm volatile("" ::UG_SW_COMMON_ARGS, "s"(a.h), "s"(a.norm_w), "s"(__float_as_int(a.eps)), "s"(a.pend), "s"(a.ld_pend), "s"(a.x_out), "s"(a.out),
-                 "s"(a.ld_out), "s"(a.pos_inc), "s"(a.len_inc));
-  else if constexpr (PRO == PRO_NORM && EPI == EPI_STORE)
-    asm volatile("" ::UG_SW_COMMON_ARGS, "s"(a.h), "s"(a.norm_w), "s"(__float_as_int(a.eps)), "s"(a.out), "s"(a.ld_out), "s"(a.pos_inc), "s"(a.len_inc));
-  else if constexpr (PRO == PRO_BF16 && EPI == EPI_RESID)
-    asm volatile("" ::UG_SW_COMMON_ARGS, "s"(a.xb), "s"(a.ldx), "s"(a.h_io));
-  else if constexpr (PRO == PRO_BF16 && EPI == EPI_ATOMIC)
-    asm volatile("" ::UG_SW_COMMON_ARGS, "s"(a.xb), "s"(a.ldx), "s"(a.out), "s"(a.ld_out), "s"(a.zero0), "s"(a.zero1), "s"(a.ss_zero), "s"(a.n0_4),
-                 "s"(a.per0), "s"(a.n1_4), "s"(a.per1), "s"(gridDim.x));                 // (gridDim: an implicit argument)
-}
-
 // NW waves per workgroup, wave w owns k-slab w (K == 256 NW) and walks MAXT tiles of 16 weight rows through a RING-slot LDS ring of
 // MAXI KiB slots.  The whole ring is requested before the operand prologue (staging only part of it first measured no faster).
 // KBLK (split-K in k-blocks of NW slabs, grid.y = k-block): the partial tile of a workgroup joins the accumulator by ONE atomic per
 // element (EPI_ATOMIC) -- the down projection, whose 287 KB operand rules the whole-K cut out: 5 atomics per output instead of 35.
 template <int PRO, int EPI, int NW, int MAXT, int RING, int MAXI, bool PEND = false, bool KBLK = false>
-__global__ __launch_bounds__(64 * NW) void gemv_sw_kernel(SwArgs a) {
+__global__ __launch_bounds__(64 * NW) void gemv_sw_kernel(const bf16_t* W_, const void* opnd_, const void* aux_, int ldw_, int K_, int R_, int nunits_,
+                                                          int upw_, int ld_opnd_, int I_, float eps_, SwArgs a) {
+  // Argument order: the 14 dwords in front are everything the launch's first loads need (operand, epilogue input, weight tiles); built with
+  // kernarg preload (Makefile) they arrive in SGPRs with the wave -- no scalar-load round trip ahead of the first vector load (0.18 us of a
+  // ~4 us launch).  opnd = the fp32 stream (PRO_NORM) or the bf16 operand; aux = norm weight (PRO_NORM) or the stream to finish (EPI_RESID).
+  // The rest of SwArgs is fetched in ONE batch (one asm statement naming every field: vmem_asm.h, UG_HOIST) where its latency hides.
+  struct {
+    const bf16_t* W; int ldw, K, R, nunits, upw; const float* h; const float* norm_w; float eps; const bf16_t* xb; int ldx; float* h_io; int I;
+  } f = {W_, ldw_, K_, R_, nunits_, upw_, (const float*)opnd_, (const float*)aux_, eps_, (const bf16_t*)opnd_, ld_opnd_, (float*)const_cast<void*>(aux_), I_};
+  asm volatile("" ::"s"(W_), "s"(opnd_), "s"(aux_), "s"(ldw_), "s"(K_), "s"(R_), "s"(nunits_), "s"(upw_), "s"(ld_opnd_), "s"(I_));
   static_assert(KBLK == (EPI == EPI_ATOMIC) && (!KBLK || PRO == PRO_BF16), "k-blocks accumulate; whole-K launches store");
   static_assert(RING <= MAXT && MAXT <= RING * MAXI, "ring too small for the reduction image");
   static_assert(MAXT <= NW, "wave t finishes tile t");
@@ -98,7 +85,17 @@ __global__ __launch_bounds__(64 * NW) void gemv_sw_kernel(SwArgs a) {
   __shared__ __attribute__((aligned(16))) float wn[PRO == PRO_NORM ? NW : 1][256];
   __shared__ float ssp[PRO == PRO_NORM ? NW : 1][16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, slot = lane & 15;
-  hoist_sw_args<PRO, EPI, PEND>(a);                  // every argument this instantiation reads in ONE batch of scalar loads
+  auto rest_of_args = [&] {                                // batch 2
+    if constexpr (EPI == EPI_ATOMIC)
+      asm volatile("" ::"s"(a.out), "s"(a.ld_out), "s"(a.zero0), "s"(a.zero1), "s"(a.ss_zero), "s"(a.n0_4), "s"(a.per0), "s"(a.n1_4), "s"(a.per1),
+                   "s"(gridDim.x));                        // (gridDim: an implicit argument)
+    else if constexpr (EPI == EPI_SWIGLU && PEND) asm volatile("" ::"s"(a.pend), "s"(a.ld_pend), "s"(a.x_out), "s"(a.act), "s"(a.ld_act));
+    else if constexpr (EPI == EPI_SWIGLU) asm volatile("" ::"s"(a.act), "s"(a.ld_act));
+    else if constexpr (EPI == EPI_STORE && PEND)
+      asm volatile("" ::"s"(a.pend), "s"(a.ld_pend), "s"(a.x_out), "s"(a.out), "s"(a.ld_out), "s"(a.pos_inc), "s"(a.len_inc));
+    else if constexpr (EPI == EPI_STORE) asm volatile("" ::"s"(a.out), "s"(a.ld_out), "s"(a.pos_inc), "s"(a.len_inc));
+  };
+  if constexpr (EPI == EPI_ATOMIC) rest_of_args();           // (its clears are the launch's first memory operations)
   if constexpr (EPI == EPI_ATOMIC) {
     // the clears this launch carries go out first (stores behind the loads would sit between them in the memory queue)
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -107,10 +104,10 @@ __global__ __launch_bounds__(64 * NW) void gemv_sw_kernel(SwArgs a) {
     if (a.zero1) { const int lo = bid * a.per1, hi = min(a.n1_4, lo + a.per1); for (int i = lo + tid; i < hi; i += nt) reinterpret_cast<float4*>(a.zero1)[i] = z; }
     if (a.ss_zero && bid == 0 && tid < 32) a.ss_zero[tid] = 0.f;
   }
-  const int u0 = blockIdx.x * a.upw, u1 = min(a.nunits, u0 + a.upw);
+  const int u0 = blockIdx.x * f.upw, u1 = min(f.nunits, u0 + f.upw);
   if (u0 >= u1) return;
-  const int K = a.K;
-  const int arow = min(slot, a.R - 1);                       // the MFMA's A row of this lane (rows past R repeat the last one)
+  const int K = f.K;
+  const int arow = min(slot, f.R - 1);                       // the MFMA's A row of this lane (rows past R repeat the last one)
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int slab = (KBLK ? (int)blockIdx.y * NW : 0) + wave_u;         // this wave's 256-wide k-slab
                                                                        // (the host admits only K that is a whole number of k-blocks)
@@ -123,7 +120,7 @@ __global__ __launch_bounds__(64 * NW) void gemv_sw_kernel(SwArgs a) {
     if (wave < MAXT) {
       const int col = min(u0 + 16 * wave + slot, u1 - 1);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) hold[j] = a.h_io[__umul24(min(g * 4 + j, a.R - 1), a.nunits) + col];
+      for (int j = 0; j < 4; ++j) hold[j] = f.h_io[__umul24(min(g * 4 + j, f.R - 1), f.nunits) + col];
     }
   }
 
@@ -133,19 +130,20 @@ __global__ __launch_bounds__(64 * NW) void gemv_sw_kernel(SwArgs a) {
   bf16x8_t xf[8];
   if constexpr (PRO == PRO_NORM) {
     const uint32_t xo = (uint32_t)(__umul24(arow, K) + wave * 256 + g * 8) * 4u;
-#define UG_LDX(u) ld16<(u) * 128>(xa[u][0], (uint64_t)a.h, xo); ld16<(u) * 128 + 16>(xa[u][1], (uint64_t)a.h, xo);
+#define UG_LDX(u) ld16<(u) * 128>(xa[u][0], (uint64_t)f.h, xo); ld16<(u) * 128 + 16>(xa[u][1], (uint64_t)f.h, xo);
     UG_LDX(0) UG_LDX(1) UG_LDX(2) UG_LDX(3) UG_LDX(4) UG_LDX(5) UG_LDX(6) UG_LDX(7)
 #undef UG_LDX
     if constexpr (PEND) {
+      rest_of_args();                                        // (behind the stream's own loads)
       const uint32_t po = (uint32_t)(__umul24(arow, a.ld_pend) + wave * 256 + g * 8) * 4u;
 #define UG_LDX(u) ld16<(u) * 128>(pa[u][0], (uint64_t)a.pend, po); ld16<(u) * 128 + 16>(pa[u][1], (uint64_t)a.pend, po);
       UG_LDX(0) UG_LDX(1) UG_LDX(2) UG_LDX(3) UG_LDX(4) UG_LDX(5) UG_LDX(6) UG_LDX(7)
 #undef UG_LDX
     }
-    ld16<0>(wv, (uint64_t)a.norm_w, (uint32_t)(wave * 256 + lane * 4) * 4u);
+    ld16<0>(wv, (uint64_t)f.norm_w, (uint32_t)(wave * 256 + lane * 4) * 4u);
   } else {
-    const uint32_t xo = (uint32_t)(__umul24(arow, a.ldx) + slab * 256 + g * 8) * 2u;
-#define UG_LDX(u) ld16<(u) * 64>(xf[u], (uint64_t)a.xb, xo);
+    const uint32_t xo = (uint32_t)(__umul24(arow, f.ldx) + slab * 256 + g * 8) * 2u;
+#define UG_LDX(u) ld16<(u) * 64>(xf[u], (uint64_t)f.xb, xo);
     UG_LDX(0) UG_LDX(1) UG_LDX(2) UG_LDX(3) UG_LDX(4) UG_LDX(5) UG_LDX(6) UG_LDX(7)
 #undef UG_LDX
   }
@@ -155,14 +153,14 @@ __global__ __launch_bounds__(64 * NW) void gemv_sw_kernel(SwArgs a) {
 #pragma unroll
   for (int i = 0; i < MAXI; ++i) {
     const int sl = 2 * i + (lane >> 5);
-    voff[i] = (uint32_t)(RM::rel_row(a, sl) * a.ldw + (((lane & 31) ^ sl) << 3)) * 2u;
+    voff[i] = (uint32_t)(RM::rel_row(f.I, sl) * f.ldw + (((lane & 31) ^ sl) << 3)) * 2u;
   }
   // stage tile t into ring slot t % RING.  ALWAYS MAXI instructions: the waits below count instructions.  A slot without a weight row
   // reads the tile's first 16 bytes (one line for the whole wave) into LDS nobody uses.
   auto stage = [&](int t) {
     const int nv = RM::nvalid(u0, u1, t);
     const int r0 = nv > 0 ? u0 + RM::UPT * t : u0;
-    const uint64_t base = (uint64_t)a.W + ((int64_t)r0 * a.ldw + slab * 256) * 2;
+    const uint64_t base = (uint64_t)f.W + ((int64_t)r0 * f.ldw + slab * 256) * 2;
     const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_addr_of(tile[wave][t % RING]));
 #pragma unroll
     for (int i = 0; i < MAXI; ++i)       // nt: every weight byte is read once per step by one CU (guide, price list row nt-weights)
@@ -170,6 +168,7 @@ __global__ __launch_bounds__(64 * NW) void gemv_sw_kernel(SwArgs a) {
   };
 #pragma unroll
   for (int t = 0; t < RING; ++t) stage(t);
+  if constexpr (EPI != EPI_ATOMIC && !PEND) rest_of_args();   // (the epilogue's arguments: their round trip hides under the operand's)
 
   wait_vm<RING * MAXI>();                                      // the operand loads are older than every DMA instruction
   if constexpr (PRO == PRO_NORM) {
@@ -183,7 +182,7 @@ __global__ __launch_bounds__(64 * NW) void gemv_sw_kernel(SwArgs a) {
         tie(pa[u][0]); tie(pa[u][1]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { xa[u][0][e] += bf2f(f2bf(pa[u][0][e])); xa[u][1][e] += bf2f(f2bf(pa[u][1][e])); }
-        if (a.x_out && blockIdx.x == u && slot < a.R) {         // eight workgroups x six waves x one k-step cover the whole stream
+        if (a.x_out && blockIdx.x == u && slot < f.R) {         // eight workgroups x six waves x one k-step cover the whole stream
           float* xo = a.x_out + (__umul24(slot, K) + wave * 256 + u * 32 + g * 8);
           *reinterpret_cast<f32x4_t*>(xo) = xa[u][0];
           *reinterpret_cast<f32x4_t*>(xo + 4) = xa[u][1];
@@ -204,7 +203,7 @@ __global__ __launch_bounds__(64 * NW) void gemv_sw_kernel(SwArgs a) {
     float tot = 0.f;
 #pragma unroll
     for (int ww = 0; ww < NW; ++ww) tot += ssp[ww][slot];      // same order in every workgroup: one value of rstd per row everywhere
-    const float rs = rsqrtf(tot / (float)K + a.eps);
+    const float rs = rsqrtf(tot / (float)K + f.eps);
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const float4 w0 = *reinterpret_cast<const float4*>(&wn[wave][u * 32 + g * 8]);
@@ -262,7 +261,7 @@ __global__ __launch_bounds__(64 * NW) void gemv_sw_kernel(SwArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int r = g * 4 + j;
-          if (r < a.R) a.act[__umul24(r, a.ld_act) + unit] = f2bf(silu_bf(bf2f(f2bf(v[j]))) * bf2f(f2bf(up[j])));
+          if (r < f.R) a.act[__umul24(r, a.ld_act) + unit] = f2bf(silu_bf(bf2f(f2bf(v[j]))) * bf2f(f2bf(up[j])));
         }
       }
     } else if constexpr (EPI == EPI_RESID) {
@@ -271,7 +270,7 @@ __global__ __launch_bounds__(64 * NW) void gemv_sw_kernel(SwArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int r = g * 4 + j;
-          if (r < a.R) a.h_io[__umul24(r, a.nunits) + col] = hold[j] + bf2f(f2bf(v[j]));
+          if (r < f.R) f.h_io[__umul24(r, f.nunits) + col] = hold[j] + bf2f(f2bf(v[j]));
         }
       }
     } else {
@@ -280,7 +279,7 @@ __global__ __launch_bounds__(64 * NW) void gemv_sw_kernel(SwArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int r = g * 4 + j;
-          if (r < a.R) {
+          if (r < f.R) {
             if constexpr (EPI == EPI_ATOMIC) atomicAdd(a.out + ((int64_t)r * a.ld_out + col), v[j]);
             else a.out[(int64_t)r * a.ld_out + col] = v[j];
           }
@@ -308,6 +307,9 @@ int units_per_wg(int nunits, int max_upw) {
   return upw > max_upw ? max_upw : upw;
 }
 
+// the kernel's leading scalar arguments (kernarg preload: see gemv_sw_kernel) out of a filled SwArgs
+#define UG_SW_LEAD_NORM(a) (a).W, (const void*)(a).h, (const void*)(a).norm_w, (a).ldw, (a).K, (a).R, (a).nunits, (a).upw, 0, (a).I, (a).eps
+#define UG_SW_LEAD_BF16(a, aux) (a).W, (const void*)(a).xb, (const void*)(aux), (a).ldw, (a).K, (a).R, (a).nunits, (a).upw, (a).ldx, 0, 0.f
 #define UG_SW_COMMON(name)                                                                                                                   \
   UG_REQUIRE(R > 0 && R <= 16 && W && ldw % 8 == 0 && ug_aligned16(W) && N > 0 && (int64_t)N * ldw < (1ll << 31) && ldw < (1 << 24),        \
              name ": need 1 <= rows <= 16, 16-byte aligned weight rows, N * ldw < 2^31 (rows=%ld N=%ld ldw=%ld)", (long)R, (long)N, (long)ldw)
@@ -339,8 +341,8 @@ extern "C" int ug_decode_sw_gate_up(const float* h, const float* pend, int64_t l
   UG_SW_PEND_ARGS("ug_decode_sw_gate_up");
   const unsigned grid = (unsigned)((a.nunits + a.upw - 1) / a.upw);
   UG_REQUIRE(!x_out || grid >= 8, "ug_decode_sw_gate_up: fewer than eight workgroups cannot write x_out");
-  if (pend) hipLaunchKernelGGL((gemv_sw_kernel<PRO_NORM, EPI_SWIGLU, 6, 5, 3, 8, true>), dim3(grid), dim3(64 * 6), 0, st, a);
-  else hipLaunchKernelGGL((gemv_sw_kernel<PRO_NORM, EPI_SWIGLU, 6, 5, 3, 8>), dim3(grid), dim3(64 * 6), 0, st, a);
+  if (pend) hipLaunchKernelGGL((gemv_sw_kernel<PRO_NORM, EPI_SWIGLU, 6, 5, 3, 8, true>), dim3(grid), dim3(64 * 6), 0, st, UG_SW_LEAD_NORM(a), a);
+  else hipLaunchKernelGGL((gemv_sw_kernel<PRO_NORM, EPI_SWIGLU, 6, 5, 3, 8>), dim3(grid), dim3(64 * 6), 0, st, UG_SW_LEAD_NORM(a), a);
   UG_CHECK_LAUNCH("ug_decode_sw_gate_up");
   return UG_OK;
 }
@@ -355,7 +357,7 @@ extern "C" int ug_decode_sw_resid(const void* x, int64_t ldx, int64_t R, const v
   a.nunits = (int)N; a.xb = (const bf16_t*)x; a.ldx = (int)ldx; a.h_io = h;
   a.upw = units_per_wg(a.nunits, 8);
   const unsigned grid = (unsigned)((a.nunits + a.upw - 1) / a.upw);
-  hipLaunchKernelGGL((gemv_sw_kernel<PRO_BF16, EPI_RESID, 6, 1, 1, 4>), dim3(grid), dim3(64 * 6), 0, st, a);
+  hipLaunchKernelGGL((gemv_sw_kernel<PRO_BF16, EPI_RESID, 6, 1, 1, 4>), dim3(grid), dim3(64 * 6), 0, st, UG_SW_LEAD_BF16(a, a.h_io), a);
   UG_CHECK_LAUNCH("ug_decode_sw_resid");
   return UG_OK;
 }
@@ -376,7 +378,7 @@ extern "C" int ug_decode_sw_kblock(const void* x, int64_t ldx, int64_t R, const 
   a.zero0 = zero0; a.zero1 = zero1; a.ss_zero = ss_zero;
   a.n0_4 = (int)(n0 >> 2); a.n1_4 = (int)(n1 >> 2);
   a.per0 = (int)((a.n0_4 + nblocks - 1) / nblocks); a.per1 = (int)((a.n1_4 + nblocks - 1) / nblocks);
-  hipLaunchKernelGGL((gemv_sw_kernel<PRO_BF16, EPI_ATOMIC, 7, 2, 2, 8, false, true>), grid, dim3(64 * 7), 0, st, a);
+  hipLaunchKernelGGL((gemv_sw_kernel<PRO_BF16, EPI_ATOMIC, 7, 2, 2, 8, false, true>), grid, dim3(64 * 7), 0, st, UG_SW_LEAD_BF16(a, nullptr), a);
   UG_CHECK_LAUNCH("ug_decode_sw_kblock");
   return UG_OK;
 }
@@ -395,8 +397,8 @@ extern "C" int ug_decode_sw_head(const float* h, const float* pend, int64_t ld_p
   UG_SW_PEND_ARGS("ug_decode_sw_head");
   const unsigned grid = (unsigned)((a.nunits + a.upw - 1) / a.upw);
   UG_REQUIRE(!x_out || grid >= 8, "ug_decode_sw_head: fewer than eight workgroups cannot write x_out");
-  if (pend) hipLaunchKernelGGL((gemv_sw_kernel<PRO_NORM, EPI_STORE, 6, 2, 2, 8, true>), dim3(grid), dim3(64 * 6), 0, st, a);
-  else hipLaunchKernelGGL((gemv_sw_kernel<PRO_NORM, EPI_STORE, 6, 2, 2, 8>), dim3(grid), dim3(64 * 6), 0, st, a);
+  if (pend) hipLaunchKernelGGL((gemv_sw_kernel<PRO_NORM, EPI_STORE, 6, 2, 2, 8, true>), dim3(grid), dim3(64 * 6), 0, st, UG_SW_LEAD_NORM(a), a);
+  else hipLaunchKernelGGL((gemv_sw_kernel<PRO_NORM, EPI_STORE, 6, 2, 2, 8>), dim3(grid), dim3(64 * 6), 0, st, UG_SW_LEAD_NORM(a), a);
   UG_CHECK_LAUNCH("ug_decode_sw_head");
   return UG_OK;
 }

@@ -16,6 +16,8 @@ src = os.path.join(ROOT, "ml-unigen_amd", "csrc")
 out = os.path.join(ROOT, "tools", "probes", "_build")
 name, target = sys.argv[1], sys.argv[2]
 flags = sys.argv[3:]
+if target in ("decode.hip", "decode_sw.hip"):                 # as the Makefile builds them (kernarg preload)
+    flags = ["-mllvm", "-amdgpu-kernarg-preload-count=16"] + flags
 os.makedirs(out, exist_ok=True)
 with tempfile.TemporaryDirectory() as td:
     scratch = os.path.join(td, "ml-unigen_amd", "csrc")
