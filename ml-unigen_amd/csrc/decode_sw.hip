@@ -95,15 +95,16 @@ __global__ __launch_bounds__(64 * NW) void gemv_sw_kernel(const bf16_t* W_, cons
       asm volatile("" ::"s"(a.pend), "s"(a.ld_pend), "s"(a.x_out), "s"(a.out), "s"(a.ld_out), "s"(a.pos_inc), "s"(a.len_inc));
     else if constexpr (EPI == EPI_STORE) asm volatile("" ::"s"(a.out), "s"(a.ld_out), "s"(a.pos_inc), "s"(a.len_inc));
   };
-  if constexpr (EPI == EPI_ATOMIC) rest_of_args();           // (its clears are the launch's first memory operations)
-  if constexpr (EPI == EPI_ATOMIC) {
-    // the clears this launch carries go out first (stores behind the loads would sit between them in the memory queue)
+  // EPI_ATOMIC: the clears this launch carries (accumulators consumed by earlier launches).  They go out BEHIND the operand loads and the
+  // first weight tiles (their arguments are not among the preloaded ones, and stores between those loads would delay them); a thread
+  // stores at most a few float4: the counted waits below over-wait by that many tile instructions at worst (vmem_asm.h, rule 1).
+  auto clears = [&] {
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     const int bid = blockIdx.y * gridDim.x + blockIdx.x, tid = threadIdx.x, nt = 64 * NW;
     if (a.zero0) { const int lo = bid * a.per0, hi = min(a.n0_4, lo + a.per0); for (int i = lo + tid; i < hi; i += nt) reinterpret_cast<float4*>(a.zero0)[i] = z; }
     if (a.zero1) { const int lo = bid * a.per1, hi = min(a.n1_4, lo + a.per1); for (int i = lo + tid; i < hi; i += nt) reinterpret_cast<float4*>(a.zero1)[i] = z; }
     if (a.ss_zero && bid == 0 && tid < 32) a.ss_zero[tid] = 0.f;
-  }
+  };
   const int u0 = blockIdx.x * f.upw, u1 = min(f.nunits, u0 + f.upw);
   if (u0 >= u1) return;
   const int K = f.K;
@@ -168,7 +169,8 @@ __global__ __launch_bounds__(64 * NW) void gemv_sw_kernel(const bf16_t* W_, cons
   };
 #pragma unroll
   for (int t = 0; t < RING; ++t) stage(t);
-  if constexpr (EPI != EPI_ATOMIC && !PEND) rest_of_args();   // (the epilogue's arguments: their round trip hides under the operand's)
+  if constexpr (!PEND) rest_of_args();                        // (the epilogue's arguments: their round trip hides under the operand's)
+  if constexpr (EPI == EPI_ATOMIC) clears();
 
   wait_vm<RING * MAXI>();                                      // the operand loads are older than every DMA instruction
   if constexpr (PRO == PRO_NORM) {
