@@ -7,6 +7,7 @@
 // with a different use of the stream; the oracle restates this rule (oracle/qwen2_ref.py: InverseCdfSampler).
 #include "common.h"
 #include "unigen_hip.h"
+#include "vmem_asm.h"
 
 namespace {
 
@@ -140,7 +141,10 @@ __global__ __launch_bounds__(ARS_T) void ar_sample_kernel(float* __restrict__ ac
   __shared__ int best_i[ARS_T / 64];
   __shared__ int chosen;
   const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int step = min(max(*pos_dev - pos0, 0), nsteps - 1);
+  // the position word (written by the head launch in front of us): a hand-issued SCALAR load (vmem_asm.h: hipcc reads such a word with a
+  // vector load and waits vmcnt(0) for it on the spot, a serialised round trip ahead of the logits' loads); used behind pass 1
+  int pos_now;
+  sld4(pos_now, pos_dev);
   float* c = acc + (int64_t)b * lda;
   float* u = acc + (int64_t)(bsz + b) * lda;
   // pass 1 (coalesced): mixed logits into LDS, accumulator rows cleared, running max / first argmax per thread
@@ -166,6 +170,10 @@ __global__ __launch_bounds__(ARS_T) void ar_sample_kernel(float* __restrict__ ac
       }
     }
   }
+  wait_lgkm0();
+  tie_s(pos_now);
+  const int step = min(max(pos_now - pos0, 0), nsteps - 1);
+  const float u01 = greedy ? 0.f : uniforms[(int64_t)step * bsz + b];      // (requested here: its round trip hides under the reductions)
   // block max + smallest index attaining it
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -205,7 +213,7 @@ __global__ __launch_bounds__(ARS_T) void ar_sample_kernel(float* __restrict__ ac
     // across waves; the grand total for the last thread.
     float upper = __shfl_down(excl, 1, 64);
     if (lane == 63) upper = (wave == ARS_T / 64 - 1) ? total : base + wtot[wave];
-    const float target = uniforms[(int64_t)step * bsz + b] * total;
+    const float target = u01 * total;
     if (excl <= target && target < upper) atomicMin(&hit, t);
     __syncthreads();
     if (t == hit) {
