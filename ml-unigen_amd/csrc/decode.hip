@@ -197,7 +197,7 @@ __global__ __launch_bounds__(64 * ADF_WAVES) void attn_decode_fused_kernel(
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int hq = blockIdx.y;
   const int grp = blockIdx.x + 8 * blockIdx.z;            // (row, kv head) group
-  // Arguments in two batches (vmem_asm.h, UG_HOIST): the early exit, the power-of-two test and the position load used to be three
+  // Arguments in two batches (vmem_asm.h, argument hoisting): the early exit, the power-of-two test and the position load used to be three
   // DEPENDENT round trips to the kernarg segment ahead of the first vector load.  Batch 1 = the kernel's first 14 argument dwords --
   // everything the accumulator loads (the ~2 us chain) need -- which arrive in SGPRs with the wave when the
   // code object is built with kernarg preload; batch 2 is requested behind the accumulator loads.
@@ -770,7 +770,7 @@ __global__ __launch_bounds__(64 * NW) void gemv_ring4_kernel(const float* __rest
   constexpr int UPW = (8 + NW - 1) / NW;           // k-steps of the operand each wave converts
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, row = lane & 15;
   const int slab = blockIdx.x + 8 * blockIdx.z, chunk = blockIdx.y;
-  asm volatile("" ::"s"(p0), "s"(p1), "s"(nw), "s"(W), "s"(R), "s"(K), "s"(ld1), "s"(ldw), "s"(N), "s"(nslabs));      // batch 1 (vmem_asm.h, UG_HOIST)
+  asm volatile("" ::"s"(p0), "s"(p1), "s"(nw), "s"(W), "s"(R), "s"(K), "s"(ld1), "s"(ldw), "s"(N), "s"(nslabs));      // batch 1 (vmem_asm.h, argument hoisting)
   auto rest_of_args = [&] {                        // batch 2: ONE asm statement (gridDim / blockDim are implicit arguments)
     if constexpr (CLR)
       asm volatile("" ::"s"(acc), "s"(sr), "s"(sn), "s"(gridDim.x), "s"(gridDim.y), "s"(blockDim.x), "s"(f.zero0), "s"(f.zero1), "s"(f.ss_zero),

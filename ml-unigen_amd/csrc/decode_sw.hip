@@ -72,7 +72,7 @@ __global__ __launch_bounds__(64 * NW) void gemv_sw_kernel(const bf16_t* W_, cons
   // Argument order: the 14 dwords in front are everything the launch's first loads need (operand, epilogue input, weight tiles); built with
   // kernarg preload (Makefile) they arrive in SGPRs with the wave -- no scalar-load round trip ahead of the first vector load (0.18 us of a
   // ~4 us launch).  opnd = the fp32 stream (PRO_NORM) or the bf16 operand; aux = norm weight (PRO_NORM) or the stream to finish (EPI_RESID).
-  // The rest of SwArgs is fetched in ONE batch (one asm statement naming every field: vmem_asm.h, UG_HOIST) where its latency hides.
+  // The rest of SwArgs is fetched in ONE batch (one asm statement naming every field: vmem_asm.h, argument hoisting) where its latency hides.
   struct {
     const bf16_t* W; int ldw, K, R, nunits, upw; const float* h; const float* norm_w; float eps; const bf16_t* xb; int ldx; float* h_io; int I;
   } f = {W_, ldw_, K_, R_, nunits_, upw_, (const float*)opnd_, (const float*)aux_, eps_, (const bf16_t*)opnd_, ld_opnd_, (float*)const_cast<void*>(aux_), I_};

@@ -51,12 +51,14 @@ __device__ __forceinline__ void ld2u(T& v, const void* p) { asm volatile("global
 template <typename T>
 __device__ __forceinline__ void tie(T& v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ uint32_t lds_addr_of(const void* p) { return (uint32_t)(uintptr_t)p; }      // low half of a generic LDS pointer
-// Kernel arguments are fetched by scalar loads where the compiler first needs them; behind an early exit or a data-dependent branch that
-// is a second, third ... DEPENDENT round trip to the kernarg segment before the kernel's first vector load (a decode launch lives
-// ~4 us; ISA scan: tools/probes/prologue_scan.py).  UG_HOIST(x) at the top of a kernel makes x a live SGPR THERE, so that every
-// argument comes in one batch of s_load behind one wait.
-#define UG_HOIST(x) asm volatile("" ::"s"(x))
-#define UG_HOISTF(x) asm volatile("" ::"s"(__float_as_int(x)))
+// Kernel arguments ("argument hoisting").  hipcc fetches a kernel argument by a scalar load where it is first needed; behind an early
+// exit or a data-dependent branch that is a second, third ... DEPENDENT round trip to the kernarg segment before the kernel's first
+// vector load (0.18 us each; a decode launch lives ~4 us; ISA scan: tools/probes/prologue_scan.py).  The decode kernels therefore
+//   (1) take the pointers / sizes their first loads need as LEADING SCALAR arguments: built with -mllvm -amdgpu-kernarg-preload-count=16
+//       (Makefile) the first 14 dwords arrive in SGPRs with the wave (a by-value struct is passed by reference and never preloaded);
+//   (2) name every other argument in ONE statement  asm volatile("" :: "s"(arg), "s"(arg), ...);  placed behind the first loads: the
+//       operands must be live SGPRs there, so all of them are fetched in one batch behind one wait (several statements would each end
+//       a scheduling region and bring the dependent trips back; implicit arguments -- gridDim, blockDim -- count too).
 // A wave-uniform word ANOTHER launch wrote (the decode position): hipcc may not treat it as constant, so it reads it with a VECTOR load
 // and waits vmcnt(0) for it on the spot -- a serialised L2 round trip at the top of the kernel.  Hand-issued scalar load instead (the
 // scalar cache is invalidated at every kernel start); use the value behind wait_lgkm0() + tie_s().

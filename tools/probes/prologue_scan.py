@@ -5,7 +5,7 @@
 
 Per kernel: instructions before the first VMEM op, number of s_load, number of lgkmcnt waits, and the sequence (L = s_load, W = wait,
 B = branch).  "LWBLLLW" = two DEPENDENT trips to the kernarg segment before the first vector load (~0.18 us each in a decode launch:
-profiles/r06_decode_forms.md); UG_HOIST / one asm statement naming every argument (vmem_asm.h) turns it into "LLLLW"."""
+profiles/r06_decode_forms.md); one asm statement naming every argument (vmem_asm.h, argument hoisting) turns it into "LLLLW"."""
 import sys,re
 for path in sys.argv[1:]:
     L=open(path).read().split('\n')
