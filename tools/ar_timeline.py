@@ -84,9 +84,20 @@ if per:
 BYTES = {"gemv_ring4_kernel<1, 3, 1, 9>": ("gate_up", 17920 * 1536 * 2), "gemv_ring4_kernel<1, 2, 2, 8>": ("down", 1536 * 8960 * 2),
          "gemv_ring4_kernel<1, 2, 2, 7>": ("down", 1536 * 8960 * 2), "gemv_ring4_kernel<1, 1, 1, 4>": ("q/k/v", 2048 * 1536 * 2),
          "gemv_ring_kernel<1, 1>": ("o", 1536 * 1536 * 2), "attn_decode_fused_kernel": ("attention (K / V cache)", 330 * 16 * 2 * 2 * 256),
-         "gemv_ring_kernel<1, 2>": ("lm-head slice", 8192 * 1536 * 2)}
+         "gemv_ring_kernel<1, 2>": ("lm-head slice", 8192 * 1536 * 2),
+         # round 6 (decode_sw.hip; the ring kernel gained a clears flag): matched by prefix below
+         "gemv_sw_kernel<0, 2,": ("gate_up", 17920 * 1536 * 2), "gemv_sw_kernel<1, 4,": ("down", 1536 * 8960 * 2),
+         "gemv_sw_kernel<1, 1,": ("o", 1536 * 1536 * 2), "gemv_sw_kernel<0, 3,": ("lm-head slice", 8192 * 1536 * 2),
+         "gemv_ring4_kernel<1, 1, 1, 4,": ("q/k/v", 2048 * 1536 * 2)}
 R4 = {"gate_up": 14.66, "down": 10.77, "attention (K / V cache)": 7.92, "q/k/v": 6.30, "o": 4.76, "lm-head slice": 7.99}
-rows = [(BYTES[nm][0], BYTES[nm][1], b / c) for nm, (c, b, g) in agg.items() if nm in BYTES]
+def _known(nm):
+    for k in BYTES:
+        if nm == k or (k.endswith(",") and nm.startswith(k)):
+            return BYTES[k]
+    return None
+
+
+rows = [(_known(nm)[0], _known(nm)[1], b / c) for nm, (c, b, g) in agg.items() if _known(nm)]
 if rows:
     print("\nHBM rate per launch (bytes the launch must stream / mean body, the 1.5 us launch boundary included in the body):\n")
     print("| launch | MB | round 4 us | round 4 TB/s | now us | now TB/s |\n|---|---|---|---|---|---|")
